@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- forward + likelihood evals/sec on synthetic FDEM soundings (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2]): 65 536 soundings x 10 zz frequencies x 8 layers, fp64,
+sharded in contiguous blocks over the N ranks (strong scaling: the total is fixed).  One STEP = one
+proposal round over the whole batch: every sounding gets a fresh conductivity vector (one of R
+pre-generated sets resident in HBM, so nothing can be cached), the fused kernel evaluates forward
+solve + chi^2 + log-likelihood, and the per-sounding summaries are gathered to rank 0 (RCCL, on a side
+stream so that it overlaps the next round).  Inputs are resident in HBM before the timed region.
+
+The JSON line also carries
+  roofline      min-flop algorithmic FLOPs of SURVEY 8(d) / kernel time (HIP events on the launch
+                stream) against the MI355X fp64 vector peak (the path is fp64-VALU bound, not HBM/MFMA),
+                plus the algorithmic HBM bytes/s for reference;
+  cpu_baseline  the C oracle (a port of the reference's scalar algorithm) timed on this host's cores on a
+                bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_TOTAL = 65536
+N_FREQ = 10
+N_LAYERS = 8
+N_SIGMA_SETS = 4
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X datasheet, per GPU
+HBM_PEAK_GBPS = 8000.0
+
+
+def flop_per_eval(L, F):
+    """SURVEY 8(d) min-flop convention: (72 L + 33) flop per (frequency, abscissa) point, 120 points per zz frequency."""
+    return (72 * L + 33) * F * 120
+
+
+def bytes_per_eval(L, F, with_pred):
+    """Algorithmic HBM traffic per eval: sigma[L] + thk[L] + height + nlayers + obs[2F] + rel + add read,
+    chi2 + logL (+ pred[2F]) written."""
+    rd = 8 * (2 * L + 1 + 2 * F + 2) + 4
+    wr = 16 + (8 * 2 * F if with_pred else 0)
+    return rd + wr
+
+
+def cpu_baseline(system, nl, sigma, thk, height, obs, sample, threads):
+    from oracle import fdem_oracle as fo
+    osys = fo.OracleSystem(system.frequencies, system.transmitter.orientation, system.transmitter.moment,
+                           np.c_[system.transmitter.x, system.transmitter.y, system.transmitter.z],
+                           system.receiver.orientation, system.receiver.moment,
+                           np.c_[system.receiver.x, system.receiver.y, system.receiver.z])
+    n = sample
+    rel = np.full(n, 0.05)
+    add = np.full(n, 5.0)
+    fo.forward_loglike_batch(osys, nl[:64], sigma[:64], thk[:64], height[:64], obs[:64], rel[:64], add[:64],
+                             nthreads=threads)  # warm-up (thread pool, page-in)
+    t0 = time.perf_counter()
+    pred, chi2, logl = fo.forward_loglike_batch(osys, nl[:n], sigma[:n], thk[:n], height[:n], obs[:n], rel, add,
+                                                nthreads=threads)
+    dt = time.perf_counter() - t0
+    return n / dt, dt, (pred, chi2, logl)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--soundings", type=int, default=B_TOTAL, help="total soundings (default: BASELINE config)")
+    ap.add_argument("--layers", type=int, default=N_LAYERS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from geobipy_amd import FdemBatch, synthetic
+    from geobipy_amd.distributed import SummaryGather, shard
+
+    Btot, L, F = args.soundings, args.layers, N_FREQ
+    system = synthetic.syn10_system()
+    start, Bloc = shard(Btot, rank, world)
+
+    # ---- synthetic inputs: drawn for the WHOLE job with one seed, then sliced, so the workload does not
+    # depend on N.  "Observed" data = forward(true model) with 5 % + 5 ppm noise; proposals = fresh sigma.
+    nl, sigma_true, thk, height = synthetic.draw_models(Btot, L, seed=synthetic.SEED + 2)
+    sl = slice(start, start + Bloc)
+    truth = FdemBatch(system, nl[sl], sigma_true[sl], thk[sl], height[sl], device=device)
+    clean = truth.forward().cpu().numpy()
+    rngn = np.random.Generator(np.random.PCG64DXSM(synthetic.SEED + 3))   # one noise field for any N
+    g1 = rngn.normal(size=(Btot, 2 * F))
+    g2 = rngn.normal(size=(Btot, 2 * F))
+    obs = clean * (1.0 + 0.05 * g1[sl]) + 5.0 * g2[sl]
+    rel = np.full(Bloc, 0.05)
+    add = np.full(Bloc, 5.0)
+    sig_sets = [synthetic.redraw_sigma(Btot, L, seed=synthetic.SEED + 10 + i)[sl] for i in range(N_SIGMA_SETS)]
+    batches = [FdemBatch(system, nl[sl], s, thk[sl], height[sl], data=obs, relative_error=rel, additive_error=add,
+                         device=device) for s in sig_sets]
+    gather = SummaryGather(Btot, 2, device)
+    side = torch.cuda.Stream(device=device) if world > 1 else None
+
+    def step(i, pending):
+        b = batches[i % N_SIGMA_SETS]
+        chi2, logl = b.forward_loglike(want_pred=False)
+        if world == 1:
+            return None          # single rank: the summaries are already resident on "rank 0"
+        # finish the previous round's gather, then start this one on the side stream behind the kernel
+        if pending is not None:
+            pending[0].wait()
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            work = gather.launch(chi2, logl)
+        return (work,)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    pending = None
+    for i in range(args.warmup):
+        pending = step(i, pending)
+    if pending is not None:
+        pending[0].wait()
+        pending = None
+    sync_all()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        pending = step(i, pending)
+    ev1.record()
+    if pending is not None:
+        pending[0].wait()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # launch stream only: the fused kernel (+ tiny copies)
+
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    if world > 1:
+        result = gather.finish()
+    else:
+        last = batches[(args.steps - 1) % N_SIGMA_SETS]
+        result = torch.stack([last.chi2, last.logL], dim=1)
+
+    if rank == 0:
+        evals = Btot * args.steps
+        value = evals / elapsed
+        fpe = flop_per_eval(L, F)
+        per_launch_evals = int(np.ceil(Btot / world))
+        achieved = per_launch_evals * fpe / (kernel_ms * 1e-3) / 1e12
+        bpe = bytes_per_eval(L, F, with_pred=False)
+        line = {
+            "metric": "forward+likelihood evals/sec (whole node)",
+            "value": value,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{Btot} FDEM soundings x {F} zz frequencies x {L} layers, fused forward+chi2+logL, "
+                                   f"contiguous shards over {world} GPU(s), gather of (chi2, logL) to rank 0 per round",
+                       "soundings": Btot, "frequencies": F, "layers": L, "seed": synthetic.SEED,
+                       "proposal_sets": N_SIGMA_SETS},
+            "roofline": {
+                "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "flop_per_eval": fpe, "evals_per_launch": per_launch_evals, "kernel_ms": kernel_ms,
+                "kernel": "k_fdem_forward<true>",
+                "hbm": {"algorithmic_bytes_per_eval": bpe,
+                        "achieved_GBps": per_launch_evals * bpe / (kernel_ms * 1e-3) / 1e9,
+                        "peak_GBps": HBM_PEAK_GBPS},
+            },
+            "finite": bool(torch.isfinite(result).all()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            sample = args.cpu_sample or max(256, min(Btot, 16 * threads))
+            sigma0 = sig_sets[0]
+            rate, dt, (p_ref, c_ref, l_ref) = cpu_baseline(system, nl, sigma0, thk, height, obs, sample, threads)
+            if dt < 5.0 and not args.cpu_sample:   # scale the sample to ~15 s of CPU work
+                sample = int(min(Btot, max(sample, rate * 15.0)))
+                rate, dt, (p_ref, c_ref, l_ref) = cpu_baseline(system, nl, sigma0, thk, height, obs, sample, threads)
+            # the same sample doubles as a parity spot-check of the benchmarked kernel
+            chi2, logl = batches[0].forward_loglike(want_pred=True)
+            torch.cuda.synchronize(device)
+            p = batches[0].predicted[:sample].cpu().numpy()
+            line["cpu_baseline"] = {"value": rate, "unit": "evals/s", "cores": threads, "kind": "port",
+                                    "sample": f"first {sample} soundings of the same batch, C oracle "
+                                              f"(oracle/fdem1d_oracle.c, gcc -O2, OpenMP {threads} threads), {dt:.1f} s"}
+            line["parity_vs_cpu"] = {"max_abs_pred_ppm": float(np.max(np.abs(p - p_ref))),
+                                     "max_abs_chi2": float(np.max(np.abs(chi2[:sample].cpu().numpy() - c_ref))),
+                                     "max_abs_logL": float(np.max(np.abs(logl[:sample].cpu().numpy() - l_ref)))}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

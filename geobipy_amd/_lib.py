@@ -1,0 +1,62 @@
+"""ctypes binding of libgeobipy_amd.so (C ABI in include/geobipy_amd.h).
+
+There is deliberately NO fallback: if the HIP library has not been built, importing a symbol from
+here raises.  Build it with ``python __graft_entry__.py`` (or ``geobipy_amd.build.build_native()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgeobipy_amd.so")
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); must list every symbol include/geobipy_amd.h declares
+SIGNATURES = {
+    "gbp_version": (ctypes.c_char_p, []),
+    "gbp_last_error": (ctypes.c_char_p, []),
+    "gbp_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "gbp_fdem_system_create": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.POINTER(c_void_p)]),
+    "gbp_fdem_system_destroy": (None, [c_void_p]),
+    "gbp_fdem_system_nfreq": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "gbp_fdem_system_h0": (c_int, [c_void_p, c_double_p]),
+    "gbp_fdem_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "gbp_gauss_loglike": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
+    "gbp_fdem_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
+    "gbp_fdem_sensitivity": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "gbp_fdem_time_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p, c_int,
+                                                                                        ctypes.POINTER(ctypes.c_float)]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise NativeLibraryError loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the gfx950 HIP library has not been built. "
+            "Run `python __graft_entry__.py` in the repo root (needs hipcc). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().gbp_last_error().decode(errors="replace")
+        raise NativeLibraryError(f"geobipy_amd native call failed (status {status}): {msg}")

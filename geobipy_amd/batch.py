@@ -1,0 +1,139 @@
+"""Device-resident batches of soundings: the batched entry points of the hot path.
+
+``FdemBatch`` keeps B soundings that share one ``FdemSystem`` as fp64 tensors in HBM and evaluates,
+for all of them in one launch, what the reference evaluates one sounding at a time in
+``Inference1D.accept_reject`` (inversion/Inference1D.py:572-597):
+``FdemDataPoint.forward`` -> ``data_misfit`` -> ``likelihood(log=True)``.
+
+HBM layout (all C-contiguous, fp64 unless noted):
+    nlayers int32[B]      sigma[B, Lmax]   thk[B, Lmax]   height[B]
+    data[B, 2F]           relative_error[B]               additive_error[B]
+    predicted[B, 2F]      chi2[B]          logL[B]        (outputs, allocated once and reused)
+PyTorch is only the allocator / stream provider here; all arithmetic happens in libgeobipy_amd.so.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev_f64(x, device, shape=None):
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+    t = t.to(device=device, dtype=torch.float64).contiguous()
+    if shape is not None:
+        t = t.expand(shape).contiguous() if t.dim() == 0 or tuple(t.shape) != tuple(shape) else t
+    return t
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class FdemBatch:
+    """B soundings on one GPU.
+
+    Parameters mirror the per-sounding objects of the reference: ``sigma``/``thk`` are
+    ``Model.values`` / ``Model.mesh.widths`` (last width = inf is ignored), ``height`` is
+    ``DataPoint.z``, ``data`` the observed ``FdemDataPoint.data`` (in-phase block then quadrature
+    block), ``relative_error`` / ``additive_error`` one scalar per sounding (DataPoint.py:274).
+    """
+
+    def __init__(self, system, nlayers, sigma, thk, height, data=None, relative_error=None, additive_error=None,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise _lib.NativeLibraryError("FdemBatch needs a HIP device (torch.cuda.is_available() is False); "
+                                          "there is no CPU fallback")
+        _lib.load()
+        self.system = system
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self._h = system.handle()
+        self.F = system.nFrequencies
+        self.sigma = _dev_f64(sigma, self.device)
+        assert self.sigma.dim() == 2, ValueError("sigma must have shape [B, Lmax]")
+        self.B, self.Lmax = self.sigma.shape
+        self.thk = _dev_f64(thk, self.device)
+        assert tuple(self.thk.shape) == (self.B, self.Lmax), ValueError("thk must have shape [B, Lmax]")
+        nl = torch.as_tensor(np.asarray(nlayers) if not torch.is_tensor(nlayers) else nlayers)
+        if nl.dim() == 0:
+            nl = nl.expand(self.B)
+        self.nlayers = nl.to(device=self.device, dtype=torch.int32).contiguous()
+        assert self.nlayers.numel() == self.B
+        self.height = _dev_f64(height, self.device, (self.B,))
+        self.data = None if data is None else _dev_f64(data, self.device)
+        if self.data is not None:
+            assert tuple(self.data.shape) == (self.B, 2 * self.F), ValueError("data must have shape [B, 2F]")
+        self.relative_error = None if relative_error is None else _dev_f64(relative_error, self.device, (self.B,))
+        self.additive_error = None if additive_error is None else _dev_f64(additive_error, self.device, (self.B,))
+        self.predicted = torch.empty((self.B, 2 * self.F), dtype=torch.float64, device=self.device)
+        self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
+
+    def validate(self):
+        """Host-side input checks the reference does with asserts (FD/fdem1d.py:29) plus sigma, thk > 0."""
+        nl = self.nlayers.cpu().numpy()
+        assert nl.min() >= 1 and nl.max() <= self.Lmax, ValueError("nlayers out of range")
+        mask = torch.arange(self.Lmax, device=self.device)[None, :] < self.nlayers[:, None]
+        assert bool((self.sigma[mask] > 0).all()), ValueError("conductivity must be > 0")
+        tmask = torch.arange(self.Lmax, device=self.device)[None, :] < (self.nlayers[:, None] - 1)
+        assert bool((self.thk[tmask] > 0).all()), ValueError("thickness must be > 0")
+        assert bool((self.height >= 0).all()), ValueError("Sensor altitude must be above the top of the model")
+
+    # -- launches -----------------------------------------------------------------------------
+    def forward(self, out=None):
+        """pred[B, 2F] (ppm) for the current sigma / thk / height; one kernel launch, no sync."""
+        out = self.predicted if out is None else out
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_fdem_forward(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                            self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
+                                            out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def forward_loglike(self, want_pred=True):
+        """Fused forward + chi^2 + log-likelihood: returns (chi2[B], logL[B]); ``self.predicted`` is
+        refreshed when ``want_pred``."""
+        assert self.data is not None and self.relative_error is not None and self.additive_error is not None, \
+            ValueError("data, relative_error and additive_error are needed for the likelihood")
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_fdem_forward_loglike(
+                self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
+                self.height.data_ptr(), self.data.data_ptr(), self.relative_error.data_ptr(),
+                self.additive_error.data_ptr(), self.predicted.data_ptr() if want_pred else None,
+                self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
+        return self.chi2, self.logL
+
+    def loglike(self, pred=None):
+        """chi^2 and logL for given predictions (DataPoint.data_misfit / likelihood(log=True))."""
+        pred = self.predicted if pred is None else _dev_f64(pred, self.device)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_gauss_loglike(self.B, 2 * self.F, pred.data_ptr(), self.data.data_ptr(),
+                                             self.relative_error.data_ptr(), self.additive_error.data_ptr(),
+                                             self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
+        return self.chi2, self.logL
+
+    def sensitivity(self, out=None):
+        """J[B, 2F, Lmax] = d pred / d ln(sigma) (FdemDataPoint.sensitivity)."""
+        if out is None:
+            out = torch.empty((self.B, 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_fdem_sensitivity(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
+                                                out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def time_forward_loglike(self, reps, want_pred=False):
+        """Average kernel time in ms over ``reps`` launches, measured with hipEvents on the launch stream."""
+        import ctypes
+        lib = _lib.load()
+        ms = ctypes.c_float()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_fdem_time_forward_loglike(
+                self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
+                self.height.data_ptr(), self.data.data_ptr(), self.relative_error.data_ptr(),
+                self.additive_error.data_ptr(), self.predicted.data_ptr() if want_pred else None,
+                self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device), int(reps), ctypes.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,347 @@
+// gbp_fdem.hip -- gfx950 kernels + C ABI (include/geobipy_amd.h) for the batched FDEM forward solve,
+// Gaussian misfit / log-likelihood and Jacobian.  Hand-written for CDNA4 wave64; no CUDA path.
+//
+// Work decomposition:
+//   workgroup  = one sounding  (NW waves; NW chosen on the host from the batch size)
+//   wave       = one frequency at a time (f = wave, wave + NW, ...)
+//   lane       = one Hankel abscissa: 64 abscissae per pass, 2 passes for the 120-point J0 filter
+//   layer recursion, csqrt/cexp in registers; sigma / thickness of the sounding are wave-uniform
+//   (scalar loads), the per-abscissa tables (40 B per point) are read coalesced from L2.
+//   Hankel sum = wave64 butterfly reduction; chi^2 / logdet = second wave reduction over channels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/geobipy_amd.h"
+#include "gbp_fdem_point.h"
+#include "gbp_fdem_tables.h"
+
+using gbp::Channel;
+using gbp::cplx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+gbp_status fail(gbp_status code, const char* fmt, const char* detail = "")
+{
+    std::snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define GBP_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return fail(GBP_ERR_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct gbp_fdem_system {
+    gbp::SystemTables t;      // host copy (channels, H0, point tables)
+    Channel* d_chan = nullptr;
+    double* d_pts = nullptr;  // SoA: lam | u0re | u0im | cre | cim, each [npts]
+};
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Forward solve for the frequencies owned by this wave; result (complex ppm) -> sh_out[f], sh_out[F+f].
+__device__ __forceinline__ void forward_channels(const Channel* __restrict__ chan, const double* __restrict__ pts,
+                                                 int npts_total, int F, int L, const double* __restrict__ sig,
+                                                 const double* __restrict__ thk, double alt, int wave, int nwaves,
+                                                 int lane, double* sh_out)
+{
+    const double* __restrict__ p_lam = pts;
+    const double* __restrict__ p_u0r = pts + npts_total;
+    const double* __restrict__ p_u0i = pts + 2 * (size_t)npts_total;
+    const double* __restrict__ p_cre = pts + 3 * (size_t)npts_total;
+    const double* __restrict__ p_cim = pts + 4 * (size_t)npts_total;
+
+    for (int f = wave; f < F; f += nwaves) {
+        const Channel ch = chan[f];
+        const double hD = ch.hd0 - 2.0 * alt;
+        const bool real_exp = ch.real_exp != 0;
+        double acc_re = 0.0, acc_im = 0.0;
+        for (int j0 = 0; j0 < ch.npts; j0 += 64) {
+            int j = j0 + lane;
+            const bool valid = j < ch.npts;
+            j = ch.off + (valid ? j : ch.npts - 1);
+            const double lam = p_lam[j];
+            const cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
+            cplx coef = gbp::mk(p_cre[j], p_cim[j]);
+            if (!valid) coef = gbp::mk(0.0, 0.0);
+            const double a = lam * lam - ch.w2me;
+            cplx num, den;
+            gbp::rte_num_den(a, ch.wmu, L, sig, thk, u0, num, den);
+            const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
+            const cplx t = gbp::hankel_term(num, den, ue, hD, coef, real_exp);
+            acc_re += t.re;
+            acc_im += t.im;
+        }
+        acc_re = wave_sum(acc_re);
+        acc_im = wave_sum(acc_im);
+        if (lane == 0) {
+            // out = 1e6 * scale * (H - H0) / H0 = g * (H - H0)
+            sh_out[f] = ch.g_re * acc_re - ch.g_im * acc_im;
+            sh_out[F + f] = ch.g_re * acc_im + ch.g_im * acc_re;
+        }
+    }
+}
+
+// chi^2 / logL of one sounding from N predicted channels held in `p` (LDS or global); executed by one wave.
+__device__ __forceinline__ void loglike_wave(int N, const double* p, const double* __restrict__ obs, double rel,
+                                             double add, int lane, double* chi2, double* logL)
+{
+    double s2 = 0.0, logdet = 0.0, na = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const double o = obs[i];
+        const bool active = o > 0.0;  // false for NaN and for non-positive data (EmDataPoint.py:54-56)
+        const double ro = rel * o;
+        const double var = ro * ro + add * add;  // DataPoint.py:274
+        if (active) {
+            const double r = (p[i] - o) * (1.0 / sqrt(var));  // DataPoint.py:523-524
+            s2 += r * r;
+            logdet += log(var);
+            na += 1.0;
+        }
+    }
+    s2 = wave_sum(s2);
+    logdet = wave_sum(logdet);
+    na = wave_sum(na);
+    if (lane == 0) {
+        *chi2 = s2;
+        // MvNormalDistribution.py:209-216 with a diagonal covariance
+        *logL = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
+    }
+}
+
+template <bool LIKE>
+__global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict__ chan,
+                                                       const double* __restrict__ pts, int npts_total, int F,
+                                                       int Lmax, const int* __restrict__ nlayers,
+                                                       const double* __restrict__ sigma,
+                                                       const double* __restrict__ thk,
+                                                       const double* __restrict__ height,
+                                                       const double* __restrict__ obs,
+                                                       const double* __restrict__ rel,
+                                                       const double* __restrict__ add, double* __restrict__ pred,
+                                                       double* __restrict__ chi2, double* __restrict__ logL)
+{
+    __shared__ double sh_out[2 * GBP_MAX_FREQ];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int L = nlayers[b];
+    const double* sig = sigma + (size_t)b * Lmax;
+    const double* th = thk + (size_t)b * Lmax;
+
+    forward_channels(chan, pts, npts_total, F, L, sig, th, height[b], wave, nwaves, lane, sh_out);
+    __syncthreads();
+
+    const int N = 2 * F;
+    if (pred != nullptr)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) pred[(size_t)b * N + i] = sh_out[i];
+    if (LIKE && wave == 0)
+        loglike_wave(N, sh_out, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
+}
+
+__global__ void k_gauss_loglike(int B, int N, const double* __restrict__ pred, const double* __restrict__ obs,
+                                const double* __restrict__ rel, const double* __restrict__ add,
+                                double* __restrict__ chi2, double* __restrict__ logL)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    loglike_wave(N, pred + (size_t)b * N, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
+}
+
+// ------------------------------------------------------------------------------------------
+// host: system tables
+// ------------------------------------------------------------------------------------------
+namespace {
+
+typedef std::complex<double> zc;
+
+int pick_waves(int B, int F)
+{
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = std::getenv("GBP_NW");
+        forced = e ? std::atoi(e) : -1;
+    }
+    int nw = forced > 0 ? forced : (8192 + B - 1) / B;  // aim for >= 8 waves per SIMD-slot worth of work
+    if (nw > F) nw = F;
+    if (nw > 16) nw = 16;
+    if (nw < 1) nw = 1;
+    return nw;
+}
+
+gbp_status check_batch(const gbp_fdem_system* sys, int B, int Lmax, const void* a, const void* b, const void* c,
+                       const void* d)
+{
+    if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
+    if (B > 0 && (!a || !b || !c || !d)) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    return GBP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gbp_version(void) { return "geobipy_amd 0.1 (gfx950)"; }
+const char* gbp_last_error(void) { return g_err; }
+
+gbp_status gbp_device_count(int* count)
+{
+    if (!count) return fail(GBP_ERR_INVALID_ARG, "count is NULL%s");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(GBP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_system_create(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
+                                  const double* rx_z, const double* tx_moment, const double* scale,
+                                  const double* rx_off, const double* separation, const double* w0,
+                                  const double* lamda0, const double* w1, const double* lamda1,
+                                  gbp_fdem_system** out)
+{
+    if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
+    *out = nullptr;
+    gbp_fdem_system* s = new (std::nothrow) gbp_fdem_system();
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "out of host memory%s");
+    const char* msg = "";
+    int rc = gbp::build_system_tables(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
+                                      lamda0, w1, lamda1, &s->t, &msg);
+    if (rc != GBP_OK) { delete s; return fail(rc, "%s", msg); }
+    const std::vector<double>& soa = s->t.soa;
+
+    hipError_t e = hipMalloc((void**)&s->d_chan, sizeof(Channel) * nF);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_pts, sizeof(double) * soa.size());
+    if (e == hipSuccess) e = hipMemcpy(s->d_chan, s->t.chan.data(), sizeof(Channel) * nF, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_pts, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gbp_fdem_system_destroy(s);
+        return fail(GBP_ERR_HIP, "system table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return GBP_OK;
+}
+
+void gbp_fdem_system_destroy(gbp_fdem_system* sys)
+{
+    if (!sys) return;
+    if (sys->d_chan) (void)hipFree(sys->d_chan);
+    if (sys->d_pts) (void)hipFree(sys->d_pts);
+    delete sys;
+}
+
+gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system* sys, int* nF)
+{
+    if (!sys || !nF) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    *nF = sys->t.nF;
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_system_h0(const gbp_fdem_system* sys, double* out)
+{
+    if (!sys || !out) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    std::memcpy(out, sys->t.h0.data(), sizeof(double) * sys->t.h0.size());
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_forward(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                            const double* sigma, const double* thk, const double* height, double* pred,
+                            void* stream)
+{
+    gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
+    if (st != GBP_OK) return st;
+    if (B == 0) return GBP_OK;
+    if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
+    const int nw = pick_waves(B, sys->t.nF);
+    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), 0, (hipStream_t)stream, sys->d_chan,
+                       sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
+                       nullptr, pred, nullptr, nullptr);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_gauss_loglike(int B, int N, const double* pred, const double* obs, const double* rel,
+                             const double* add, double* chi2, double* logL, void* stream)
+{
+    if (B < 0 || N < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and N >= 1%s");
+    if (B == 0) return GBP_OK;
+    if (!pred || !obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    const int wpb = 4;
+    hipLaunchKernelGGL(k_gauss_loglike, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, B, N,
+                       pred, obs, rel, add, chi2, logL);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                    const double* sigma, const double* thk, const double* height,
+                                    const double* obs, const double* rel, const double* add, double* pred,
+                                    double* chi2, double* logL, void* stream)
+{
+    gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
+    if (st != GBP_OK) return st;
+    if (B == 0) return GBP_OK;
+    if (!obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    const int nw = pick_waves(B, sys->t.nF);
+    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), 0, (hipStream_t)stream, sys->d_chan,
+                       sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
+                       chi2, logL);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                         const double* sigma, const double* thk, const double* height,
+                                         const double* obs, const double* rel, const double* add, double* pred,
+                                         double* chi2, double* logL, void* stream, int reps, float* avg_ms)
+{
+    if (!avg_ms || reps < 1) return fail(GBP_ERR_INVALID_ARG, "avg_ms NULL or reps < 1%s");
+    hipEvent_t e0, e1;
+    GBP_HIP(hipEventCreate(&e0));
+    GBP_HIP(hipEventCreate(&e1));
+    GBP_HIP(hipEventRecord(e0, (hipStream_t)stream));
+    gbp_status st = GBP_OK;
+    for (int i = 0; i < reps && st == GBP_OK; ++i)
+        st = gbp_fdem_forward_loglike(sys, B, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred, chi2, logL,
+                                      stream);
+    GBP_HIP(hipEventRecord(e1, (hipStream_t)stream));
+    GBP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    GBP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = ms / reps;
+    return st;
+}
+
+gbp_status gbp_fdem_sensitivity(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                const double* sigma, const double* thk, const double* height, double* J,
+                                void* stream)
+{
+    (void)sys; (void)B; (void)Lmax; (void)nlayers; (void)sigma; (void)thk; (void)height; (void)J; (void)stream;
+    return fail(GBP_ERR_INVALID_ARG, "gbp_fdem_sensitivity: not built yet%s");
+}
+
+}  // extern "C"

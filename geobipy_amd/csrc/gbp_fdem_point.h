@@ -1,0 +1,83 @@
+// gbp_fdem_point.h -- one abscissa point of the 1-D layered-earth FDEM kernel.
+//
+// Replaces, for a single (frequency, abscissa) pair, the reference's
+//   initCoefficients   forwardmodelling/Electromagnetic/FD/fdem1d_numba.py:157-191
+//   M1_0 + cTanh       fdem1d_numba.py:194-219, 441-448
+// and the integrand of Hzz/Hxx/Hxz/Hzx (fdem1d_numba.py:306-438).
+//
+// Re-derivation (not a transcription).  The reference recurses the surface admittance
+//   Y_k = Yn_k (Y_{k+1} + Yn_k tanh(u_k t_k)) / (Yn_k + Y_{k+1} tanh(u_k t_k)),  Yn_k = u_k / (i w mu0)
+// with one complex tanh (exp + division) and one complex division per layer.  With kappa == 0 for
+// every layer (the wrapper passes zeros, FD/fdem1d.py:36-37) the factor 1/(i w mu0) is common to all
+// Yn_k and cancels: with Yh = Y * (i w mu0) the recursion is homogeneous in u_k.  Writing
+// Yh_{k+1} = N / D (projective form) and e = exp(-2 u_k t_k),
+//   A = u_k D + N,   B = u_k D - N,
+//   N' = u_k (A - e B),   D' = A + e B,
+// which is exactly Y_k = u_k (1 - rho e)/(1 + rho e), rho = B / A, with NO division and no tanh:
+// 3 complex multiplies + 4 complex adds per layer.  The reflection coefficient needs the only
+// division:  rTE = (u_0 D - N) / (u_0 D + N).
+//
+// The Hankel integrand is then rTE * exp(ue * hDiff) * coef, where the free-space part of the
+// reference's H (a0 * a1 * w) is dropped analytically: the reference forms H and H0 separately and
+// subtracts (FD:68); we accumulate H - H0 directly, which removes the cancellation against the
+// ~60x larger alternating filter terms of H0 (hard part 1).  H0 itself depends only on
+// the acquisition system and is precomputed on the host once per system.
+#pragma once
+#include "gbp_math.h"
+
+namespace gbp {
+
+// Per-frequency constants (device copy lives in the system handle).
+struct Channel {
+    double wmu;         // omega * mu0                      (zn = i * wmu, FD:177)
+    double w2me;        // (omega eps0) * (omega mu0)       (-Re(yn zn), FD:176-178)
+    double hd0;         // rx_z - 2 tx_z : hDiff = rHeight - tHeight = hd0 - 2 * altitude (FD/fdem1d.py:31-32)
+    double g_re, g_im;  // 1e6 * scale / H0                 (FD:68)
+    int off, npts;      // slice of the point tables
+    int real_exp;       // 1: exponent uses lambda (Hxx, Hxz), 0: u0 (Hzz, Hzx)
+    int tid;
+};
+
+// rTE numerator / denominator for one point.  a = lambda^2 - w2me, sig/thk: the sounding's L layers
+// (thk[L-1] is never read -- the reference passes inf there).
+GBP_HD void rte_num_den(double a, double wmu, int L, const double* __restrict__ sig,
+                        const double* __restrict__ thk, cplx u0, cplx& num, cplx& den)
+{
+    cplx N = csqrt_upper(a, wmu * sig[L - 1]);  // basement: Yh_L = u_L
+    cplx D = mk(1.0, 0.0);
+    for (int k = L - 2; k >= 0; --k) {
+        cplx u = csqrt_upper(a, wmu * sig[k]);
+        double t2 = -2.0 * thk[k];
+        cplx e = cexp_neg(t2 * u.re, t2 * u.im);
+        cplx uD = u * D;
+        cplx A = uD + N, B = uD - N;
+        cplx eB = e * B;
+        N = u * (A - eB);
+        D = A + eB;
+        if ((k & 3) == 3) {  // keep |N|, |D| away from the fp64 range limits for deep models
+            int s = -frexp_exp(__builtin_fmax(__builtin_fabs(D.re), __builtin_fabs(D.im)));
+            N = mk(ldexp_i(N.re, s), ldexp_i(N.im, s));
+            D = mk(ldexp_i(D.re, s), ldexp_i(D.im, s));
+        }
+    }
+    cplx uD = u0 * D;
+    num = uD - N;
+    den = uD + N;
+}
+
+// One term of H - H0: rTE * exp(ue * hD) * coef
+GBP_HD cplx hankel_term(cplx num, cplx den, cplx ue, double hD, cplx coef, bool real_exp)
+{
+    cplx E;
+    if (real_exp)
+        E = mk(exp_neg(ue.re * hD), 0.0);
+    else
+        E = cexp_neg(ue.re * hD, ue.im * hD);
+    // normalise the denominator so that |den|^2 cannot overflow for deep models
+    int s = -frexp_exp(__builtin_fmax(__builtin_fabs(den.re), __builtin_fabs(den.im)));
+    num = mk(ldexp_i(num.re, s), ldexp_i(num.im, s));
+    den = mk(ldexp_i(den.re, s), ldexp_i(den.im, s));
+    return cdiv(num * (E * coef), den);
+}
+
+}  // namespace gbp

@@ -1,0 +1,137 @@
+// gbp_fdem_tables.h -- host-side (CPU, once per acquisition system) construction of the per-abscissa
+// tables the kernels read.  Pure C++ (no HIP) so that tests can build the same tables without a GPU.
+//
+// For every frequency f and every abscissa j the kernel needs
+//   lam            lambda_j                       (system/FdemSystem.py:67-101)
+//   u0             un[0] = sqrt(lambda^2 - w^2 mu0 eps0): the air layer of initCoefficients
+//                  (forwardmodelling/Electromagnetic/FD/fdem1d_numba.py:172-185 with sigma = 0)
+//   coef           everything of the Hankel integrand that does not depend on the earth model or the
+//                  altitude: zz  +lambda^3/u0 * w0 * m/(4 pi r)            (FD:410-438)
+//                            xx  -lambda0^2 d0 w0 (J0 part), -lambda1 d1 w1 (J1 part)  (FD:306-355)
+//                            xz/zx  -lambda1^2 d1 w1                        (FD:358-408)
+// and per frequency the free-space field H0 (FD:68 denominator), accumulated sequentially in the
+// reference's order, folded into g = 1e6 * scale / H0.
+#pragma once
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "../../include/geobipy_amd.h"
+#include "gbp_fdem_point.h"
+
+namespace gbp {
+
+struct SystemTables {
+    int nF = 0, npts = 0, max_pts = 0;
+    std::vector<Channel> chan;
+    std::vector<double> h0;   // (re, im) per frequency
+    std::vector<double> soa;  // lam | u0re | u0im | cre | cim, each [npts]
+};
+
+// returns GBP_OK or an error code; `msg` receives a static description on failure
+inline int build_system_tables(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
+                               const double* rx_z, const double* tx_moment, const double* scale,
+                               const double* rx_off, const double* separation, const double* w0,
+                               const double* lamda0, const double* w1, const double* lamda1, SystemTables* s,
+                               const char** msg)
+{
+    typedef std::complex<double> zc;
+    if (nF < 1 || nF > GBP_MAX_FREQ) { *msg = "nF must be in [1, 64]"; return GBP_ERR_INVALID_ARG; }
+    if (!tid || !frequencies || !tx_z || !rx_z || !tx_moment || !scale || !rx_off || !separation || !w0 ||
+        !lamda0 || !w1 || !lamda1) { *msg = "NULL system array"; return GBP_ERR_INVALID_ARG; }
+    for (int f = 0; f < nF; ++f) {
+        if (tid[f] != 1 && tid[f] != 3 && tid[f] != 7 && tid[f] != 9) {
+            *msg = "tensor id outside {1,3,7,9}"; return GBP_ERR_UNSUPPORTED_TID;
+        }
+        if (!(frequencies[f] > 0.0) || !std::isfinite(frequencies[f]) || !(separation[f] > 0.0) ||
+            !std::isfinite(separation[f])) {
+            *msg = "frequency and separation must be finite and > 0"; return GBP_ERR_BAD_SYSTEM;
+        }
+    }
+    s->nF = nF;
+    s->chan.assign(nF, Channel());
+    s->h0.assign(2 * (size_t)nF, 0.0);
+    s->max_pts = 0;
+    std::vector<double> lam, u0r, u0i, cre, cim;
+
+    const double pi = 3.14159265358979323846;
+    const double mu0 = 4.e-7 * pi;                        // fdem1d_numba.py:15
+    const double c = 299792458.0;
+    const double eps0 = 1.0 / (mu0 * std::pow(c, 2.0));   // fdem1d_numba.py:17
+
+
+    for (int f = 0; f < nF; ++f) {
+        Channel& ch = s->chan[f];
+        const double omega = 2.0 * pi * frequencies[f];   // fdem1d_numba.py:166-168
+        ch.wmu = omega * mu0;
+        ch.w2me = (omega * eps0) * (omega * mu0);
+        ch.hd0 = rx_z[f] - 2.0 * tx_z[f];
+        ch.off = (int)lam.size();
+        ch.tid = tid[f];
+        const double tH = tx_z[f], rH = -tH + rx_z[f];     // fdem1d.py:31-32 at altitude 0
+        const double hS = rH + tH;                         // independent of the altitude
+        const double m = tx_moment[f], r = separation[f], rx = rx_off[f];
+        const double* l0 = lamda0 + (size_t)f * GBP_NC0;
+        const double* l1 = lamda1 + (size_t)f * GBP_NC1;
+        zc H0(0.0, 0.0);
+        auto push = [&](double l, zc u, zc cf) {
+            lam.push_back(l); u0r.push_back(u.real()); u0i.push_back(u.imag());
+            cre.push_back(cf.real()); cim.push_back(cf.imag());
+        };
+        auto air_u = [&](double l) { return std::sqrt(zc(l * l - ch.w2me, 0.0)); };  // un[0], FD:182 with sigma = 0
+        if (tid[f] == 9) {                                 // Hzz, fdem1d_numba.py:410-438
+            ch.real_exp = 0;
+            const double a2 = m / (4.0 * pi * r);
+            for (int j = 0; j < GBP_NC0; ++j) {
+                const double w_ = a2 * w0[j];
+                const zc u = air_u(l0[j]);
+                const zc a1 = zc(std::pow(l0[j], 3.0), 0.0) / u;
+                H0 += (std::exp(-u * hS) * a1) * w_;
+                push(l0[j], u, a1 * w_);
+            }
+        } else if (tid[f] == 1) {                          // Hxx, fdem1d_numba.py:306-355
+            ch.real_exp = 1;
+            const double ri = 1.0 / r;
+            const double c0 = -(m / (4.0 * pi)) * ri;
+            const double d0 = c0 * std::pow(rx * ri, 2.0);
+            const double d1 = c0 * (ri - ((2.0 * std::pow(rx, 2.0)) * std::pow(ri, 3.0)));
+            double h0 = 0.0;
+            for (int j = 0; j < GBP_NC1; ++j) {            // free-space sum in the reference's interleaved order
+                if (j < GBP_NC0) h0 += (std::exp(-l0[j] * hS) * (l0[j] * l0[j])) * (d0 * w0[j]);
+                h0 += (std::exp(-l1[j] * hS) * l1[j]) * (d1 * w1[j]);
+            }
+            H0 = zc(h0, 0.0);
+            for (int j = 0; j < GBP_NC0; ++j) push(l0[j], air_u(l0[j]), zc(-(l0[j] * l0[j]) * (d0 * w0[j]), 0.0));
+            for (int j = 0; j < GBP_NC1; ++j) push(l1[j], air_u(l1[j]), zc(-l1[j] * (d1 * w1[j]), 0.0));
+        } else {                                           // Hxz (3) / Hzx (7), fdem1d_numba.py:358-408
+            ch.real_exp = (tid[f] == 3) ? 1 : 0;
+            const double d1 = (rx * m) / (4.0 * pi * r);
+            for (int j = 0; j < GBP_NC1; ++j) {
+                const double w_ = d1 * w1[j];
+                const double a1 = l1[j] * l1[j];
+                const zc u = air_u(l1[j]);
+                if (tid[f] == 3) H0 += zc((std::exp(-l1[j] * hS) * a1) * w_, 0.0);
+                else             H0 += (std::exp(-u * hS) * a1) * w_;
+                push(l1[j], u, zc(-a1 * w_, 0.0));
+            }
+        }
+        ch.npts = (int)lam.size() - ch.off;
+        if (ch.npts > s->max_pts) s->max_pts = ch.npts;
+        const zc g = zc(1.e6 * scale[f], 0.0) / H0;        // fdem1d_numba.py:68
+        ch.g_re = g.real();
+        ch.g_im = g.imag();
+        s->h0[2 * f] = H0.real();
+        s->h0[2 * f + 1] = H0.imag();
+    }
+    s->npts = (int)lam.size();
+    s->soa.clear();
+    s->soa.reserve(5 * lam.size());
+    s->soa.insert(s->soa.end(), lam.begin(), lam.end());
+    s->soa.insert(s->soa.end(), u0r.begin(), u0r.end());
+    s->soa.insert(s->soa.end(), u0i.begin(), u0i.end());
+    s->soa.insert(s->soa.end(), cre.begin(), cre.end());
+    s->soa.insert(s->soa.end(), cim.begin(), cim.end());
+    return GBP_OK;
+}
+
+}  // namespace gbp

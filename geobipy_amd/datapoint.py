@@ -1,0 +1,174 @@
+"""FdemDataPoint: the reference's per-sounding interface on top of the batched GPU path.
+
+Mirrors (names, argument meaning, error behaviour) the hot-path members of
+``geobipy/src/classes/data/datapoint/{DataPoint,EmDataPoint,FdemDataPoint}.py``:
+``forward`` (:524-545), ``sensitivity`` / ``fm_dlogc`` (:530-559), ``std`` (DataPoint.py:268-282),
+``active`` (EmDataPoint.py:44-56), ``deltaD`` (DataPoint.py:200-214), ``data_misfit`` (:502-525),
+``likelihood`` (:491-500).  Each call is a B = 1 launch of the same kernels ``FdemBatch`` uses; a
+datapoint keeps no CPU implementation of any of them.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from .batch import FdemBatch
+from .model import Model
+from .system import FdemSystem
+
+
+class FdemDataPoint:
+    def __init__(self, x=0.0, y=0.0, z=0.0, elevation=0.0, data=None, std=None, predictedData=None, system=None,
+                 lineNumber=0.0, fiducial=0.0):
+        self.system = system
+        self.x, self.y, self.elevation = np.float64(x), np.float64(y), np.float64(elevation)
+        self.z = np.atleast_1d(np.asarray(z, dtype=np.float64)).copy()
+        self.lineNumber, self.fiducial = lineNumber, fiducial
+        self.units = "ppm"
+        n = self.nChannels
+        self._data = np.zeros(n) if data is None else np.asarray(data, dtype=np.float64).copy()
+        assert self._data.size == n, ValueError("data must have size {}".format(n))
+        if std is None:
+            std = np.ones(n) if data is None else 0.1 * self._data
+        self._std = np.asarray(std, dtype=np.float64).copy()
+        self._predictedData = np.zeros(n) if predictedData is None else np.asarray(predictedData, np.float64).copy()
+        self._relative_error = np.full(self.nSystems, 0.01)
+        self._additive_error = np.zeros(self.nSystems)
+        self._sensitivity_matrix = None
+
+    # -- system -------------------------------------------------------------------------------
+    @property
+    def system(self):
+        return self._system
+
+    @system.setter
+    def system(self, value):
+        if value is None:
+            raise ValueError("FdemDataPoint needs an FdemSystem (or a path to a .stm file)")
+        if isinstance(value, (str, FdemSystem)):
+            value = [value]
+        assert all(isinstance(s, (str, FdemSystem)) for s in value), TypeError(
+            "System must have items of type str or geobipy.FdemSystem")
+        assert len(value) == 1, ValueError("one FdemSystem per datapoint is supported")
+        self._system = [FdemSystem.read(s) if isinstance(s, str) else s for s in value]
+
+    @property
+    def nSystems(self):
+        return 1
+
+    @property
+    def nFrequencies(self):
+        return np.asarray([s.nFrequencies for s in self._system])
+
+    @property
+    def nChannels(self):
+        return int(2 * self._system[0].nFrequencies)
+
+    # -- data / errors (DataPoint.py) -----------------------------------------------------------
+    @property
+    def data(self):
+        return self._data
+
+    @data.setter
+    def data(self, values):
+        v = np.asarray(values, dtype=np.float64)
+        assert v.size == self.nChannels
+        self._data = v.copy()
+
+    @property
+    def predictedData(self):
+        return self._predictedData
+
+    @property
+    def relative_error(self):
+        return self._relative_error
+
+    @relative_error.setter
+    def relative_error(self, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        assert v.size == self.nSystems, ValueError("relative_error must be a list of size equal to the number of systems")
+        assert np.all(v > 0.0), ValueError("Relative error {} must be > 0.0".format(v))
+        self._relative_error = v.copy()
+
+    @property
+    def additive_error(self):
+        return self._additive_error
+
+    @additive_error.setter
+    def additive_error(self, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        assert v.size == self.nSystems, ValueError("additive_error must have size 1")
+        self._additive_error = v.copy()
+
+    @property
+    def active(self):
+        d = self._data.copy()
+        d[d <= 0.0] = np.nan
+        return ~np.isnan(d)                                   # EmDataPoint.py:44-56
+
+    @property
+    def n_active_channels(self):
+        return self.active.sum()
+
+    @property
+    def std(self):
+        assert np.all(self.relative_error > 0.0), ValueError("relative_error must be > 0.0")
+        variance = ((self.relative_error * self._data) ** 2.0) + (self.additive_error ** 2.0)   # DataPoint.py:274
+        self._std[:] = np.sqrt(variance)
+        return self._std
+
+    @property
+    def deltaD(self):
+        return self._predictedData - self._data               # DataPoint.py:200-214
+
+    @property
+    def sensitivity_matrix(self):
+        return self._sensitivity_matrix
+
+    def __deepcopy__(self, memo={}):
+        out = FdemDataPoint.__new__(FdemDataPoint)
+        for k, v in self.__dict__.items():
+            setattr(out, k, v if k == "_system" else deepcopy(v, memo))
+        return out
+
+    # -- hot path: every call below is a GPU launch ----------------------------------------------
+    def _batch(self, mod):
+        assert np.isinf(mod.mesh.edges[-1]), ValueError(
+            "mod.edges must have last entry be infinity for forward modelling.")       # FdemDataPoint.py:541
+        assert self.z[0] >= mod.mesh.relative_to, "Sensor altitude must be above the top of the model"  # fdem1d.py:29
+        L = int(mod.mesh.nCells)
+        thk = np.array(mod.mesh.widths, dtype=np.float64)
+        thk[-1] = 0.0          # never read by the kernel (the reference passes inf)
+        return FdemBatch(self._system[0], np.array([L]), mod.values[None, :], thk[None, :], self.z[:1],
+                         data=self._data[None, :], relative_error=self._relative_error[:1],
+                         additive_error=self._additive_error[:1])
+
+    def forward(self, mod):
+        """Forward model the data from the given model (FdemDataPoint.py:524-545)."""
+        assert isinstance(mod, Model), TypeError("Invalid model class for forward modeling [1D]")
+        self._predictedData[:] = self._batch(mod).forward().cpu().numpy()[0]
+
+    def sensitivity(self, mod, **kwargs):
+        """J[2F, L] = d predictedData / d ln(sigma) (FdemDataPoint.py:530-559)."""
+        assert isinstance(mod, Model), TypeError("Invalid model class for sensitivity matrix [1D]")
+        self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0]
+        return self._sensitivity_matrix
+
+    def fm_dlogc(self, mod):
+        self.forward(mod)
+        self.sensitivity(mod)
+
+    def _loglike(self):
+        b = FdemBatch(self._system[0], np.array([1]), np.ones((1, 1)), np.zeros((1, 1)), self.z[:1],
+                      data=self._data[None, :], relative_error=self._relative_error[:1],
+                      additive_error=self._additive_error[:1])
+        chi2, logl = b.loglike(self._predictedData[None, :])
+        return float(chi2.cpu()[0]), float(logl.cpu()[0])
+
+    def data_misfit(self):
+        """|| W_d (d_obs - d_pre) ||_2^2 over the active channels (DataPoint.py:502-525)."""
+        return np.float64(self._loglike()[0])
+
+    def likelihood(self, log):
+        """Gaussian likelihood of the predicted data (DataPoint.py:491-500, MvNormalDistribution.py:201-216)."""
+        ll = self._loglike()[1]
+        return np.float64(ll) if log else np.float64(np.exp(ll))

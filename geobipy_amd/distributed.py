@@ -1,0 +1,70 @@
+"""Sharding soundings over the GPUs of a node and gathering per-sounding summaries.
+
+Soundings are independent (the reference farms them one per MPI rank,
+inversion/Inference3D.py:518-635), so the only exchange is ONE gather of the per-sounding
+summaries (chi^2, logL: 16 B per sounding) to rank 0.  One process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Blocks follow the reference's
+own rule ``loadBalance1D_shrinkingArrays`` (base/MPI.py:172-201).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition(N, nChunks):
+    """starts[nChunks], sizes[nChunks]: equal blocks, the first N % nChunks blocks get one extra."""
+    sizes = np.full(nChunks, N // nChunks, dtype=np.int64)
+    sizes[: N % nChunks] += 1
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    return starts, sizes
+
+
+def shard(N, rank=None, world=None):
+    """(start, size) of this rank's contiguous block of the sounding index."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    starts, sizes = partition(N, world)
+    return int(starts[rank]), int(sizes[rank])
+
+
+class SummaryGather:
+    """Gathers [rows_local, C] fp64 summaries of every rank into one [N, C] tensor on rank 0.
+
+    Blocks may differ by one row, so every rank contributes a block padded to the largest size and
+    rank 0 strips the padding; buffers are allocated once.  ``launch`` enqueues the collective on the
+    current stream (or the given side stream, so that it overlaps the next round's kernel) and returns
+    without synchronising.
+    """
+
+    def __init__(self, N, C, device, group=None):
+        self.N, self.C, self.group = N, C, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.starts, self.sizes = partition(N, self.world)
+        self.pad = int(self.sizes.max())
+        self.send = torch.zeros((self.pad, C), dtype=torch.float64, device=device)
+        self.recv = [torch.empty((self.pad, C), dtype=torch.float64, device=device) for _ in range(self.world)] \
+            if (self.rank == 0 and self.world > 1) else None
+        self.out = torch.empty((N, C), dtype=torch.float64, device=device) if self.rank == 0 else None
+
+    def launch(self, *columns):
+        """columns: C tensors of shape [rows_local]; copies them into the send block and starts the gather."""
+        n = int(self.sizes[self.rank])
+        for c, col in enumerate(columns):
+            self.send[:n, c].copy_(col[:n])
+        if self.world == 1:
+            self.out[:n].copy_(self.send[:n])
+            return None
+        return dist.gather(self.send, self.recv, dst=0, group=self.group, async_op=True)
+
+    def finish(self, work=None):
+        """Wait for the collective and assemble the [N, C] result on rank 0 (None elsewhere)."""
+        if work is not None:
+            work.wait()
+        if self.rank != 0:
+            return None
+        if self.world > 1:
+            for r in range(self.world):
+                s, n = int(self.starts[r]), int(self.sizes[r])
+                self.out[s:s + n].copy_(self.recv[r][:n])
+        return self.out

@@ -1,0 +1,130 @@
+/*
+ * geobipy_amd.h -- C ABI of libgeobipy_amd.so: the MI355X (gfx950) implementation of GeoBIPy's
+ * per-sounding hot path (1-D layered-earth FDEM forward solve, its Jacobian, Gaussian data misfit
+ * and log-likelihood), batched over soundings.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns gbp_status, 0 = ok.
+ *   - pointers marked [dev] are DEVICE pointers (HBM, fp64/int32, C-contiguous); pointers marked
+ *     [host] are host pointers.  The library never allocates or frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Launches are
+ *     stream-ordered; the library never synchronises behind the caller's back.
+ *   - the acquisition system (filter tables, per-frequency constants) is uploaded once into an
+ *     opaque handle; the caller keeps ownership of the arrays passed to gbp_fdem_system_create.
+ *
+ * Reference interfaces replaced (paths under /root/reference/geobipy/src/classes/):
+ *   nbFdem1dfwd            forwardmodelling/Electromagnetic/FD/fdem1d_numba.py:24-68
+ *   nbFdem1dsen            forwardmodelling/Electromagnetic/FD/fdem1d_numba.py:71-121
+ *   fdem1dfwd / fdem1dsen  forwardmodelling/Electromagnetic/FD/fdem1d.py:10-52, 87-129
+ *   DataPoint.std          data/datapoint/DataPoint.py:268-282
+ *   EmDataPoint.active     data/datapoint/EmDataPoint.py:44-56
+ *   DataPoint.data_misfit  data/datapoint/DataPoint.py:502-525
+ *   DataPoint.likelihood   data/datapoint/DataPoint.py:491-500 (-> statistics/MvNormalDistribution.py:201-216)
+ */
+#ifndef GEOBIPY_AMD_H
+#define GEOBIPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int gbp_status;
+enum {
+    GBP_OK = 0,
+    GBP_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size, nF > GBP_MAX_FREQ ...            */
+    GBP_ERR_UNSUPPORTED_TID = -2, /* tensor id outside {1, 3, 7, 9}: the reference leaves H undefined
+                                     for those (fdem1d_numba.py:57-66); we refuse                     */
+    GBP_ERR_BAD_SYSTEM = -3,    /* non-finite / non-positive frequency or separation                  */
+    GBP_ERR_HIP = -4,           /* a HIP runtime call failed; see gbp_last_error()                    */
+    GBP_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                           */
+};
+
+#define GBP_MAX_FREQ 64   /* frequencies per system */
+#define GBP_NC0 120       /* J0 filter length  (fdem1d_numba.py:18) */
+#define GBP_NC1 140       /* J1 filter length  (fdem1d_numba.py:19) */
+
+typedef struct gbp_fdem_system gbp_fdem_system;
+
+/* Library / device info ------------------------------------------------------------------ */
+const char *gbp_version(void);
+const char *gbp_last_error(void);          /* thread-local text of the last failure            */
+gbp_status gbp_device_count(int *count);   /* [host] out                                        */
+
+/*
+ * Acquisition system: the per-system arguments of nbFdem1dfwd (fdem1d_numba.py:25), i.e. exactly
+ * what FD/fdem1d.py:31-49 extracts from an FdemSystem, all [host], length nF unless noted:
+ *   tid          tensor_id = 1 + 3*rx_orient + tx_orient       (system/FdemSystem.py:199-203)
+ *   frequencies  Hz
+ *   tx_z, rx_z   vertical loop offsets: tHeight = altitude + tx_z, rHeight = -tHeight + rx_z
+ *   tx_moment    `moments` argument;  scale = tx_moment * rx_moment
+ *   rx_off       loop_offsets[0, :] (x separation), separation = |rx - tx|
+ *   w0[120], lamda0[nF,120], w1[140], lamda1[nF,140]  filter weights / abscissae
+ *                                                               (system/FdemSystem.py:67-101, 279-337)
+ * The handle owns device copies of derived tables; destroy with gbp_fdem_system_destroy.
+ */
+gbp_status gbp_fdem_system_create(int nF, const int32_t *tid, const double *frequencies,
+                                  const double *tx_z, const double *rx_z, const double *tx_moment,
+                                  const double *scale, const double *rx_off, const double *separation,
+                                  const double *w0, const double *lamda0, const double *w1,
+                                  const double *lamda1, gbp_fdem_system **out);
+void gbp_fdem_system_destroy(gbp_fdem_system *sys);
+gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system *sys, int *nF);
+/* free-space field H0 per frequency as (re, im) pairs, [host] out[2*nF] (fdem1d_numba.py:68 denominator) */
+gbp_status gbp_fdem_system_h0(const gbp_fdem_system *sys, double *out);
+
+/*
+ * Batched forward solve.  Replaces B calls of FdemDataPoint.forward -> fdem1dfwd -> nbFdem1dfwd.
+ *   nlayers [dev] int32[B]        layers per sounding (1 <= nlayers[b] <= Lmax)
+ *   sigma   [dev] f64[B, Lmax]    conductivity S/m          (Model.values)
+ *   thk     [dev] f64[B, Lmax]    layer thickness m; entry nlayers[b]-1 (the half-space, inf in the
+ *                                 reference's mesh.widths) is never read
+ *   height  [dev] f64[B]          sensor altitude above the top of the model (DataPoint.z)
+ *   pred    [dev] f64[B, 2*nF]    out: [Re(out_0..F-1), Im(out_0..F-1)] in ppm
+ *                                 (data/datapoint/FdemDataPoint.py:544-545)
+ */
+gbp_status gbp_fdem_forward(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                            const double *sigma, const double *thk, const double *height,
+                            double *pred, void *stream);
+
+/*
+ * Gaussian data misfit + log-likelihood for B soundings of N channels each.
+ *   pred, obs [dev] f64[B, N];  rel, add [dev] f64[B] (one relative / additive error per sounding,
+ *   DataPoint.py:274);  chi2, logL [dev] f64[B] out.
+ *   std_i = sqrt((rel*obs_i)^2 + add^2); channel i active iff obs_i > 0 and not NaN;
+ *   chi2 = sum_active ((pred-obs)/std)^2;  logL = -(Na/2) ln 2pi - sum_active ln std - chi2/2.
+ */
+gbp_status gbp_gauss_loglike(int B, int N, const double *pred, const double *obs, const double *rel,
+                             const double *add, double *chi2, double *logL, void *stream);
+
+/*
+ * Fused forward + misfit + log-likelihood (one launch; what Inference1D.accept_reject evaluates at
+ * every proposal, inversion/Inference1D.py:572-597).  pred may be NULL when only chi2 / logL are wanted.
+ */
+gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                    const double *sigma, const double *thk, const double *height,
+                                    const double *obs, const double *rel, const double *add,
+                                    double *pred, double *chi2, double *logL, void *stream);
+
+/*
+ * Batched Jacobian d pred / d ln(sigma_k) (ppm).  Replaces FdemDataPoint.sensitivity -> fdem1dsen ->
+ * nbFdem1dsen.   J [dev] f64[B, 2*nF, Lmax] out (columns >= nlayers[b] are set to 0);
+ * rows [0,nF) real part, [nF,2nF) imaginary part (FdemDataPoint.py:553-557).
+ */
+gbp_status gbp_fdem_sensitivity(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                const double *sigma, const double *thk, const double *height,
+                                double *J, void *stream);
+
+/* Timing helper for bench.py: average kernel time (ms) of `reps` launches of the fused kernel,
+ * measured with hipEvents recorded on `stream` around the launches. */
+gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                         const double *sigma, const double *thk, const double *height,
+                                         const double *obs, const double *rel, const double *add,
+                                         double *pred, double *chi2, double *logL, void *stream,
+                                         int reps, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOBIPY_AMD_H */

@@ -7,7 +7,7 @@
  * "port" CPU baseline timed by bench.py.  Nothing under geobipy_amd/ may call it.
  *
  * Parity pin: validated in the build container against (i) the imported
- * reference (tests/golden/make_golden.py, fixtures in tests/golden/*.npz) and
+ * reference (tests/golden/make_golden.py, fixtures in the .npz fixtures in tests/golden) and
  * (ii) the reference's own known-answer files tests/data_checks/resolve_*_clean.csv
  * (copied to tests/golden/) with the reference's np.allclose criterion and the
  * tighter |d| <= 1e-7 ppm + 1e-9|ref| bound.

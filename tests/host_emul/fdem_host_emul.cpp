@@ -1,0 +1,67 @@
+// tests/host_emul/fdem_host_emul.cpp -- TEST-ONLY host build of the device math headers.
+//
+// Compiles geobipy_amd/csrc/gbp_math.h + gbp_fdem_point.h + gbp_fdem_tables.h with g++ so that the
+// numerical scheme of the HIP kernels (projective admittance recursion, hand-written fp64
+// sqrt/exp/sincos, H - H0 accumulated directly) can be checked against the oracle in the CPU test
+// tier (`-m "not gpu"`).  It is NOT part of the product: geobipy_amd never loads it, and the GPU
+// tests check the real kernels through the C ABI.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../geobipy_amd/csrc/gbp_fdem_tables.h"
+
+extern "C" {
+
+// forward for B soundings, same argument meaning as gbp_fdem_system_create + gbp_fdem_forward (host pointers)
+int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
+                      const double* rx_z, const double* tx_moment, const double* scale, const double* rx_off,
+                      const double* separation, const double* w0, const double* lamda0, const double* w1,
+                      const double* lamda1, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                      const double* thk, const double* height, double* pred)
+{
+    gbp::SystemTables t;
+    const char* msg = "";
+    int rc = gbp::build_system_tables(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
+                                      lamda0, w1, lamda1, &t, &msg);
+    if (rc != 0) return rc;
+    const double* p_lam = t.soa.data();
+    const double* p_u0r = p_lam + t.npts;
+    const double* p_u0i = p_lam + 2 * (size_t)t.npts;
+    const double* p_cre = p_lam + 3 * (size_t)t.npts;
+    const double* p_cim = p_lam + 4 * (size_t)t.npts;
+    for (int b = 0; b < B; ++b) {
+        const int L = nlayers[b];
+        const double* sig = sigma + (size_t)b * Lmax;
+        const double* th = thk + (size_t)b * Lmax;
+        for (int f = 0; f < nF; ++f) {
+            const gbp::Channel& ch = t.chan[f];
+            const double hD = ch.hd0 - 2.0 * height[b];
+            double are = 0.0, aim = 0.0;
+            for (int j = ch.off; j < ch.off + ch.npts; ++j) {
+                const double lam = p_lam[j];
+                gbp::cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
+                gbp::cplx coef = gbp::mk(p_cre[j], p_cim[j]);
+                gbp::cplx num, den;
+                gbp::rte_num_den(lam * lam - ch.w2me, ch.wmu, L, sig, th, u0, num, den);
+                gbp::cplx ue = ch.real_exp ? gbp::mk(lam, 0.0) : u0;
+                gbp::cplx term = gbp::hankel_term(num, den, ue, hD, coef, ch.real_exp != 0);
+                are += term.re;
+                aim += term.im;
+            }
+            pred[(size_t)b * 2 * nF + f] = ch.g_re * are - ch.g_im * aim;
+            pred[(size_t)b * 2 * nF + nF + f] = ch.g_re * aim + ch.g_im * are;
+        }
+    }
+    return 0;
+}
+
+// accuracy probes for the scalar kernels
+void emul_exp_neg(int n, const double* x, double* y) { for (int i = 0; i < n; ++i) y[i] = gbp::exp_neg(x[i]); }
+void emul_sincos(int n, const double* x, double* s, double* c) { for (int i = 0; i < n; ++i) gbp::sincos_cw(x[i], s[i], c[i]); }
+void emul_csqrt(int n, const double* a, const double* b, double* re, double* im)
+{
+    for (int i = 0; i < n; ++i) { gbp::cplx z = gbp::csqrt_upper(a[i], b[i]); re[i] = z.re; im[i] = z.im; }
+}
+void emul_rcp(int n, const double* x, double* y) { for (int i = 0; i < n; ++i) y[i] = gbp::rcp(x[i]); }
+}

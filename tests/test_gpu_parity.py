@@ -1,0 +1,230 @@
+"""GPU tier (-m gpu): parity of the HIP path, called through the C ABI, against the oracle and the fixtures.
+
+Tolerances (SURVEY section 7 hard part 1):
+    predicted data  |d| <= 1e-7 ppm + 1e-9 |ref|     chi^2, logL  |d| <= 1e-6 + 1e-9 |ref|
+/root/reference is never touched here: fixtures come from tests/golden, the checker is oracle/.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import (GOLDEN, LIKE_ATOL, LIKE_RTOL, PRED_ATOL, PRED_RTOL, WEDGE_CONDUCTIVITY, oracle_system,
+                      read_clean_csv, wedge_models)
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from geobipy_amd import _lib
+    _lib.load()      # the native library must be the thing that runs: fail loudly if absent
+
+
+def close(a, b, atol, rtol):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.all(np.abs(a - b) <= atol + rtol * np.abs(b))
+
+
+def product_system(name):
+    from geobipy_amd import FdemSystem
+    return FdemSystem.read(os.path.join(GOLDEN, f"{name}.stm"))
+
+
+def pad(a, Lmax, fill):
+    out = np.full((a.shape[0], Lmax), fill, dtype=np.float64)
+    out[:, : a.shape[1]] = a
+    return out
+
+
+@pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
+def test_fixtures_of_imported_reference(golden_npz, name):
+    """forward, chi^2, logL for every fixture (all tensor ids, L = 1..30, NaN channels) in ONE ragged batch."""
+    from geobipy_amd import FdemBatch
+    g, s = golden_npz, product_system(name)
+    Lmax = 32
+    nl, sig, thk, h, obs, rel, add, pred, chi2, logl = [], [], [], [], [], [], [], [], [], []
+    for L in [1, 2, 3, 5, 8, 30]:
+        k = f"{name}_L{L}"
+        n = g[k + "/sigma"].shape[0]
+        t = g[k + "/thk"].copy()
+        t[:, -1] = 0.0
+        nl += [L] * n
+        sig.append(pad(g[k + "/sigma"], Lmax, 1.0))
+        thk.append(pad(t, Lmax, 0.0))
+        for lst, key in [(h, "height"), (obs, "obs"), (rel, "rel"), (add, "add"), (pred, "pred"), (chi2, "chi2"),
+                         (logl, "logL")]:
+            lst.append(g[f"{k}/{key}"])
+    cat = np.concatenate
+    b = FdemBatch(s, np.array(nl), cat(sig), cat(thk), cat(h), data=cat(obs), relative_error=cat(rel),
+                  additive_error=cat(add))
+    b.validate()
+    c2, ll = b.forward_loglike()
+    torch.cuda.synchronize()
+    assert close(b.predicted.cpu().numpy(), cat(pred), PRED_ATOL, PRED_RTOL)
+    assert close(c2.cpu().numpy(), cat(chi2), LIKE_ATOL, LIKE_RTOL)
+    assert close(ll.cpu().numpy(), cat(logl), LIKE_ATOL, LIKE_RTOL)
+    # un-fused entry points give the same numbers
+    p2 = b.forward(out=torch.empty_like(b.predicted)).cpu().numpy()
+    assert np.array_equal(p2, b.predicted.cpu().numpy())
+    c3, l3 = b.loglike(torch.as_tensor(cat(pred)))
+    assert close(c3.cpu().numpy(), cat(chi2), LIKE_ATOL, LIKE_RTOL)
+    assert close(l3.cpu().numpy(), cat(logl), LIKE_ATOL, LIKE_RTOL)
+
+
+@pytest.mark.parametrize("model_type", sorted(WEDGE_CONDUCTIVITY))
+def test_reference_known_answer_files(model_type):
+    """The reference's own test (tests/test_synthetic_data.py:16-30): 79-sounding wedge vs resolve_*_clean.csv."""
+    from geobipy_amd import FdemBatch
+    s = product_system("resolve")
+    csv = read_clean_csv(os.path.join(GOLDEN, f"resolve_{model_type}_clean.csv"))
+    thk = wedge_models()
+    sig = np.tile(np.asarray(WEDGE_CONDUCTIVITY[model_type]), (79, 1))
+    p = FdemBatch(s, np.full(79, 3), sig, thk, np.full(79, 30.0)).forward().cpu().numpy()
+    assert np.allclose(p, csv)                                   # the reference's criterion
+    assert close(p, csv, PRED_ATOL, PRED_RTOL)                   # ours
+
+
+def test_datapoint_interface_config1():
+    """BASELINE config 1 through the reference-style objects (FdemDataPoint / Model / RectilinearMesh1D)."""
+    from geobipy_amd import FdemDataPoint, Model, RectilinearMesh1D
+    csv0 = read_clean_csv(os.path.join(GOLDEN, "resolve_glacial_clean.csv"))[0]
+    mod = Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 5.0, 7.5, np.inf]), values=np.r_[1e-2, 1e-1, 0.03333333])
+    dp = FdemDataPoint(x=0.0, y=0.0, z=30.0, elevation=0.0, data=1.03 * csv0, std=None,
+                       system=os.path.join(GOLDEN, "resolve.stm"))
+    dp.relative_error = 0.05
+    dp.additive_error = 5.0
+    dp.forward(mod)
+    ref = np.array([41.08919660004556, 225.2575637837353, 151.27195180787993, 837.5752928944062,
+                    1922.7662024927201, 2513.018568364122, 136.76679901024212, 406.1487690660227,
+                    209.11121320604505, 807.6012738287338, 869.5433434122464, 649.9213242250147])
+    assert close(dp.predictedData, ref, PRED_ATOL, PRED_RTOL)
+    assert abs(dp.data_misfit() - 3.4175602330457497) <= LIKE_ATOL
+    assert abs(dp.likelihood(log=True) - (-51.18449066872814)) <= LIKE_ATOL
+    assert np.isclose(dp.likelihood(log=False), np.exp(-51.18449066872814), rtol=1e-6)
+    with pytest.raises(AssertionError):      # last edge must be infinite (FdemDataPoint.py:541)
+        dp.forward(Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 5.0, 7.5]), values=np.r_[1e-2, 1e-1]))
+
+
+@pytest.mark.parametrize("B,L", [(4096, 5), (1000, 8), (37, 1), (1, 3)])
+def test_random_batches_vs_oracle(B, L):
+    """BASELINE config 2 shape (4096 x 10 freq x 5 layers) and friends against the oracle on identical inputs."""
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=100 + B)
+    clean = FdemBatch(s, nl, sig, thk, h).forward().cpu().numpy()
+    obs = synthetic.noisy_observations(clean, seed=200 + B)
+    obs[::7, 3] = np.nan
+    prop = synthetic.redraw_sigma(B, L, seed=300 + B)
+    rel, add = np.full(B, 0.05), np.full(B, 5.0)
+    b = FdemBatch(s, nl, prop, thk, h, data=obs, relative_error=rel, additive_error=add)
+    c2, ll = b.forward_loglike()
+    torch.cuda.synchronize()
+    n = min(B, 512)          # the oracle finishes these in seconds
+    p_ref, c_ref, l_ref = fo.forward_loglike_batch(oracle_system("syn10"), nl[:n], prop[:n], thk[:n], h[:n], obs[:n],
+                                                   rel[:n], add[:n], nthreads=0)
+    assert close(b.predicted[:n].cpu().numpy(), p_ref, PRED_ATOL, PRED_RTOL)
+    assert close(c2[:n].cpu().numpy(), c_ref, LIKE_ATOL, LIKE_RTOL)
+    assert close(ll[:n].cpu().numpy(), l_ref, LIKE_ATOL, LIKE_RTOL)
+    assert torch.isfinite(b.predicted).all() and torch.isfinite(c2).all() and torch.isfinite(ll).all()
+
+
+def test_ragged_layers_padding_and_order_independence():
+    """Ragged batch (1..30 layers): padding columns are never read and results do not depend on batch order."""
+    from geobipy_amd import FdemBatch, synthetic
+    rng = np.random.default_rng(5)
+    s = product_system("resolve")
+    B, Lmax = 600, 30
+    nl = rng.integers(1, Lmax + 1, size=B).astype(np.int32)
+    _, sig, thk, h = synthetic.draw_models(B, Lmax, seed=11)
+    p1 = FdemBatch(s, nl, sig, thk, h).forward().cpu().numpy()
+    sig2, thk2 = sig.copy(), thk.copy()
+    for i in range(B):
+        sig2[i, nl[i]:] = np.nan          # poison everything the kernel must not read
+        thk2[i, nl[i] - 1:] = np.nan
+    p2 = FdemBatch(s, nl, sig2, thk2, h).forward().cpu().numpy()
+    assert np.array_equal(p1, p2) and np.isfinite(p1).all()
+    perm = rng.permutation(B)
+    p3 = FdemBatch(s, nl[perm], sig[perm], thk[perm], h[perm]).forward().cpu().numpy()
+    assert np.array_equal(p3, p1[perm])
+    # wider row stride, same answer
+    p4 = FdemBatch(s, nl, pad(sig, 40, 7.0), pad(thk, 40, 3.0), h).forward().cpu().numpy()
+    assert np.array_equal(p4, p1)
+
+
+def test_full_size_properties():
+    """BASELINE full size (65 536 x 10 freq x 8 layers): size-independent properties instead of the oracle.
+    (a) splitting a layer in two with equal conductivity leaves the response unchanged;
+    (b) a layered model with all-equal conductivities equals the half-space;
+    (c) chi^2 / logL from the fused kernel equal the stand-alone likelihood kernel on the same predictions;
+    (d) a spot sample agrees with the oracle."""
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    B, L = 65536, 8
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=42)
+    base = FdemBatch(s, nl, sig, thk, h)
+    p = base.forward().clone()
+    # (a) split layer 2 (0-based) into two halves -> 9 layers
+    sig9 = np.concatenate([sig[:, :3], sig[:, 2:]], axis=1)
+    thk9 = np.concatenate([thk[:, :2], 0.5 * thk[:, 2:3], 0.5 * thk[:, 2:3], thk[:, 3:]], axis=1)
+    p9 = FdemBatch(s, np.full(B, 9), sig9, thk9, h).forward()
+    assert torch.all((p9 - p).abs() <= PRED_ATOL + PRED_RTOL * p.abs())
+    # (b) uniform conductivity == half-space
+    sigu = np.repeat(sig[:, :1], L, axis=1)
+    pu = FdemBatch(s, nl, sigu, thk, h).forward().clone()
+    ph = FdemBatch(s, np.ones(B, dtype=np.int32), sig[:, :1].copy(), np.zeros((B, 1)), h).forward()
+    assert torch.all((pu - ph).abs() <= PRED_ATOL + PRED_RTOL * ph.abs())
+    # (c) fused vs stand-alone likelihood
+    obs = synthetic.noisy_observations(p.cpu().numpy(), seed=43)
+    fb = FdemBatch(s, nl, synthetic.redraw_sigma(B, L, seed=44), thk, h, data=obs, relative_error=np.full(B, 0.05),
+                   additive_error=np.full(B, 5.0))
+    c2, ll = fb.forward_loglike()
+    c2, ll = c2.clone(), ll.clone()
+    c2b, llb = fb.loglike(fb.predicted)
+    assert torch.all((c2 - c2b).abs() <= 1e-9 * (1 + c2b.abs())) and torch.all((ll - llb).abs() <= 1e-9 * (1 + llb.abs()))
+    assert torch.isfinite(c2).all() and torch.isfinite(ll).all()
+    # (d) spot sample vs oracle
+    idx = np.arange(0, B, B // 256)
+    p_ref, c_ref, l_ref = fo.forward_loglike_batch(oracle_system("syn10"), nl[idx], fb.sigma.cpu().numpy()[idx],
+                                                   thk[idx], h[idx], obs[idx], np.full(idx.size, 0.05),
+                                                   np.full(idx.size, 5.0), nthreads=0)
+    assert close(fb.predicted.cpu().numpy()[idx], p_ref, PRED_ATOL, PRED_RTOL)
+    assert close(c2.cpu().numpy()[idx], c_ref, LIKE_ATOL, LIKE_RTOL)
+    assert close(ll.cpu().numpy()[idx], l_ref, LIKE_ATOL, LIKE_RTOL)
+
+
+def test_edge_cases():
+    from geobipy_amd import FdemBatch, _lib, synthetic
+    from geobipy_amd.system import CircularLoop, FdemSystem
+    s = synthetic.syn10_system()
+    # empty batch: legal, no launch
+    nl, sig, thk, h = synthetic.draw_models(0, 3)
+    b = FdemBatch(s, nl, sig.reshape(0, 3), thk.reshape(0, 3), h, data=np.zeros((0, 20)), relative_error=np.zeros(0),
+                  additive_error=np.zeros(0))
+    assert b.forward().shape == (0, 20)
+    assert b.forward_loglike()[0].shape == (0,)
+    # all channels inactive: chi2 = 0, logL = 0 (N_a = 0)
+    nl, sig, thk, h = synthetic.draw_models(3, 4, seed=1)
+    b = FdemBatch(s, nl, sig, thk, h, data=-np.ones((3, 20)), relative_error=np.full(3, 0.05),
+                  additive_error=np.full(3, 5.0))
+    c2, ll = b.forward_loglike()
+    assert torch.all(c2 == 0) and torch.all(ll == 0)
+    # unsupported tensor id (Tx y): refused at system creation, like the oracle
+    bad = FdemSystem([1000.0], CircularLoop(orientation=["y"], moment=[1.0], x=[0.0], y=[0.0], z=[0.0]),
+                     CircularLoop(orientation=["z"], moment=[1.0], x=[8.0], y=[0.0], z=[0.0]))
+    with pytest.raises(_lib.NativeLibraryError):
+        bad.handle()
+    # very thick / very conductive layers (exp underflow path) and very resistive thin ones stay finite
+    nl = np.array([3, 3], dtype=np.int32)
+    sig = np.array([[10.0, 5.0, 1.0], [1e-6, 1e-6, 1e-6]])
+    thk = np.array([[500.0, 800.0, 0.0], [0.01, 0.01, 0.0]])
+    p = FdemBatch(s, nl, sig, thk, np.array([30.0, 30.0])).forward()
+    assert torch.isfinite(p).all()
+    from oracle import fdem_oracle as fo
+    ref = np.stack([fo.predicted_data(oracle_system("syn10"), sig[i], thk[i], 30.0) for i in range(2)])
+    assert close(p.cpu().numpy(), ref, PRED_ATOL, PRED_RTOL)
