@@ -51,6 +51,31 @@ struct gbp_fdem_system {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+using namespace gbp;  // constants named by GBP_MATHK_INIT
+__constant__ gbp::MathK GBP_K = GBP_MATHK_INIT;
+__device__ const double GBP_EXP2_64[64] = GBP_EXP2_64_LIST;
+__device__ const double GBP_SINCOS_64[128] = GBP_SINCOS_64_LIST;
+
+// per-workgroup copy of the lookup tables in LDS + the scalar constants in SGPRs
+struct MathLds {
+    double exp2_64[64];
+    gbp::SinCos sincos_64[64];
+};
+__device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
+{
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+        lds.exp2_64[i] = GBP_EXP2_64[i];
+        lds.sincos_64[i].s = GBP_SINCOS_64[2 * i];
+        lds.sincos_64[i].c = GBP_SINCOS_64[2 * i + 1];
+    }
+    __syncthreads();
+    gbp::MathCtx M;
+    M.k = GBP_K;
+    M.exp2_64 = lds.exp2_64;
+    M.sincos_64 = lds.sincos_64;
+    return M;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -59,7 +84,7 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // Forward solve for the frequencies owned by this wave; result (complex ppm) -> sh_out[f], sh_out[F+f].
-__device__ __forceinline__ void forward_channels(const Channel* __restrict__ chan, const double* __restrict__ pts,
+__device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Channel* __restrict__ chan, const double* __restrict__ pts,
                                                  int npts_total, int F, int L, const double* __restrict__ sig,
                                                  const double* __restrict__ thk, double alt, int wave, int nwaves,
                                                  int lane, double* sh_out)
@@ -85,9 +110,9 @@ __device__ __forceinline__ void forward_channels(const Channel* __restrict__ cha
             if (!valid) coef = gbp::mk(0.0, 0.0);
             const double a = lam * lam - ch.w2me;
             cplx num, den;
-            gbp::rte_num_den(a, ch.wmu, L, sig, thk, u0, num, den);
+            gbp::rte_num_den(M, a, ch.wmu, L, sig, thk, u0, num, den);
             const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
-            const cplx t = gbp::hankel_term(num, den, ue, hD, coef, real_exp);
+            const cplx t = gbp::hankel_term(M, num, den, ue, hD, coef, real_exp);
             acc_re += t.re;
             acc_im += t.im;
         }
@@ -141,6 +166,8 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
                                                        double* __restrict__ chi2, double* __restrict__ logL)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
+    __shared__ MathLds sh_math;
+    const gbp::MathCtx M = math_setup(sh_math);
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
 
-    forward_channels(chan, pts, npts_total, F, L, sig, th, height[b], wave, nwaves, lane, sh_out);
+    forward_channels(M, chan, pts, npts_total, F, L, sig, th, height[b], wave, nwaves, lane, sh_out);
     __syncthreads();
 
     const int N = 2 * F;

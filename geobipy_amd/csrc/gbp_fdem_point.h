@@ -40,7 +40,7 @@ struct Channel {
 
 // rTE numerator / denominator for one point.  a = lambda^2 - w2me, sig/thk: the sounding's L layers
 // (thk[L-1] is never read -- the reference passes inf there).
-GBP_HD void rte_num_den(double a, double wmu, int L, const double* __restrict__ sig,
+GBP_HD void rte_num_den(const MathCtx& M, double a, double wmu, int L, const double* __restrict__ sig,
                         const double* __restrict__ thk, cplx u0, cplx& num, cplx& den)
 {
     cplx N = csqrt_upper(a, wmu * sig[L - 1]);  // basement: Yh_L = u_L
@@ -48,7 +48,7 @@ GBP_HD void rte_num_den(double a, double wmu, int L, const double* __restrict__ 
     for (int k = L - 2; k >= 0; --k) {
         cplx u = csqrt_upper(a, wmu * sig[k]);
         double t2 = -2.0 * thk[k];
-        cplx e = cexp_neg(t2 * u.re, t2 * u.im);
+        cplx e = cexp_neg(M, t2 * u.re, t2 * u.im);
         cplx uD = u * D;
         cplx A = uD + N, B = uD - N;
         cplx eB = e * B;
@@ -66,13 +66,13 @@ GBP_HD void rte_num_den(double a, double wmu, int L, const double* __restrict__ 
 }
 
 // One term of H - H0: rTE * exp(ue * hD) * coef
-GBP_HD cplx hankel_term(cplx num, cplx den, cplx ue, double hD, cplx coef, bool real_exp)
+GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD, cplx coef, bool real_exp)
 {
     cplx E;
     if (real_exp)
-        E = mk(exp_neg(ue.re * hD), 0.0);
+        E = mk(exp_neg(M, ue.re * hD), 0.0);
     else
-        E = cexp_neg(ue.re * hD, ue.im * hD);
+        E = cexp_neg(M, ue.re * hD, ue.im * hD);
     // normalise the denominator so that |den|^2 cannot overflow for deep models
     int s = -frexp_exp(__builtin_fmax(__builtin_fabs(den.re), __builtin_fabs(den.im)));
     num = mk(ldexp_i(num.re, s), ldexp_i(num.im, s));

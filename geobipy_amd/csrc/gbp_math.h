@@ -6,10 +6,11 @@
 // written here by hand with the minimum number of fp64 issues:
 //   * sqrt_rsqrt : one v_rsq_f64 seed + two coupled Goldschmidt steps + one residual correction,
 //                  returning BOTH sqrt(x) and 1/(2 sqrt(x)) (the complex sqrt needs both).
-//   * exp_neg    : Cody-Waite reduction by ln2 + degree-13 Horner + v_ldexp_f64.
-//   * sincos_cw  : 3-term FMA Cody-Waite reduction by pi/2 (exact to |x| ~ 1e6, far beyond the
-//                  |arg| < ~1500 the recursion can produce before exp underflows) + the classic
-//                  minimax kernels on [-pi/4, pi/4].
+//   * exp_neg    : reduction by ln2/64, 64-entry 2^(j/64) table in LDS, degree-5 Taylor, v_ldexp_f64.
+//   * sincos_tab : reduction by pi/32 (2-term FMA Cody-Waite, exact far beyond the |arg| < ~1500 the
+//                  recursion can produce before exp underflows), 64-entry sin/cos table in LDS,
+//                  degree-7/8 Taylor kernels and the angle-addition formulas -- no quadrant selects.
+//   Polynomial coefficients live in SGPRs (struct MathK) so that each Horner step is ONE v_fma_f64.
 // All functions are also compilable by a host C++ compiler (GBP_HD expands to `inline`) so that
 // tests can check their accuracy against libm without a GPU; the product only ever runs them on
 // the device.
@@ -22,6 +23,8 @@
 #include <cmath>
 #define GBP_HD inline
 #endif
+
+#include "gbp_math_tables.h"
 
 namespace gbp {
 
@@ -91,6 +94,20 @@ GBP_HD void sqrt_rsqrt(double x, double& g, double& h)
     g = __builtin_fma(d, h, g);
 }
 
+// sqrt(x) only, ~1.5 ulp (no residual correction): used for |z| inside csqrt_upper, where it is averaged
+// with |a| and square-rooted again.
+GBP_HD double sqrt_fast(double x)
+{
+    double y = rsq_seed(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-g, h, 0.5);
+    return __builtin_fma(g, r, g);
+}
+
 GBP_HD double rcp(double x)
 {
     double y = rcp_seed(x);
@@ -104,8 +121,7 @@ GBP_HD double rcp(double x)
 // principal sqrt(a + i b) for b >= 0 (b = omega mu0 sigma > 0 in every earth layer).
 GBP_HD cplx csqrt_upper(double a, double b)
 {
-    double m, hm;
-    sqrt_rsqrt(__builtin_fma(a, a, b * b), m, hm);
+    double m = sqrt_fast(__builtin_fma(a, a, b * b));
     double s = 0.5 * (m + __builtin_fabs(a));
     double g, h;
     sqrt_rsqrt(s, g, h);
@@ -113,73 +129,75 @@ GBP_HD cplx csqrt_upper(double a, double b)
     return (a >= 0.0) ? mk(g, o) : mk(o, g);
 }
 
-// exp(x) for x <= 0 (any x < -745.2 flushes to 0; x > 0 small is still accurate up to ~700).
-GBP_HD double exp_neg(double x)
+// Scalar constants of the transcendental kernels.  On the device they are loaded once per wave from
+// __constant__ memory with scalar loads and stay in SGPRs, so every Horner step is a single
+// v_fma_f64 (vgpr, vgpr, sgpr) -- literal fp64 constants would cost one v_mov_b64 per step.
+struct MathK {
+    double inv_ln2_64, ln2_64_hi, ln2_64_lo, e5, e4, e3;             // exp:    64/ln2, ln2/64 (hi, lo), 1/120, 1/24, 1/6
+    double inv_pi_32, pi_32_hi, pi_32_lo, s3, s2, s1, c4, c3, c2;    // sincos: 32/pi, pi/32 (hi, lo), Taylor coefficients
+};
+struct alignas(16) SinCos {
+    double s, c;
+};
+// constants + lookup tables (LDS on the device: EXP2_64 is conflict-free for ds_read_b64 because its 64
+// entries cover the 64 banks exactly once; SINCOS_64 is one ds_read_b128 per lane)
+struct MathCtx {
+    MathK k;
+    const double* exp2_64;   // 2^(j/64), j = 0..63
+    const SinCos* sincos_64; // sin, cos of 2 pi j / 64
+};
+
+#define GBP_MATHK_INIT                                                                                    \
+    {                                                                                                     \
+        INV_LN2_64, LN2_64_HI, LN2_64_LO, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, INV_PI_32, PI_32_HI,          \
+            PI_32_LO, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0, 1.0 / 40320.0, -1.0 / 720.0, 1.0 / 24.0     \
+    }
+
+// exp(x) for x <= 0 (flushes to 0 below ~-745; accurate for small positive x too).
+//   x = k ln2/64 + r, |r| <= ln2/128:  exp(x) = 2^(k>>6) * 2^((k&63)/64) * (1 + r + ... + r^5/120)
+// truncation r^6/720 < 3.6e-17; 16 VALU issues + one LDS read.
+GBP_HD double exp_neg(const MathCtx& M, double x)
 {
-    const double L2E = 1.4426950408889634074;
-    const double LN2HI = 6.93147180369123816490e-01;
-    const double LN2LO = 1.90821492927058770002e-10;
-    double xx = x < -746.0 ? -746.0 : x;
-    double kf = __builtin_rint(xx * L2E);
-    double r = __builtin_fma(-kf, LN2HI, xx);
-    r = __builtin_fma(-kf, LN2LO, r);
-    double p = 1.6059043836821613e-10;                   // 1/13!
-    p = __builtin_fma(p, r, 2.08767569878681e-09);        // 1/12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);       // 1/11!
-    p = __builtin_fma(p, r, 2.755731922398589e-07);       // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);      // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873e-05);        // 1/8!
-    p = __builtin_fma(p, r, 1.984126984126984e-04);       // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889e-03);      // 1/6!
-    p = __builtin_fma(p, r, 8.333333333333333e-03);       // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);      // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);      // 1/3!
+    double xx = __builtin_fmax(x, -800.0);
+    double kf = __builtin_rint(xx * M.k.inv_ln2_64);
+    double r = __builtin_fma(-kf, M.k.ln2_64_hi, xx);
+    r = __builtin_fma(-kf, M.k.ln2_64_lo, r);
+    double p = __builtin_fma(M.k.e5, r, M.k.e4);
+    p = __builtin_fma(p, r, M.k.e3);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    double v = ldexp_i(p, (int)kf);
-    return x < -746.0 ? 0.0 : v;
+    int k = (int)kf;
+    double t = M.exp2_64[k & 63];
+    return ldexp_i(t * p, k >> 6);
 }
 
-// sin and cos of x, |x| < ~1e6.
-GBP_HD void sincos_cw(double x, double& s, double& c)
+// sin and cos of x for |x| < ~1e6 (beyond that the caller's exp factor has long underflowed).
+//   x = k pi/32 + r, |r| <= pi/64: angle addition with the tabulated sin/cos of k pi/32 and degree-7/8
+//   Taylor kernels (truncation < 5e-18); no quadrant logic.  21 VALU issues + one LDS read.
+GBP_HD void sincos_tab(const MathCtx& M, double x, double& s, double& c)
 {
-    const double TWO_OVER_PI = 6.36619772367581382433e-01;
-    const double P1 = 1.5707963267948966;
-    const double P2 = 6.123233995736766e-17;
-    const double P3 = -1.4973849048591698e-33;
-    double kf = __builtin_rint(x * TWO_OVER_PI);
-    double r = __builtin_fma(-kf, P1, x);
-    r = __builtin_fma(-kf, P2, r);
-    r = __builtin_fma(-kf, P3, r);
+    double kf = __builtin_rint(x * M.k.inv_pi_32);
+    double r = __builtin_fma(-kf, M.k.pi_32_hi, x);
+    r = __builtin_fma(-kf, M.k.pi_32_lo, r);
+    SinCos t = M.sincos_64[((int)kf) & 63];
     double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
-    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
-    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
-    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
-    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(M.k.s3, z, M.k.s2);
+    ps = __builtin_fma(ps, z, M.k.s1);
     double sr = __builtin_fma(ps * z, r, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
-    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
-    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
-    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
-    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(M.k.c4, z, M.k.c3);
+    pc = __builtin_fma(pc, z, M.k.c2);
     double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
-    int k = (int)kf;
-    double so = (k & 1) ? cr : sr;
-    double co = (k & 1) ? sr : cr;
-    s = (k & 2) ? -so : so;
-    c = ((k + 1) & 2) ? -co : co;
+    s = __builtin_fma(t.s, cr, t.c * sr);
+    c = __builtin_fma(t.c, cr, -(t.s * sr));
 }
 
 // exp(x + i t) for x <= 0
-GBP_HD cplx cexp_neg(double x, double t)
+GBP_HD cplx cexp_neg(const MathCtx& M, double x, double t)
 {
-    double e = exp_neg(x);
+    double e = exp_neg(M, x);
     double s, c;
-    sincos_cw(t, s, c);
+    sincos_tab(M, t, s, c);
     return mk(e * c, e * s);
 }
 

@@ -11,6 +11,21 @@
 
 #include "../../geobipy_amd/csrc/gbp_fdem_tables.h"
 
+namespace {
+alignas(16) const double H_EXP2[64] = GBP_EXP2_64_LIST;
+alignas(16) const double H_SINCOS[128] = GBP_SINCOS_64_LIST;
+gbp::MathCtx host_ctx()
+{
+    using namespace gbp;
+    MathCtx M;
+    const MathK k = GBP_MATHK_INIT;
+    M.k = k;
+    M.exp2_64 = H_EXP2;
+    M.sincos_64 = reinterpret_cast<const SinCos*>(H_SINCOS);
+    return M;
+}
+}  // namespace
+
 extern "C" {
 
 // forward for B soundings, same argument meaning as gbp_fdem_system_create + gbp_fdem_forward (host pointers)
@@ -25,6 +40,7 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
     int rc = gbp::build_system_tables(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
                                       lamda0, w1, lamda1, &t, &msg);
     if (rc != 0) return rc;
+    const gbp::MathCtx M = host_ctx();
     const double* p_lam = t.soa.data();
     const double* p_u0r = p_lam + t.npts;
     const double* p_u0i = p_lam + 2 * (size_t)t.npts;
@@ -43,9 +59,9 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
                 gbp::cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
                 gbp::cplx coef = gbp::mk(p_cre[j], p_cim[j]);
                 gbp::cplx num, den;
-                gbp::rte_num_den(lam * lam - ch.w2me, ch.wmu, L, sig, th, u0, num, den);
+                gbp::rte_num_den(M, lam * lam - ch.w2me, ch.wmu, L, sig, th, u0, num, den);
                 gbp::cplx ue = ch.real_exp ? gbp::mk(lam, 0.0) : u0;
-                gbp::cplx term = gbp::hankel_term(num, den, ue, hD, coef, ch.real_exp != 0);
+                gbp::cplx term = gbp::hankel_term(M, num, den, ue, hD, coef, ch.real_exp != 0);
                 are += term.re;
                 aim += term.im;
             }
@@ -57,8 +73,8 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
 }
 
 // accuracy probes for the scalar kernels
-void emul_exp_neg(int n, const double* x, double* y) { for (int i = 0; i < n; ++i) y[i] = gbp::exp_neg(x[i]); }
-void emul_sincos(int n, const double* x, double* s, double* c) { for (int i = 0; i < n; ++i) gbp::sincos_cw(x[i], s[i], c[i]); }
+void emul_exp_neg(int n, const double* x, double* y) { const gbp::MathCtx M = host_ctx(); for (int i = 0; i < n; ++i) y[i] = gbp::exp_neg(M, x[i]); }
+void emul_sincos(int n, const double* x, double* s, double* c) { const gbp::MathCtx M = host_ctx(); for (int i = 0; i < n; ++i) gbp::sincos_tab(M, x[i], s[i], c[i]); }
 void emul_csqrt(int n, const double* a, const double* b, double* re, double* im)
 {
     for (int i = 0; i < n; ++i) { gbp::cplx z = gbp::csqrt_upper(a[i], b[i]); re[i] = z.re; im[i] = z.im; }
