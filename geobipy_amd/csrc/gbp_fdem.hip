@@ -84,10 +84,13 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // Forward solve for the frequencies owned by this wave; result (complex ppm) -> sh_out[f], sh_out[F+f].
-__device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Channel* __restrict__ chan, const double* __restrict__ pts,
-                                                 int npts_total, int F, int L, const double* __restrict__ sig,
-                                                 const double* __restrict__ thk, double alt, int wave, int nwaves,
-                                                 int lane, double* sh_out)
+//   sh_t2[k]  = -2 thk[k]                          (block-wide, written by the caller)
+//   sh_lay[k] = {(wmu sigma_k)^2, wmu sigma_k/sqrt2} (this wave's slice, rewritten per frequency)
+__device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Channel* __restrict__ chan,
+                                                 const double* __restrict__ pts, int npts_total, int F, int L,
+                                                 const double* __restrict__ sig, const double* sh_t2,
+                                                 gbp::LayerK* sh_lay, double alt, int wave, int nwaves, int lane,
+                                                 double* sh_out)
 {
     const double* __restrict__ p_lam = pts;
     const double* __restrict__ p_u0r = pts + npts_total;
@@ -97,6 +100,12 @@ __device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Ch
 
     for (int f = wave; f < F; f += nwaves) {
         const Channel ch = chan[f];
+        for (int k = lane; k < L; k += 64) {
+            const double b = ch.wmu * sig[k];
+            sh_lay[k].b2 = b * b;
+            sh_lay[k].bc = b * 0.70710678118654752440;
+        }
+        __builtin_amdgcn_wave_barrier();
         const double hD = ch.hd0 - 2.0 * alt;
         const bool real_exp = ch.real_exp != 0;
         double acc_re = 0.0, acc_im = 0.0;
@@ -110,7 +119,7 @@ __device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Ch
             if (!valid) coef = gbp::mk(0.0, 0.0);
             const double a = lam * lam - ch.w2me;
             cplx num, den;
-            gbp::rte_num_den(M, a, ch.wmu, L, sig, thk, u0, num, den);
+            gbp::rte_num_den(M, a, L, sh_lay, sh_t2, u0, num, den);
             const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
             const cplx t = gbp::hankel_term(M, num, den, ue, hD, coef, real_exp);
             acc_re += t.re;
@@ -123,6 +132,7 @@ __device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Ch
             sh_out[f] = ch.g_re * acc_re - ch.g_im * acc_im;
             sh_out[F + f] = ch.g_re * acc_im + ch.g_im * acc_re;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
-    const gbp::MathCtx M = math_setup(sh_math);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];  // LayerK[nwaves][Lmax] | t2[Lmax]
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,8 +185,12 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const int L = nlayers[b];
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
+    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * Lmax;
+    double* sh_t2 = reinterpret_cast<double*>(sh_dyn + (size_t)nwaves * Lmax * sizeof(gbp::LayerK));
+    for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
+    const gbp::MathCtx M = math_setup(sh_math);  // ends with __syncthreads()
 
-    forward_channels(M, chan, pts, npts_total, F, L, sig, th, height[b], wave, nwaves, lane, sh_out);
+    forward_channels(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, height[b], wave, nwaves, lane, sh_out);
     __syncthreads();
 
     const int N = 2 * F;
@@ -196,6 +210,30 @@ __global__ void k_gauss_loglike(int B, int N, const double* __restrict__ pred, c
     loglike_wave(N, pred + (size_t)b * N, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
 }
 
+// Evaluates the device math kernels element-wise (test hook: tests/test_gpu_math.py checks their
+// accuracy on the real hardware, where v_rsq_f64 / v_rcp_f64 seeds differ from the host's).
+__global__ void k_debug_math(int op, int n, const double* __restrict__ x, const double* __restrict__ y,
+                             double* __restrict__ o0, double* __restrict__ o1)
+{
+    __shared__ MathLds sh_math;
+    const gbp::MathCtx M = math_setup(sh_math);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double a = x[i], b = y ? y[i] : 0.0, r0 = 0.0, r1 = 0.0;
+        switch (op) {
+        case 0: r0 = gbp::exp_neg(M, a); break;
+        case 1: gbp::sincos_tab(M, a, r0, r1); break;
+        case 2: { cplx z = gbp::csqrt_upper(a, b); r0 = z.re; r1 = z.im; break; }
+        case 3: r0 = gbp::rcp(a); break;
+        case 4: r0 = gbp::rsq_seed(a); break;
+        case 5: r0 = gbp::rcp_seed(a); break;
+        case 6: gbp::sqrt_rsqrt(a, r0, r1); break;
+        default: break;
+        }
+        o0[i] = r0;
+        if (o1) o1[i] = r1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host: system tables
 // ------------------------------------------------------------------------------------------
@@ -203,7 +241,7 @@ namespace {
 
 typedef std::complex<double> zc;
 
-int pick_waves(int B, int F)
+int pick_waves(int B, int F, int Lmax)
 {
     static int forced = -2;
     if (forced == -2) {
@@ -213,15 +251,20 @@ int pick_waves(int B, int F)
     int nw = forced > 0 ? forced : (8192 + B - 1) / B;  // aim for >= 8 waves per SIMD-slot worth of work
     if (nw > F) nw = F;
     if (nw > 16) nw = 16;
+    while (nw > 1 && (size_t)nw * Lmax * 16 + (size_t)Lmax * 8 > 60000) --nw;
     if (nw < 1) nw = 1;
     return nw;
 }
+
+size_t dyn_lds_bytes(int nw, int Lmax) { return (size_t)nw * Lmax * sizeof(gbp::LayerK) + (size_t)Lmax * sizeof(double); }
+const int GBP_MAX_LAYERS = 2048;  // LDS budget: (16 nw + 8) * Lmax bytes <= 64 KiB at nw = 1
 
 gbp_status check_batch(const gbp_fdem_system* sys, int B, int Lmax, const void* a, const void* b, const void* c,
                        const void* d)
 {
     if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
+    if (Lmax > GBP_MAX_LAYERS) return fail(GBP_ERR_INVALID_ARG, "Lmax must be <= 2048%s");
     if (B > 0 && (!a || !b || !c || !d)) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
     return GBP_OK;
 }
@@ -301,8 +344,8 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system* sys, int B, int Lmax, const i
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
-    const int nw = pick_waves(B, sys->t.nF);
-    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), 0, (hipStream_t)stream, sys->d_chan,
+    const int nw = pick_waves(B, sys->t.nF, Lmax);
+    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr);
     GBP_HIP(hipGetLastError());
@@ -331,8 +374,8 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax,
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
     if (!obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
-    const int nw = pick_waves(B, sys->t.nF);
-    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), 0, (hipStream_t)stream, sys->d_chan,
+    const int nw = pick_waves(B, sys->t.nF, Lmax);
+    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
                        chi2, logL);
     GBP_HIP(hipGetLastError());
@@ -361,6 +404,16 @@ gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system* sys, int B, int 
     (void)hipEventDestroy(e1);
     *avg_ms = ms / reps;
     return st;
+}
+
+gbp_status gbp_debug_math(int op, int n, const double* x, const double* y, double* out0, double* out1, void* stream)
+{
+    if (n < 0 || op < 0 || op > 6) return fail(GBP_ERR_INVALID_ARG, "bad op or n%s");
+    if (n == 0) return GBP_OK;
+    if (!x || !out0) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    hipLaunchKernelGGL(k_debug_math, dim3(1024), dim3(256), 0, (hipStream_t)stream, op, n, x, y, out0, out1);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
 }
 
 gbp_status gbp_fdem_sensitivity(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,

@@ -38,23 +38,31 @@ struct Channel {
     int tid;
 };
 
-// rTE numerator / denominator for one point.  a = lambda^2 - w2me, sig/thk: the sounding's L layers
-// (thk[L-1] is never read -- the reference passes inf there).
-GBP_HD void rte_num_den(const MathCtx& M, double a, double wmu, int L, const double* __restrict__ sig,
-                        const double* __restrict__ thk, cplx u0, cplx& num, cplx& den)
+// Per-layer, per-frequency constants of one sounding (wave-uniform; the kernel keeps them in LDS and
+// every lane reads them by broadcast, so no VALU issue is spent on uniform arithmetic in the layer loop).
+struct alignas(16) LayerK {
+    double b2;  // (omega mu0 sigma_k)^2
+    double bc;  // omega mu0 sigma_k / sqrt(2)
+};
+
+// rTE numerator / denominator for one point.  a = lambda^2 - w2me; lay[k], t2[k] = -2 thk[k] for the
+// sounding's L layers (t2[L-1] is never read -- the reference passes inf there).
+GBP_HD void rte_num_den(const MathCtx& M, double a, int L, const LayerK* __restrict__ lay,
+                        const double* __restrict__ t2, cplx u0, cplx& num, cplx& den)
 {
-    cplx N = csqrt_upper(a, wmu * sig[L - 1]);  // basement: Yh_L = u_L
+    cplx N = csqrt_upper2(a, lay[L - 1].b2, lay[L - 1].bc);  // basement: Yh_L = u_L
     cplx D = mk(1.0, 0.0);
     for (int k = L - 2; k >= 0; --k) {
-        cplx u = csqrt_upper(a, wmu * sig[k]);
-        double t2 = -2.0 * thk[k];
-        cplx e = cexp_neg(M, t2 * u.re, t2 * u.im);
+        const LayerK lk = lay[k];
+        const double tk = t2[k];
+        cplx u = csqrt_upper2(a, lk.b2, lk.bc);
+        cplx e = cexp_neg(M, tk * u.re, tk * u.im);
         cplx uD = u * D;
         cplx A = uD + N, B = uD - N;
         cplx eB = e * B;
         N = u * (A - eB);
         D = A + eB;
-        if ((k & 3) == 3) {  // keep |N|, |D| away from the fp64 range limits for deep models
+        if ((k & 7) == 7) {  // keep |N|, |D| away from the fp64 range limits for deep models
             int s = -frexp_exp(__builtin_fmax(__builtin_fabs(D.re), __builtin_fabs(D.im)));
             N = mk(ldexp_i(N.re, s), ldexp_i(N.im, s));
             D = mk(ldexp_i(D.re, s), ldexp_i(D.im, s));
@@ -73,10 +81,8 @@ GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD
         E = mk(exp_neg(M, ue.re * hD), 0.0);
     else
         E = cexp_neg(M, ue.re * hD, ue.im * hD);
-    // normalise the denominator so that |den|^2 cannot overflow for deep models
-    int s = -frexp_exp(__builtin_fmax(__builtin_fabs(den.re), __builtin_fabs(den.im)));
-    num = mk(ldexp_i(num.re, s), ldexp_i(num.im, s));
-    den = mk(ldexp_i(den.re, s), ldexp_i(den.im, s));
+    // |den| is at most 8 layers of growth away from the last renormalisation (<= ~1e30, >= ~1e-50),
+    // so |den|^2 is safely inside the fp64 range
     return cdiv(num * (E * coef), den);
 }
 

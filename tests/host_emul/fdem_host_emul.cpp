@@ -50,8 +50,16 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
         const int L = nlayers[b];
         const double* sig = sigma + (size_t)b * Lmax;
         const double* th = thk + (size_t)b * Lmax;
+        std::vector<gbp::LayerK> lay(L);
+        std::vector<double> t2(L, 0.0);
+        for (int k = 0; k < L - 1; ++k) t2[k] = -2.0 * th[k];
         for (int f = 0; f < nF; ++f) {
             const gbp::Channel& ch = t.chan[f];
+            for (int k = 0; k < L; ++k) {
+                const double bb = ch.wmu * sig[k];
+                lay[k].b2 = bb * bb;
+                lay[k].bc = bb * 0.70710678118654752440;
+            }
             const double hD = ch.hd0 - 2.0 * height[b];
             double are = 0.0, aim = 0.0;
             for (int j = ch.off; j < ch.off + ch.npts; ++j) {
@@ -59,7 +67,7 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
                 gbp::cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
                 gbp::cplx coef = gbp::mk(p_cre[j], p_cim[j]);
                 gbp::cplx num, den;
-                gbp::rte_num_den(M, lam * lam - ch.w2me, ch.wmu, L, sig, th, u0, num, den);
+                gbp::rte_num_den(M, lam * lam - ch.w2me, L, lay.data(), t2.data(), u0, num, den);
                 gbp::cplx ue = ch.real_exp ? gbp::mk(lam, 0.0) : u0;
                 gbp::cplx term = gbp::hankel_term(M, num, den, ue, hD, coef, ch.real_exp != 0);
                 are += term.re;
@@ -79,5 +87,6 @@ void emul_csqrt(int n, const double* a, const double* b, double* re, double* im)
 {
     for (int i = 0; i < n; ++i) { gbp::cplx z = gbp::csqrt_upper(a[i], b[i]); re[i] = z.re; im[i] = z.im; }
 }
+void emul_sqrt_rsqrt(int n, const double* x, double* g, double* y) { for (int i = 0; i < n; ++i) gbp::sqrt_rsqrt(x[i], g[i], y[i]); }
 void emul_rcp(int n, const double* x, double* y) { for (int i = 0; i < n; ++i) y[i] = gbp::rcp(x[i]); }
 }
