@@ -49,6 +49,16 @@ def bytes_per_eval(L, F, with_pred):
     return rd + wr
 
 
+def measured_traffic(Btot, L, world):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in
+    separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note) -- only for the profiled shape."""
+    path = os.path.join(ROOT, "profiles", "r1", f"summary_bench_{Btot}x{N_FREQ}x{L}.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    d = json.load(open(path))["derived"]
+    return d["hbm_fetch_bytes_x2_gfx950_correction"] + d["hbm_write_bytes_raw"]
+
+
 def cpu_baseline(system, nl, sigma, thk, height, obs, sample, threads):
     from oracle import fdem_oracle as fo
     osys = fo.OracleSystem(system.frequencies, system.transmitter.orientation, system.transmitter.moment,
@@ -196,7 +206,7 @@ def main():
                        "proposal_sets": N_SIGMA_SETS},
             "roofline": {
                 "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(Btot, L, world),
                 "flop_per_eval": fpe, "evals_per_launch": per_launch_evals, "kernel_ms": kernel_ms,
                 "kernel": "k_fdem_forward<true>",
                 "hbm": {"algorithmic_bytes_per_eval": bpe,
