@@ -67,6 +67,7 @@ class FdemBatch:
         self.additive_error = None if additive_error is None else _dev_f64(additive_error, self.device, (self.B,))
         self.predicted = torch.empty((self.B, 2 * self.F), dtype=torch.float64, device=self.device)
         self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        self._max_layers = None
         self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
 
     def validate(self):
@@ -114,15 +115,24 @@ class FdemBatch:
                                              self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
         return self.chi2, self.logL
 
-    def sensitivity(self, out=None):
-        """J[B, 2F, Lmax] = d pred / d ln(sigma) (FdemDataPoint.sensitivity)."""
+    def sensitivity(self, out=None, exact=False, max_layers=None):
+        """J[B, 2F, Lmax] = d pred / d ln(sigma) (FdemDataPoint.sensitivity -> nbFdem1dsen).
+
+        ``exact=False`` reproduces the reference's expression (which is not the true derivative above the
+        half-space); ``exact=True`` returns the true derivative.  ``max_layers`` is an
+        upper bound of ``nlayers`` (default: computed once from the batch) that sizes the kernel's LDS."""
         if out is None:
             out = torch.empty((self.B, 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
+        if max_layers is None:
+            if self._max_layers is None:
+                self._max_layers = int(self.nlayers.max().item()) if self.B > 0 else 1
+            max_layers = self._max_layers
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_sensitivity(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
-                                                self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
-                                                out.data_ptr(), _stream_ptr(self.device)))
+            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                   self.sigma.data_ptr(), self.thk.data_ptr(),
+                                                   self.height.data_ptr(), out.data_ptr(), int(max_layers),
+                                                   1 if exact else 0, _stream_ptr(self.device)))
         return out
 
     def time_forward_loglike(self, reps, want_pred=False):

@@ -200,6 +200,96 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
         loglike_wave(N, sh_out, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
 }
 
+// Jacobian kernel: same decomposition as k_fdem_forward; each lane keeps d rTE / d ln sigma_m for its
+// abscissa in LDS (row m, column lane, row stride 65 slots so that the row sums below are conflict-free),
+// lane m then sums row m over the 64 abscissae.  J[b, f, m] = Re(g * sum), J[b, F + f, m] = Im(g * sum).
+#define GBP_SENS_STRIDE 65
+template <bool EXACT>
+__global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ chan, const double* __restrict__ pts,
+                                                    int npts_total, int F, int Lmax, int Lalloc,
+                                                    const int* __restrict__ nlayers,
+                                                    const double* __restrict__ sigma,
+                                                    const double* __restrict__ thk,
+                                                    const double* __restrict__ height, double* __restrict__ J)
+{
+    __shared__ MathLds sh_math;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    // layout: cplx D[nwaves][Lalloc][65] | LayerK lay[nwaves][Lalloc] | double t2[Lalloc]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int L = nlayers[b];
+    const double* sig = sigma + (size_t)b * Lmax;
+    const double* th = thk + (size_t)b * Lmax;
+    cplx* sh_D = reinterpret_cast<cplx*>(sh_dyn) + (size_t)wave * Lalloc * GBP_SENS_STRIDE;
+    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn + (size_t)nwaves * Lalloc * GBP_SENS_STRIDE * sizeof(cplx)) +
+                          (size_t)wave * Lalloc;
+    double* sh_t2 = reinterpret_cast<double*>(sh_dyn + (size_t)nwaves * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)));
+    for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
+    const gbp::MathCtx M = math_setup(sh_math);
+    const double alt = height[b];
+    const int N = 2 * F;
+
+    const double* __restrict__ p_lam = pts;
+    const double* __restrict__ p_u0r = pts + npts_total;
+    const double* __restrict__ p_u0i = pts + 2 * (size_t)npts_total;
+    const double* __restrict__ p_cre = pts + 3 * (size_t)npts_total;
+    const double* __restrict__ p_cim = pts + 4 * (size_t)npts_total;
+
+    for (int f = wave; f < F; f += nwaves) {
+        const Channel ch = chan[f];
+        for (int k = lane; k < L; k += 64) {
+            const double bb = ch.wmu * sig[k];
+            sh_lay[k].b2 = bb * bb;
+            sh_lay[k].bc = bb * 0.70710678118654752440;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double hD = ch.hd0 - 2.0 * alt;
+        const bool real_exp = ch.real_exp != 0;
+        for (int m0 = 0; m0 < L; m0 += 64) {          // layers handled by this lane in the row sums
+            const int m = m0 + lane;
+            double acc_re = 0.0, acc_im = 0.0;
+            // (for L <= 64, the common case, this outer loop runs once)
+            for (int j0 = 0; j0 < ch.npts; j0 += 64) {
+                {
+                    int j = j0 + lane;
+                    const bool valid = j < ch.npts;
+                    j = ch.off + (valid ? j : ch.npts - 1);
+                    const double lam = p_lam[j];
+                    const cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
+                    cplx coef = gbp::mk(p_cre[j], p_cim[j]);
+                    if (!valid) coef = gbp::mk(0.0, 0.0);
+                    const double a = lam * lam - ch.w2me;
+                    const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
+                    cplx E;
+                    if (real_exp) E = gbp::mk(gbp::exp_neg(M, ue.re * hD), 0.0);
+                    else E = gbp::cexp_neg(M, ue.re * hD, ue.im * hD);
+                    gbp::sens_point<EXACT>(M, a, L, sh_lay, sh_t2, u0, E * coef, sh_D + lane, GBP_SENS_STRIDE);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (m < L) {
+                    const cplx* row = sh_D + (size_t)m * GBP_SENS_STRIDE;
+                    double sr = 0.0, si = 0.0;
+#pragma unroll 8
+                    for (int i = 0; i < 64; ++i) { sr += row[i].re; si += row[i].im; }
+                    acc_re += sr;
+                    acc_im += si;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (m < L) {
+                J[((size_t)b * N + f) * Lmax + m] = ch.g_re * acc_re - ch.g_im * acc_im;
+                J[((size_t)b * N + F + f) * Lmax + m] = ch.g_re * acc_im + ch.g_im * acc_re;
+            }
+        }
+        for (int m = L + lane; m < Lmax; m += 64) {   // unused columns
+            J[((size_t)b * N + f) * Lmax + m] = 0.0;
+            J[((size_t)b * N + F + f) * Lmax + m] = 0.0;
+        }
+    }
+}
+
 __global__ void k_gauss_loglike(int B, int N, const double* __restrict__ pred, const double* __restrict__ obs,
                                 const double* __restrict__ rel, const double* __restrict__ add,
                                 double* __restrict__ chi2, double* __restrict__ logL)
@@ -420,8 +510,37 @@ gbp_status gbp_fdem_sensitivity(const gbp_fdem_system* sys, int B, int Lmax, con
                                 const double* sigma, const double* thk, const double* height, double* J,
                                 void* stream)
 {
-    (void)sys; (void)B; (void)Lmax; (void)nlayers; (void)sigma; (void)thk; (void)height; (void)J; (void)stream;
-    return fail(GBP_ERR_INVALID_ARG, "gbp_fdem_sensitivity: not built yet%s");
+    return gbp_fdem_sensitivity_ex(sys, B, Lmax, nlayers, sigma, thk, height, J, Lmax, 0, stream);
+}
+
+gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                   const double* sigma, const double* thk, const double* height, double* J,
+                                   int max_layers, int exact, void* stream)
+{
+    gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
+    if (st != GBP_OK) return st;
+    if (B == 0) return GBP_OK;
+    if (!J) return fail(GBP_ERR_INVALID_ARG, "J is NULL%s");
+    if (max_layers < 1 || max_layers > Lmax) max_layers = Lmax;
+    const size_t per_wave = (size_t)max_layers * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK));
+    if (per_wave + (size_t)max_layers * 8 > 150000)
+        return fail(GBP_ERR_INVALID_ARG, "too many layers for the Jacobian kernel's LDS working set (max ~140)%s");
+    int nw = pick_waves(B, sys->t.nF, Lmax);
+    while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
+    const size_t lds = nw * per_wave + (size_t)max_layers * 8;
+    if (exact) {
+        if (lds > 48 * 1024)
+            GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fdem_sens<true>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
+                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J);
+    } else {
+        if (lds > 48 * 1024)
+            GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fdem_sens<false>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
+                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J);
+    }
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
 }
 
 }  // extern "C"

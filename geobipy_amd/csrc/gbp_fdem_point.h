@@ -86,4 +86,61 @@ GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD
     return cdiv(num * (E * coef), den);
 }
 
+// ------------------------------------------------------------------------------------------
+// Jacobian: d rTE / d ln(sigma_m) for every layer m of one abscissa point, times Q = E * coef
+// (replaces calcFdemSensitivity1D + M1_1, fdem1d_numba.py:130-154, 222-303).
+//
+// Chain rule through the admittance recursion, in the kappa = 0 "hat" units of this file:
+//   d rTE / d Yh_1       = -2 u_0 / (u_0 + Yh_1)^2                               (FD:292-295 "s0")
+//   d Yh_k / d Yh_{k+1}  = u_k^2 (1 - T^2) / den^2 = 4 u_k^2 e / Dd^2            (FD:267 "accumulate")
+//   sigma_k d u_k / d sigma_k = i b_k / (2 u_k),   b_k = omega mu0 sigma_k
+//   d Yh_k / d u_k       = bracket / Dd^2,  Dd = u(1+e) + Yh'(1-e),  e = exp(-2 u t), with
+//     exact     : (Y'^2 + u^2)(1 - e^2) + 2 u Y' (1-e)^2 - 4 t u e (Y'^2 - u^2)
+//     reference : (Y'^2 - u^2)(1 - e^2) + 2 u^2 (1+e)^2 + 2 u Y' (1-e)^2 - 4 t u e (Y'^2 - u^2)
+// The reference's bracket (FD:269-274: "(Y_2 - Yn_2) * tanuh + 2.0 * Yn_2") is NOT the derivative of its
+// own forward recursion for layers above the half-space -- the correct term is (Y_2 + Yn_2) * tanuh; a
+// finite-difference check of the reference shows O(1) relative errors there.
+// Parity means reproducing the reference, so EXACT = false is the default; EXACT = true gives the true
+// derivative.  The basement layer (d Yh_L / d u_L = 1) agrees in both.
+//
+// Bottom-up sweep with suffix propagation: D[m] holds d Yh_{k} / d ln sigma_m for all m >= k and is
+// multiplied by "accumulate" as the sweep moves up (the reference stores accumulate[] and sens[] for all
+// (layer, frequency, abscissa) and does a prefix product afterwards).  D lives in LDS on the device:
+// element m of this lane is D[m * stride].
+template <bool EXACT>
+GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restrict__ lay,
+                       const double* __restrict__ t2, cplx u0, cplx Q, cplx* D, int stride)
+{
+    const double RSQRT2 = 0.70710678118654752440;
+    cplx Y = csqrt_upper2(a, lay[L - 1].b2, lay[L - 1].bc);
+    D[(L - 1) * stride] = cdiv(mk(0.0, lay[L - 1].bc * RSQRT2), Y);  // i b / (2 u_L)
+    for (int k = L - 2; k >= 0; --k) {
+        const LayerK lk = lay[k];
+        const double tk = t2[k];  // -2 t_k
+        const cplx u = csqrt_upper2(a, lk.b2, lk.bc);
+        const cplx e = cexp_neg(M, tk * u.re, tk * u.im);
+        const cplx ep = mk(1.0 + e.re, e.im), em = mk(1.0 - e.re, -e.im);
+        const cplx Nn = Y * ep + u * em;
+        const cplx Dd = u * ep + Y * em;
+        const cplx inv = cdiv(mk(1.0, 0.0), Dd);
+        const cplx inv2 = inv * inv;
+        const cplx u2 = u * u, Y2 = Y * Y, uY = u * Y;
+        const cplx d = Y2 - u2;
+        const cplx epm = ep * em, em2 = em * em;
+        cplx br = (uY * em2) * 2.0 + ((u * e) * d) * (2.0 * tk);
+        if (EXACT)
+            br = br + (Y2 + u2) * epm;
+        else
+            br = br + d * epm + (u2 * (ep * ep)) * 2.0;
+        const cplx W = cdiv(mk(0.0, lk.bc * RSQRT2), u) * (br * inv2);
+        const cplx acc = ((u2 * e) * inv2) * 4.0;
+        for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * acc;
+        D[k * stride] = W;
+        Y = (u * Nn) * inv;
+    }
+    const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
+    const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
+    for (int m = 0; m < L; ++m) D[m * stride] = D[m * stride] * QQ;
+}
+
 }  // namespace gbp

@@ -116,6 +116,18 @@ gbp_status gbp_fdem_sensitivity(const gbp_fdem_system *sys, int B, int Lmax, con
                                 const double *sigma, const double *thk, const double *height,
                                 double *J, void *stream);
 
+/*
+ * Same with two knobs:
+ *   max_layers  an upper bound of nlayers[] known to the caller (sizes the kernel's LDS working set;
+ *               pass Lmax when unknown).  Soundings with nlayers > max_layers are undefined behaviour.
+ *   exact       0: reproduce the reference's M1_1 formula bit-for-tolerance (default of
+ *               gbp_fdem_sensitivity); 1: the true derivative of the forward recursion -- the reference's
+ *               expression at fdem1d_numba.py:269-274 is not.
+ */
+gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                   const double *sigma, const double *thk, const double *height,
+                                   double *J, int max_layers, int exact, void *stream);
+
 /* Timing helper for bench.py: average kernel time (ms) of `reps` launches of the fused kernel,
  * measured with hipEvents recorded on `stream` around the launches. */
 gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,

@@ -228,3 +228,66 @@ def test_edge_cases():
     from oracle import fdem_oracle as fo
     ref = np.stack([fo.predicted_data(oracle_system("syn10"), sig[i], thk[i], 30.0) for i in range(2)])
     assert close(p.cpu().numpy(), ref, PRED_ATOL, PRED_RTOL)
+
+
+@pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
+def test_jacobian_fixtures_of_imported_reference(golden_npz, name):
+    """FdemDataPoint.sensitivity -> nbFdem1dsen fixtures (reference formula), ragged batch, all tensor ids."""
+    from geobipy_amd import FdemBatch
+    g, s = golden_npz, product_system(name)
+    Lmax = 32
+    nl, sig, thk, h, Jref = [], [], [], [], []
+    for L in [1, 2, 3, 5, 8, 30]:
+        k = f"{name}_L{L}"
+        n = g[k + "/sigma"].shape[0]
+        t = g[k + "/thk"].copy()
+        t[:, -1] = 0.0
+        nl += [L] * n
+        sig.append(pad(g[k + "/sigma"], Lmax, 1.0))
+        thk.append(pad(t, Lmax, 0.0))
+        h.append(g[k + "/height"])
+        Jp = np.zeros((n, g[k + "/J"].shape[1], Lmax))
+        Jp[:, :, :L] = g[k + "/J"]
+        Jref.append(Jp)
+    cat = np.concatenate
+    b = FdemBatch(s, np.array(nl), cat(sig), cat(thk), cat(h))
+    J = b.sensitivity().cpu().numpy()
+    assert close(J, cat(Jref), PRED_ATOL, PRED_RTOL)
+    assert np.array_equal(b.sensitivity(max_layers=Lmax).cpu().numpy(), J)      # LDS sizing does not change results
+
+
+def test_jacobian_random_batch_vs_oracle_and_finite_differences():
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    osys = oracle_system("syn10")
+    B, L = 2048, 6
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=77, Lmax=8)
+    b = FdemBatch(s, nl, sig, thk, h)
+    J = b.sensitivity().cpu().numpy()
+    assert J.shape == (B, 20, 8) and np.all(J[:, :, L:] == 0.0) and np.isfinite(J).all()
+    for i in range(0, B, 97):
+        Jo = fo.sensitivity(osys, sig[i, :L], thk[i, :L], h[i])
+        assert close(J[i, :, :L], np.vstack([Jo.real, Jo.imag]), PRED_ATOL, PRED_RTOL)
+    # exact mode = true derivative of the GPU forward (central differences in ln sigma)
+    Je = b.sensitivity(exact=True).cpu().numpy()
+    eps = 1e-4
+    for m in range(L):
+        sp, sm = sig.copy(), sig.copy()
+        sp[:, m] *= np.exp(eps)
+        sm[:, m] *= np.exp(-eps)
+        fd = (FdemBatch(s, nl, sp, thk, h).forward().cpu().numpy() - FdemBatch(s, nl, sm, thk, h).forward().cpu().numpy()) / (2 * eps)
+        assert np.all(np.abs(Je[:, :, m] - fd) <= 2e-4 + 1e-6 * np.abs(fd))
+    # the half-space column agrees between the two modes; the others do not (reference formula, DESIGN 3.4)
+    assert close(J[:, :, L - 1], Je[:, :, L - 1], PRED_ATOL, 1e-8)
+
+
+def test_datapoint_sensitivity_and_fm_dlogc():
+    from geobipy_amd import FdemDataPoint, Model, RectilinearMesh1D
+    from oracle import fdem_oracle as fo
+    mod = Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 5.0, 7.5, np.inf]), values=np.r_[1e-2, 1e-1, 0.03333333])
+    dp = FdemDataPoint(z=30.0, system=os.path.join(GOLDEN, "resolve.stm"))
+    dp.fm_dlogc(mod)
+    Jo = fo.sensitivity(oracle_system("resolve"), mod.values, [5.0, 2.5, np.inf], 30.0)
+    assert dp.sensitivity_matrix.shape == (12, 3)
+    assert close(dp.sensitivity_matrix, np.vstack([Jo.real, Jo.imag]), PRED_ATOL, PRED_RTOL)

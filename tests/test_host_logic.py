@@ -172,3 +172,39 @@ def test_kernel_scheme_on_host_vs_reference_fixtures(emul, golden_npz, name):
         assert rc == 0
         ref = golden_npz[k + "/pred"]
         assert np.all(np.abs(pred - ref) <= PRED_ATOL + PRED_RTOL * np.abs(ref)), k
+
+
+@pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
+def test_jacobian_scheme_on_host_vs_reference_fixtures(emul, golden_npz, name):
+    """sens_point (suffix-propagated chain rule) reproduces the reference's nbFdem1dsen fixtures (exact = 0),
+    and in exact mode it is the true derivative of the forward solve (central differences of the oracle)."""
+    from oracle import fdem_oracle as fo
+    s = oracle_system(name)
+    keep = [I(s.tid), D(s.frequencies), D(s.tx_xyz[:, 2]), D(s.rx_xyz[:, 2]), D(s.tx_moment), D(s.scale),
+            D(s.rx_off), D(s.separation), D(s.w0), D(s.lamda0), D(s.w1), D(s.lamda1)]
+    for L in [1, 2, 3, 5, 8, 30]:
+        k = f"{name}_L{L}"
+        sig, thk, h = golden_npz[k + "/sigma"], golden_npz[k + "/thk"].copy(), golden_npz[k + "/height"]
+        thk[:, -1] = 0.0
+        B = sig.shape[0]
+        J = np.empty((B, 2 * s.nF, L))
+        rc = emul.emul_fdem_sens(s.nF, *[q[1] for q in keep], B, L, I(np.full(B, L))[1], D(sig)[1], D(thk)[1],
+                                 D(h)[1], 0, J.ctypes.data_as(dp))
+        assert rc == 0
+        ref = golden_npz[k + "/J"]
+        assert np.all(np.abs(J - ref) <= PRED_ATOL + PRED_RTOL * np.abs(ref)), k
+    # exact mode vs central differences (L = 5, first two soundings)
+    k = f"{name}_L5"
+    sig, thk, h = golden_npz[k + "/sigma"][:2], golden_npz[k + "/thk"][:2].copy(), golden_npz[k + "/height"][:2]
+    thk[:, -1] = 0.0
+    J = np.empty((2, 2 * s.nF, 5))
+    emul.emul_fdem_sens(s.nF, *[q[1] for q in keep], 2, 5, I(np.full(2, 5))[1], D(sig)[1], D(thk)[1], D(h)[1], 1,
+                        J.ctypes.data_as(dp))
+    eps = 1e-4      # the oracle forward carries ~5e-9 ppm rounding noise -> 5e-5 in the difference quotient
+    for b in range(2):
+        for m in range(5):
+            sp, sm = sig[b].copy(), sig[b].copy()
+            sp[m] *= np.exp(eps)
+            sm[m] *= np.exp(-eps)
+            fd = (fo.predicted_data(s, sp, thk[b], h[b]) - fo.predicted_data(s, sm, thk[b], h[b])) / (2 * eps)
+            assert np.all(np.abs(J[b, :, m] - fd) <= 2e-4 + 1e-6 * np.abs(fd)), (name, b, m)
