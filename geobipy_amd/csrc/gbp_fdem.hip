@@ -45,7 +45,7 @@ gbp_status fail(gbp_status code, const char* fmt, const char* detail = "")
 struct gbp_fdem_system {
     gbp::SystemTables t;      // host copy (channels, H0, point tables)
     Channel* d_chan = nullptr;
-    double* d_pts = nullptr;  // SoA: lam | u0re | u0im | cre | cim, each [npts]
+    double* d_pts = nullptr;  // SoA, GBP_PT_FIELDS arrays of [npts] (gbp_fdem_point.h)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -71,6 +71,10 @@ __device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
     __syncthreads();
     gbp::MathCtx M;
     M.k = GBP_K;
+    M.e4_v = M.k.e4;
+    M.s2_v = M.k.s2;
+    M.c3_v = M.k.c3;
+    asm volatile("" : "+v"(M.e4_v), "+v"(M.s2_v), "+v"(M.c3_v));  // opaque: stays in VGPRs, not re-materialised
     M.exp2_64 = lds.exp2_64;
     M.sincos_64 = lds.sincos_64;
     return M;
@@ -83,54 +87,96 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// Forward solve for the frequencies owned by this wave; result (complex ppm) -> sh_out[f], sh_out[F+f].
-//   sh_t2[k]  = -2 thk[k]                          (block-wide, written by the caller)
-//   sh_lay[k] = {(wmu sigma_k)^2, wmu sigma_k/sqrt2} (this wave's slice, rewritten per frequency)
-__device__ __forceinline__ void forward_channels(const gbp::MathCtx& M, const Channel* __restrict__ chan,
-                                                 const double* __restrict__ pts, int npts_total, int F, int L,
-                                                 const double* __restrict__ sig, const double* sh_t2,
-                                                 gbp::LayerK* sh_lay, double alt, int wave, int nwaves, int lane,
-                                                 double* sh_out)
+// Per-frequency layer constants of this sounding -> LDS (lanes k < L), then a wave barrier.
+__device__ __forceinline__ void setup_layers(gbp::LayerK* lay, double wmu, const double* __restrict__ sig, int L,
+                                             int lane)
 {
-    const double* __restrict__ p_lam = pts;
-    const double* __restrict__ p_u0r = pts + npts_total;
-    const double* __restrict__ p_u0i = pts + 2 * (size_t)npts_total;
-    const double* __restrict__ p_cre = pts + 3 * (size_t)npts_total;
-    const double* __restrict__ p_cim = pts + 4 * (size_t)npts_total;
+    for (int k = lane; k < L; k += 64) {
+        const double b = wmu * sig[k];
+        lay[k].b2 = b * b;
+        lay[k].bc = b * 0.70710678118654752440;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
-    for (int f = wave; f < F; f += nwaves) {
-        const Channel ch = chan[f];
-        for (int k = lane; k < L; k += 64) {
-            const double b = ch.wmu * sig[k];
-            sh_lay[k].b2 = b * b;
-            sh_lay[k].bc = b * 0.70710678118654752440;
+// Forward solve over a contiguous range of 64-point passes of the sounding's FLATTENED (frequency, abscissa)
+// point list (P points: 120 per zz frequency, 140 per xz/zx, 260 per xx).  Flattening matters because 120 is
+// not a multiple of 64: per-frequency passes would idle 8 of 128 lanes, the flat list idles < 64 of P.
+// A pass may straddle two frequencies ("cur" below the boundary lane, "next" above it): each lane picks its
+// frequency's layer constants (two LDS slots) and altitude term, and accumulates into acc_c / acc_n; when a
+// frequency completes (or the range ends) the wave reduces and stores the partial sum in sh_part[f].
+__device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Channel* __restrict__ chan,
+                                               const double* __restrict__ pts, int P, int F, int L,
+                                               const double* __restrict__ sig, const double* sh_t2,
+                                               gbp::LayerK* sh_lay /* [2][Lmax] */, int Lmax, double alt, int p0,
+                                               int p1, int lane, cplx* sh_part /* [F] of this wave */)
+{
+    if (p0 >= p1) return;
+    int cur = 0;
+    while (cur + 1 < F && chan[cur].off + chan[cur].npts <= 64 * p0) ++cur;
+    int slot = 0;
+    bool cur_ready = false;
+    double acc_cr = 0.0, acc_ci = 0.0, acc_nr = 0.0, acc_ni = 0.0;
+    for (int p = p0; p < p1; ++p) {
+        const Channel cc = chan[cur];
+        if (!cur_ready) {
+            setup_layers(sh_lay + (size_t)slot * Lmax, cc.wmu, sig, L, lane);
+            cur_ready = true;
         }
-        __builtin_amdgcn_wave_barrier();
-        const double hD = ch.hd0 - 2.0 * alt;
-        const bool real_exp = ch.real_exp != 0;
-        double acc_re = 0.0, acc_im = 0.0;
-        for (int j0 = 0; j0 < ch.npts; j0 += 64) {
-            int j = j0 + lane;
-            const bool valid = j < ch.npts;
-            j = ch.off + (valid ? j : ch.npts - 1);
-            const double lam = p_lam[j];
-            const cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
-            cplx coef = gbp::mk(p_cre[j], p_cim[j]);
-            if (!valid) coef = gbp::mk(0.0, 0.0);
-            const double a = lam * lam - ch.w2me;
-            cplx num, den;
-            gbp::rte_num_den(M, a, L, sh_lay, sh_t2, u0, num, den);
-            const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
-            const cplx t = gbp::hankel_term(M, num, den, ue, hD, coef, real_exp);
-            acc_re += t.re;
-            acc_im += t.im;
+        const int base = 64 * p;
+        const int end_cur = cc.off + cc.npts;
+        const bool has_next = (base + 64 > end_cur) && (cur + 1 < F);
+        double hD = cc.hd0 - 2.0 * alt;
+        const gbp::LayerK* lay = sh_lay + (size_t)slot * Lmax;
+        int j = base + lane;
+        const bool valid = j < P;
+        bool in_next = false;
+        if (has_next) {
+            const Channel cn = chan[cur + 1];
+            setup_layers(sh_lay + (size_t)(slot ^ 1) * Lmax, cn.wmu, sig, L, lane);
+            in_next = j >= end_cur;
+            if (in_next) {
+                hD = cn.hd0 - 2.0 * alt;
+                lay = sh_lay + (size_t)(slot ^ 1) * Lmax;
+            }
         }
-        acc_re = wave_sum(acc_re);
-        acc_im = wave_sum(acc_im);
-        if (lane == 0) {
-            // out = 1e6 * scale * (H - H0) / H0 = g * (H - H0)
-            sh_out[f] = ch.g_re * acc_re - ch.g_im * acc_im;
-            sh_out[F + f] = ch.g_re * acc_im + ch.g_im * acc_re;
+        gbp::Point pt;
+        if (base + 64 > P) {   // ragged tail of the point list (wave-uniform branch)
+            pt = gbp::load_point(pts, P, valid ? j : P - 1);
+            if (!valid) pt.coef = gbp::mk(0.0, 0.0);
+        } else {
+            pt = gbp::load_point(pts, P, j);
+        }
+        cplx num, den;
+        gbp::rte_num_den(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
+        const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
+        if (has_next) {
+            acc_cr += in_next ? 0.0 : t.re;
+            acc_ci += in_next ? 0.0 : t.im;
+            acc_nr += in_next ? t.re : 0.0;
+            acc_ni += in_next ? t.im : 0.0;
+        } else {
+            acc_cr += t.re;
+            acc_ci += t.im;
+        }
+
+        const bool done = base + 64 >= end_cur;   // frequency `cur` has no points beyond this pass
+        const bool last = p == p1 - 1;
+        if (done || last) {
+            const double sr = wave_sum(acc_cr), si = wave_sum(acc_ci);
+            if (lane == 0) sh_part[cur] = gbp::mk(sr, si);
+            if (last && has_next) {
+                const double nr = wave_sum(acc_nr), ni = wave_sum(acc_ni);
+                if (lane == 0) sh_part[cur + 1] = gbp::mk(nr, ni);
+            }
+            if (done) {
+                ++cur;
+                acc_cr = acc_nr; acc_ci = acc_ni;
+                acc_nr = 0.0; acc_ni = 0.0;
+                cur_ready = has_next;
+                slot ^= 1;
+                if (cur >= F) break;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -177,7 +223,8 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];  // LayerK[nwaves][Lmax] | t2[Lmax]
+    // dynamic LDS: LayerK lay[nwaves][2][Lmax] | cplx part[nwaves][F] | double t2[Lmax]
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,12 +232,29 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const int L = nlayers[b];
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
-    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * Lmax;
-    double* sh_t2 = reinterpret_cast<double*>(sh_dyn + (size_t)nwaves * Lmax * sizeof(gbp::LayerK));
+    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
+    cplx* sh_part_all = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
+    double* sh_t2 = reinterpret_cast<double*>(sh_part_all + (size_t)nwaves * F);
     for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
+    for (int i = threadIdx.x; i < nwaves * F; i += blockDim.x) sh_part_all[i] = gbp::mk(0.0, 0.0);
     const gbp::MathCtx M = math_setup(sh_math);  // ends with __syncthreads()
 
-    forward_channels(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, height[b], wave, nwaves, lane, sh_out);
+    const int npass = (npts_total + 63) >> 6;
+    const int per = (npass + nwaves - 1) / nwaves;
+    const int p0 = wave * per;
+    const int p1 = min(npass, p0 + per);
+    forward_passes(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
+                   sh_part_all + (size_t)wave * F);
+    __syncthreads();
+
+    // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum over waves (fixed order: deterministic)
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        double sr = 0.0, si = 0.0;
+        for (int w = 0; w < nwaves; ++w) { sr += sh_part_all[w * F + f].re; si += sh_part_all[w * F + f].im; }
+        const Channel ch = chan[f];
+        sh_out[f] = ch.g_re * sr - ch.g_im * si;
+        sh_out[F + f] = ch.g_re * si + ch.g_im * sr;
+    }
     __syncthreads();
 
     const int N = 2 * F;
@@ -231,41 +295,23 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     const double alt = height[b];
     const int N = 2 * F;
 
-    const double* __restrict__ p_lam = pts;
-    const double* __restrict__ p_u0r = pts + npts_total;
-    const double* __restrict__ p_u0i = pts + 2 * (size_t)npts_total;
-    const double* __restrict__ p_cre = pts + 3 * (size_t)npts_total;
-    const double* __restrict__ p_cim = pts + 4 * (size_t)npts_total;
-
     for (int f = wave; f < F; f += nwaves) {
         const Channel ch = chan[f];
-        for (int k = lane; k < L; k += 64) {
-            const double bb = ch.wmu * sig[k];
-            sh_lay[k].b2 = bb * bb;
-            sh_lay[k].bc = bb * 0.70710678118654752440;
-        }
-        __builtin_amdgcn_wave_barrier();
+        setup_layers(sh_lay, ch.wmu, sig, L, lane);
         const double hD = ch.hd0 - 2.0 * alt;
-        const bool real_exp = ch.real_exp != 0;
         for (int m0 = 0; m0 < L; m0 += 64) {          // layers handled by this lane in the row sums
             const int m = m0 + lane;
             double acc_re = 0.0, acc_im = 0.0;
             // (for L <= 64, the common case, this outer loop runs once)
             for (int j0 = 0; j0 < ch.npts; j0 += 64) {
                 {
-                    int j = j0 + lane;
+                    const int j = j0 + lane;
                     const bool valid = j < ch.npts;
-                    j = ch.off + (valid ? j : ch.npts - 1);
-                    const double lam = p_lam[j];
-                    const cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
-                    cplx coef = gbp::mk(p_cre[j], p_cim[j]);
-                    if (!valid) coef = gbp::mk(0.0, 0.0);
-                    const double a = lam * lam - ch.w2me;
-                    const cplx ue = real_exp ? gbp::mk(lam, 0.0) : u0;
-                    cplx E;
-                    if (real_exp) E = gbp::mk(gbp::exp_neg(M, ue.re * hD), 0.0);
-                    else E = gbp::cexp_neg(M, ue.re * hD, ue.im * hD);
-                    gbp::sens_point<EXACT>(M, a, L, sh_lay, sh_t2, u0, E * coef, sh_D + lane, GBP_SENS_STRIDE);
+                    gbp::Point pt = gbp::load_point(pts, npts_total, ch.off + (valid ? j : ch.npts - 1));
+                    if (!valid) pt.coef = gbp::mk(0.0, 0.0);
+                    const cplx E = gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD);
+                    gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, E * pt.coef, sh_D + lane,
+                                           GBP_SENS_STRIDE);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (m < L) {
@@ -331,7 +377,13 @@ namespace {
 
 typedef std::complex<double> zc;
 
-int pick_waves(int B, int F, int Lmax)
+size_t dyn_lds_bytes(int nw, int Lmax, int F)
+{
+    return (size_t)nw * 2 * Lmax * sizeof(gbp::LayerK) + (size_t)nw * F * sizeof(cplx) + (size_t)Lmax * sizeof(double);
+}
+
+// waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches
+int pick_waves(int B, int F, int Lmax, int max_waves)
 {
     static int forced = -2;
     if (forced == -2) {
@@ -339,22 +391,21 @@ int pick_waves(int B, int F, int Lmax)
         forced = e ? std::atoi(e) : -1;
     }
     int nw = forced > 0 ? forced : (8192 + B - 1) / B;  // aim for >= 8 waves per SIMD-slot worth of work
-    if (nw > F) nw = F;
+    if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;
-    while (nw > 1 && (size_t)nw * Lmax * 16 + (size_t)Lmax * 8 > 60000) --nw;
+    while (nw > 1 && dyn_lds_bytes(nw, Lmax, F) > 60000) --nw;
     if (nw < 1) nw = 1;
     return nw;
 }
 
-size_t dyn_lds_bytes(int nw, int Lmax) { return (size_t)nw * Lmax * sizeof(gbp::LayerK) + (size_t)Lmax * sizeof(double); }
-const int GBP_MAX_LAYERS = 2048;  // LDS budget: (16 nw + 8) * Lmax bytes <= 64 KiB at nw = 1
+const int GBP_MAX_LAYERS = 1024;  // LDS budget: (32 nw + 8) * Lmax bytes <= 64 KiB at nw = 1
 
 gbp_status check_batch(const gbp_fdem_system* sys, int B, int Lmax, const void* a, const void* b, const void* c,
                        const void* d)
 {
     if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
-    if (Lmax > GBP_MAX_LAYERS) return fail(GBP_ERR_INVALID_ARG, "Lmax must be <= 2048%s");
+    if (Lmax > GBP_MAX_LAYERS) return fail(GBP_ERR_INVALID_ARG, "Lmax must be <= 1024%s");
     if (B > 0 && (!a || !b || !c || !d)) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
     return GBP_OK;
 }
@@ -434,8 +485,8 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system* sys, int B, int Lmax, const i
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
-    const int nw = pick_waves(B, sys->t.nF, Lmax);
-    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax), (hipStream_t)stream, sys->d_chan,
+    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
+    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr);
     GBP_HIP(hipGetLastError());
@@ -464,8 +515,8 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax,
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
     if (!obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
-    const int nw = pick_waves(B, sys->t.nF, Lmax);
-    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax), (hipStream_t)stream, sys->d_chan,
+    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
+    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
                        chi2, logL);
     GBP_HIP(hipGetLastError());
@@ -525,7 +576,7 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, 
     const size_t per_wave = (size_t)max_layers * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK));
     if (per_wave + (size_t)max_layers * 8 > 150000)
         return fail(GBP_ERR_INVALID_ARG, "too many layers for the Jacobian kernel's LDS working set (max ~140)%s");
-    int nw = pick_waves(B, sys->t.nF, Lmax);
+    int nw = pick_waves(B, sys->t.nF, Lmax, sys->t.nF);
     while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
     const size_t lds = nw * per_wave + (size_t)max_layers * 8;
     if (exact) {

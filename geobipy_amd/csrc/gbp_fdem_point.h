@@ -34,9 +34,26 @@ struct Channel {
     double hd0;         // rx_z - 2 tx_z : hDiff = rHeight - tHeight = hd0 - 2 * altitude (FD/fdem1d.py:31-32)
     double g_re, g_im;  // 1e6 * scale / H0                 (FD:68)
     int off, npts;      // slice of the point tables
-    int real_exp;       // 1: exponent uses lambda (Hxx, Hxz), 0: u0 (Hzz, Hzx)
+    int real_exp;       // 1: exponent uses lambda (Hxx, Hxz), 0: u0 (Hzz, Hzx) -- folded into the ue table
     int tid;
 };
+
+#define GBP_PT_FIELDS 7  // a | u0.re | u0.im | coef.re | coef.im | ue.re | ue.im
+
+// One abscissa point as the kernels read it (SoA in memory, see gbp_fdem_tables.h)
+struct Point {
+    double a;
+    cplx u0, coef, ue;
+};
+GBP_HD Point load_point(const double* __restrict__ pts, int npts_total, int j)
+{
+    Point p;
+    p.a = pts[j];
+    p.u0 = mk(pts[(size_t)npts_total + j], pts[2 * (size_t)npts_total + j]);
+    p.coef = mk(pts[3 * (size_t)npts_total + j], pts[4 * (size_t)npts_total + j]);
+    p.ue = mk(pts[5 * (size_t)npts_total + j], pts[6 * (size_t)npts_total + j]);
+    return p;
+}
 
 // Per-layer, per-frequency constants of one sounding (wave-uniform; the kernel keeps them in LDS and
 // every lane reads them by broadcast, so no VALU issue is spent on uniform arithmetic in the layer loop).
@@ -74,13 +91,9 @@ GBP_HD void rte_num_den(const MathCtx& M, double a, int L, const LayerK* __restr
 }
 
 // One term of H - H0: rTE * exp(ue * hD) * coef
-GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD, cplx coef, bool real_exp)
+GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD, cplx coef)
 {
-    cplx E;
-    if (real_exp)
-        E = mk(exp_neg(M, ue.re * hD), 0.0);
-    else
-        E = cexp_neg(M, ue.re * hD, ue.im * hD);
+    const cplx E = cexp_neg(M, ue.re * hD, ue.im * hD);  // ue.im == 0 for the real-exponent kernels
     // |den| is at most 8 layers of growth away from the last renormalisation (<= ~1e30, >= ~1e-50),
     // so |den|^2 is safely inside the fp64 range
     return cdiv(num * (E * coef), den);

@@ -2,9 +2,10 @@
 // tables the kernels read.  Pure C++ (no HIP) so that tests can build the same tables without a GPU.
 //
 // For every frequency f and every abscissa j the kernel needs
-//   lam            lambda_j                       (system/FdemSystem.py:67-101)
+//   a              lambda_j^2 - w^2 mu0 eps0      (system/FdemSystem.py:67-109; FD:176-182)
 //   u0             un[0] = sqrt(lambda^2 - w^2 mu0 eps0): the air layer of initCoefficients
 //                  (forwardmodelling/Electromagnetic/FD/fdem1d_numba.py:172-185 with sigma = 0)
+//   ue             exponent of the integrand: u0 (Hzz, Hzx) or lambda (Hxx, Hxz)
 //   coef           everything of the Hankel integrand that does not depend on the earth model or the
 //                  altitude: zz  +lambda^3/u0 * w0 * m/(4 pi r)            (FD:410-438)
 //                            xx  -lambda0^2 d0 w0 (J0 part), -lambda1 d1 w1 (J1 part)  (FD:306-355)
@@ -25,7 +26,7 @@ struct SystemTables {
     int nF = 0, npts = 0, max_pts = 0;
     std::vector<Channel> chan;
     std::vector<double> h0;   // (re, im) per frequency
-    std::vector<double> soa;  // lam | u0re | u0im | cre | cim, each [npts]
+    std::vector<double> soa;  // GBP_PT_FIELDS arrays of [npts]: a | u0re | u0im | cre | cim | uere | ueim
 };
 
 // returns GBP_OK or an error code; `msg` receives a static description on failure
@@ -52,7 +53,7 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
     s->chan.assign(nF, Channel());
     s->h0.assign(2 * (size_t)nF, 0.0);
     s->max_pts = 0;
-    std::vector<double> lam, u0r, u0i, cre, cim;
+    std::vector<double> pa, u0r, u0i, cre, cim, uer, uei;
 
     const double pi = 3.14159265358979323846;
     const double mu0 = 4.e-7 * pi;                        // fdem1d_numba.py:15
@@ -66,7 +67,7 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
         ch.wmu = omega * mu0;
         ch.w2me = (omega * eps0) * (omega * mu0);
         ch.hd0 = rx_z[f] - 2.0 * tx_z[f];
-        ch.off = (int)lam.size();
+        ch.off = (int)pa.size();
         ch.tid = tid[f];
         const double tH = tx_z[f], rH = -tH + rx_z[f];     // fdem1d.py:31-32 at altitude 0
         const double hS = rH + tH;                         // independent of the altitude
@@ -74,9 +75,12 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
         const double* l0 = lamda0 + (size_t)f * GBP_NC0;
         const double* l1 = lamda1 + (size_t)f * GBP_NC1;
         zc H0(0.0, 0.0);
+        // a = lambda^2 - w2me: real part of un^2 before the i*wmu*sigma term (FD:178-182); ue: the
+        // exponent of the integrand, u0 for Hzz/Hzx and lambda for Hxx/Hxz
         auto push = [&](double l, zc u, zc cf) {
-            lam.push_back(l); u0r.push_back(u.real()); u0i.push_back(u.imag());
+            pa.push_back(l * l - ch.w2me); u0r.push_back(u.real()); u0i.push_back(u.imag());
             cre.push_back(cf.real()); cim.push_back(cf.imag());
+            uer.push_back(ch.real_exp ? l : u.real()); uei.push_back(ch.real_exp ? 0.0 : u.imag());
         };
         auto air_u = [&](double l) { return std::sqrt(zc(l * l - ch.w2me, 0.0)); };  // un[0], FD:182 with sigma = 0
         if (tid[f] == 9) {                                 // Hzz, fdem1d_numba.py:410-438
@@ -115,7 +119,7 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
                 push(l1[j], u, zc(-a1 * w_, 0.0));
             }
         }
-        ch.npts = (int)lam.size() - ch.off;
+        ch.npts = (int)pa.size() - ch.off;
         if (ch.npts > s->max_pts) s->max_pts = ch.npts;
         const zc g = zc(1.e6 * scale[f], 0.0) / H0;        // fdem1d_numba.py:68
         ch.g_re = g.real();
@@ -123,14 +127,10 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
         s->h0[2 * f] = H0.real();
         s->h0[2 * f + 1] = H0.imag();
     }
-    s->npts = (int)lam.size();
+    s->npts = (int)pa.size();
     s->soa.clear();
-    s->soa.reserve(5 * lam.size());
-    s->soa.insert(s->soa.end(), lam.begin(), lam.end());
-    s->soa.insert(s->soa.end(), u0r.begin(), u0r.end());
-    s->soa.insert(s->soa.end(), u0i.begin(), u0i.end());
-    s->soa.insert(s->soa.end(), cre.begin(), cre.end());
-    s->soa.insert(s->soa.end(), cim.begin(), cim.end());
+    s->soa.reserve(GBP_PT_FIELDS * pa.size());
+    for (const std::vector<double>* v : {&pa, &u0r, &u0i, &cre, &cim, &uer, &uei}) s->soa.insert(s->soa.end(), v->begin(), v->end());
     return GBP_OK;
 }
 

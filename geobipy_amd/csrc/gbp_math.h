@@ -142,6 +142,10 @@ struct alignas(16) SinCos {
 // entries cover the 64 banks exactly once; SINCOS_64 is one ds_read_b128 per lane)
 struct MathCtx {
     MathK k;
+    // e4, s2, c3 again, but pinned in VGPRs: the first Horner step of each polynomial has TWO constant
+    // operands (c_n * r + c_{n-1}) and a VALU instruction may read only one SGPR pair, so the compiler
+    // would otherwise re-materialise one of them with a v_mov_b64 in every layer iteration.
+    double e4_v, s2_v, c3_v;
     const double* exp2_64;   // 2^(j/64), j = 0..63
     const SinCos* sincos_64; // sin, cos of 2 pi j / 64
 };
@@ -161,7 +165,7 @@ GBP_HD double exp_neg(const MathCtx& M, double x)
     double kf = __builtin_rint(xx * M.k.inv_ln2_64);
     double r = __builtin_fma(-kf, M.k.ln2_64_hi, xx);
     r = __builtin_fma(-kf, M.k.ln2_64_lo, r);
-    double p = __builtin_fma(M.k.e5, r, M.k.e4);
+    double p = __builtin_fma(M.k.e5, r, M.e4_v);
     p = __builtin_fma(p, r, M.k.e3);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
@@ -181,10 +185,10 @@ GBP_HD void sincos_tab(const MathCtx& M, double x, double& s, double& c)
     r = __builtin_fma(-kf, M.k.pi_32_lo, r);
     SinCos t = M.sincos_64[((int)kf) & 63];
     double z = r * r;
-    double ps = __builtin_fma(M.k.s3, z, M.k.s2);
+    double ps = __builtin_fma(M.k.s3, z, M.s2_v);
     ps = __builtin_fma(ps, z, M.k.s1);
     double sr = __builtin_fma(ps * z, r, r);
-    double pc = __builtin_fma(M.k.c4, z, M.k.c3);
+    double pc = __builtin_fma(M.k.c4, z, M.c3_v);
     pc = __builtin_fma(pc, z, M.k.c2);
     double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
     s = __builtin_fma(t.s, cr, t.c * sr);

@@ -20,6 +20,9 @@ gbp::MathCtx host_ctx()
     MathCtx M;
     const MathK k = GBP_MATHK_INIT;
     M.k = k;
+    M.e4_v = k.e4;
+    M.s2_v = k.s2;
+    M.c3_v = k.c3;
     M.exp2_64 = H_EXP2;
     M.sincos_64 = reinterpret_cast<const SinCos*>(H_SINCOS);
     return M;
@@ -41,11 +44,7 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
                                       lamda0, w1, lamda1, &t, &msg);
     if (rc != 0) return rc;
     const gbp::MathCtx M = host_ctx();
-    const double* p_lam = t.soa.data();
-    const double* p_u0r = p_lam + t.npts;
-    const double* p_u0i = p_lam + 2 * (size_t)t.npts;
-    const double* p_cre = p_lam + 3 * (size_t)t.npts;
-    const double* p_cim = p_lam + 4 * (size_t)t.npts;
+    const double* pts = t.soa.data();
     for (int b = 0; b < B; ++b) {
         const int L = nlayers[b];
         const double* sig = sigma + (size_t)b * Lmax;
@@ -63,13 +62,10 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
             const double hD = ch.hd0 - 2.0 * height[b];
             double are = 0.0, aim = 0.0;
             for (int j = ch.off; j < ch.off + ch.npts; ++j) {
-                const double lam = p_lam[j];
-                gbp::cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
-                gbp::cplx coef = gbp::mk(p_cre[j], p_cim[j]);
+                const gbp::Point pt = gbp::load_point(pts, t.npts, j);
                 gbp::cplx num, den;
-                gbp::rte_num_den(M, lam * lam - ch.w2me, L, lay.data(), t2.data(), u0, num, den);
-                gbp::cplx ue = ch.real_exp ? gbp::mk(lam, 0.0) : u0;
-                gbp::cplx term = gbp::hankel_term(M, num, den, ue, hD, coef, ch.real_exp != 0);
+                gbp::rte_num_den(M, pt.a, L, lay.data(), t2.data(), pt.u0, num, den);
+                gbp::cplx term = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
                 are += term.re;
                 aim += term.im;
             }
@@ -93,11 +89,7 @@ int emul_fdem_sens(int nF, const int32_t* tid, const double* frequencies, const 
                                       lamda0, w1, lamda1, &t, &msg);
     if (rc != 0) return rc;
     const gbp::MathCtx M = host_ctx();
-    const double* p_lam = t.soa.data();
-    const double* p_u0r = p_lam + t.npts;
-    const double* p_u0i = p_lam + 2 * (size_t)t.npts;
-    const double* p_cre = p_lam + 3 * (size_t)t.npts;
-    const double* p_cim = p_lam + 4 * (size_t)t.npts;
+    const double* pts = t.soa.data();
     for (int b = 0; b < B; ++b) {
         const int L = nlayers[b];
         const double* sig = sigma + (size_t)b * Lmax;
@@ -116,14 +108,10 @@ int emul_fdem_sens(int nF, const int32_t* tid, const double* frequencies, const 
             }
             const double hD = ch.hd0 - 2.0 * height[b];
             for (int j = ch.off; j < ch.off + ch.npts; ++j) {
-                const double lam = p_lam[j];
-                gbp::cplx u0 = gbp::mk(p_u0r[j], p_u0i[j]);
-                gbp::cplx coef = gbp::mk(p_cre[j], p_cim[j]);
-                gbp::cplx ue = ch.real_exp ? gbp::mk(lam, 0.0) : u0;
-                gbp::cplx E = ch.real_exp ? gbp::mk(gbp::exp_neg(M, ue.re * hD), 0.0)
-                                          : gbp::cexp_neg(M, ue.re * hD, ue.im * hD);
-                if (exact) gbp::sens_point<true>(M, lam * lam - ch.w2me, L, lay.data(), t2.data(), u0, E * coef, D.data(), 1);
-                else gbp::sens_point<false>(M, lam * lam - ch.w2me, L, lay.data(), t2.data(), u0, E * coef, D.data(), 1);
+                const gbp::Point pt = gbp::load_point(pts, t.npts, j);
+                const gbp::cplx E = gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD);
+                if (exact) gbp::sens_point<true>(M, pt.a, L, lay.data(), t2.data(), pt.u0, E * pt.coef, D.data(), 1);
+                else gbp::sens_point<false>(M, pt.a, L, lay.data(), t2.data(), pt.u0, E * pt.coef, D.data(), 1);
                 for (int m = 0; m < L; ++m) acc[m] = acc[m] + D[m];
             }
             for (int m = 0; m < Lmax; ++m) {
