@@ -20,11 +20,13 @@ SIGNATURES = {
     "gbp_last_error": (ctypes.c_char_p, []),
     "gbp_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "gbp_fdem_system_create": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.POINTER(c_void_p)]),
+    "gbp_hankel_system_create_raw": (c_int, [c_int, c_int32_p] + [c_double_p] * 4 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_destroy": (None, [c_void_p]),
     "gbp_fdem_system_nfreq": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "gbp_fdem_system_h0": (c_int, [c_void_p, c_double_p]),
     "gbp_fdem_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_gauss_loglike": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
+    "gbp_gauss_loglike_std": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_fdem_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
     "gbp_fdem_sensitivity": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_fdem_sensitivity_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),

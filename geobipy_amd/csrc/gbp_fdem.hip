@@ -336,6 +336,36 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     }
 }
 
+// chi^2 / logL with an explicit per-channel standard deviation (TdemDataPoint.std is time dependent)
+__global__ void k_gauss_loglike_std(int B, int N, const double* __restrict__ pred, const double* __restrict__ obs,
+                                    const double* __restrict__ sd, double* __restrict__ chi2,
+                                    double* __restrict__ logL)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const double* p = pred + (size_t)b * N;
+    const double* o = obs + (size_t)b * N;
+    const double* s = sd + (size_t)b * N;
+    double s2 = 0.0, logdet = 0.0, na = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const double oi = o[i];
+        if (oi > 0.0) {
+            const double r = (p[i] - oi) * (1.0 / s[i]);
+            s2 += r * r;
+            logdet += 2.0 * log(s[i]);
+            na += 1.0;
+        }
+    }
+    s2 = wave_sum(s2);
+    logdet = wave_sum(logdet);
+    na = wave_sum(na);
+    if (lane == 0) {
+        chi2[b] = s2;
+        logL[b] = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
+    }
+}
+
 __global__ void k_gauss_loglike(int B, int N, const double* __restrict__ pred, const double* __restrict__ obs,
                                 const double* __restrict__ rel, const double* __restrict__ add,
                                 double* __restrict__ chi2, double* __restrict__ logL)
@@ -455,6 +485,46 @@ gbp_status gbp_fdem_system_create(int nF, const int32_t* tid, const double* freq
     return GBP_OK;
 }
 
+gbp_status gbp_hankel_system_create_raw(int nF, const int32_t* npts, const double* wmu, const double* hd0,
+                                        const double* g, const double* tables, gbp_fdem_system** out)
+{
+    if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
+    *out = nullptr;
+    if (nF < 1 || nF > GBP_MAX_FREQ) return fail(GBP_ERR_INVALID_ARG, "nF must be in [1, 128]%s");
+    if (!npts || !wmu || !hd0 || !g || !tables) return fail(GBP_ERR_INVALID_ARG, "NULL system array%s");
+    gbp_fdem_system* s = new (std::nothrow) gbp_fdem_system();
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "out of host memory%s");
+    gbp::SystemTables& t = s->t;
+    t.nF = nF;
+    t.chan.assign(nF, Channel());
+    t.h0.assign(2 * (size_t)nF, 1.0);
+    int P = 0;
+    for (int f = 0; f < nF; ++f) {
+        if (npts[f] < 64 || !(wmu[f] > 0.0) || !std::isfinite(wmu[f])) {
+            delete s;
+            return fail(GBP_ERR_BAD_SYSTEM, "each frequency needs >= 64 points and wmu > 0%s");
+        }
+        Channel& ch = t.chan[f];
+        ch.wmu = wmu[f]; ch.w2me = 0.0; ch.hd0 = hd0[f]; ch.g_re = g[2 * f]; ch.g_im = g[2 * f + 1];
+        ch.off = P; ch.npts = npts[f]; ch.real_exp = 0; ch.tid = 0;
+        if (npts[f] > t.max_pts) t.max_pts = npts[f];
+        P += npts[f];
+    }
+    t.npts = P;
+    t.soa.assign(tables, tables + (size_t)GBP_PT_FIELDS * P);
+    const std::vector<double>& soa = t.soa;
+    hipError_t e = hipMalloc((void**)&s->d_chan, sizeof(Channel) * nF);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_pts, sizeof(double) * soa.size());
+    if (e == hipSuccess) e = hipMemcpy(s->d_chan, s->t.chan.data(), sizeof(Channel) * nF, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_pts, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gbp_fdem_system_destroy(s);
+        return fail(GBP_ERR_HIP, "system table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return GBP_OK;
+}
+
 void gbp_fdem_system_destroy(gbp_fdem_system* sys)
 {
     if (!sys) return;
@@ -502,6 +572,19 @@ gbp_status gbp_gauss_loglike(int B, int N, const double* pred, const double* obs
     const int wpb = 4;
     hipLaunchKernelGGL(k_gauss_loglike, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, B, N,
                        pred, obs, rel, add, chi2, logL);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_gauss_loglike_std(int B, int N, const double* pred, const double* obs, const double* sd, double* chi2,
+                                 double* logL, void* stream)
+{
+    if (B < 0 || N < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and N >= 1%s");
+    if (B == 0) return GBP_OK;
+    if (!pred || !obs || !sd || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    const int wpb = 4;
+    hipLaunchKernelGGL(k_gauss_loglike_std, dim3((B + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, B, N,
+                       pred, obs, sd, chi2, logL);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

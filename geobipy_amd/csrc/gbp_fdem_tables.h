@@ -37,7 +37,7 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
                                const char** msg)
 {
     typedef std::complex<double> zc;
-    if (nF < 1 || nF > GBP_MAX_FREQ) { *msg = "nF must be in [1, 64]"; return GBP_ERR_INVALID_ARG; }
+    if (nF < 1 || nF > GBP_MAX_FREQ) { *msg = "nF must be in [1, 128]"; return GBP_ERR_INVALID_ARG; }
     if (!tid || !frequencies || !tx_z || !rx_z || !tx_moment || !scale || !rx_off || !separation || !w0 ||
         !lamda0 || !w1 || !lamda1) { *msg = "NULL system array"; return GBP_ERR_INVALID_ARG; }
     for (int f = 0; f < nF; ++f) {

@@ -1,0 +1,352 @@
+"""Time-domain EM (TDEM) forward solve on the GPU: ``TdemSystem`` + ``TdemBatch``.
+
+Reference path: ``TdemDataPoint.forward`` (data/datapoint/TdemDataPoint.py:997-1022) ->
+``tdem1dfwd`` / ``gaTdem1dfwd`` (forwardmodelling/Electromagnetic/TD/tdem1d.py:13-37, 89-96) ->
+``gatdaem1d.TDAEMSystem.forwardmodel(Geometry, Earth)``.  The arithmetic lives in GA-AEM's C++ library,
+which is neither vendored nor pinned by the reference and is absent here, so this module RESTATES the
+published pipeline from the ``.stm`` system-file semantics and is pinned only at the reference's CSV
+boundary (tests/golden/skytem_*_clean.csv, tempest_*_clean.csv; see DESIGN.md section 3.7 for the measured
+agreement -- "parity unpinned" in the sense of the project rules):
+
+  1. frequency domain: quasi-static layered-earth response of a horizontal circular loop (or vertical
+     magnetic dipole) transmitter at spline-node frequencies, vertical (J0 filter) and inline horizontal
+     (J1 filter) secondary field at the receiver.  This is the SAME reflection-coefficient recursion and
+     Hankel digital filter as the FDEM path and runs in the same HIP kernel (``k_fdem_forward`` on a handle
+     built by ``gbp_hankel_system_create_raw``).
+  2. time domain: everything after the spline nodes is LINEAR in the nodal values and independent of the
+     sounding -- cubic spline in log-frequency onto the harmonics of the base frequency, multiplication by
+     the spectrum of the digitised (bipolar, periodic) current waveform, by i*omega*mu0 (dB/dt) or mu0 (B)
+     and by the receiver low-pass filters, inverse FFT over one period, window averaging.  It is therefore
+     folded ONCE per system into a dense operator W[2*n_nodes, n_windows] (numpy, host) and applied to the
+     whole batch as one fp64 GEMM on the GPU:  windows[B, n_windows] = nodal[B, 2*n_nodes] @ W.
+
+Conventions recovered from the reference's fixtures: moment = NumberOfTurns * PeakCurrent * LoopArea;
+an order-n ``LowPassFilter`` is n cascaded first-order sections; a waveform table that covers half a period
+is continued with opposite polarity; "dB/dt" output is the receiver voltage convention -dB/dt; the
+reference negates GA-AEM's z components (TdemDataPoint.py:1013-1015), which makes Z positive-up.
+Limitations: level flight (pitch = roll = yaw = 0) and one Tx-Rx offset per batch.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .filters import W0_J0_120, W1_J1_140, base_abscissae
+
+MU0 = 4.0e-7 * np.pi
+
+
+def read_stm(filename):
+    """Parse a GA-AEM ``.stm`` time-domain system file into a dict (blocks are flattened)."""
+    d = {"WaveFormCurrent": [], "WindowTimes": []}
+    mode = None
+    with open(filename) as f:
+        for line in f:
+            s = line.split("//")[0].strip()
+            if not s:
+                continue
+            if "WaveFormCurrent Begin" in s:
+                mode = "WaveFormCurrent"
+            elif "WindowTimes Begin" in s:
+                mode = "WindowTimes"
+            elif s.endswith(" End") or s == "End":
+                mode = None
+            elif mode is not None:
+                d[mode].append([float(x) for x in s.split()])
+            elif "=" in s:
+                k, v = [x.strip() for x in s.split("=", 1)]
+                d[k] = v
+    d["WaveFormCurrent"] = np.asarray(d["WaveFormCurrent"], dtype=np.float64)
+    d["WindowTimes"] = np.asarray(d["WindowTimes"], dtype=np.float64)
+    return d
+
+
+class _Windows:
+    def __init__(self, times):
+        self.start, self.end = times[:, 0].copy(), times[:, 1].copy()
+        self.centre = 0.5 * (self.start + self.end)
+
+
+class _Waveform:
+    def __init__(self, tc):
+        self.transmitterTime, self.transmitterCurrent = tc[:, 0].copy(), tc[:, 1].copy()
+
+
+class TdemSystem:
+    """Time-domain acquisition system read from a ``.stm`` file (mirrors what the reference uses of
+    ``gatdaem1d.TDAEMSystem`` / system/TdemSystem_GAAEM.py: ``windows.centre``, ``nwindows``,
+    ``loopRadius()``, ``waveform``, ``components``, ``off_time``)."""
+
+    def __init__(self, system_filename, nodes_per_decade=8):
+        d = read_stm(system_filename)
+        self.filename = system_filename
+        self.base_frequency = float(d["BaseFrequency"])
+        self.sample_frequency = float(d["WaveformDigitisingFrequency"])
+        self.moment = float(d.get("NumberOfTurns", 1)) * float(d.get("PeakCurrent", 1)) * float(d.get("LoopArea", 1))
+        self.waveform = _Waveform(d["WaveFormCurrent"])
+        self.windows = _Windows(d["WindowTimes"])
+        assert np.min(np.diff(self.windows.centre)) > 0.0, ValueError(
+            "Receiver window times must monotonically increase for system " + system_filename)
+        self.weighting = d.get("WindowWeightingScheme", "Boxcar")
+        fc = [float(x) for x in d.get("CutOffFrequency", "").split()]
+        od = [int(float(x)) for x in d.get("Order", "").split()]
+        self.lowpass = list(zip(fc, od))
+        self._loop_radius = float(d.get("ModellingLoopRadius", 0.0))
+        self.output_type = d.get("OutputType", "dB/dt").strip()
+        self.scaling = {c: float(d.get(c.upper() + "OutputScaling", 0.0)) for c in "xyz"}
+        self._components = [c for c in "xyz" if self.scaling[c] != 0.0]
+        assert "y" not in self._components, NotImplementedError("Y component output is not supported")
+        self.nodes_per_decade = nodes_per_decade
+        self.off_time = self.windows.centre
+        self._op = None
+
+    # -- gatdaem1d-like accessors --------------------------------------------------------------------
+    @property
+    def nwindows(self):
+        return self.windows.centre.size
+
+    def loopRadius(self):
+        return self._loop_radius
+
+    @property
+    def components(self):
+        return self._components
+
+    @property
+    def n_components(self):
+        return len(self._components)
+
+    @property
+    def isGA(self):
+        return True
+
+    # -- frequency nodes and the linear time-domain operator ---------------------------------------------
+    @property
+    def n_samples(self):
+        return int(round(self.sample_frequency / self.base_frequency))
+
+    def node_frequencies(self):
+        """Spline nodes: log-spaced from half the base frequency (keeps the spline end condition away from the
+        first harmonic) to just above Nyquist."""
+        lo, hi = np.log10(0.5 * self.base_frequency), np.log10(1.1 * 0.5 * self.sample_frequency)
+        n = int(np.ceil((hi - lo) * self.nodes_per_decade)) + 1
+        return 10.0 ** np.linspace(lo, hi, n)
+
+    def digitised_current(self):
+        """One period of the transmitter current sampled at the digitising frequency; a table that spans
+        half a period is continued with opposite polarity."""
+        N = self.n_samples
+        wt, wc = self.waveform.transmitterTime, self.waveform.transmitterCurrent
+        t = wt[0] + np.arange(N) / self.sample_frequency
+        T = 1.0 / self.base_frequency
+        if abs((wt[-1] - wt[0]) - 0.5 * T) <= 2.0 / self.sample_frequency:
+            half = N // 2
+            c = np.interp(t[:half], wt, wc)
+            cur = np.concatenate([c, -c, np.zeros(N - 2 * half)])
+        else:
+            cur = np.interp(t, wt, wc)
+        return t, cur
+
+    def window_matrix(self, t):
+        """A[n_windows, N]: window value = A @ time series (area under the linear interpolant / width, or
+        boxcar mean of the samples inside the window)."""
+        N = t.size
+        dt = 1.0 / self.sample_frequency
+        A = np.zeros((self.nwindows, N))
+        for w, (a, b) in enumerate(zip(self.windows.start, self.windows.end)):
+            if self.weighting.lower().startswith("area"):
+                q = np.linspace(a, b, 257)                      # trapezoid over the linear interpolant
+                wq = np.full(q.size, (b - a) / (q.size - 1))
+                wq[0] *= 0.5
+                wq[-1] *= 0.5
+                pos = (q - t[0]) / dt
+                i0 = np.clip(np.floor(pos).astype(int), 0, N - 2)
+                fr = pos - i0
+                np.add.at(A[w], i0, wq * (1.0 - fr) / (b - a))
+                np.add.at(A[w], i0 + 1, wq * fr / (b - a))
+            else:
+                m = (t >= a) & (t <= b)
+                A[w, m] = 1.0 / m.sum()
+        return A
+
+    def time_operator(self):
+        """W[2*n_nodes, n_windows] with windows = [Re(nodal), Im(nodal)] @ W, for nodal = mu0-free
+        secondary field H(f_node) per unit moment; includes moment, mu0, i*omega (dB/dt -> -dB/dt),
+        low-pass filters, waveform spectrum, inverse FFT and window averaging."""
+        if self._op is not None:
+            return self._op
+        from scipy.interpolate import CubicSpline
+        fn = self.node_frequencies()
+        n = fn.size
+        N = self.n_samples
+        t, cur = self.digitised_current()
+        I = np.fft.rfft(cur)
+        fk = np.arange(N // 2 + 1) * self.base_frequency
+        S = np.zeros((fk.size, n))
+        S[1:] = CubicSpline(np.log(fn), np.eye(n), bc_type="natural")(np.log(np.clip(fk[1:], fn[0], fn[-1])))
+        fac = np.full(fk.size, MU0 * self.moment, dtype=complex)
+        if self.output_type.lower().startswith("db"):
+            fac = fac * (-1j * 2.0 * np.pi * fk)                 # receiver voltage convention: -dB/dt
+        for fc, order in self.lowpass:
+            fac = fac * (1.0 / (1.0 + 1j * fk / fc)) ** order
+        fac[0] = 0.0
+        A = self.window_matrix(t)
+        G = (I * fac)[:, None] * S                                  # spectrum of the response to unit Re nodes
+        W = np.empty((2 * n, self.nwindows))
+        W[:n] = (A @ np.fft.irfft(G, N, axis=0)).T
+        W[n:] = (A @ np.fft.irfft(1j * G, N, axis=0)).T
+        self._op = W
+        return W
+
+    # -- Hankel tables of the frequency-domain stage ------------------------------------------------------
+    def hankel_tables(self, dx, dy, dz):
+        """Raw point tables for gbp_hankel_system_create_raw, one "frequency" per (component, node).
+
+        Vertical field of a horizontal loop of radius a carrying the current of a unit-moment dipole, at
+        horizontal distance r and total height (z_tx + z_rx) = 2*altitude + dz:
+            Hz = 1/(2 pi a) Int rTE e^{-lam (2 alt + dz)} lam J1(lam a) J0(lam r) dlam      (a -> 0: lam^2/4pi)
+            Hx = -(dx/r) * same with J1(lam r)
+        """
+        from scipy.special import j1
+        r = float(np.hypot(dx, dy))
+        a = self._loop_radius
+        rs = r if r > 0.0 else (a if a > 0.0 else 1.0)           # abscissa scale when the receiver is on the axis
+        l0, l1 = base_abscissae()
+        fn = self.node_frequencies()
+        npts, wmu, hd0, g, cols = [], [], [], [], []
+        for comp in self._components:
+            if comp == "z":
+                lam, w = l0 / rs, W0_J0_120 / rs
+                if r == 0.0:                                       # J0(0) = 1: plain integral via the filter at scale rs
+                    raise NotImplementedError("coincident-axis receiver needs r > 0")
+            else:
+                lam, w = l1 / rs, W1_J1_140 / rs * (-dx / r)
+            src = lam * j1(lam * a) / (2.0 * np.pi * a) if a > 0.0 else lam * lam / (4.0 * np.pi)
+            coef = src * w * self.scaling[comp]
+            for f in fn:
+                npts.append(lam.size)
+                wmu.append(2.0 * np.pi * f * MU0)
+                hd0.append(-dz)
+                g.extend([1.0, 0.0])
+                z = np.zeros_like(lam)
+                cols.append(np.stack([lam * lam, lam, z, coef, z, lam, z]))   # a, u0, coef, ue
+        tables = np.concatenate(cols, axis=1)                      # [7, P]
+        return (np.asarray(npts, np.int32), np.asarray(wmu), np.asarray(hd0), np.asarray(g),
+                np.ascontiguousarray(tables))
+
+    def primary_field(self, dx, dy, dz):
+        """Free-space dipole field at the receiver in the output units (x, then z with the reference's
+        negated-z convention), e.g. Tempest PX / PZ."""
+        R = np.sqrt(dx * dx + dy * dy + dz * dz)
+        k = MU0 * self.moment / (4.0 * np.pi)
+        bx = k * 3.0 * dx * dz / R ** 5 * self.scaling["x"]
+        bz = -k * (3.0 * dz * dz / R ** 5 - 1.0 / R ** 3) * self.scaling["z"]
+        return bx, bz
+
+
+class _RawHandle:
+    def __init__(self, npts, wmu, hd0, g, tables):
+        lib = _lib.load()
+        self._lib = lib
+        h = ctypes.c_void_p()
+        dp = lambda x: x.ctypes.data_as(_lib.c_double_p)
+        self._keep = (npts, wmu, hd0, g, tables)
+        _lib.check(lib.gbp_hankel_system_create_raw(int(npts.size), npts.ctypes.data_as(_lib.c_int32_p), dp(wmu),
+                                                    dp(hd0), dp(g), dp(tables), ctypes.byref(h)))
+        self.ptr = h
+        self.nF = int(npts.size)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._lib.gbp_fdem_system_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class TdemBatch:
+    """B TDEM soundings on one GPU, all systems of a (multi-moment) acquisition in one object.
+
+    ``systems``: list of TdemSystem (e.g. SkyTEM high and low moment); ``offset`` = (dx, dy, dz) of the
+    receiver relative to the transmitter (Loop_pair, system/Loop_pair.py:63-77), shared by the batch.
+    Channel layout of ``predicted``: system 0 components x then z, each over its windows, then system 1 ...
+    (the reference's ``predicted_secondary_field`` layout).
+    """
+
+    def __init__(self, systems, nlayers, sigma, thk, height, offset, data=None, relative_error=None,
+                 additive_error=None, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.NativeLibraryError("TdemBatch needs a HIP device; there is no CPU fallback")
+        self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.offset = tuple(float(v) for v in offset)
+        dev = lambda a, dt=torch.float64: torch.as_tensor(np.asarray(a), dtype=dt).to(self.device).contiguous()
+        self.sigma, self.thk = dev(sigma), dev(thk)
+        self.B, self.Lmax = self.sigma.shape
+        self.nlayers = dev(np.broadcast_to(np.asarray(nlayers), (self.B,)), torch.int32)
+        self.height = dev(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,)))
+        self._h, self._W, self._nodal = [], [], []
+        with torch.cuda.device(self.device):
+            for s in self.systems:
+                h = _RawHandle(*s.hankel_tables(*self.offset))
+                self._h.append(h)
+                n = s.node_frequencies().size
+                W = s.time_operator()
+                # block-diagonal over components: nodal layout is [Re(comp0 nodes), Re(comp1 nodes), Im(...), Im(...)]
+                nc = s.n_components
+                Wb = np.zeros((2 * nc * n, nc * s.nwindows))
+                for c in range(nc):
+                    Wb[c * n:(c + 1) * n, c * s.nwindows:(c + 1) * s.nwindows] = W[:n]
+                    Wb[nc * n + c * n: nc * n + (c + 1) * n, c * s.nwindows:(c + 1) * s.nwindows] = W[n:]
+                self._W.append(dev(Wb))
+                self._nodal.append(torch.empty((self.B, 2 * nc * n), dtype=torch.float64, device=self.device))
+        self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
+        self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
+        self.data = None if data is None else dev(data)
+        self.relative_error = None if relative_error is None else dev(relative_error)
+        self.additive_error = None if additive_error is None else dev(additive_error)
+        self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
+
+    def forward(self):
+        """predicted[B, nChannels]: frequency-domain HIP kernel per system, then one fp64 GEMM per system."""
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        col = 0
+        with torch.cuda.device(self.device):
+            for s, h, W, nodal in zip(self.systems, self._h, self._W, self._nodal):
+                _lib.check(lib.gbp_fdem_forward(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
+                                                nodal.data_ptr(), stream))
+                n = W.shape[1]
+                torch.matmul(nodal, W, out=self.predicted[:, col:col + n])
+                col += n
+        return self.predicted
+
+    def std(self):
+        """TdemDataPoint.std (data/datapoint/TdemDataPoint.py:361-365):
+        sigma_i^2 = (rel_sys * d_i)^2 + (add_sys * sqrt(1e-3 / t_i))^2, rel/add one value per system."""
+        out = torch.empty_like(self.data)
+        col = 0
+        for i, s in enumerate(self.systems):
+            n = s.n_components * s.nwindows
+            t = torch.as_tensor(np.tile(s.off_time, s.n_components), dtype=torch.float64, device=self.device)
+            rel = self.relative_error[:, i:i + 1]
+            add = self.additive_error[:, i:i + 1]
+            out[:, col:col + n] = torch.sqrt((rel * self.data[:, col:col + n]) ** 2 + (add * torch.sqrt(1e-3 / t)) ** 2)
+            col += n
+        return out
+
+    def forward_loglike(self):
+        """forward + chi^2 + log-likelihood (DataPoint.data_misfit / likelihood with the TDEM error model)."""
+        self.forward()
+        sd = self.std()
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.gbp_gauss_loglike_std(self.B, self.nChannels, self.predicted.data_ptr(),
+                                                 self.data.data_ptr(), sd.data_ptr(), self.chi2.data_ptr(),
+                                                 self.logL.data_ptr(),
+                                                 torch.cuda.current_stream(self.device).cuda_stream))
+        return self.chi2, self.logL

@@ -41,7 +41,7 @@ enum {
     GBP_ERR_NO_DEVICE = -5      /* no gfx950 device visible                                           */
 };
 
-#define GBP_MAX_FREQ 64   /* frequencies per system */
+#define GBP_MAX_FREQ 128  /* frequencies per system (TDEM: components x spline nodes) */
 #define GBP_NC0 120       /* J0 filter length  (fdem1d_numba.py:18) */
 #define GBP_NC1 140       /* J1 filter length  (fdem1d_numba.py:19) */
 
@@ -69,6 +69,19 @@ gbp_status gbp_fdem_system_create(int nF, const int32_t *tid, const double *freq
                                   const double *scale, const double *rx_off, const double *separation,
                                   const double *w0, const double *lamda0, const double *w1,
                                   const double *lamda1, gbp_fdem_system **out);
+/*
+ * Generic Hankel-kernel system from caller-built tables (used by the TDEM path, whose frequency-domain
+ * stage is the same layered-earth recursion at quasi-static spline-node frequencies; replaces the
+ * frequency-domain part of gatdaem1d's forwardmodel, call site TD/tdem1d.py:89-96).  All [host]:
+ *   npts[nF]      abscissa points of each frequency (>= 64)
+ *   wmu[nF]       omega * mu0;  hd0[nF]: exponent height offset, hDiff = hd0 - 2 * altitude
+ *   g[2 nF]       complex output scale per frequency (re, im)
+ *   tables        7 arrays of P = sum(npts) doubles: a = lambda^2 | u0.re | u0.im | coef.re | coef.im |
+ *                 ue.re | ue.im   (term = rTE * exp(ue * hDiff) * coef, summed per frequency)
+ * The resulting handle is used with gbp_fdem_forward: pred[b] = [Re(out_f), Im(out_f)].
+ */
+gbp_status gbp_hankel_system_create_raw(int nF, const int32_t *npts, const double *wmu, const double *hd0,
+                                        const double *g, const double *tables, gbp_fdem_system **out);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);
 gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system *sys, int *nF);
 /* free-space field H0 per frequency as (re, im) pairs, [host] out[2*nF] (fdem1d_numba.py:68 denominator) */
@@ -97,6 +110,11 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system *sys, int B, int Lmax, const i
  */
 gbp_status gbp_gauss_loglike(int B, int N, const double *pred, const double *obs, const double *rel,
                              const double *add, double *chi2, double *logL, void *stream);
+
+/* Same with an explicit standard deviation per channel, sd [dev] f64[B, N] (TdemDataPoint.std,
+ * data/datapoint/TdemDataPoint.py:329-376, is time-gate dependent). */
+gbp_status gbp_gauss_loglike_std(int B, int N, const double *pred, const double *obs, const double *sd,
+                                 double *chi2, double *logL, void *stream);
 
 /*
  * Fused forward + misfit + log-likelihood (one launch; what Inference1D.accept_reject evaluates at

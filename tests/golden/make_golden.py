@@ -7,6 +7,8 @@ Runs only in the build container (needs /root/reference; never on the GPU box):
 
 What it writes (data only -- inputs and the reference's outputs):
   * resolve.stm, syn10.stm, mixed.stm      system description files (.stm CSV rows)
+  * SkytemHM/LM.stm, tempest.stm,          TDEM system files and the reference's TDEM known-answer files
+    skytem_/tempest_<type>_clean.csv        (gatdaem1d outputs; the only pin the TDEM path has)
   * resolve_<type>_clean.csv (x6)          copies of the reference's own known-answer files
                                            /root/reference/tests/data_checks/ (test_synthetic_data.py:16-30)
   * fdem_golden.npz                        seeded random soundings per (system, nLayers):
@@ -94,6 +96,12 @@ def main():
 
     # --- data files --------------------------------------------------------------------------
     shutil.copyfile(SUP + "/resolve.stm", HERE + "/resolve.stm")
+    for f in ["SkytemHM.stm", "SkytemLM.stm", "tempest.stm"]:          # TDEM system files (GA-AEM .stm format)
+        shutil.copyfile(SUP + "/" + f, HERE + "/" + f)
+    for t in ["glacial", "saline_clay", "resistive_dolomites", "resistive_basement", "coastal_salt_water",
+              "ice_over_salt_water"]:                                   # TDEM known answers (test_synthetic_data.py:32-65)
+        for fam in ["skytem", "tempest"]:
+            shutil.copyfile(REF + f"/tests/data_checks/{fam}_{t}_clean.csv", HERE + f"/{fam}_{t}_clean.csv")
     for t in ["glacial", "saline_clay", "resistive_dolomites", "resistive_basement", "coastal_salt_water",
               "ice_over_salt_water"]:
         shutil.copyfile(REF + f"/tests/data_checks/resolve_{t}_clean.csv", HERE + f"/resolve_{t}_clean.csv")
