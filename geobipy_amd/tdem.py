@@ -282,7 +282,7 @@ class TdemBatch:
         self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.offset = tuple(float(v) for v in offset)
-        dev = lambda a, dt=torch.float64: torch.as_tensor(np.asarray(a), dtype=dt).to(self.device).contiguous()
+        dev = lambda a, dt=torch.float64: torch.as_tensor(np.array(a), dtype=dt).to(self.device).contiguous()
         self.sigma, self.thk = dev(sigma), dev(thk)
         self.B, self.Lmax = self.sigma.shape
         self.nlayers = dev(np.broadcast_to(np.asarray(nlayers), (self.B,)), torch.int32)
