@@ -120,13 +120,15 @@ def test_gpu_tdem_likelihood_and_config4_shape():
     nl, sig, thk, h = synthetic.draw_models(B, L, seed=4)
     systems = [TdemSystem(os.path.join(GOLDEN, "SkytemHM.stm")), TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))]
     clean = TdemBatch(systems, nl, sig, thk, h, SKYTEM_OFFSET).forward().clone()
-    assert clean.shape == (B, 45) and torch.isfinite(clean).all() and bool((clean > 0).all())
+    assert clean.shape == (B, 45) and torch.isfinite(clean).all()
+    assert float((clean > 0).double().mean()) > 0.99       # an offset receiver can see sign reversals at early gates
     rel, add = np.full((B, 2), 0.03), np.tile([1e-15, 1e-14], (B, 1))
     b = TdemBatch(systems, nl, sig, thk, h, SKYTEM_OFFSET, data=clean.cpu().numpy() * 1.02, relative_error=rel,
                   additive_error=add)
     c2, ll = b.forward_loglike()
     sd = b.std().cpu().numpy()
     d = clean.cpu().numpy()
-    c_ref = np.sum(((d - 1.02 * d) / sd) ** 2, axis=1)
-    l_ref = -0.5 * 45 * np.log(2 * np.pi) - np.sum(np.log(sd), axis=1) - 0.5 * c_ref
+    act = 1.02 * d > 0                                      # EmDataPoint.active: only positive data count
+    c_ref = np.sum(np.where(act, ((d - 1.02 * d) / sd) ** 2, 0.0), axis=1)
+    l_ref = -0.5 * act.sum(axis=1) * np.log(2 * np.pi) - np.sum(np.where(act, np.log(sd), 0.0), axis=1) - 0.5 * c_ref
     assert np.allclose(c2.cpu().numpy(), c_ref, rtol=1e-9) and np.allclose(ll.cpu().numpy(), l_ref, rtol=1e-9)
