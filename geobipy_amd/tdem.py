@@ -350,3 +350,113 @@ class TdemBatch:
                                                  self.logL.data_ptr(),
                                                  torch.cuda.current_stream(self.device).cuda_stream))
         return self.chi2, self.logL
+
+
+class TdemDataPoint:
+    """Per-sounding TDEM interface mirroring the hot-path members of the reference's ``TdemDataPoint``
+    (data/datapoint/TdemDataPoint.py): ``forward`` (:997-1022), ``std`` (:329-376), ``active``, ``deltaD``,
+    ``data_misfit`` and ``likelihood`` (DataPoint.py:491-525).  ``system`` is a list of TdemSystem (or .stm
+    paths); the receiver offset comes from the loop pair (``receiver - transmitter``).  Every evaluation is a
+    B = 1 launch of the batched GPU path."""
+
+    def __init__(self, x=0.0, y=0.0, z=0.0, elevation=0.0, data=None, std=None, predictedData=None, system=None,
+                 transmitter_loop=None, receiver_loop=None, lineNumber=0.0, fiducial=0.0):
+        if isinstance(system, (str, TdemSystem)):
+            system = [system]
+        self.system = [TdemSystem(s) if isinstance(s, str) else s for s in system]
+        self.x, self.y, self.elevation = np.float64(x), np.float64(y), np.float64(elevation)
+        self.z = np.atleast_1d(np.asarray(z, dtype=np.float64)).copy()
+        self.lineNumber, self.fiducial = lineNumber, fiducial
+        tx, rx = transmitter_loop, receiver_loop
+        self.offset = (float(rx.x[0] - tx.x[0]), float(rx.y[0] - tx.y[0]), float(rx.z[0] - tx.z[0]))
+        assert all(float(v[0]) == 0.0 for lp in (tx, rx) for v in (lp.pitch, lp.roll, lp.yaw)), \
+            NotImplementedError("only level flight (pitch = roll = yaw = 0) is supported")
+        n = self.nChannels
+        self._data = np.zeros(n) if data is None else np.asarray(data, dtype=np.float64).copy()
+        self._predictedData = np.zeros(n) if predictedData is None else np.asarray(predictedData, np.float64).copy()
+        self._relative_error = np.full(self.nSystems, 0.01)
+        self._additive_error = np.zeros(self.nSystems)
+        self.units = r"$\\frac{V}{m^{2}}$"
+
+    @property
+    def nSystems(self):
+        return len(self.system)
+
+    @property
+    def nChannels(self):
+        return int(sum(s.n_components * s.nwindows for s in self.system))
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def predictedData(self):
+        return self._predictedData
+
+    predicted_secondary_field = predictedData
+
+    @property
+    def relative_error(self):
+        return self._relative_error
+
+    @relative_error.setter
+    def relative_error(self, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        assert v.size == self.nSystems and np.all(v > 0.0), ValueError("relative_error must be > 0, one per system")
+        self._relative_error = v.copy()
+
+    @property
+    def additive_error(self):
+        return self._additive_error
+
+    @additive_error.setter
+    def additive_error(self, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        assert v.size == self.nSystems, ValueError("additive_error must have one value per system")
+        self._additive_error = v.copy()
+
+    @property
+    def active(self):
+        d = self._data.copy()
+        d[d <= 0.0] = np.nan
+        return ~np.isnan(d)
+
+    @property
+    def deltaD(self):
+        return self._predictedData - self._data
+
+    def _batch(self, mod=None):
+        if mod is None:
+            L, sig, thk = 1, np.ones((1, 1)), np.zeros((1, 1))
+        else:
+            assert np.isinf(mod.mesh.edges[-1]), ValueError("mod.edges must have last entry be infinity")
+            L = int(mod.mesh.nCells)
+            thk = np.array(mod.mesh.widths, dtype=np.float64)[None, :]
+            thk[0, -1] = 0.0
+            sig = np.asarray(mod.values, dtype=np.float64)[None, :]
+        return TdemBatch(self.system, np.array([L]), sig, thk, self.z[:1], self.offset, data=self._data[None, :],
+                         relative_error=self._relative_error[None, :], additive_error=self._additive_error[None, :])
+
+    @property
+    def std(self):
+        return self._batch().std().cpu().numpy()[0]
+
+    def forward(self, mod):
+        self._predictedData[:] = self._batch(mod).forward().cpu().numpy()[0]
+
+    def _loglike(self):
+        b = self._batch()
+        b.predicted.copy_(torch.as_tensor(self._predictedData[None, :]))
+        sd = b.std()
+        _lib.check(_lib.load().gbp_gauss_loglike_std(1, self.nChannels, b.predicted.data_ptr(), b.data.data_ptr(),
+                                                     sd.data_ptr(), b.chi2.data_ptr(), b.logL.data_ptr(),
+                                                     torch.cuda.current_stream(b.device).cuda_stream))
+        return float(b.chi2.cpu()[0]), float(b.logL.cpu()[0])
+
+    def data_misfit(self):
+        return np.float64(self._loglike()[0])
+
+    def likelihood(self, log):
+        ll = self._loglike()[1]
+        return np.float64(ll) if log else np.float64(np.exp(ll))
