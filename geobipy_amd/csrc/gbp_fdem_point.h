@@ -147,12 +147,14 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
             br = br + d * epm + (u2 * (ep * ep)) * 2.0;
         const cplx W = cdiv(mk(0.0, lk.bc * RSQRT2), u) * (br * inv2);
         const cplx acc = ((u2 * e) * inv2) * 4.0;
+#pragma unroll 4
         for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * acc;
         D[k * stride] = W;
         Y = (u * Nn) * inv;
     }
     const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
     const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
+#pragma unroll 4
     for (int m = 0; m < L; ++m) D[m * stride] = D[m * stride] * QQ;
 }
 
