@@ -2,7 +2,7 @@
 
 Soundings are independent (the reference farms them one per MPI rank,
 inversion/Inference3D.py:518-635), so the only exchange is ONE gather of the per-sounding
-summaries (chi^2, logL: 16 B per sounding) to rank 0.  One process per GPU, ``torch.distributed``
+summaries (chi^2, logL: 16 B per sounding), assembled on rank 0.  One process per GPU, ``torch.distributed``
 (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).  Blocks follow the reference's
 own rule ``loadBalance1D_shrinkingArrays`` (base/MPI.py:172-201).
 """
@@ -28,7 +28,8 @@ def shard(N, rank=None, world=None):
 
 
 class SummaryGather:
-    """Gathers [rows_local, C] fp64 summaries of every rank into one [N, C] tensor on rank 0.
+    """Gathers [rows_local, C] fp64 summaries of every rank into one [N, C] tensor on rank 0 (one
+    ``all_gather_into_tensor`` per round).
 
     Blocks may differ by one row, so every rank contributes a block padded to the largest size and
     rank 0 strips the padding; buffers are allocated once.  ``launch`` enqueues the collective on the
@@ -43,8 +44,10 @@ class SummaryGather:
         self.starts, self.sizes = partition(N, self.world)
         self.pad = int(self.sizes.max())
         self.send = torch.zeros((self.pad, C), dtype=torch.float64, device=device)
-        self.recv = [torch.empty((self.pad, C), dtype=torch.float64, device=device) for _ in range(self.world)] \
-            if (self.rank == 0 and self.world > 1) else None
+        # all_gather_into_tensor is the one collective every backend implements natively (RCCL ring /
+        # direct all-gather over xGMI); the 16 B/sounding payload makes the extra copies on ranks != 0 free
+        self.recv = torch.empty((self.world * self.pad, C), dtype=torch.float64, device=device) \
+            if self.world > 1 else None
         self.out = torch.empty((N, C), dtype=torch.float64, device=device) if self.rank == 0 else None
 
     def launch(self, *columns):
@@ -55,7 +58,7 @@ class SummaryGather:
         if self.world == 1:
             self.out[:n].copy_(self.send[:n])
             return None
-        return dist.gather(self.send, self.recv, dst=0, group=self.group, async_op=True)
+        return dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
 
     def finish(self, work=None):
         """Wait for the collective and assemble the [N, C] result on rank 0 (None elsewhere)."""
@@ -66,5 +69,5 @@ class SummaryGather:
         if self.world > 1:
             for r in range(self.world):
                 s, n = int(self.starts[r]), int(self.sizes[r])
-                self.out[s:s + n].copy_(self.recv[r][:n])
+                self.out[s:s + n].copy_(self.recv[r * self.pad: r * self.pad + n])
         return self.out
