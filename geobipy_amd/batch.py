@@ -39,7 +39,7 @@ class FdemBatch:
     """
 
     def __init__(self, system, nlayers, sigma, thk, height, data=None, relative_error=None, additive_error=None,
-                 device=None):
+                 device=None, hankel_eps_ppm=0.0):
         if not torch.cuda.is_available():
             raise _lib.NativeLibraryError("FdemBatch needs a HIP device (torch.cuda.is_available() is False); "
                                           "there is no CPU fallback")
@@ -47,7 +47,9 @@ class FdemBatch:
         self.system = system
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
-            self._h = system.handle()
+            self._h_exact = system.handle()
+        self._h = self._h_exact
+        self.hankel_eps_ppm = float(hankel_eps_ppm)
         self.F = system.nFrequencies
         self.sigma = _dev_f64(sigma, self.device)
         assert self.sigma.dim() == 2, ValueError("sigma must have shape [B, Lmax]")
@@ -60,6 +62,10 @@ class FdemBatch:
         self.nlayers = nl.to(device=self.device, dtype=torch.int32).contiguous()
         assert self.nlayers.numel() == self.B
         self.height = _dev_f64(height, self.device, (self.B,))
+        if self.hankel_eps_ppm > 0.0 and self.B > 0:
+            # opt-in accuracy-budgeted abscissa window: the altitude floor of THIS batch (one sync, at construction)
+            with torch.cuda.device(self.device):
+                self._h = system.handle(self.hankel_eps_ppm, float(self.height.min().item()))
         self.data = None if data is None else _dev_f64(data, self.device)
         if self.data is not None:
             assert tuple(self.data.shape) == (self.B, 2 * self.F), ValueError("data must have shape [B, 2F]")
@@ -129,7 +135,7 @@ class FdemBatch:
             max_layers = self._max_layers
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h_exact.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
                                                    self.sigma.data_ptr(), self.thk.data_ptr(),
                                                    self.height.data_ptr(), out.data_ptr(), int(max_layers),
                                                    1 if exact else 0, _stream_ptr(self.device)))

@@ -463,6 +463,16 @@ gbp_status gbp_fdem_system_create(int nF, const int32_t* tid, const double* freq
                                   const double* lamda0, const double* w1, const double* lamda1,
                                   gbp_fdem_system** out)
 {
+    return gbp_fdem_system_create_windowed(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
+                                           lamda0, w1, lamda1, 0.0, 0.0, out);
+}
+
+gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
+                                           const double* rx_z, const double* tx_moment, const double* scale,
+                                           const double* rx_off, const double* separation, const double* w0,
+                                           const double* lamda0, const double* w1, const double* lamda1,
+                                           double eps_ppm, double min_altitude, gbp_fdem_system** out)
+{
     if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
     *out = nullptr;
     gbp_fdem_system* s = new (std::nothrow) gbp_fdem_system();
@@ -471,6 +481,8 @@ gbp_status gbp_fdem_system_create(int nF, const int32_t* tid, const double* freq
     int rc = gbp::build_system_tables(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
                                       lamda0, w1, lamda1, &s->t, &msg);
     if (rc != GBP_OK) { delete s; return fail(rc, "%s", msg); }
+    if (eps_ppm > 0.0 && !(min_altitude >= 0.0)) { delete s; return fail(GBP_ERR_INVALID_ARG, "min_altitude must be >= 0%s"); }
+    gbp::window_system_tables(&s->t, eps_ppm, min_altitude);
     const std::vector<double>& soa = s->t.soa;
 
     hipError_t e = hipMalloc((void**)&s->d_chan, sizeof(Channel) * nF);
@@ -531,6 +543,13 @@ void gbp_fdem_system_destroy(gbp_fdem_system* sys)
     if (sys->d_chan) (void)hipFree(sys->d_chan);
     if (sys->d_pts) (void)hipFree(sys->d_pts);
     delete sys;
+}
+
+gbp_status gbp_fdem_system_npoints(const gbp_fdem_system* sys, int* npts)
+{
+    if (!sys || !npts) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    *npts = sys->t.npts;
+    return GBP_OK;
 }
 
 gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system* sys, int* nF)

@@ -13,6 +13,7 @@
 // and per frequency the free-space field H0 (FD:68 denominator), accumulated sequentially in the
 // reference's order, folded into g = 1e6 * scale / H0.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <vector>
@@ -132,6 +133,54 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
     s->soa.reserve(GBP_PT_FIELDS * pa.size());
     for (const std::vector<double>* v : {&pa, &u0r, &u0i, &cre, &cim, &uer, &uei}) s->soa.insert(s->soa.end(), v->begin(), v->end());
     return GBP_OK;
+}
+
+// Accuracy-budgeted abscissa window.  |rTE| <= 1 for a passive layered earth (checked numerically over
+// 2000 random models in the design notes), so abscissa j of frequency f contributes at most
+//   T_j = |g_f| * |coef_j| * exp(Re(ue_j) * hDiff)   [ppm],   hDiff <= hd0_f - 2 * min_altitude
+// to the output.  Dropping a prefix (small lambda: coef ~ lambda^2 w -> 0) and a suffix (large lambda:
+// exp(-2 z lambda) -> 0) of each frequency's abscissae whose bounds sum to <= eps_ppm/2 each changes no output
+// by more than eps_ppm.  At eps = 1e-12 ppm (1e-5 of the parity tolerance, 5000x below the reference's own
+// arithmetic noise) roughly half of the 120 abscissae go.  At least 64 points per frequency are kept so that
+// a 64-lane pass never spans more than two frequencies.  eps_ppm <= 0 leaves the tables untouched.
+inline void window_system_tables(SystemTables* s, double eps_ppm, double min_altitude)
+{
+    if (!(eps_ppm > 0.0)) return;
+    const int P = s->npts;
+    std::vector<std::vector<double>> cols(GBP_PT_FIELDS);
+    std::vector<Channel> chan = s->chan;
+    int newP = 0, max_pts = 0;
+    for (int f = 0; f < s->nF; ++f) {
+        const Channel& ch = s->chan[f];
+        const double hD = ch.hd0 - 2.0 * min_altitude;
+        const double gabs = std::hypot(ch.g_re, ch.g_im);
+        std::vector<double> T(ch.npts);
+        for (int j = 0; j < ch.npts; ++j) {
+            const int q = ch.off + j;
+            const double cabs = std::hypot(s->soa[3 * (size_t)P + q], s->soa[4 * (size_t)P + q]);
+            T[j] = gabs * cabs * std::exp(s->soa[5 * (size_t)P + q] * std::min(hD, 0.0));
+        }
+        int lo = 0, hi = ch.npts;
+        double acc = 0.0;
+        while (lo < hi && acc + T[lo] <= 0.5 * eps_ppm) acc += T[lo++];
+        acc = 0.0;
+        while (hi > lo && acc + T[hi - 1] <= 0.5 * eps_ppm) acc += T[--hi];
+        while (hi - lo < 64 && (lo > 0 || hi < ch.npts)) {   // keep >= 64 points: re-admit the larger neighbour
+            if (lo > 0 && (hi >= ch.npts || T[lo - 1] >= T[hi])) --lo; else ++hi;
+        }
+        chan[f].off = newP;
+        chan[f].npts = hi - lo;
+        newP += hi - lo;
+        if (hi - lo > max_pts) max_pts = hi - lo;
+        for (int k = 0; k < GBP_PT_FIELDS; ++k)
+            cols[k].insert(cols[k].end(), s->soa.begin() + (size_t)k * P + ch.off + lo,
+                           s->soa.begin() + (size_t)k * P + ch.off + hi);
+    }
+    s->chan = chan;
+    s->npts = newP;
+    s->max_pts = max_pts;
+    s->soa.clear();
+    for (int k = 0; k < GBP_PT_FIELDS; ++k) s->soa.insert(s->soa.end(), cols[k].begin(), cols[k].end());
 }
 
 }  // namespace gbp

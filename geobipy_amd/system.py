@@ -163,29 +163,46 @@ class FdemSystem:
             separation=f64(self.loop_separation), w0=f64(self.w0), lamda0=f64(lam0), w1=f64(self.w1),
             lamda1=f64(lam1))
 
-    def handle(self):
-        """Opaque gbp_fdem_system* on the current HIP device (tables uploaded once, then cached)."""
-        if self._handle is None:
-            self._handle = NativeSystem(self.native_args())
-        return self._handle
+    def handle(self, eps_ppm=0.0, min_altitude=0.0):
+        """Opaque gbp_fdem_system* on the current HIP device (tables uploaded once, then cached).
+
+        ``eps_ppm > 0`` selects the accuracy-budgeted abscissa window (see gbp_fdem_system_create_windowed):
+        valid for soundings at altitude >= ``min_altitude``; handles are cached per (eps, altitude floor)."""
+        if not eps_ppm > 0.0:
+            if self._handle is None:
+                self._handle = NativeSystem(self.native_args())
+            return self._handle
+        key = (float(eps_ppm), float(np.floor(min_altitude)))      # 1 m altitude bins keep the cache small
+        if not hasattr(self, "_windowed"):
+            self._windowed = {}
+        if key not in self._windowed:
+            self._windowed[key] = NativeSystem(self.native_args(), eps_ppm=key[0], min_altitude=key[1])
+        return self._windowed[key]
 
 
 class NativeSystem:
     """RAII wrapper of gbp_fdem_system_create / _destroy."""
 
-    def __init__(self, a):
+    def __init__(self, a, eps_ppm=0.0, min_altitude=0.0):
         import ctypes
         lib = _lib.load()
         self._lib = lib
         self.nF = int(a["frequencies"].size)
         dp = lambda x: x.ctypes.data_as(_lib.c_double_p)
         h = ctypes.c_void_p()
-        st = lib.gbp_fdem_system_create(
+        st = lib.gbp_fdem_system_create_windowed(
             self.nF, a["tid"].ctypes.data_as(_lib.c_int32_p), dp(a["frequencies"]), dp(a["tx_z"]), dp(a["rx_z"]),
             dp(a["tx_moment"]), dp(a["scale"]), dp(a["rx_off"]), dp(a["separation"]), dp(a["w0"]),
-            dp(a["lamda0"]), dp(a["w1"]), dp(a["lamda1"]), ctypes.byref(h))
+            dp(a["lamda0"]), dp(a["w1"]), dp(a["lamda1"]), float(eps_ppm), float(min_altitude), ctypes.byref(h))
         _lib.check(st)
         self.ptr = h
+
+    @property
+    def npoints(self):
+        import ctypes
+        n = ctypes.c_int()
+        _lib.check(self._lib.gbp_fdem_system_npoints(self.ptr, ctypes.byref(n)))
+        return n.value
 
     def h0(self):
         out = np.empty(2 * self.nF)

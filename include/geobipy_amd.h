@@ -82,7 +82,20 @@ gbp_status gbp_fdem_system_create(int nF, const int32_t *tid, const double *freq
  */
 gbp_status gbp_hankel_system_create_raw(int nF, const int32_t *npts, const double *wmu, const double *hd0,
                                         const double *g, const double *tables, gbp_fdem_system **out);
+/*
+ * Same system with an accuracy-budgeted abscissa window (opt-in): abscissae whose contribution to ANY output
+ * is provably (|rTE| <= 1) below eps_ppm in total, for every sounding at altitude >= min_altitude, are left
+ * out of the tables (typically half of the 120 at eps_ppm = 1e-12).  eps_ppm <= 0 = all abscissae, i.e.
+ * gbp_fdem_system_create.  Not for gbp_fdem_sensitivity (the bound does not cover the Jacobian).
+ */
+gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t *tid, const double *frequencies,
+                                           const double *tx_z, const double *rx_z, const double *tx_moment,
+                                           const double *scale, const double *rx_off, const double *separation,
+                                           const double *w0, const double *lamda0, const double *w1,
+                                           const double *lamda1, double eps_ppm, double min_altitude,
+                                           gbp_fdem_system **out);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);
+gbp_status gbp_fdem_system_npoints(const gbp_fdem_system *sys, int *npts);  /* abscissa points evaluated per sounding */
 gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system *sys, int *nF);
 /* free-space field H0 per frequency as (re, im) pairs, [host] out[2*nF] (fdem1d_numba.py:68 denominator) */
 gbp_status gbp_fdem_system_h0(const gbp_fdem_system *sys, double *out);

@@ -32,6 +32,12 @@ gbp::MathCtx host_ctx()
 extern "C" {
 
 // forward for B soundings, same argument meaning as gbp_fdem_system_create + gbp_fdem_forward (host pointers)
+static double g_window_eps = 0.0, g_window_alt = 0.0;
+static int g_last_npts = 0;
+// test knob: the next emul_fdem_forward calls use the accuracy-budgeted abscissa window (eps <= 0: all abscissae)
+void emul_set_window(double eps_ppm, double min_altitude) { g_window_eps = eps_ppm; g_window_alt = min_altitude; }
+int emul_last_npoints() { return g_last_npts; }
+
 int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
                       const double* rx_z, const double* tx_moment, const double* scale, const double* rx_off,
                       const double* separation, const double* w0, const double* lamda0, const double* w1,
@@ -43,6 +49,8 @@ int emul_fdem_forward(int nF, const int32_t* tid, const double* frequencies, con
     int rc = gbp::build_system_tables(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0,
                                       lamda0, w1, lamda1, &t, &msg);
     if (rc != 0) return rc;
+    gbp::window_system_tables(&t, g_window_eps, g_window_alt);
+    g_last_npts = t.npts;
     const gbp::MathCtx M = host_ctx();
     const double* pts = t.soa.data();
     for (int b = 0; b < B; ++b) {

@@ -291,3 +291,21 @@ def test_datapoint_sensitivity_and_fm_dlogc():
     Jo = fo.sensitivity(oracle_system("resolve"), mod.values, [5.0, 2.5, np.inf], 30.0)
     assert dp.sensitivity_matrix.shape == (12, 3)
     assert close(dp.sensitivity_matrix, np.vstack([Jo.real, Jo.imag]), PRED_ATOL, PRED_RTOL)
+
+
+def test_abscissa_window_mode():
+    """Opt-in accuracy-budgeted abscissa window: same results to within the budget, fewer abscissa points."""
+    from geobipy_amd import FdemBatch, synthetic
+    s = synthetic.syn10_system()
+    B, L = 8192, 8
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=21)
+    exact = FdemBatch(s, nl, sig, thk, h)
+    p0 = exact.forward().clone()
+    for eps in [1e-12, 1e-10]:
+        win = FdemBatch(s, nl, sig, thk, h, hankel_eps_ppm=eps)
+        assert win._h.npoints < 0.75 * exact._h.npoints and win._h.npoints >= 64 * 10
+        p1 = win.forward()
+        assert float((p1 - p0).abs().max()) <= eps + 1e-13 * float(p0.abs().max())
+    # the Jacobian always uses the full tables
+    assert torch.equal(FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64], hankel_eps_ppm=1e-12).sensitivity(),
+                       FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64]).sensitivity())

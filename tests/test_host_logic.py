@@ -210,3 +210,37 @@ def test_jacobian_scheme_on_host_vs_reference_fixtures(emul, golden_npz, name):
             # 'mixed' has ~6e-8 ppm of rounding noise in the oracle forward (non-zero hSum, real-exponent kernels)
             atol = 2e-3 if name == "mixed" else 2e-4
             assert np.all(np.abs(J[b, :, m] - fd) <= atol + 1e-6 * np.abs(fd)), (name, b, m)
+
+
+@pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
+def test_abscissa_window_bound_on_host(emul, name):
+    """Opt-in accuracy-budgeted abscissa window (gbp_fdem_system_create_windowed): the outputs move by less than
+    the budget for every sounding at or above the altitude floor, and about half of the abscissae go."""
+    s = oracle_system(name)
+    rng = np.random.default_rng(9)
+    B, L = 64, 6
+    sig = np.exp(rng.uniform(np.log(1e-4), np.log(5.0), (B, L)))
+    thk = np.exp(rng.uniform(np.log(0.5), np.log(80.0), (B, L)))
+    floor = 20.0
+    h = np.r_[floor, rng.uniform(floor, 120.0, B - 1)]
+    keep = [I(s.tid), D(s.frequencies), D(s.tx_xyz[:, 2]), D(s.rx_xyz[:, 2]), D(s.tx_moment), D(s.scale),
+            D(s.rx_off), D(s.separation), D(s.w0), D(s.lamda0), D(s.w1), D(s.lamda1)]
+
+    def run():
+        pred = np.empty((B, 2 * s.nF))
+        rc = emul.emul_fdem_forward(s.nF, *[q[1] for q in keep], B, L, I(np.full(B, L))[1], D(sig)[1], D(thk)[1],
+                                    D(h)[1], pred.ctypes.data_as(dp))
+        assert rc == 0
+        return pred, emul.emul_last_npoints()
+
+    emul.emul_set_window.argtypes = [ctypes.c_double, ctypes.c_double]
+    emul.emul_set_window(0.0, 0.0)
+    full, n_full = run()
+    try:
+        for eps in [1e-12, 1e-9]:
+            emul.emul_set_window(eps, floor)
+            win, n_win = run()
+            assert np.max(np.abs(win - full)) <= eps + 1e-13 * np.max(np.abs(full))
+            assert n_win < 0.75 * n_full
+    finally:
+        emul.emul_set_window(0.0, 0.0)
