@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--soundings", type=int, default=B_TOTAL, help="total soundings (default: BASELINE config)")
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-windowed", action="store_true", help="skip the extra opt-in abscissa-window measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -222,7 +223,7 @@ def main():
             },
             "finite": bool(torch.isfinite(result).all()),
         }
-        if world == 1:
+        if world == 1 and not args.no_windowed:
             # opt-in mode, reported next to (never instead of) the exact headline: abscissae whose total
             # contribution is provably below 1e-12 ppm for this batch's altitude floor are not evaluated
             eps = 1e-12
