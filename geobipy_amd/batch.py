@@ -141,6 +141,25 @@ class FdemBatch:
                                                    1 if exact else 0, _stream_ptr(self.device)))
         return out
 
+    def find_best_halfspace(self, minConductivity=1e-4, maxConductivity=1e4, nSamples=100):
+        """Best-fitting half-space conductivity of every sounding: brute-force search over a log grid
+        (EmDataPoint.find_best_halfspace, data/datapoint/EmDataPoint.py:148-186 -- 100 forward + misfit
+        evaluations per sounding in the reference; here ONE launch over B * nSamples half-spaces).
+        Returns (sigma_best[B], chi2_best[B])."""
+        assert maxConductivity > minConductivity, ValueError("Maximum conductivity must be greater than the minimum")
+        c = torch.logspace(np.log10(minConductivity), np.log10(maxConductivity), nSamples, dtype=torch.float64,
+                           device=self.device)
+        n = self.B * nSamples
+        rep = lambda t: t.repeat_interleave(nSamples, dim=0)
+        trial = FdemBatch(self.system, torch.ones(n, dtype=torch.int32), c.repeat(self.B)[:, None],
+                          torch.zeros((n, 1), dtype=torch.float64), rep(self.height), data=rep(self.data),
+                          relative_error=rep(self.relative_error), additive_error=rep(self.additive_error),
+                          device=self.device)
+        chi2, _ = trial.forward_loglike(want_pred=False)
+        chi2 = chi2.view(self.B, nSamples)
+        best = torch.argmin(chi2, dim=1)          # first minimum, like numpy.argmin in the reference
+        return c[best], chi2.gather(1, best[:, None])[:, 0]
+
     def time_forward_loglike(self, reps, want_pred=False):
         """Average kernel time in ms over ``reps`` launches, measured with hipEvents on the launch stream."""
         import ctypes

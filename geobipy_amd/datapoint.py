@@ -164,6 +164,15 @@ class FdemDataPoint:
         chi2, logl = b.loglike(self._predictedData[None, :])
         return float(chi2.cpu()[0]), float(logl.cpu()[0])
 
+    def find_best_halfspace(self, minConductivity=1e-4, maxConductivity=1e4, nSamples=100):
+        """Half-space Model that best fits the data (EmDataPoint.py:148-186)."""
+        from .model import RectilinearMesh1D
+        b = FdemBatch(self._system[0], np.array([1]), np.ones((1, 1)), np.zeros((1, 1)), self.z[:1],
+                      data=self._data[None, :], relative_error=self._relative_error[:1],
+                      additive_error=self._additive_error[:1])
+        sig, _ = b.find_best_halfspace(minConductivity, maxConductivity, nSamples)
+        return Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, np.inf]), values=sig.cpu().numpy())
+
     def data_misfit(self):
         """|| W_d (d_obs - d_pre) ||_2^2 over the active channels (DataPoint.py:502-525)."""
         return np.float64(self._loglike()[0])

@@ -309,6 +309,7 @@ class TdemBatch:
         self.additive_error = None if additive_error is None else dev(additive_error)
         self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
         self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
+        self._max_layers = None
 
     def forward(self):
         """predicted[B, nChannels]: frequency-domain HIP kernel per system, then one fp64 GEMM per system."""
@@ -324,6 +325,28 @@ class TdemBatch:
                 torch.matmul(nodal, W, out=self.predicted[:, col:col + n])
                 col += n
         return self.predicted
+
+    def sensitivity(self):
+        """J[B, nChannels, Lmax] = d predicted / d ln(sigma) (the reference obtains it from gatdaem1d's
+        derivative call, TD/tdem1d.py:98-154): exact frequency-domain Jacobian of the nodal values (Jacobian
+        kernel on the raw handle) pushed through the same linear time-domain operator, one GEMM per system."""
+        lib = _lib.load()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        out = torch.empty((self.B, self.nChannels, self.Lmax), dtype=torch.float64, device=self.device)
+        if self._max_layers is None:
+            self._max_layers = int(self.nlayers.max().item()) if self.B > 0 else 1
+        col = 0
+        with torch.cuda.device(self.device):
+            for h, W in zip(self._h, self._W):
+                Jn = torch.empty((self.B, W.shape[0], self.Lmax), dtype=torch.float64, device=self.device)
+                _lib.check(lib.gbp_fdem_sensitivity_ex(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                       self.sigma.data_ptr(), self.thk.data_ptr(),
+                                                       self.height.data_ptr(), Jn.data_ptr(), self._max_layers, 1,
+                                                       stream))
+                n = W.shape[1]
+                out[:, col:col + n, :] = torch.einsum("bfl,fw->bwl", Jn, W)
+                col += n
+        return out
 
     def std(self):
         """TdemDataPoint.std (data/datapoint/TdemDataPoint.py:361-365):

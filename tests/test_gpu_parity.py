@@ -309,3 +309,25 @@ def test_abscissa_window_mode():
     # the Jacobian always uses the full tables
     assert torch.equal(FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64], hankel_eps_ppm=1e-12).sensitivity(),
                        FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64]).sensitivity())
+
+
+def test_find_best_halfspace_matches_brute_force():
+    """EmDataPoint.find_best_halfspace (100-point log grid, argmin of the misfit) for a whole batch in one launch."""
+    from geobipy_amd import FdemBatch, FdemDataPoint, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    osys = oracle_system("syn10")
+    B = 16
+    nl, sig, thk, h = synthetic.draw_models(B, 1, seed=31)
+    clean = FdemBatch(s, nl, sig, thk, h).forward().cpu().numpy()
+    obs = synthetic.noisy_observations(clean, seed=32)
+    b = FdemBatch(s, nl, sig, thk, h, data=obs, relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0))
+    best, chi2 = b.find_best_halfspace()
+    grid = np.logspace(-4, 4, 100)
+    for i in range(B):
+        phi = [fo.gauss_loglike(fo.predicted_data(osys, [c], [np.inf], h[i]), obs[i], 0.05, 5.0)[1] for c in grid]
+        assert np.isclose(best[i].item(), grid[int(np.argmin(phi))], rtol=1e-12)
+        assert abs(chi2[i].item() - min(phi)) <= LIKE_ATOL + LIKE_RTOL * min(phi)
+    dp = FdemDataPoint(z=h[0], data=obs[0], system=s)
+    dp.relative_error, dp.additive_error = 0.05, 5.0
+    assert np.isclose(dp.find_best_halfspace().values[0], best[0].item(), rtol=1e-12)

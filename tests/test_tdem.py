@@ -155,3 +155,25 @@ def test_tdem_datapoint_interface():
     chi2 = np.sum(((dp.predictedData - dp.data) / sd) ** 2)
     assert np.isclose(dp.data_misfit(), chi2, rtol=1e-9)
     assert np.isclose(dp.likelihood(log=True), -0.5 * 45 * np.log(2 * np.pi) - np.sum(np.log(sd)) - 0.5 * chi2, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_tdem_sensitivity_vs_finite_differences():
+    torch = pytest.importorskip("torch")
+    from geobipy_amd import synthetic
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    B, L = 64, 4
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=12, Lmax=6)
+    systems = [TdemSystem(os.path.join(GOLDEN, "SkytemHM.stm")), TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))]
+    tb = TdemBatch(systems, nl, sig, thk, h, SKYTEM_OFFSET)
+    J = tb.sensitivity().cpu().numpy()
+    assert J.shape == (B, 45, 6) and np.all(J[:, :, L:] == 0.0)
+    scale = np.abs(tb.forward().cpu().numpy()).max(axis=1, keepdims=True)     # d/dln(sigma) is in data units
+    eps = 1e-4
+    for m in range(L):
+        sp, sm = sig.copy(), sig.copy()
+        sp[:, m] *= np.exp(eps)
+        sm[:, m] *= np.exp(-eps)
+        fd = (TdemBatch(systems, nl, sp, thk, h, SKYTEM_OFFSET).forward().cpu().numpy()
+              - TdemBatch(systems, nl, sm, thk, h, SKYTEM_OFFSET).forward().cpu().numpy()) / (2 * eps)
+        assert np.all(np.abs(J[:, :, m] - fd) <= 1e-6 * scale)
