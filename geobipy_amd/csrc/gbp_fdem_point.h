@@ -125,28 +125,34 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
                        const double* __restrict__ t2, cplx u0, cplx Q, cplx* D, int stride)
 {
     const double RSQRT2 = 0.70710678118654752440;
+    // i b / (2 u) = (b/2) (u.im + i u.re) / |u|^2
+    auto ihb_over_u = [&](double bc, cplx u) {
+        const double f = (bc * RSQRT2) * rcp(__builtin_fma(u.re, u.re, u.im * u.im));
+        return mk(f * u.im, f * u.re);
+    };
     cplx Y = csqrt_upper2(a, lay[L - 1].b2, lay[L - 1].bc);
-    D[(L - 1) * stride] = cdiv(mk(0.0, lay[L - 1].bc * RSQRT2), Y);  // i b / (2 u_L)
+    D[(L - 1) * stride] = ihb_over_u(lay[L - 1].bc, Y);
     for (int k = L - 2; k >= 0; --k) {
         const LayerK lk = lay[k];
         const double tk = t2[k];  // -2 t_k
         const cplx u = csqrt_upper2(a, lk.b2, lk.bc);
         const cplx e = cexp_neg(M, tk * u.re, tk * u.im);
-        const cplx ep = mk(1.0 + e.re, e.im), em = mk(1.0 - e.re, -e.im);
-        const cplx Nn = Y * ep + u * em;
-        const cplx Dd = u * ep + Y * em;
+        // with S = u + Y', De = u - Y':  Dd = S + e De,  Nn = S - e De,  Yh = u Nn / Dd
+        //   exact bracket = (1 - e)(S^2 + e De^2) - 2 tk u e S De        (= dYh/du * Dd^2)
+        //   reference     = exact + 4 u^2 e (1 + e)                      (FD:269-274, see above)
+        //   accumulate    = 4 u^2 e / Dd^2
+        const cplx S = u + Y, De = u - Y;
+        const cplx eDe = e * De;
+        const cplx Dd = S + eDe, Nn = S - eDe;
         const cplx inv = cdiv(mk(1.0, 0.0), Dd);
         const cplx inv2 = inv * inv;
-        const cplx u2 = u * u, Y2 = Y * Y, uY = u * Y;
-        const cplx d = Y2 - u2;
-        const cplx epm = ep * em, em2 = em * em;
-        cplx br = (uY * em2) * 2.0 + ((u * e) * d) * (2.0 * tk);
-        if (EXACT)
-            br = br + (Y2 + u2) * epm;
-        else
-            br = br + d * epm + (u2 * (ep * ep)) * 2.0;
-        const cplx W = cdiv(mk(0.0, lk.bc * RSQRT2), u) * (br * inv2);
-        const cplx acc = ((u2 * e) * inv2) * 4.0;
+        const cplx ue = u * e;
+        const cplx P1 = mk(1.0 - e.re, -e.im) * (S * S + eDe * De);
+        const cplx P2 = (ue * (S * De)) * (2.0 * tk);
+        const cplx acc = ((u * ue) * inv2) * 4.0;
+        cplx dY = (P1 - P2) * inv2;
+        if (!EXACT) dY = dY + acc * mk(1.0 + e.re, e.im);
+        const cplx W = ihb_over_u(lk.bc, u) * dY;
 #pragma unroll 4
         for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * acc;
         D[k * stride] = W;
