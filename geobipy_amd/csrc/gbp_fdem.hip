@@ -299,10 +299,15 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
         const Channel ch = chan[f];
         setup_layers(sh_lay, ch.wmu, sig, L, lane);
         const double hD = ch.hd0 - 2.0 * alt;
-        for (int m0 = 0; m0 < L; m0 += 64) {          // layers handled by this lane in the row sums
-            const int m = m0 + lane;
-            double acc_re = 0.0, acc_im = 0.0;
-            // (for L <= 64, the common case, this outer loop runs once)
+        // Row sums: lanes are arranged as 8 rows x 8 segments; lane (row, seg) adds the entries seg, seg + 8, ...
+        // of row m0 + row (consecutive lanes -> consecutive 16-byte slots: conflict-free ds_read_b128), the 8
+        // segment partials are combined with three xor-shuffles once per frequency.
+        const int row = lane >> 3, seg = lane & 7;
+        constexpr int NG = 8;                          // 8 row groups of 8 layers are summed per evaluation
+        for (int m0 = 0; m0 < L; m0 += 8 * NG) {       // (L <= 64: this loop runs once; deeper models re-evaluate)
+            double acc_re[NG], acc_im[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { acc_re[g] = 0.0; acc_im[g] = 0.0; }
             for (int j0 = 0; j0 < ch.npts; j0 += 64) {
                 {
                     const int j = j0 + lane;
@@ -314,19 +319,34 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                            GBP_SENS_STRIDE);
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (m < L) {
-                    const cplx* row = sh_D + (size_t)m * GBP_SENS_STRIDE;
-                    double sr = 0.0, si = 0.0;
-#pragma unroll 8
-                    for (int i = 0; i < 64; ++i) { sr += row[i].re; si += row[i].im; }
-                    acc_re += sr;
-                    acc_im += si;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (m0 + 8 * g < L) {              // wave-uniform
+                        const int m = m0 + 8 * g + row;
+                        if (m < L) {
+                            const cplx* rowp = sh_D + (size_t)m * GBP_SENS_STRIDE + seg;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) { acc_re[g] += rowp[8 * i].re; acc_im[g] += rowp[8 * i].im; }
+                        }
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (m < L) {
-                J[((size_t)b * N + f) * Lmax + m] = ch.g_re * acc_re - ch.g_im * acc_im;
-                J[((size_t)b * N + F + f) * Lmax + m] = ch.g_re * acc_im + ch.g_im * acc_re;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (m0 + 8 * g < L) {
+                    double sr = acc_re[g], si = acc_im[g];
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {
+                        sr += __shfl_xor(sr, o, 64);
+                        si += __shfl_xor(si, o, 64);
+                    }
+                    const int m = m0 + 8 * g + row;
+                    if (m < L && seg == 0) {
+                        J[((size_t)b * N + f) * Lmax + m] = ch.g_re * sr - ch.g_im * si;
+                        J[((size_t)b * N + F + f) * Lmax + m] = ch.g_re * si + ch.g_im * sr;
+                    }
+                }
             }
         }
         for (int m = L + lane; m < Lmax; m += 64) {   // unused columns

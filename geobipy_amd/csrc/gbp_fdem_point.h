@@ -152,16 +152,23 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
         const cplx acc = ((u * ue) * inv2) * 4.0;
         cplx dY = (P1 - P2) * inv2;
         if (!EXACT) dY = dY + acc * mk(1.0 + e.re, e.im);
-        const cplx W = ihb_over_u(lk.bc, u) * dY;
-#pragma unroll 4
-        for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * acc;
-        D[k * stride] = W;
+        cplx W = ihb_over_u(lk.bc, u) * dY;
         Y = (u * Nn) * inv;
-    }
-    const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
-    const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
+        cplx fac = acc;
+        if (k == 0) {  // top layer: fold d rTE / d Yh_1 and the Hankel factor Q into this last sweep
+            const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
+            const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
+            fac = acc * QQ;
+            W = W * QQ;
+        }
 #pragma unroll 4
-    for (int m = 0; m < L; ++m) D[m * stride] = D[m * stride] * QQ;
+        for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * fac;
+        D[k * stride] = W;
+    }
+    if (L == 1) {  // half-space only: no layer loop ran
+        const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
+        D[0] = D[0] * (Q * ((u0 * (i0 * i0)) * -2.0));
+    }
 }
 
 }  // namespace gbp
