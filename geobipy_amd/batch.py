@@ -121,25 +121,45 @@ class FdemBatch:
                                              self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
         return self.chi2, self.logL
 
-    def sensitivity(self, out=None, exact=False, max_layers=None):
+    def sensitivity(self, out=None, exact=False, max_layers=None, bucket=True):
         """J[B, 2F, Lmax] = d pred / d ln(sigma) (FdemDataPoint.sensitivity -> nbFdem1dsen).
 
         ``exact=False`` reproduces the reference's expression (which is not the true derivative above the
         half-space); ``exact=True`` returns the true derivative.  ``max_layers`` is an
-        upper bound of ``nlayers`` (default: computed once from the batch) that sizes the kernel's LDS."""
+        upper bound of ``nlayers`` (default: computed once from the batch) that sizes the kernel's LDS working
+        set.  With ``bucket=True`` a ragged batch whose deepest model has more than 8 layers is split by layer
+        count (<= 8, <= 16, rest) into separate launches, so that the many shallow models of an rjMCMC
+        population are not run at the low occupancy the few deep ones force (1040 B of LDS per layer and wave)."""
         if out is None:
             out = torch.empty((self.B, 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
         if max_layers is None:
             if self._max_layers is None:
                 self._max_layers = int(self.nlayers.max().item()) if self.B > 0 else 1
             max_layers = self._max_layers
+        if bucket and max_layers > 8 and self.B >= 512:
+            lo = 0
+            for hi in (8, 16, self.Lmax):
+                if hi <= lo or lo >= max_layers:
+                    continue
+                idx = torch.nonzero((self.nlayers > lo) & (self.nlayers <= hi)).flatten()
+                if idx.numel() > 0:
+                    sub = torch.empty((idx.numel(), 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
+                    self._launch_sens(self.nlayers[idx].contiguous(), self.sigma[idx].contiguous(),
+                                      self.thk[idx].contiguous(), self.height[idx].contiguous(), sub,
+                                      min(hi, max_layers), exact)
+                    out[idx] = sub
+                lo = hi
+            return out
+        self._launch_sens(self.nlayers, self.sigma, self.thk, self.height, out, max_layers, exact)
+        return out
+
+    def _launch_sens(self, nlayers, sigma, thk, height, out, max_layers, exact):
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h_exact.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
-                                                   self.sigma.data_ptr(), self.thk.data_ptr(),
-                                                   self.height.data_ptr(), out.data_ptr(), int(max_layers),
-                                                   1 if exact else 0, _stream_ptr(self.device)))
-        return out
+            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h_exact.ptr, nlayers.numel(), self.Lmax, nlayers.data_ptr(),
+                                                   sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
+                                                   out.data_ptr(), int(max_layers), 1 if exact else 0,
+                                                   _stream_ptr(self.device)))
 
     def find_best_halfspace(self, minConductivity=1e-4, maxConductivity=1e4, nSamples=100):
         """Best-fitting half-space conductivity of every sounding: brute-force search over a log grid

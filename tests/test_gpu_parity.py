@@ -331,3 +331,15 @@ def test_find_best_halfspace_matches_brute_force():
     dp = FdemDataPoint(z=h[0], data=obs[0], system=s)
     dp.relative_error, dp.additive_error = 0.05, 5.0
     assert np.isclose(dp.find_best_halfspace().values[0], best[0].item(), rtol=1e-12)
+
+
+def test_jacobian_bucketing_by_layer_count_is_transparent():
+    """Ragged rjMCMC-like population (mostly shallow, a few 30-layer models): bucketed launches = one launch."""
+    from geobipy_amd import FdemBatch, synthetic
+    rng = np.random.default_rng(8)
+    s = product_system("resolve")
+    B, Lmax = 2000, 30
+    nl = np.where(rng.uniform(size=B) < 0.9, rng.integers(1, 7, size=B), rng.integers(7, Lmax + 1, size=B)).astype(np.int32)
+    _, sig, thk, h = synthetic.draw_models(B, Lmax, seed=13)
+    b = FdemBatch(s, nl, sig, thk, h)
+    assert torch.equal(b.sensitivity(bucket=True), b.sensitivity(bucket=False))
