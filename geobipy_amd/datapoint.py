@@ -127,10 +127,58 @@ class FdemDataPoint:
     def __deepcopy__(self, memo={}):
         out = FdemDataPoint.__new__(FdemDataPoint)
         for k, v in self.__dict__.items():
+            if k == "_ws":
+                continue                      # device workspace is per object, rebuilt lazily
             setattr(out, k, v if k == "_system" else deepcopy(v, memo))
         return out
 
     # -- hot path: every call below is a GPU launch ----------------------------------------------
+    # One persistent B = 1 device workspace per datapoint: inputs are packed on the host into a pinned buffer and
+    # travel in ONE copy, forward() runs the fused forward + chi^2 + logL kernel, and the results come back in ONE
+    # copy; data_misfit() / likelihood() reuse them while nothing they depend on has changed.
+    _LCAP = 64
+
+    def _workspace(self):
+        import torch
+        ws = getattr(self, "_ws", None)
+        if ws is None:
+            N, Lc = self.nChannels, self._LCAP
+            n_in = 2 * Lc + 1 + N + 2
+            ws = dict(
+                host=torch.empty(n_in, dtype=torch.float64).pin_memory(), dev=torch.empty(n_in, dtype=torch.float64, device="cuda"),
+                nl=torch.ones(1, dtype=torch.int32, device="cuda"), nl_host=torch.ones(1, dtype=torch.int32).pin_memory(),
+                out=torch.empty(N + 2, dtype=torch.float64, device="cuda"), out_host=torch.empty(N + 2, dtype=torch.float64).pin_memory(),
+                handle=self._system[0].handle(), stamp=None)
+            self._ws = ws
+        return ws
+
+    def _stamp(self):
+        return (self._predictedData.tobytes(), self._data.tobytes(), self._relative_error.tobytes(),
+                self._additive_error.tobytes())
+
+    def _pack(self, ws, mod):
+        import torch
+        N, Lc = self.nChannels, self._LCAP
+        h = ws["host"].numpy()
+        L = 1
+        if mod is not None:
+            assert np.isinf(mod.mesh.edges[-1]), ValueError(
+                "mod.edges must have last entry be infinity for forward modelling.")       # FdemDataPoint.py:541
+            assert self.z[0] >= mod.mesh.relative_to, "Sensor altitude must be above the top of the model"  # fdem1d.py:29
+            L = int(mod.mesh.nCells)
+            if L > Lc:
+                return None
+            h[:L] = mod.values
+            h[Lc:Lc + L - 1] = mod.mesh.widths[:-1]
+        h[2 * Lc] = self.z[0]
+        h[2 * Lc + 1:2 * Lc + 1 + N] = self._data
+        h[2 * Lc + 1 + N] = self._relative_error[0]
+        h[2 * Lc + 2 + N] = self._additive_error[0]
+        ws["nl_host"][0] = L
+        ws["nl"].copy_(ws["nl_host"], non_blocking=True)
+        ws["dev"].copy_(ws["host"], non_blocking=True)
+        return L
+
     def _batch(self, mod):
         assert np.isinf(mod.mesh.edges[-1]), ValueError(
             "mod.edges must have last entry be infinity for forward modelling.")       # FdemDataPoint.py:541
@@ -144,8 +192,28 @@ class FdemDataPoint:
 
     def forward(self, mod):
         """Forward model the data from the given model (FdemDataPoint.py:524-545)."""
+        import torch
+        from . import _lib
         assert isinstance(mod, Model), TypeError("Invalid model class for forward modeling [1D]")
-        self._predictedData[:] = self._batch(mod).forward().cpu().numpy()[0]
+        ws = self._workspace()
+        L = self._pack(ws, mod)
+        if L is None:                       # deeper than the packed workspace: generic path
+            self._predictedData[:] = self._batch(mod).forward().cpu().numpy()[0]
+            ws["stamp"] = None
+            return
+        N, Lc = self.nChannels, self._LCAP
+        base, es = ws["dev"].data_ptr(), 8
+        _lib.check(_lib.load().gbp_fdem_forward_loglike(
+            ws["handle"].ptr, 1, Lc, ws["nl"].data_ptr(), base, base + es * Lc, base + es * 2 * Lc,
+            base + es * (2 * Lc + 1), base + es * (2 * Lc + 1 + N), base + es * (2 * Lc + 2 + N),
+            ws["out"].data_ptr(), ws["out"].data_ptr() + es * N, ws["out"].data_ptr() + es * (N + 1),
+            torch.cuda.current_stream().cuda_stream))
+        ws["out_host"].copy_(ws["out"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        o = ws["out_host"].numpy()
+        self._predictedData[:] = o[:N]
+        ws["chi2"], ws["logL"] = float(o[N]), float(o[N + 1])
+        ws["stamp"] = self._stamp()
 
     def sensitivity(self, mod, **kwargs):
         """J[2F, L] = d predictedData / d ln(sigma) (FdemDataPoint.py:530-559)."""
@@ -158,11 +226,25 @@ class FdemDataPoint:
         self.sensitivity(mod)
 
     def _loglike(self):
-        b = FdemBatch(self._system[0], np.array([1]), np.ones((1, 1)), np.zeros((1, 1)), self.z[:1],
-                      data=self._data[None, :], relative_error=self._relative_error[:1],
-                      additive_error=self._additive_error[:1])
-        chi2, logl = b.loglike(self._predictedData[None, :])
-        return float(chi2.cpu()[0]), float(logl.cpu()[0])
+        import torch
+        from . import _lib
+        ws = self._workspace()
+        if ws["stamp"] is not None and ws["stamp"] == self._stamp():
+            return ws["chi2"], ws["logL"]          # computed by the fused kernel of the last forward()
+        N, Lc = self.nChannels, self._LCAP
+        self._pack(ws, None)
+        ws["out_host"][:N] = torch.from_numpy(self._predictedData)
+        ws["out"].copy_(ws["out_host"], non_blocking=True)
+        base, es, ob = ws["dev"].data_ptr(), 8, ws["out"].data_ptr()
+        _lib.check(_lib.load().gbp_gauss_loglike(1, N, ob, base + es * (2 * Lc + 1), base + es * (2 * Lc + 1 + N),
+                                                 base + es * (2 * Lc + 2 + N), ob + es * N, ob + es * (N + 1),
+                                                 torch.cuda.current_stream().cuda_stream))
+        ws["out_host"].copy_(ws["out"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        o = ws["out_host"].numpy()
+        ws["chi2"], ws["logL"] = float(o[N]), float(o[N + 1])
+        ws["stamp"] = self._stamp()
+        return ws["chi2"], ws["logL"]
 
     def find_best_halfspace(self, minConductivity=1e-4, maxConductivity=1e4, nSamples=100):
         """Half-space Model that best fits the data (EmDataPoint.py:148-186)."""

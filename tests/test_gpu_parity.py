@@ -105,6 +105,18 @@ def test_datapoint_interface_config1():
     assert abs(dp.data_misfit() - 3.4175602330457497) <= LIKE_ATOL
     assert abs(dp.likelihood(log=True) - (-51.18449066872814)) <= LIKE_ATOL
     assert np.isclose(dp.likelihood(log=False), np.exp(-51.18449066872814), rtol=1e-6)
+    # the fused results cached by forward() are dropped as soon as anything they depend on changes
+    from oracle import fdem_oracle as fo
+    dp.relative_error = 0.08
+    _, c2, ll, _ = fo.gauss_loglike(dp.predictedData, dp.data, 0.08, 5.0)
+    assert abs(dp.data_misfit() - c2) <= LIKE_ATOL and abs(dp.likelihood(log=True) - ll) <= LIKE_ATOL
+    dp.predictedData[2] += 1.0
+    _, c2, ll, _ = fo.gauss_loglike(dp.predictedData, dp.data, 0.08, 5.0)
+    assert abs(dp.data_misfit() - c2) <= LIKE_ATOL and abs(dp.likelihood(log=True) - ll) <= LIKE_ATOL
+    import copy
+    dp2 = copy.deepcopy(dp)                       # Inference1D deep-copies the datapoint every iteration
+    dp2.forward(mod)
+    assert close(dp2.predictedData, ref, PRED_ATOL, PRED_RTOL) and dp2.system is dp.system
     with pytest.raises(AssertionError):      # last edge must be infinite (FdemDataPoint.py:541)
         dp.forward(Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 5.0, 7.5]), values=np.r_[1e-2, 1e-1]))
 
