@@ -159,10 +159,22 @@ struct MathCtx {
 // exp(x) for x <= 0 (flushes to 0 below ~-745; accurate for small positive x too).
 //   x = k ln2/64 + r, |r| <= ln2/128:  exp(x) = 2^(k>>6) * 2^((k&63)/64) * (1 + r + ... + r^5/120)
 // truncation r^6/720 < 3.6e-17; 16 VALU issues + one LDS read.
+// round-to-nearest integer of x * inv via the 1.5 * 2^52 trick: t = fma(x, inv, MAGIC) holds the integer in
+// its low mantissa bits (so the int32 is the low dword of t, no v_cvt) and kf = t - MAGIC; 2 issues instead of
+// mul + v_rndne_f64 + v_cvt_i32_f64.  Valid for |x * inv| < 2^31.
+GBP_HD double round_mul(double x, double inv, int& k)
+{
+    const double MAGIC = 6755399441055744.0;  // 1.5 * 2^52
+    const double t = __builtin_fma(x, inv, MAGIC);
+    k = (int)(unsigned)__builtin_bit_cast(unsigned long long, t);
+    return t - MAGIC;
+}
+
 GBP_HD double exp_neg(const MathCtx& M, double x)
 {
     double xx = __builtin_fmax(x, -800.0);
-    double kf = __builtin_rint(xx * M.k.inv_ln2_64);
+    int k;
+    double kf = round_mul(xx, M.k.inv_ln2_64, k);
     double r = __builtin_fma(-kf, M.k.ln2_64_hi, xx);
     r = __builtin_fma(-kf, M.k.ln2_64_lo, r);
     double p = __builtin_fma(M.k.e5, r, M.e4_v);
@@ -170,20 +182,20 @@ GBP_HD double exp_neg(const MathCtx& M, double x)
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    int k = (int)kf;
     double t = M.exp2_64[k & 63];
     return ldexp_i(t * p, k >> 6);
 }
 
-// sin and cos of x for |x| < ~1e6 (beyond that the caller's exp factor has long underflowed).
+// sin and cos of x for |x| < ~2e8 (beyond that the caller's exp factor has long underflowed).
 //   x = k pi/32 + r, |r| <= pi/64: angle addition with the tabulated sin/cos of k pi/32 and degree-7/8
 //   Taylor kernels (truncation < 5e-18); no quadrant logic.  21 VALU issues + one LDS read.
 GBP_HD void sincos_tab(const MathCtx& M, double x, double& s, double& c)
 {
-    double kf = __builtin_rint(x * M.k.inv_pi_32);
+    int k;
+    double kf = round_mul(x, M.k.inv_pi_32, k);
     double r = __builtin_fma(-kf, M.k.pi_32_hi, x);
     r = __builtin_fma(-kf, M.k.pi_32_lo, r);
-    SinCos t = M.sincos_64[((int)kf) & 63];
+    SinCos t = M.sincos_64[k & 63];
     double z = r * r;
     double ps = __builtin_fma(M.k.s3, z, M.s2_v);
     ps = __builtin_fma(ps, z, M.k.s1);
