@@ -86,6 +86,12 @@ class FdemBatch:
         assert bool((self.thk[tmask] > 0).all()), ValueError("thickness must be > 0")
         assert bool((self.height >= 0).all()), ValueError("Sensor altitude must be above the top of the model")
 
+    def status(self, pred=None):
+        """int8[B]: 0 = finite predictions, 1 = a non-finite value somewhere (the batch is never aborted; the
+        reference would have carried the NaN/inf of one sounding into that sounding's chain only)."""
+        pred = self.predicted if pred is None else pred
+        return (~torch.isfinite(pred).all(dim=1)).to(torch.int8)
+
     # -- launches -----------------------------------------------------------------------------
     def forward(self, out=None):
         """pred[B, 2F] (ppm) for the current sigma / thk / height; one kernel launch, no sync."""
