@@ -85,3 +85,20 @@ def test_gpu_replays_the_callers_calls(trace):
                    additive_error=trace["add"][nxt])
     c2, _ = fb.forward_loglike()
     assert close(c2.cpu().numpy(), trace["chi2"][nxt], LIKE_ATOL, LIKE_RTOL)
+
+
+def test_detail_fixture_is_the_same_run(trace):
+    """tests/golden/mcmc_detail.npz (per-iteration internals of the same reference run: RNG state, action, remapped
+    model, stochastic-Newton H / mean, proposal terms) is the groundwork fixture for SURVEY row f-2; it must
+    describe exactly the run whose hot-path calls are replayed above."""
+    d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
+    assert np.array_equal(d["accepted"], trace["accepted"]) and np.array_equal(d["new_k"], trace["k"])
+    assert d["rng_state"].shape == (400, 6) and len(np.unique(d["rng_state"][:, 1])) == 400
+    # every accepted proposal's misfit is one of the misfits the caller asked the hot path for
+    chi2_calls = trace["chi2"][trace["kind"] == MISFIT]
+    acc = np.flatnonzero(d["accepted"])
+    assert all(np.any(np.isclose(chi2_calls, d["new_misfit"][i], rtol=1e-14)) for i in acc)
+    # structural moves keep the layer count consistent: insert +1, delete -1
+    rk, ck, a = d["rem_k"], d["cur_k"], d["action"]
+    assert np.all(rk[a == 1] == ck[a == 1] + 1) and np.all(rk[a == 2] == ck[a == 2] - 1)
+    assert np.all(rk[(a == 0) | (a == 3)] == ck[(a == 0) | (a == 3)])
