@@ -1,0 +1,254 @@
+"""Reversible-jump moves of the 1-D model -- host-side restatement (work in progress).
+
+So far: the structural move ``RectilinearMesh1D.perturb`` (mesh/RectilinearMesh1D.py:993-1120) with the value
+remapping of ``insert_edge`` (:805-839) and ``delete_edge`` (:643-689), consuming a ``numpy.random.Generator`` in
+exactly the reference's order, so that a seeded reference run can be replayed
+decision by decision (tests/test_rjmcmc.py against tests/golden/mcmc_detail.npz).  The stochastic-Newton value
+proposal, the priors and the acceptance ratio are the next pieces; the Jacobian / forward values they consume come from the GPU kernels (or, in the CPU tests, from the oracle).
+"""
+import numpy as np
+
+NONE, INSERT, DELETE, PERTURB = 0, 1, 2, 3
+
+
+class StructurePrior:
+    """The knobs of the structural move (options file keys of the reference: maximum_number_of_layers,
+    minimum_depth, maximum_depth, minimum_thickness, probability_of_birth / death / perturb / no_change)."""
+
+    def __init__(self, max_cells, min_edge, max_edge, min_width, probabilities):
+        self.max_cells, self.max_edge, self.min_width = int(max_cells), max_edge, min_width
+        # the reference raises the minimum depth to the minimum thickness (RectilinearMesh1D.py:358-360)
+        self.min_edge = max(min_edge, min_width)
+        p = np.asarray(probabilities, dtype=np.float64)
+        self.pmf = np.cumsum(p / p.sum())          # CategoricalDistribution: searchsorted(cumsum(p), u)
+
+
+def perturb_structure(prng, prior, edges, values, n_tries=10):
+    """One structural move.  ``edges``: interior interface depths (k - 1 values, increasing); ``values``: k layer values.
+
+    Returns (action, index, value, new_edges, remapped_values) with the reference's ``mesh.action`` triple:
+    ('insert', i, depth) | ('delete', i, depth) | ('perturb', i, dz) | ('none', 0, 0.0), i indexing the full edge
+    array [0, e_1 .. e_{k-1}, inf] like the reference.
+    """
+    edges = np.asarray(edges, dtype=np.float64)
+    values = np.asarray(values, dtype=np.float64)
+    full = np.r_[0.0, edges, np.inf]
+    k = values.size
+    while True:
+        while True:                                  # RectilinearMesh1D.py:1041-1049
+            event = int(np.searchsorted(prior.pmf, prng.uniform(size=1))[0])
+            if not ((k == 1 and event in (1, 2)) or (k == prior.max_cells and event == 0)):
+                break
+        if event == 3:
+            return NONE, 0, 0.0, edges.copy(), values.copy()
+        if event == 0:                               # birth, :1061-1081
+            ok = False
+            for tries in range(1, n_tries + 1):
+                new_edge = np.exp(prng.uniform(low=np.log(prior.min_edge), high=np.log(prior.max_edge), size=1))[0]
+                i = int(np.searchsorted(full, new_edge))
+                z = np.insert(full, i, new_edge)
+                ok = np.min(np.diff(z)) > prior.min_width and tries < n_tries
+                if ok or tries == n_tries:
+                    break
+            if ok:
+                return INSERT, i, float(new_edge), z[1:-1], np.insert(values, i, values[i - 1])
+            continue                                 # 10 failed tries: draw a new event
+        if event == 1:                               # death, :1083-1087
+            i = int(np.int64(prng.uniform(low=0, high=k - 1, size=1)[0])) + 1
+            merged = 0.5 * (values[i - 1] + values[i])
+            v = np.delete(values, i)
+            v[i - 1] = merged
+            return DELETE, i, float(full[i]), np.delete(full, i)[1:-1], v
+        ok = False                                   # perturb, :1089-1118
+        for tries in range(1, n_tries + 1):
+            z = full.copy()
+            i = int(np.int32(prng.uniform(low=1, high=full.size - 1, size=1)[0]))
+            dz = np.sign(prng.normal()) * prior.min_width * prng.uniform()
+            z[i] += dz
+            ok = (np.min(np.diff(z)) > prior.min_width and z[1] > prior.min_edge and z[-2] < prior.max_edge
+                  and tries < n_tries)
+            if ok or tries == n_tries:
+                break
+        if ok:
+            return PERTURB, i, float(dz), z[1:-1], values.copy()
+
+
+class ValuePrior:
+    """Priors on the layer conductivities as Inference1D.initialize_model sets them (inversion/Inference1D.py:497-509,
+    model/Model.py:727-746): log-normal on the values, mean = best half-space, variance = ln(1 + factor)^2; and a
+    normal prior on the vertical gradient of ln(sigma) with standard deviation gradient_standard_deviation."""
+
+    def __init__(self, value_mean, factor=10.0, gradient_std=1.5, solve_gradient=True):
+        self.log_mean = np.log(value_mean)
+        self.value_precision = 1.0 / np.log(1.0 + factor) ** 2.0
+        self.gradient_precision = 1.0 / gradient_std ** 2.0
+        self.solve_gradient = solve_gradient
+
+
+def gradient_operator(edges):
+    """RectilinearMesh1D.gradient_operator (mesh/RectilinearMesh1D.py:747-786) for a mesh [0, edges..., inf]."""
+    k = edges.size + 1
+    if k == 1:
+        return np.ones((1, 1))
+    full = np.r_[0.0, edges, np.inf]
+    x = np.abs(np.diff(full))
+    e2e = full[-2] - full[0]
+    x[-1] = x[0] if k == 2 else x[-2] + e2e
+    tmp = 1.0 / (0.5 * (x[:-1] + x[1:]) * (k - 1))
+    out = np.zeros((k - 1, k))
+    idx = np.arange(k - 1)
+    out[idx, idx] = -tmp
+    out[idx, idx + 1] = tmp
+    return out
+
+
+def model_prior_derivative(vp, edges, values, order):
+    """Model.prior_derivative (model/Model.py:421-430): Wm'Wm (order 2) or Wm'Wm (ln sigma - ln sigma_ref) (order 1)."""
+    k = values.size
+    op = np.eye(k) * vp.value_precision
+    if vp.solve_gradient:
+        Wz = gradient_operator(edges)
+        op = op + Wz.T @ (np.eye(max(1, k - 1)) * vp.gradient_precision) @ Wz
+    return op if order == 2 else op @ (np.log(values) - vp.log_mean)
+
+
+def stochastic_newton(vp, edges, values, J, predicted, data, std, alpha=1.0):
+    """Mean and covariance of the log-normal value proposal (Model.stochastic_newton_perturbation,
+    model/Model.py:368-419; DataPoint.prior_derivative, data/datapoint/DataPoint.py:340-349):
+        H = inv(J' Wd'Wd J + Wm'Wm),  g = J' Wd'Wd (pred - obs) + Wm'Wm (ln sigma - ln sigma_ref),
+        mean = exp(ln sigma - alpha H g)
+    J: d pred / d ln sigma [N, k] at the remapped model (or the stale one the datapoint carries when the
+    structure did not change), active channels only = data > 0."""
+    active = data > 0.0
+    Ja = J[active]
+    P = 1.0 / std[active] ** 2.0
+    hess = model_prior_derivative(vp, edges, values, 2) + Ja.T @ (P[:, None] * Ja)
+    grad = model_prior_derivative(vp, edges, values, 1) + Ja.T @ (P * (predicted[active] - data[active]))
+    H = np.linalg.inv(hess)
+    pk = -(H @ grad)
+    return np.exp(np.log(values) + alpha * pk), H
+
+
+def propose_values(prng, mean, H):
+    """MvLogNormal(mean, H, linearSpace=True).rng (statistics/MvNormalDistribution.py:179-181)."""
+    return np.exp(np.atleast_1d(np.squeeze(prng.multivariate_normal(np.log(mean), H, size=1))))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# data-error moves, priors, proposal densities, and one full accept/reject step
+# ------------------------------------------------------------------------------------------------------------
+class ErrorPrior:
+    """Log-uniform prior [lo, hi] and log-normal random-walk proposal of one error level
+    (DataPoint.set_priors / set_proposals, data/datapoint/DataPoint.py:575-644)."""
+
+    def __init__(self, lo, hi, proposal_variance):
+        self.lo, self.hi, self.var = np.log(lo), np.log(hi), proposal_variance
+
+    def log_prior(self, x):
+        lx = np.log(x)
+        return -np.log(self.hi - self.lo) if (self.lo <= lx <= self.hi) else -np.inf
+
+    def propose(self, prng, current):
+        """StatArray.propose with imposePrior=True, log=True (statistics/StatArray.py:578-638)."""
+        draw = lambda: float(np.exp(np.atleast_1d(np.squeeze(
+            prng.multivariate_normal(np.array([np.log(current)]), np.array([[self.var]]), size=1)))[0]))
+        x = draw()
+        tries = 0
+        while self.log_prior(x) == -np.inf:
+            x = draw()
+            tries += 1
+            if tries == 10:
+                return current
+        return x
+
+
+def mvn_logpdf(x, mean, cov):
+    """MvNormal.probability(log=True) (statistics/MvNormalDistribution.py:201-216)."""
+    d = x - mean
+    sign, logdet = np.linalg.slogdet(cov)
+    return -(0.5 * x.size) * np.log(2.0 * np.pi) - 0.5 * sign * logdet - 0.5 * d @ (np.linalg.inv(cov) @ d)
+
+
+def model_log_prior(sp, vp, edges, values):
+    """Model.probability(solve_value=False, solve_gradient=True) (model/Model.py:533-575): uniform prior on the
+    number of layers (mesh/RectilinearMesh1D.py:1351-1382; the order-statistics prior on the interfaces is
+    commented out in the reference) + normal prior on the vertical gradient of ln sigma (Model.py:213-234)."""
+    k = values.size
+    lp = -np.log(sp.max_cells - 1.0)
+    if not vp.solve_gradient:
+        return lp
+    if k == 1:   # the reference evaluates a two-layer copy of the half-space: zero gradient
+        g = np.zeros(1)
+    else:
+        widths = np.diff(np.r_[0.0, edges])
+        g = np.diff(np.log(values)) / np.log(widths)
+    return lp + mvn_logpdf(g, np.zeros(g.size), np.eye(g.size) / vp.gradient_precision)
+
+
+def gauss_loglike(pred, data, std):
+    """chi^2 and log-likelihood over the active (data > 0) channels -- host-side twin of gbp_gauss_loglike for the
+    engines that do not return them (DataPoint.py:491-525)."""
+    a = data > 0.0
+    r = (pred[a] - data[a]) / std[a]
+    chi2 = float(np.sum(r * r))
+    return chi2, float(-(0.5 * a.sum()) * np.log(2.0 * np.pi) - np.sum(np.log(std[a])) - 0.5 * chi2)
+
+
+class ChainState:
+    """What Inference1D carries between iterations for one sounding."""
+
+    def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit):
+        self.edges, self.values = np.array(edges, dtype=np.float64), np.array(values, dtype=np.float64)
+        self.rel, self.add = float(rel), float(add)
+        self.pred, self.J = np.array(pred, dtype=np.float64), np.array(J, dtype=np.float64)
+        self.prior, self.like, self.misfit = float(prior), float(like), float(misfit)
+
+    @property
+    def k(self):
+        return self.values.size
+
+
+def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0):
+    """One iteration of Inference1D.accept_reject (inversion/Inference1D.py:537-631) for the Resolve-style option
+    set (solve_gradient, solve relative / additive error, no height move).  ``engine.forward(edges, values)`` and
+    ``engine.sensitivity(edges, values)`` are the hot path (GPU kernels in the product).  Returns (accepted, state)."""
+    prng.random()                                               # Inference1D.py:542
+    action, _, _, edges, rem = perturb_structure(prng, sp, state.edges, state.values)
+    if action != NONE:                                          # fm_dlogc(remapped), Model.py:383-384
+        pred_rem, J = engine.forward(edges, rem), engine.sensitivity(edges, rem)
+    else:
+        pred_rem, J = state.pred, state.J
+    std = np.sqrt((state.rel * data) ** 2.0 + state.add ** 2.0)
+    mean, H = stochastic_newton(vp, edges, rem, J, pred_rem, data, std, alpha)
+    prop = propose_values(prng, mean, H)
+    rel = rel_prior.propose(prng, state.rel)                    # DataPoint.perturb, DataPoint.py:531-573
+    add = add_prior.propose(prng, state.add)
+    pred = engine.forward(edges, prop)
+    std_t = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+    misfit, like = gauss_loglike(pred, data, std_t)
+    prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
+    if prior == -np.inf:
+        return False, state
+    prior += model_log_prior(sp, vp, edges, prop)
+    if prior == -np.inf:
+        return False, state
+    q_fwd = q_rev = 1.0
+    if action in (INSERT, DELETE):                              # Model.proposal_probabilities, Model.py:577-659
+        J = engine.sensitivity(edges, prop)
+        a = data > 0.0
+        grad = model_prior_derivative(vp, edges, prop, 1) + J[a].T @ ((pred[a] - data[a]) / std_t[a] ** 2.0)
+        # ln sigma' - alpha * pk with pk = -H g; the reference exponentiates in long double (expReal,
+        # base/utilities.py:827-856), so the reverse mean only degenerates beyond exp(+-11356)
+        mean_r = np.exp(np.longdouble(1.0) * (np.log(prop) + alpha * (H @ grad)))
+        if np.any(np.isinf(mean_r)) or np.any(mean_r == 0.0):
+            q_fwd = q_rev = -np.inf
+        else:
+            q_fwd = mvn_logpdf(np.log(rem), np.log(mean_r).astype(np.float64), H)
+            q_rev = mvn_logpdf(np.log(prop), np.log(rem), H)
+    log_ratio = (prior - state.prior) + (like - state.like) + (q_fwd - q_rev)
+    # expReal(log_ratio) > U(0,1): inf above 11356, NaN (from -inf - -inf) compares False
+    ratio = np.inf if log_ratio > 11356.0 else np.exp(np.longdouble(log_ratio))
+    accepted = bool(ratio > prng.uniform())
+    if not accepted:
+        return False, state
+    return True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit)

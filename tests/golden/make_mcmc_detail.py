@@ -6,7 +6,8 @@ resolve_options and seed, 400 iterations), but recording for EVERY iteration the
 Inference1D.accept_reject (inversion/Inference1D.py:537-631) has to reproduce:
 
   rng_state        PCG64DXSM state at the start of the iteration (so each iteration can be replayed alone)
-  cur_*            current model (k, interface depths, conductivities), errors, prior / likelihood before the step
+  cur_*            current model (k, interface depths, conductivities), errors, prior / likelihood before the step,
+                   and the datapoint's predicted data and (possibly stale) sensitivity matrix it carries
   action, a_index, a_value      RectilinearMesh1D.perturb outcome (mesh/RectilinearMesh1D.py:993-1120)
   rem_*            remapped model;  H, mean          stochastic-Newton proposal (model/Model.py:368-419)
   prop_*           proposed conductivities and error levels
@@ -80,7 +81,7 @@ def main():
 
     Model.stochastic_newton_perturbation, Model.proposal_probabilities, Model.probability = snp, pp, mp
 
-    keys = ["rng_state", "cur_k", "cur_edges", "cur_sigma", "cur_rel", "cur_add", "cur_prior", "cur_like", "cur_misfit",
+    keys = ["cur_J", "cur_pred", "rng_state", "cur_k", "cur_edges", "cur_sigma", "cur_rel", "cur_add", "cur_prior", "cur_like", "cur_misfit",
             "action", "a_index", "a_value", "rem_k", "rem_edges", "rem_sigma", "H", "mean", "prop_sigma", "prop_rel",
             "prop_add", "t_model_prior", "q_fwd", "q_rev", "accepted", "new_k", "new_misfit", "new_prior", "new_like"]
     rec = {k: [] for k in keys}
@@ -93,6 +94,11 @@ def main():
         m64 = (1 << 64) - 1
         rec["rng_state"].append(np.array([s >> 64, s & m64, inc >> 64, inc & m64, st["has_uint32"], st["uinteger"]],
                                          dtype=np.uint64))
+        Jc = np.zeros((12, LMAX))
+        Jm = np.asarray(inf.datapoint.sensitivity_matrix, dtype=float)
+        Jc[:, : Jm.shape[1]] = Jm
+        rec["cur_J"].append(Jc)
+        rec["cur_pred"].append(np.asarray(inf.datapoint.predictedData, dtype=float).copy())
         rec["cur_k"].append(int(inf.model.nCells.item()))
         rec["cur_edges"].append(pad(np.asarray(inf.model.mesh.edges)[1:-1]))
         rec["cur_sigma"].append(pad(inf.model.values))
