@@ -1,0 +1,217 @@
+"""Per-sounding rjMCMC driver on top of the GPU hot path.
+
+``Inference1D`` mirrors how the reference's harness uses its class of the same name
+(inversion/Inference3D.py:617-620: ``Inference1D(prng=..., **options).initialize(datapoint)`` then ``accept_reject()``
+/ ``update()`` per iteration, inversion/Inference1D.py:353-464, 537-631, 705-790) for FDEM data with the
+Resolve-style option set (solve_gradient, solve relative / additive error, no height move).  The sampler logic is
+the host-side restatement in ``rjmcmc.py``; every forward solve, Jacobian and likelihood goes through the HIP
+kernels.  With the reference's seed it reproduces the reference's chain decision by decision
+(tests/test_rjmcmc.py).  ``BatchedInference`` runs many soundings in lockstep, each with its own generator, and
+batches their kernel calls: one forward launch and one Jacobian launch per phase instead of one per sounding.
+Posterior hit-maps / HDF output of the reference (row f-4) are not part of this module.
+"""
+import numpy as np
+
+from . import rjmcmc
+from .batch import FdemBatch
+
+
+class GpuEngine:
+    """forward / sensitivity of single soundings or lists of soundings through FdemBatch (one launch per call)."""
+
+    def __init__(self, system, z, lmax=32):
+        self.system, self.z, self.lmax = system, float(z), int(lmax)
+
+    def _batch(self, models, heights=None):
+        n = len(models)
+        nl = np.array([v.size for _, v in models], dtype=np.int32)
+        sig = np.ones((n, self.lmax))
+        thk = np.zeros((n, self.lmax))
+        for i, (e, v) in enumerate(models):
+            sig[i, : v.size] = v
+            thk[i, : v.size - 1] = np.diff(np.r_[0.0, e])
+        h = np.full(n, self.z) if heights is None else np.asarray(heights, dtype=np.float64)
+        return FdemBatch(self.system, nl, sig, thk, h), nl
+
+    def forward_many(self, models, heights=None):
+        b, _ = self._batch(models, heights)
+        return b.forward().cpu().numpy()
+
+    def sensitivity_many(self, models, heights=None):
+        b, nl = self._batch(models, heights)
+        J = b.sensitivity(max_layers=int(nl.max())).cpu().numpy()
+        return [J[i][:, : nl[i]] for i in range(len(models))]
+
+    def forward(self, edges, values):
+        return self.forward_many([(edges, values)])[0]
+
+    def sensitivity(self, edges, values):
+        return self.sensitivity_many([(edges, values)])[0]
+
+
+OPTION_DEFAULTS = dict(covariance_scaling=1.0, gradient_standard_deviation=1.5, factor=10.0, minimum_thickness=1.0,
+                       solve_gradient=True)
+
+
+def _priors_from_options(o, value_mean):
+    sp = rjmcmc.StructurePrior(o["maximum_number_of_layers"], o["minimum_depth"], o["maximum_depth"],
+                               o["minimum_thickness"],
+                               [o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
+                                o["probability_of_no_change"]])
+    vp = rjmcmc.ValuePrior(value_mean, o["factor"], o["gradient_standard_deviation"], o["solve_gradient"])
+    rp = rjmcmc.ErrorPrior(o["minimum_relative_error"], o["maximum_relative_error"], o["relative_error_proposal_variance"])
+    ap = rjmcmc.ErrorPrior(o["minimum_additive_error"], o["maximum_additive_error"], o["additive_error_proposal_variance"])
+    return sp, vp, rp, ap
+
+
+def initial_state(engine, data, o):
+    """Inference1D.initialize (inversion/Inference1D.py:353-464, 485-535): best half-space out of 100 log-spaced
+    conductivities (EmDataPoint.find_best_halfspace), its forward / Jacobian, prior and likelihood."""
+    rel, add = o["initial_relative_error"], o["initial_additive_error"]
+    std = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+    grid = np.logspace(-4.0, 4.0, 100)
+    none = np.zeros(0)
+    preds = engine.forward_many([(none, np.array([c])) for c in grid])
+    phi = [rjmcmc.gauss_loglike(p, data, std)[0] for p in preds]
+    sigma = np.array([grid[int(np.argmin(phi))]])
+    sp, vp, rp, ap = _priors_from_options(o, sigma.item())
+    pred, J = engine.forward(none, sigma), engine.sensitivity(none, sigma)
+    misfit, like = rjmcmc.gauss_loglike(pred, data, std)
+    prior = rjmcmc.model_log_prior(sp, vp, none, sigma) + rp.log_prior(rel) + ap.log_prior(add)
+    return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit)
+
+
+class Inference1D:
+    """rjMCMC for one FDEM sounding.  ``options``: the keys of the reference's options file
+    (documentation_source/source/supplementary/options_files/resolve_options)."""
+
+    def __init__(self, prng=None, engine=None, **options):
+        assert isinstance(prng, np.random.Generator), TypeError("prng must have type np.random.Generator")
+        self.prng, self.engine = prng, engine
+        self.options = dict(OPTION_DEFAULTS)
+        self.options.update({k: v for k, v in options.items() if v is not None})
+        self.n_markov_chains = int(self.options.get("n_markov_chains", 100000))
+        self.iteration, self.accepted = 0, False
+
+    def initialize(self, datapoint):
+        """``datapoint``: geobipy_amd.FdemDataPoint (its data, altitude and system are used)."""
+        self.data = np.asarray(datapoint.data, dtype=np.float64)
+        if self.engine is None:
+            self.engine = GpuEngine(datapoint.system[0], datapoint.z[0])
+        self.priors, self.state = initial_state(self.engine, self.data, self.options)
+        self.halfspace = self.state.values.copy()
+        self.iteration = 0
+        self.data_misfit_v = np.zeros(2 * self.n_markov_chains)
+        self.data_misfit_v[0] = self.state.misfit
+        self.acceptance_v = np.zeros(2 * self.n_markov_chains, dtype=np.uint8)
+        self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, 0
+
+    # the quantities the reference exposes on its Inference1D
+    @property
+    def data_misfit(self):
+        return self.state.misfit
+
+    @property
+    def prior(self):
+        return self.state.prior
+
+    @property
+    def likelihood(self):
+        return self.state.like
+
+    @property
+    def posterior(self):
+        return self.state.like + self.state.prior
+
+    @property
+    def model(self):
+        from .model import Model, RectilinearMesh1D
+        return Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, self.state.edges, np.inf]), values=self.state.values)
+
+    def accept_reject(self):
+        sp, vp, rp, ap = self.priors
+        self.accepted, self.state = rjmcmc.accept_reject(self.prng, self.state, self.data, self.engine, sp, vp, rp, ap,
+                                                         self.options["covariance_scaling"])
+        return False
+
+    def update(self):
+        """Bookkeeping of Inference1D.update (:705-790) that does not need the posterior histograms."""
+        self.iteration += 1
+        self.data_misfit_v[self.iteration - 1] = self.state.misfit
+        if self.posterior > self.best_posterior:
+            self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
+        self.acceptance_v[self.iteration] = self.accepted
+
+    def infer(self, n_iterations=None):
+        for _ in range(self.n_markov_chains if n_iterations is None else n_iterations):
+            self.accept_reject()
+            self.update()
+        return self.state
+
+
+class BatchedInference:
+    """Many soundings in lockstep: same sampler, same per-sounding random streams as independent ``Inference1D`` runs
+    (so each chain is the chain the reference would produce from that seed), but the kernel calls of one phase of
+    the step are issued as ONE batched launch over all chains:
+
+        phase A  forward + Jacobian at the remapped models of the chains whose structure changed
+        phase B  forward at every proposed model
+        phase C  Jacobian at the proposed model of the chains that inserted / deleted a layer
+
+    The host logic between the phases is the per-chain code of rjmcmc.accept_reject, re-entered with the phase
+    results (a generator-based coroutine per chain keeps the random stream order intact)."""
+
+    def __init__(self, system, heights, data, prngs, **options):
+        self.options = dict(OPTION_DEFAULTS)
+        self.options.update({k: v for k, v in options.items() if v is not None})
+        self.data = np.asarray(data, dtype=np.float64)
+        self.heights = np.asarray(heights, dtype=np.float64)
+        self.prngs = list(prngs)
+        self.B = self.data.shape[0]
+        self.engine = GpuEngine(system, 0.0, lmax=int(self.options["maximum_number_of_layers"]) + 2)
+        self.states, self.priors = [], []
+        o = self.options
+        grid = np.logspace(-4.0, 4.0, 100)
+        none = np.zeros(0)
+        # initialisation: B x 100 half-space forwards in one launch, then B forwards + B Jacobians
+        preds = self.engine.forward_many([(none, np.array([c])) for _ in range(self.B) for c in grid],
+                                         np.repeat(self.heights, 100)).reshape(self.B, 100, -1)
+        sig0 = []
+        for b in range(self.B):
+            std = np.sqrt((o["initial_relative_error"] * self.data[b]) ** 2.0 + o["initial_additive_error"] ** 2.0)
+            phi = [rjmcmc.gauss_loglike(preds[b, i], self.data[b], std)[0] for i in range(100)]
+            sig0.append(np.array([grid[int(np.argmin(phi))]]))
+        models = [(none, s) for s in sig0]
+        P = self.engine.forward_many(models, self.heights)
+        J = self.engine.sensitivity_many(models, self.heights)
+        for b in range(self.B):
+            pr = _priors_from_options(o, sig0[b].item())
+            rel, add = o["initial_relative_error"], o["initial_additive_error"]
+            std = np.sqrt((rel * self.data[b]) ** 2.0 + add ** 2.0)
+            misfit, like = rjmcmc.gauss_loglike(P[b], self.data[b], std)
+            prior = rjmcmc.model_log_prior(pr[0], pr[1], none, sig0[b]) + pr[2].log_prior(rel) + pr[3].log_prior(add)
+            self.priors.append(pr)
+            self.states.append(rjmcmc.ChainState(none, sig0[b], rel, add, P[b], J[b], prior, like, misfit))
+        self.accepted = np.zeros(self.B, dtype=bool)
+        self.iteration = 0
+
+    def step(self):
+        """One rjMCMC iteration of every chain with three batched kernel phases."""
+        alpha = self.options["covariance_scaling"]
+        gens = [rjmcmc.accept_reject_phases(self.prngs[b], self.states[b], self.data[b], *self.priors[b], alpha)
+                for b in range(self.B)]
+        requests = [next(g) for g in gens]                      # up to phase A
+        for phase in range(3):
+            idx = [b for b in range(self.B) if requests[b] is not None and requests[b][0] == phase]
+            if idx:
+                models = [requests[b][1] for b in idx]
+                h = self.heights[idx]
+                want_f, want_j = phase in (0, 1), phase in (0, 2)
+                F = self.engine.forward_many(models, h) if want_f else [None] * len(idx)
+                Jm = self.engine.sensitivity_many(models, h) if want_j else [None] * len(idx)
+                for q, b in enumerate(idx):
+                    requests[b] = gens[b].send((F[q], Jm[q]))
+        for b in range(self.B):                                  # every coroutine has now returned its verdict
+            self.accepted[b], self.states[b] = requests[b][1], requests[b][2]
+        self.iteration += 1
+        return self.accepted

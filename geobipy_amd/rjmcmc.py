@@ -208,14 +208,20 @@ class ChainState:
         return self.values.size
 
 
-def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0):
+def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0):
     """One iteration of Inference1D.accept_reject (inversion/Inference1D.py:537-631) for the Resolve-style option
-    set (solve_gradient, solve relative / additive error, no height move).  ``engine.forward(edges, values)`` and
-    ``engine.sensitivity(edges, values)`` are the hot path (GPU kernels in the product).  Returns (accepted, state)."""
+    set (solve_gradient, solve relative / additive error, no height move), written as a coroutine around the hot
+    path: it yields ``(phase, (edges, values))`` whenever it needs the kernels --
+        phase 0: forward + Jacobian at the remapped model (fm_dlogc, Model.py:383-384)
+        phase 1: forward at the proposed model (Inference1D.py:572)
+        phase 2: Jacobian at the proposed model (reversible-jump step, Model.py:612)
+    -- is sent back ``(predicted, J)``, and finally yields ``(3, accepted, state)``.  The random stream is consumed
+    in exactly the reference's order, so a driver may interleave the coroutines of many chains and batch each
+    phase into one launch."""
     prng.random()                                               # Inference1D.py:542
     action, _, _, edges, rem = perturb_structure(prng, sp, state.edges, state.values)
-    if action != NONE:                                          # fm_dlogc(remapped), Model.py:383-384
-        pred_rem, J = engine.forward(edges, rem), engine.sensitivity(edges, rem)
+    if action != NONE:
+        pred_rem, J = yield (0, (edges, rem))
     else:
         pred_rem, J = state.pred, state.J
     std = np.sqrt((state.rel * data) ** 2.0 + state.add ** 2.0)
@@ -223,18 +229,20 @@ def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha
     prop = propose_values(prng, mean, H)
     rel = rel_prior.propose(prng, state.rel)                    # DataPoint.perturb, DataPoint.py:531-573
     add = add_prior.propose(prng, state.add)
-    pred = engine.forward(edges, prop)
+    pred, _ = yield (1, (edges, prop))
     std_t = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
     misfit, like = gauss_loglike(pred, data, std_t)
     prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
     if prior == -np.inf:
-        return False, state
+        yield (3, False, state)
+        return
     prior += model_log_prior(sp, vp, edges, prop)
     if prior == -np.inf:
-        return False, state
+        yield (3, False, state)
+        return
     q_fwd = q_rev = 1.0
     if action in (INSERT, DELETE):                              # Model.proposal_probabilities, Model.py:577-659
-        J = engine.sensitivity(edges, prop)
+        _, J = yield (2, (edges, prop))
         a = data > 0.0
         grad = model_prior_derivative(vp, edges, prop, 1) + J[a].T @ ((pred[a] - data[a]) / std_t[a] ** 2.0)
         # ln sigma' - alpha * pk with pk = -H g; the reference exponentiates in long double (expReal,
@@ -247,8 +255,23 @@ def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha
             q_rev = mvn_logpdf(np.log(prop), np.log(rem), H)
     log_ratio = (prior - state.prior) + (like - state.like) + (q_fwd - q_rev)
     # expReal(log_ratio) > U(0,1): inf above 11356, NaN (from -inf - -inf) compares False
-    ratio = np.inf if log_ratio > 11356.0 else np.exp(np.longdouble(log_ratio))
-    accepted = bool(ratio > prng.uniform())
+    with np.errstate(invalid="ignore"):
+        ratio = np.inf if log_ratio > 11356.0 else np.exp(np.longdouble(log_ratio))
+        accepted = bool(ratio > prng.uniform())
     if not accepted:
-        return False, state
-    return True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit)
+        yield (3, False, state)
+        return
+    yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit))
+
+
+def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0):
+    """Drive ``accept_reject_phases`` for one chain with ``engine.forward(edges, values)`` /
+    ``engine.sensitivity(edges, values)`` (GPU kernels in the product).  Returns (accepted, state)."""
+    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha)
+    req = next(g)
+    while req[0] != 3:
+        phase, (e, v) = req
+        F = engine.forward(e, v) if phase in (0, 1) else None
+        Jm = engine.sensitivity(e, v) if phase in (0, 2) else None
+        req = g.send((F, Jm))
+    return req[1], req[2]
