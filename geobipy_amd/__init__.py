@@ -12,7 +12,8 @@ from .model import Model, RectilinearMesh1D
 from .datapoint import FdemDataPoint
 from .batch import FdemBatch
 from .tdem import TdemBatch, TdemDataPoint, TdemSystem
-from . import synthetic
+from .inference import BatchedInference, Inference1D
+from . import rjmcmc, synthetic
 
 __all__ = ["CircularLoop", "FdemSystem", "Model", "RectilinearMesh1D", "FdemDataPoint", "FdemBatch", "TdemSystem", "TdemDataPoint", "TdemBatch",
-           "synthetic"]
+           "Inference1D", "BatchedInference", "rjmcmc", "synthetic"]

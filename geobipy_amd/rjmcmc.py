@@ -122,8 +122,9 @@ def stochastic_newton(vp, edges, values, J, predicted, data, std, alpha=1.0):
     active = data > 0.0
     Ja = J[active]
     P = 1.0 / std[active] ** 2.0
-    hess = model_prior_derivative(vp, edges, values, 2) + Ja.T @ (P[:, None] * Ja)
-    grad = model_prior_derivative(vp, edges, values, 1) + Ja.T @ (P * (predicted[active] - data[active]))
+    op = model_prior_derivative(vp, edges, values, 2)
+    hess = op + Ja.T @ (P[:, None] * Ja)
+    grad = op @ (np.log(values) - vp.log_mean) + Ja.T @ (P * (predicted[active] - data[active]))
     H = np.linalg.inv(hess)
     pk = -(H @ grad)
     return np.exp(np.log(values) + alpha * pk), H
@@ -149,9 +150,11 @@ class ErrorPrior:
         return -np.log(self.hi - self.lo) if (self.lo <= lx <= self.hi) else -np.inf
 
     def propose(self, prng, current):
-        """StatArray.propose with imposePrior=True, log=True (statistics/StatArray.py:578-638)."""
-        draw = lambda: float(np.exp(np.atleast_1d(np.squeeze(
-            prng.multivariate_normal(np.array([np.log(current)]), np.array([[self.var]]), size=1)))[0]))
+        """StatArray.propose with imposePrior=True, log=True (statistics/StatArray.py:578-638).  The reference draws
+        with Generator.multivariate_normal on a 1 x 1 covariance, which numpy evaluates as
+        mean + standard_normal() * sqrt(var) (SVD of a positive 1 x 1 matrix: s = var, vh = 1)."""
+        lc, sd = np.log(current), np.sqrt(self.var)
+        draw = lambda: float(np.exp(lc + prng.standard_normal() * sd))
         x = draw()
         tries = 0
         while self.log_prior(x) == -np.inf:
