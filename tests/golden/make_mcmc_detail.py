@@ -22,13 +22,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from make_golden import REF, SUP, import_reference   # noqa: E402
 
-N_ITER = 400
+N_ITER = 400        # iterations recorded in full detail
+N_LONG = 3000       # iterations of the same run whose decisions / layer counts / misfits are recorded
 LMAX = 30
 ACTIONS = {"none": 0, "insert": 1, "delete": 2, "perturb": 3}
 
 
 def main():
+    global N_LONG
     import numpy as np
+    deep = len(sys.argv) > 1 and sys.argv[1] == "deep"   # birth-heavy variant on another sounding -> mcmc_deep.npz
     import_reference()
     from geobipy import FdemData, Inference1D, get_prng
     from geobipy.src.inversion import user_parameters as up
@@ -37,8 +40,13 @@ def main():
     opt_file = REF + "/documentation_source/source/supplementary/options_files/resolve_options"
     options = up.user_parameters.read(opt_file, data_directory=SUP)
     options["system_filename"] = SUP + "/resolve.stm"
-    options.update(n_markov_chains=N_ITER, save_hdf5=False, interactive_plot=True, update_plot_every=100000)
-    dp = FdemData.read_csv(SUP + "/resolve_glacial.csv", system=options["system_filename"]).datapoint(30)
+    options.update(n_markov_chains=N_LONG, save_hdf5=False, interactive_plot=True, update_plot_every=100000)
+    if deep:
+        options.update(probability_of_birth=0.5, probability_of_death=0.1, probability_of_perturb=0.2,
+                       probability_of_no_change=0.2)
+        N_LONG = 1200
+        options["n_markov_chains"] = N_LONG
+    dp = FdemData.read_csv(SUP + "/resolve_glacial.csv", system=options["system_filename"]).datapoint(60 if deep else 30)
     prng = get_prng(seed=options["seed"])
     inf = Inference1D(prng=prng, world=None, **options)
     inf.initialize(dp)
@@ -130,7 +138,15 @@ def main():
         rec["new_misfit"].append(float(inf.data_misfit))
         rec["new_prior"].append(float(inf.prior))
         rec["new_like"].append(float(inf.likelihood))
+    long_acc, long_k, long_misfit = list(rec["accepted"]), list(rec["new_k"]), list(rec["new_misfit"])
+    for it in range(N_ITER, N_LONG):
+        inf.accept_reject()
+        inf.update()
+        long_acc.append(bool(inf.accepted))
+        long_k.append(int(inf.model.nCells.item()))
+        long_misfit.append(float(inf.data_misfit))
     out = {k: np.asarray(v) for k, v in rec.items()}
+    out["long_accepted"], out["long_k"], out["long_misfit"] = np.array(long_acc), np.array(long_k), np.array(long_misfit)
     out["data"] = np.asarray(dp.data, dtype=float)
     out["z"] = np.float64(dp.z.item())
     out["halfspace"] = np.asarray(inf.halfspace, dtype=float)
@@ -142,8 +158,16 @@ def main():
                                                      "minimum_additive_error", "maximum_additive_error",
                                                      "relative_error_proposal_variance",
                                                      "additive_error_proposal_variance"]], dtype=float)
-    np.savez_compressed(HERE + "/mcmc_detail.npz", **out)
+    if deep:     # decisions-only fixture: the starting state (iteration 0) and the whole decision sequence
+        keep = ["rng_state", "cur_k", "cur_edges", "cur_sigma", "cur_rel", "cur_add", "cur_prior", "cur_like",
+                "cur_misfit", "cur_J", "cur_pred"]
+        out = {k: (v[:1] if k in keep else v) for k, v in out.items()
+               if k in keep or k in ("long_accepted", "long_k", "long_misfit", "data", "z", "halfspace", "options")}
+        np.savez_compressed(HERE + "/mcmc_deep.npz", **out)
+    else:
+        np.savez_compressed(HERE + "/mcmc_detail.npz", **out)
     a = out["action"]
+    print("long run: acceptance", out["long_accepted"].mean(), "k max", out["long_k"].max())
     print("iterations", N_ITER, "actions none/insert/delete/perturb", [(a == i).sum() for i in range(4)],
           "accepted", out["accepted"].mean(), "k max", out["new_k"].max())
 

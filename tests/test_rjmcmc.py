@@ -99,7 +99,7 @@ class OracleEngine:
         return np.vstack([J.real, J.imag])
 
 
-def chain_setup(d):
+def chain_setup(d):   # works for both fixtures: the state of iteration 0 and the options array
     from geobipy_amd import rjmcmc
     o = d["options"]
     sp = rjmcmc.StructurePrior(max_cells=o[0], min_edge=o[1], max_edge=o[2], min_width=o[3], probabilities=o[4:8])
@@ -136,6 +136,26 @@ def test_full_chain_reproduces_the_reference_decisions():
     assert np.array_equal(acc, d["accepted"])
     assert np.array_equal(ks, d["new_k"])
     assert np.allclose(mis, d["new_misfit"], rtol=1e-9)
+
+
+def test_birth_heavy_chain_reproduces_the_reference_decisions():
+    """A second reference run (another sounding, birth probability 0.5) with many rejected births and up to 4 layers: 1200 iterations of
+    identical decisions exercise deaths / perturbations of deeper models and larger stochastic-Newton systems."""
+    d = np.load(os.path.join(GOLDEN, "mcmc_deep.npz"))
+    n = d["long_accepted"].size
+    acc, ks, mis, _ = run_chain(dict(d, accepted=d["long_accepted"]), OracleEngine("resolve", float(d["z"])), n)
+    assert d["long_k"].max() >= 4
+    assert np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
+    assert np.allclose(mis, d["long_misfit"], rtol=1e-7)
+
+
+def test_long_chain_reproduces_the_reference_decisions():
+    """The same without resynchronisation for 3000 iterations (1448 accepted proposals)."""
+    d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
+    n = d["long_accepted"].size
+    acc, ks, mis, _ = run_chain(d, OracleEngine("resolve", float(d["z"])), n)
+    assert n == 3000 and np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
+    assert np.allclose(mis, d["long_misfit"], rtol=1e-8)
 
 
 def test_initial_state_matches_the_reference_initialisation():
