@@ -19,8 +19,10 @@ from .batch import FdemBatch
 class GpuEngine:
     """forward / sensitivity of single soundings or lists of soundings through FdemBatch (one launch per call)."""
 
-    def __init__(self, system, z, lmax=32):
-        self.system, self.z, self.lmax = system, float(z), int(lmax)
+    def __init__(self, system, z, lmax=32, exact_jacobian=False):
+        # exact_jacobian=False reproduces the reference's Jacobian expression (DESIGN.md section 3.4), which is what a
+        # chain needs to follow the reference decision by decision; True uses the true derivative in the proposals
+        self.system, self.z, self.lmax, self.exact = system, float(z), int(lmax), bool(exact_jacobian)
 
     def _batch(self, models, heights=None):
         n = len(models)
@@ -39,7 +41,7 @@ class GpuEngine:
 
     def sensitivity_many(self, models, heights=None):
         b, nl = self._batch(models, heights)
-        J = b.sensitivity(max_layers=int(nl.max())).cpu().numpy()
+        J = b.sensitivity(max_layers=int(nl.max()), exact=self.exact).cpu().numpy()
         return [J[i][:, : nl[i]] for i in range(len(models))]
 
     def forward(self, edges, values):
@@ -168,7 +170,8 @@ class BatchedInference:
         self.heights = np.asarray(heights, dtype=np.float64)
         self.prngs = list(prngs)
         self.B = self.data.shape[0]
-        self.engine = GpuEngine(system, 0.0, lmax=int(self.options["maximum_number_of_layers"]) + 2)
+        self.engine = GpuEngine(system, 0.0, lmax=int(self.options["maximum_number_of_layers"]) + 2,
+                                exact_jacobian=bool(self.options.pop("exact_jacobian", False)))
         self.states, self.priors = [], []
         o = self.options
         grid = np.logspace(-4.0, 4.0, 100)
