@@ -14,8 +14,38 @@ c_void_p = ctypes.c_void_p
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
+
+
+class RjOptions(ctypes.Structure):
+    """gbp_rj_options (include/geobipy_amd.h)."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("max_layers", "n_channels", "solve_gradient", "solve_relative_error",
+                                               "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins")]
+                + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
+                                                  "value_precision", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
+                                                  "add_min", "add_max", "add_sd", "depth_bin_width", "value_half_width")]
+                + [("seed", ctypes.c_uint64)])
+
+
+RJ_CHAIN_FIELDS = ("data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
+                   "action", "k_r", "nl_a", "nl_c", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
+                   "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
+                   "hitmap", "best_posterior", "best_k", "best_edges", "best_sigma")
+
+
+class RjChains(ctypes.Structure):
+    """gbp_rj_chains: B and the device pointers in declaration order."""
+    _fields_ = [("B", ctypes.c_int32)] + [(n, c_void_p) for n in RJ_CHAIN_FIELDS]
+
+
+_rj_o, _rj_c = ctypes.POINTER(RjOptions), ctypes.POINTER(RjChains)
+
 # name -> (restype, argtypes); must list every symbol include/geobipy_amd.h declares
 SIGNATURES = {
+    "gbp_rj_propose": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
+    "gbp_rj_newton": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
+    "gbp_rj_accept": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
+    "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
+    "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gbp_version": (ctypes.c_char_p, []),
     "gbp_last_error": (ctypes.c_char_p, []),
     "gbp_device_count": (c_int, [ctypes.POINTER(c_int)]),

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int L = nlayers[b];
+    if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform): none of its outputs are written
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
     gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int L = nlayers[b];
+    if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
     cplx* sh_D = reinterpret_cast<cplx*>(sh_dyn) + (size_t)wave * Lalloc * GBP_SENS_STRIDE;
@@ -717,3 +719,5 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, 
 }
 
 }  // extern "C"
+
+#include "gbp_rjmcmc.h"

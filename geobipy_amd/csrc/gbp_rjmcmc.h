@@ -1,0 +1,561 @@
+// Device-resident rjMCMC step (include/geobipy_amd.h, section "Device-resident rjMCMC step").
+// Included at the end of gbp_fdem.hip (same translation unit: shares fail() / GBP_HIP and the kernel launchers).
+//
+// Three kernels hold the host logic of one iteration of the reference's Inference1D.accept_reject
+// (inversion/Inference1D.py:537-631); between them the forward / Jacobian kernels above are entered with
+// per-chain layer counts of 0 for the chains that do not need them (a workgroup whose sounding has 0 layers exits).
+//   k_rj_propose  one thread per chain: structural move, value remapping, error proposals
+//   k_rj_newton   one wave per chain:  Gauss-Newton precision, its Cholesky factor in LDS, mean and sample
+//   k_rj_accept   one wave per chain:  priors, reversible-jump proposal ratio, Metropolis test, state update, posteriors
+#pragma once
+
+namespace rj {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter = (chain, iteration, stream, draw), key = seed
+// ---------------------------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline U4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3)
+{
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__host__ __device__ inline double u53(uint32_t a, uint32_t b)      // [0, 1) with 53 random bits
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+
+struct Rng {                                                    // sequential draws of one (chain, iteration, stream)
+    uint64_t seed; uint32_t chain, iter, stream, n; double buf; bool have;
+    __device__ Rng(uint64_t s, uint32_t c, uint32_t i, uint32_t st) : seed(s), chain(c), iter(i), stream(st), n(0), buf(0.0), have(false) {}
+    __device__ double uniform()
+    {
+        if (have) { have = false; return buf; }
+        const U4 r = philox(seed, chain, iter, stream, n++);
+        buf = u53(r.z, r.w); have = true;
+        return u53(r.x, r.y);
+    }
+    __device__ double normal()
+    {
+        const double u1 = uniform(), u2 = uniform();
+        return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
+    }
+};
+
+__device__ inline void normal_pair(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t j, double& z0, double& z1)
+{
+    const U4 r = philox(seed, chain, iter, stream, j);
+    const double rad = sqrt(-2.0 * log(1.0 - u53(r.x, r.y))), ang = TWO_PI * u53(r.z, r.w);
+    z0 = rad * cos(ang); z1 = rad * sin(ang);
+}
+
+enum { NONE = 0, INSERT = 1, DELETE = 2, PERTURB = 3 };
+constexpr double INF = __builtin_huge_val();
+constexpr double LOG_2PI = 1.8378770664093454835606594728112;
+
+__device__ inline double propose_error(Rng& r, double cur, double sd, double lo, double hi)
+{   // StatArray.propose(imposePrior=True, log=True), statistics/StatArray.py:578-638: redraw while outside the prior,
+    // give up (keep the current value) at the 10th redraw
+    const double lc = log(cur), llo = log(lo), lhi = log(hi);
+    double x = lc + sd * r.normal();
+    int tries = 0;
+    while (!(x >= llo && x <= lhi)) {
+        x = lc + sd * r.normal();
+        if (++tries == 10) return cur;
+    }
+    return exp(x);
+}
+
+__device__ inline int bucket_of(int k) { return k <= 8 ? 0 : (k <= 16 ? 1 : 2); }
+
+__global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B) return;
+    const int K = o.max_layers;
+    const double* e = c.edges + (size_t)b * K;
+    const double* s = c.sigma + (size_t)b * K;
+    const int k = c.k[b];
+    Rng r(o.seed, (uint32_t)b, iter, 0);
+    int action = NONE, idx = 0;
+    double val = 0.0;
+    const double lo = log(o.min_edge), hi = log(o.max_edge), mw = o.min_width;
+    bool done = false;
+    for (int round = 0; round < 8 && !done; ++round) {          // RectilinearMesh1D.perturb: redraw the event when the tries run out
+        const double pb = (k == K) ? 0.0 : o.p_birth, pd = (k == 1) ? 0.0 : o.p_death, pp = (k == 1) ? 0.0 : o.p_perturb;
+        const double u = r.uniform() * (pb + pd + pp + o.p_none);
+        if (u < pb) {                                           // birth (:1061-1081); the reference's 10th try always fails
+            for (int t = 0; t < 9; ++t) {
+                const double depth = exp(lo + r.uniform() * (hi - lo));
+                int pos = 0;
+                while (pos < k - 1 && e[pos] < depth) ++pos;
+                const double prev = pos > 0 ? e[pos - 1] : 0.0, next = pos < k - 1 ? e[pos] : INF;
+                if (depth - prev > mw && next - depth > mw) { action = INSERT; idx = pos + 1; val = depth; done = true; break; }
+            }
+        } else if (u < pb + pd) {                               // death (:1083-1087)
+            int i = (int)floor(r.uniform() * (double)(k - 1));
+            idx = min(i, k - 2) + 1; action = DELETE; done = true;
+        } else if (u < pb + pd + pp) {                          // perturb (:1089-1118)
+            for (int t = 0; t < 9; ++t) {
+                const int i = min((int)floor(1.0 + r.uniform() * (double)(k - 1)), k - 1);
+                const double n = r.normal();
+                const double dz = (n > 0.0 ? 1.0 : (n < 0.0 ? -1.0 : 0.0)) * mw * r.uniform();
+                const int ii = i - 1;
+                const double ne = e[ii] + dz;
+                const double prev = ii > 0 ? e[ii - 1] : 0.0, next = ii < k - 2 ? e[ii + 1] : INF;
+                const double first = ii == 0 ? ne : e[0], last = ii == k - 2 ? ne : e[k - 2];
+                if (ne - prev > mw && next - ne > mw && first > o.min_edge && last < o.max_edge) {
+                    action = PERTURB; idx = i; val = dz; done = true; break;
+                }
+            }
+        } else {
+            done = true;
+        }
+    }
+    // remapped model (Model.perturb_structure: insert copies the layer above, delete averages the merged pair)
+    double* er = c.edges_r + (size_t)b * K;
+    double* sr = c.sigma_r + (size_t)b * K;
+    double* tr = c.thk_r + (size_t)b * K;
+    const int kr = k + (action == INSERT) - (action == DELETE);
+    for (int j = 0; j < K; ++j) {
+        double ev = INF, sv = 1.0;
+        if (action == INSERT) {
+            if (j < kr - 1) ev = j < idx - 1 ? e[j] : (j == idx - 1 ? val : e[j - 1]);
+            if (j < kr) sv = j < idx ? s[j] : s[j - 1];
+        } else if (action == DELETE) {
+            if (j < kr - 1) ev = j < idx - 1 ? e[j] : e[j + 1];
+            if (j < kr) sv = j < idx - 1 ? s[j] : (j == idx - 1 ? 0.5 * (s[idx - 1] + s[idx]) : s[j + 1]);
+        } else {
+            if (j < kr - 1) ev = e[j] + ((action == PERTURB && j == idx - 1) ? val : 0.0);
+            if (j < kr) sv = s[j];
+        }
+        er[j] = ev; sr[j] = sv;
+    }
+    for (int j = 0; j < K; ++j) tr[j] = j < kr - 1 ? er[j] - (j > 0 ? er[j - 1] : 0.0) : 0.0;
+    c.action[b] = action;
+    c.k_r[b] = kr;
+    const int bk = bucket_of(kr);
+    const bool jump = action == INSERT || action == DELETE;
+    c.nl_a[b] = action != NONE ? kr : 0;
+    c.nl_c[b] = jump ? kr : 0;
+    for (int i = 0; i < 3; ++i) {
+        c.nl_a[(size_t)(1 + i) * c.B + b] = (action != NONE && bk == i) ? kr : 0;
+        c.nl_c[(size_t)(1 + i) * c.B + b] = (jump && bk == i) ? kr : 0;
+    }
+    // error levels (DataPoint.perturb: relative then additive)
+    c.rel_p[b] = o.solve_relative_error ? propose_error(r, c.rel[b], o.rel_sd, o.rel_min, o.rel_max) : c.rel[b];
+    c.add_p[b] = o.solve_additive_error ? propose_error(r, c.add[b], o.add_sd, o.add_min, o.add_max) : c.add[b];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared per-chain algebra (one wave = one chain, matrices in LDS with row stride K + 1)
+// ---------------------------------------------------------------------------------------------------------------
+// t2[j] = gradient_precision * Wz[j, j]^2 of RectilinearMesh1D.gradient_operator (mesh/RectilinearMesh1D.py:747-786)
+__device__ inline double width_x(const double* e, int k, int j)
+{
+    if (j < k - 1) return e[j] - (j > 0 ? e[j - 1] : 0.0);
+    if (k == 2) return e[0];
+    return (e[k - 2] - (k > 2 ? e[k - 3] : 0.0)) + e[k - 2];
+}
+
+__device__ inline void prior_t2(const gbp_rj_options& o, const double* e, int k, int lane, double* t2)
+{
+    if (lane < k - 1) {
+        const double c2c = 0.5 * (width_x(e, k, lane) + width_x(e, k, lane + 1)) * (double)(k - 1);
+        t2[lane] = o.solve_gradient ? o.gradient_precision / (c2c * c2c) : 0.0;
+    }
+}
+
+// (Wm'Wm v)_i for the tridiagonal prior operator (Model.prior_derivative, model/Model.py:421-430)
+__device__ inline double prior_apply(const gbp_rj_options& o, const double* t2, int k, int i, const double* v)
+{
+    if (k == 1) return (o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0)) * v[0];
+    const double up = i > 0 ? t2[i - 1] : 0.0, dn = i < k - 1 ? t2[i] : 0.0;
+    double y = (o.value_precision + up + dn) * v[i];
+    if (i > 0) y -= up * v[i - 1];
+    if (i < k - 1) y -= dn * v[i + 1];
+    return y;
+}
+
+__device__ inline double prior_entry(const gbp_rj_options& o, const double* t2, int k, int i, int j)   // j <= i
+{
+    if (k == 1) return o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
+    if (i == j) return o.value_precision + (i > 0 ? t2[i - 1] : 0.0) + (i < k - 1 ? t2[i] : 0.0);
+    return j == i - 1 ? -t2[j] : 0.0;
+}
+
+// data weights with the error levels (rel, add): P = active / std^2, PR = P * (pred - data)  (DataPoint.py:268-282, 340-349)
+__device__ inline void data_weights(const double* data, const double* pred, double rel, double add, int N, int lane, double* P, double* PR)
+{
+    for (int n = lane; n < N; n += 64) {
+        const double d = data[n];
+        const bool act = d > 0.0;
+        const double rd = rel * d, w = act ? 1.0 / (rd * rd + add * add) : 0.0;
+        P[n] = w;
+        PR[n] = act ? w * (pred[n] - d) : 0.0;
+    }
+}
+
+// solve C C' x = g in place (g -> x), C lower in A (row stride KS); lane-parallel column sweeps
+__device__ inline void chol_solve(const double* A, int KS, int k, int lane, double* g, bool forward, bool backward)
+{
+    if (forward)
+        for (int j = 0; j < k; ++j) {
+            if (lane == j) g[j] = g[j] / A[j * KS + j];
+            __syncthreads();
+            if (lane > j && lane < k) g[lane] -= A[lane * KS + j] * g[j];
+            __syncthreads();
+        }
+    if (backward)
+        for (int j = k - 1; j >= 0; --j) {
+            if (lane == j) g[j] = g[j] / A[j * KS + j];
+            __syncthreads();
+            if (lane < j) g[lane] -= A[j * KS + lane] * g[j];
+            __syncthreads();
+        }
+}
+
+__device__ inline double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LDS carve-up of both wave-per-chain kernels
+struct Lds {
+    double *A, *g, *t2, *v, *w, *P, *PR, *row;
+    __device__ Lds(unsigned char* base, int K, int N)
+    {
+        double* p = reinterpret_cast<double*>(base);
+        A = p; p += (size_t)K * (K + 1);
+        g = p; p += K; t2 = p; p += K; v = p; p += K; w = p; p += K; row = p; p += K;
+        P = p; p += N; PR = p;
+    }
+    static size_t bytes(int K, int N) { return ((size_t)K * (K + 1) + 5 * (size_t)K + 2 * (size_t)N) * sizeof(double); }
+};
+
+__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{   // Model.stochastic_newton_perturbation (model/Model.py:368-419): precision = J'PJ + Wm'Wm at the remapped model,
+    // mean = ln sigma - alpha * precision^-1 g, sample ~ N(mean, precision^-1) = mean + C^-T z with precision = C C'
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int K = o.max_layers, N = o.n_channels, KS = K + 1;
+    Lds s(sh_dyn, K, N);
+    const int k = c.k_r[b];
+    const bool changed = c.action[b] != NONE;
+    const double* J = (changed ? c.J_r : c.J) + (size_t)b * N * K;
+    const double* pred = (changed ? c.pred_r : c.pred) + (size_t)b * N;
+    const double* e = c.edges_r + (size_t)b * K;
+    const double* sr = c.sigma_r + (size_t)b * K;
+    data_weights(c.data + (size_t)b * N, pred, c.rel[b], c.add[b], N, lane, s.P, s.PR);
+    prior_t2(o, e, k, lane, s.t2);
+    const double lmp = c.log_mean_prior[b];
+    const double ls = lane < k ? log(sr[lane]) : 0.0;
+    if (lane < k) s.v[lane] = ls - lmp;
+    __syncthreads();
+    double acc[64];                                              // row `lane` of J'PJ, columns <= lane
+    double gi = 0.0;
+    // the compiler keeps acc[] in registers only with a static bound; K <= 64
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = 0.0;
+    for (int n = 0; n < N; ++n) {
+        if (lane < k) s.row[lane] = J[(size_t)n * K + lane];
+        __syncthreads();
+        if (lane < k) {
+            const double ji = s.row[lane], jp = ji * s.P[n];
+            gi += ji * s.PR[n];
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                if (j <= lane && j < k) acc[j] += jp * s.row[j];
+        }
+        __syncthreads();
+    }
+    if (lane < k) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j)
+            if (j <= lane && j < k) s.A[lane * KS + j] = acc[j] + prior_entry(o, s.t2, k, lane, j);
+        s.g[lane] = gi + prior_apply(o, s.t2, k, lane, s.v);
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {                                // Cholesky, lower, in place
+        if (lane == j) {
+            double d = s.A[j * KS + j];
+            for (int m = 0; m < j; ++m) d -= s.A[j * KS + m] * s.A[j * KS + m];
+            s.A[j * KS + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (lane > j && lane < k) {
+            double d = s.A[lane * KS + j];
+            for (int m = 0; m < j; ++m) d -= s.A[lane * KS + m] * s.A[j * KS + m];
+            s.A[lane * KS + j] = d / s.A[j * KS + j];
+        }
+        __syncthreads();
+    }
+    double* C = c.chol + (size_t)b * K * K;
+    if (lane < k)
+        for (int j = 0; j <= lane; ++j) C[(size_t)lane * K + j] = s.A[lane * KS + j];
+    chol_solve(s.A, KS, k, lane, s.g, true, true);
+    if (lane < 32) {
+        double z0, z1;
+        normal_pair(o.seed, (uint32_t)b, iter, 1, (uint32_t)lane, z0, z1);
+        if (2 * lane < K) s.w[2 * lane] = z0;
+        if (2 * lane + 1 < K) s.w[2 * lane + 1] = z1;
+    }
+    __syncthreads();
+    chol_solve(s.A, KS, k, lane, s.w, false, true);
+    if (lane < K) {
+        const double lp = lane < k ? (ls - o.alpha * s.g[lane]) + s.w[lane] : 0.0;
+        c.log_prop[(size_t)b * K + lane] = lp;
+        c.sigma_p[(size_t)b * K + lane] = lane < k ? exp(lp) : 1.0;
+    }
+}
+
+__device__ inline double log_uniform_prior(double x, double lo, double hi)
+{
+    const double lx = log(x), llo = log(lo), lhi = log(hi);
+    return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
+}
+
+__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int K = o.max_layers, N = o.n_channels, KS = K + 1;
+    Lds s(sh_dyn, K, N);
+    const int k = c.k_r[b], action = c.action[b];
+    const double* e = c.edges_r + (size_t)b * K;
+    const double* lpv = c.log_prop + (size_t)b * K;
+    const double* tr = c.thk_r + (size_t)b * K;
+    const double lmp = c.log_mean_prior[b];
+    // priors of the proposal (Model.probability :533-575: uniform on k, normal on the gradient of ln sigma)
+    double prior_p = -log((double)K - 1.0);
+    if (o.solve_gradient) {
+        double g2 = 0.0;
+        if (lane < k - 1) { const double g = (lpv[lane + 1] - lpv[lane]) / log(tr[lane]); g2 = g * g; }
+        g2 = wave_sum(g2);
+        const double n = (double)max(1, k - 1);
+        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
+    }
+    const double rel_p = c.rel_p[b], add_p = c.add_p[b];
+    if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);
+    if (o.solve_additive_error) prior_p += log_uniform_prior(add_p, o.add_min, o.add_max);
+    double dq = 0.0;
+    if (action == INSERT || action == DELETE) {                  // Model.proposal_probabilities (model/Model.py:577-659)
+        const double* Jp = c.J_p + (size_t)b * N * K;
+        const double* C = c.chol + (size_t)b * K * K;
+        data_weights(c.data + (size_t)b * N, c.pred_p + (size_t)b * N, rel_p, add_p, N, lane, s.P, s.PR);
+        prior_t2(o, e, k, lane, s.t2);
+        if (lane < k) {
+            for (int j = 0; j <= lane; ++j) s.A[lane * KS + j] = C[(size_t)lane * K + j];
+            s.v[lane] = lpv[lane] - lmp;
+        }
+        __syncthreads();
+        if (lane < k) {
+            double gi = prior_apply(o, s.t2, k, lane, s.v);
+            for (int n = 0; n < N; ++n) gi += Jp[(size_t)n * K + lane] * s.PR[n];
+            s.g[lane] = gi;
+        }
+        __syncthreads();
+        chol_solve(s.A, KS, k, lane, s.g, true, true);           // H g'
+        const double lrem = lane < k ? log(c.sigma_r[(size_t)b * K + lane]) : 0.0;
+        bool bad = false;
+        if (lane < k) {
+            const double mean_r = lpv[lane] + o.alpha * s.g[lane];
+            bad = !(fabs(mean_r) < 11356.0);                     // the reference's long-double exp over/underflows there
+            s.v[lane] = lrem - mean_r;                           // d1: ln sigma_rem - reverse mean
+            s.w[lane] = lpv[lane] - lrem;                        // d2: ln sigma' - ln sigma_rem
+        }
+        __syncthreads();
+        double q1 = 0.0, q2 = 0.0;                               // |C' d|^2 = d' precision d
+        if (lane < k) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int i = lane; i < k; ++i) { const double cij = s.A[i * KS + lane]; a1 += cij * s.v[i]; a2 += cij * s.w[i]; }
+            q1 = a1 * a1; q2 = a2 * a2;
+        }
+        q1 = wave_sum(q1); q2 = wave_sum(q2);
+        dq = -0.5 * q1 + 0.5 * q2;
+        if (__any(bad)) dq = __builtin_nan("");
+    }
+    const double like_p = c.like_p[b];
+    const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
+    const U4 rr = philox(o.seed, (uint32_t)b, iter, 2, 0);
+    const bool accept = log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
+    __syncthreads();
+    if (lane == 0) c.log_ratio[b] = log_ratio;
+    if (accept) {
+        if (lane < K) {
+            c.edges[(size_t)b * K + lane] = e[lane];
+            c.sigma[(size_t)b * K + lane] = c.sigma_p[(size_t)b * K + lane];
+        }
+        for (int n = lane; n < N; n += 64) c.pred[(size_t)b * N + n] = c.pred_p[(size_t)b * N + n];
+        if (action != NONE) {
+            const double* Js = (action == PERTURB ? c.J_r : c.J_p) + (size_t)b * N * K;
+            double* Jd = c.J + (size_t)b * N * K;
+            for (int i = lane; i < N * K; i += 64) Jd[i] = Js[i];
+        }
+        if (lane == 0) {
+            c.k[b] = k; c.rel[b] = rel_p; c.add[b] = add_p;
+            c.prior[b] = prior_p; c.like[b] = like_p; c.misfit[b] = c.misfit_p[b];
+            c.n_accepted[b] += 1;
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    // bookkeeping on the post-step state (Inference1D.update :705-790)
+    const int kc = accept ? k : c.k[b];
+    const double* ec = c.edges + (size_t)b * K;
+    const double* sc = c.sigma + (size_t)b * K;
+    const double post = (accept ? prior_p + like_p : c.prior[b] + c.like[b]);
+    if (post > c.best_posterior[b]) {
+        if (lane < K) { c.best_edges[(size_t)b * K + lane] = ec[lane]; c.best_sigma[(size_t)b * K + lane] = sc[lane]; }
+        __syncthreads();
+        if (lane == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
+    }
+    if (accumulate) {
+        if (lane == 0) c.k_hist[(size_t)b * (K + 1) + kc] += 1;
+        if (c.edge_hist != nullptr && lane < kc - 1) {           // interfaces across which sigma changes by > 50 %
+            const double ratio = sc[lane + 1] / sc[lane];        //   (RectilinearMesh1D.update_posteriors :1595-1610)
+            if (ratio <= 0.5 || ratio >= 1.5) {
+                const int bin = min(max((int)floor(ec[lane] / o.depth_bin_width), 0), o.n_depth_bins - 1);
+                atomicAdd(c.edge_hist + (size_t)b * o.n_depth_bins + bin, 1);
+            }
+        }
+        if (c.hitmap != nullptr) {                               // conductivity-depth hit map (Model.update_parameter_posterior :819-847)
+            const double inv_ln10 = 0.43429448190325182765, W = o.value_half_width;
+            for (int cell = lane; cell < o.n_depth_bins; cell += 64) {
+                const double zc = ((double)cell + 0.5) * o.depth_bin_width;
+                int layer = 0;
+                while (layer < kc - 1 && ec[layer] <= zc) ++layer;
+                const double v = (log(sc[layer]) - lmp) * inv_ln10;
+                const int bin = min(max((int)floor((v + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
+                c.hitmap[((size_t)b * o.n_depth_bins + cell) * o.n_value_bins + bin] += 1;
+            }
+        }
+    }
+}
+
+__global__ void k_rj_debug_random(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, int n, double* uni, double* nor)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng r(seed, chain, iter, stream);
+    for (int i = 0; i < n; ++i) uni[i] = r.uniform();
+    for (int j = 0; 2 * j < n; ++j) {
+        double z0, z1;
+        normal_pair(seed, chain, iter, stream, (uint32_t)j, z0, z1);
+        nor[2 * j] = z0;
+        if (2 * j + 1 < n) nor[2 * j + 1] = z1;
+    }
+}
+
+}  // namespace rj
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
+{
+    if (!o || !c) return fail(GBP_ERR_INVALID_ARG, "options / chains is NULL%s");
+    if (o->max_layers < 2 || o->max_layers > 64) return fail(GBP_ERR_INVALID_ARG, "max_layers must be in [2, 64]%s");
+    if (o->n_channels < 1 || o->n_channels > 2 * GBP_MAX_FREQ) return fail(GBP_ERR_INVALID_ARG, "n_channels out of range%s");
+    if (c->B < 0) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0%s");
+    if (!(o->min_width > 0.0) || !(o->max_edge > o->min_edge) || !(o->min_edge > 0.0))
+        return fail(GBP_ERR_INVALID_ARG, "need 0 < min_edge < max_edge and min_width > 0%s");
+    if ((c->edge_hist || c->hitmap) && (o->n_depth_bins < 1 || !(o->depth_bin_width > 0.0)))
+        return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
+    if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");
+    const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
+                          c->like, c->misfit, c->action, c->k_r, c->nl_a, c->nl_c, c->edges_r, c->sigma_r, c->thk_r, c->rel_p,
+                          c->add_p, c->pred_r, c->J_r, c->chol, c->log_prop, c->sigma_p, c->pred_p, c->misfit_p, c->like_p,
+                          c->J_p, c->log_ratio, c->n_accepted, c->k_hist, c->best_posterior, c->best_k, c->best_edges, c->best_sigma};
+    if (c->B > 0)
+        for (const void* p : need)
+            if (!p) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer in gbp_rj_chains%s");
+    return GBP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK || c->B == 0) return st;
+    hipLaunchKernelGGL(rj::k_rj_propose, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK || c->B == 0) return st;
+    hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+                       *c, (uint32_t)iteration);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK || c->B == 0) return st;
+    hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+                       *c, (uint32_t)iteration, accumulate);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
+                      int n_iterations, int accumulate, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK) return st;
+    if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
+    const int B = c->B, K = o->max_layers;
+    if (B == 0) return GBP_OK;
+    const int caps[3] = {8 < K ? 8 : K, 16 < K ? 16 : K, K};
+    const int nb = K <= 8 ? 1 : (K <= 16 ? 2 : 3);
+    for (int it = 0; it < n_iterations; ++it) {
+        const int64_t iter = first_iteration + it;
+        if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
+        // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
+        if ((st = gbp_fdem_forward(sys, B, K, c->nl_a, c->sigma_r, c->thk_r, c->height, c->pred_r, stream)) != GBP_OK) return st;
+        for (int i = 0; i < nb; ++i)
+            if ((st = gbp_fdem_sensitivity_ex(sys, B, K, c->nl_a + (size_t)(1 + i) * B, c->sigma_r, c->thk_r, c->height, c->J_r,
+                                              caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+        if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
+        // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
+        if ((st = gbp_fdem_forward_loglike(sys, B, K, c->k_r, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
+                                           c->pred_p, c->misfit_p, c->like_p, stream)) != GBP_OK) return st;
+        // Jacobian at the proposals that changed dimension (Model.py:612)
+        for (int i = 0; i < nb; ++i)
+            if ((st = gbp_fdem_sensitivity_ex(sys, B, K, c->nl_c + (size_t)(1 + i) * B, c->sigma_p, c->thk_r, c->height, c->J_p,
+                                              caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+        if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
+    }
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n, double* uniforms,
+                               double* normals, void* stream)
+{
+    if (n < 0 || !uniforms || !normals) return fail(GBP_ERR_INVALID_ARG, "bad n or NULL pointer%s");
+    hipLaunchKernelGGL(rj::k_rj_debug_random, dim3(1), dim3(1), 0, (hipStream_t)stream, seed, (uint32_t)chain, (uint32_t)iteration,
+                       (uint32_t)stream_id, n, uniforms, normals);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+}  // extern "C"

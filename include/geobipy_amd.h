@@ -102,7 +102,8 @@ gbp_status gbp_fdem_system_h0(const gbp_fdem_system *sys, double *out);
 
 /*
  * Batched forward solve.  Replaces B calls of FdemDataPoint.forward -> fdem1dfwd -> nbFdem1dfwd.
- *   nlayers [dev] int32[B]        layers per sounding (1 <= nlayers[b] <= Lmax)
+ *   nlayers [dev] int32[B]        layers per sounding (1 <= nlayers[b] <= Lmax); nlayers[b] == 0 skips sounding b:
+ *                                 none of its outputs are written (forward, fused and Jacobian entries alike)
  *   sigma   [dev] f64[B, Lmax]    conductivity S/m          (Model.values)
  *   thk     [dev] f64[B, Lmax]    layer thickness m; entry nlayers[b]-1 (the half-space, inf in the
  *                                 reference's mesh.widths) is never read
@@ -173,6 +174,85 @@ gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system *sys, int B, int 
  * y and out1 may be NULL where unused. */
 gbp_status gbp_debug_math(int op, int n, const double *x, const double *y, double *out0, double *out1,
                           void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident rjMCMC step: one iteration of Inference1D.accept_reject
+ * (inversion/Inference1D.py:537-631) for B soundings at once, FDEM data, Resolve-style option set
+ * (layer conductivities + relative / additive error; no height move).  Pieces restated per chain:
+ *   structural move      RectilinearMesh1D.perturb            mesh/RectilinearMesh1D.py:1018-1118
+ *   value remapping      Model.perturb_structure / insert / delete  model/Model.py:316-366
+ *   value proposal       Model.stochastic_newton_perturbation model/Model.py:368-419
+ *   error proposals      DataPoint.perturb                    data/datapoint/DataPoint.py:531-573
+ *   priors               Model.probability :533-575, DataPoint.probability :454-489
+ *   jump proposal ratio  Model.proposal_probabilities         model/Model.py:577-659
+ *   accept / bookkeeping Inference1D.accept_reject :597-631, update :705-790
+ * Same Markov kernel as the reference; the random numbers come from a counter-based generator
+ * (Philox4x32-10 keyed by `seed`, counter = chain, iteration, stream, draw), so a chain is a valid
+ * draw of the same sampler, not the reference's own draw for a numpy seed (the host-side
+ * geobipy_amd.Inference1D does that).  All arrays are [dev]; [B, K] arrays have row stride K.
+ */
+typedef struct gbp_rj_options {
+    int32_t max_layers;          /* K = maximum_number_of_layers                                      */
+    int32_t n_channels;          /* N = 2 * nF                                                         */
+    int32_t solve_gradient, solve_relative_error, solve_additive_error, exact_jacobian;
+    int32_t n_depth_bins, n_value_bins;   /* posterior grids (interface histogram / hit-map)          */
+    double min_edge, max_edge, min_width; /* min_edge already raised to min_width (RectilinearMesh1D.py:358-360) */
+    double p_birth, p_death, p_perturb, p_none;
+    double value_precision;      /* 1 / ln(1 + factor)^2                                              */
+    double gradient_precision;   /* 1 / gradient_standard_deviation^2                                 */
+    double alpha;                /* covariance_scaling                                                 */
+    double rel_min, rel_max, rel_sd, add_min, add_max, add_sd;   /* sd = sqrt(proposal variance)      */
+    double depth_bin_width;      /* interface histogram / hit-map depth cell                           */
+    double value_half_width;     /* hit-map spans log10(sigma / prior mean) in [-w, w]                 */
+    uint64_t seed;
+} gbp_rj_options;
+
+typedef struct gbp_rj_chains {
+    int32_t B;
+    /* per-sounding constants */
+    const double *data;            /* [B, N]  observed data (<= 0: inactive channel)                   */
+    const double *height;          /* [B]                                                              */
+    const double *log_mean_prior;  /* [B]     ln of the best half-space conductivity                   */
+    /* chain state */
+    int32_t *k;                    /* [B]     layers                                                   */
+    double *edges, *sigma;         /* [B, K]  interface depths (k - 1 used, +inf padded), conductivities (1 padded) */
+    double *rel, *add;             /* [B]                                                              */
+    double *pred, *J;              /* [B, N], [B, N, K]  carried prediction / Jacobian                  */
+    double *prior, *like, *misfit; /* [B]                                                              */
+    /* proposal scratch (written by the step) */
+    int32_t *action, *k_r;         /* [B]     0 none, 1 insert, 2 delete, 3 perturb; layers after the move */
+    int32_t *nl_a, *nl_c;          /* [4, B]  k_r of the chains needing the phase A / C kernels, else 0: row 0 all,
+                                      rows 1-3 split by layer count (<= 8, <= 16, more)                  */
+    double *edges_r, *sigma_r, *thk_r;        /* [B, K] remapped model                                 */
+    double *rel_p, *add_p;                    /* [B]    proposed errors                                */
+    double *pred_r, *J_r;                     /* [B, N], [B, N, K] at the remapped model               */
+    double *chol;                             /* [B, K, K] lower Cholesky factor of the proposal precision */
+    double *log_prop, *sigma_p;               /* [B, K] proposed ln sigma, sigma                       */
+    double *pred_p, *misfit_p, *like_p, *J_p; /* proposal: [B, N], [B], [B], [B, N, K]                  */
+    double *log_ratio;                        /* [B]   ln acceptance ratio of the last step            */
+    /* bookkeeping */
+    int64_t *n_accepted;           /* [B]                                                              */
+    int32_t *k_hist;               /* [B, K + 1]            posterior of the layer count               */
+    int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
+    int32_t *hitmap;               /* [B, n_depth_bins, n_value_bins] or NULL                           */
+    double *best_posterior;        /* [B]                                                              */
+    int32_t *best_k;
+    double *best_edges, *best_sigma;          /* [B, K]                                                */
+} gbp_rj_chains;
+
+/* The three host-logic stages of one iteration, exposed separately for the tests ... */
+gbp_status gbp_rj_propose(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, void *stream);
+gbp_status gbp_rj_newton(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, void *stream);
+gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, int accumulate,
+                         void *stream);
+/* ... and n_iterations complete iterations (propose, forward + Jacobian of the remapped models, newton, fused
+ * forward + likelihood of the proposals, Jacobian of the jump proposals, accept), all stream-ordered, no host
+ * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
+gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
+                      int64_t first_iteration, int n_iterations, int accumulate, void *stream);
+/* Test hook: n uniforms and n standard normals of stream (chain, iteration, stream_id) as the kernels draw them. */
+gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
+                               double *uniforms, double *normals, void *stream);
 
 #ifdef __cplusplus
 }

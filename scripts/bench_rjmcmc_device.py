@@ -1,5 +1,6 @@
-"""Throughput of the device-resident rjMCMC (geobipy_amd/rjmcmc_gpu.py; SURVEY row f-2, BASELINE config 5 shape):
-B Resolve soundings, all chains advancing in lockstep as tensor programs + three kernel entries per iteration."""
+"""Throughput of the device-resident rjMCMC (geobipy_amd/rjmcmc_gpu.py -> gbp_rj_run;
+SURVEY row f-2, BASELINE config 5 shape): B Resolve soundings, all chains advancing in lockstep, eleven launches per iteration,
+no host synchronisation between iterations."""
 import os, sys, time
 import numpy as np
 import torch
@@ -14,7 +15,7 @@ d = np.load(os.path.join(G, "mcmc_detail.npz"))
 s = FdemSystem.read(os.path.join(G, "resolve.stm"))
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
-for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192").split(",")]:
+for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192,65536").split(",")]:
     rng = np.random.default_rng(1)
     data = np.tile(d["data"], (B, 1)) * rng.uniform(0.7, 1.4, B)[:, None]
     heights = rng.uniform(25.0, 40.0, B)

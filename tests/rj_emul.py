@@ -1,0 +1,155 @@
+"""Host emulation of the three stage kernels of the device-resident rjMCMC step (geobipy_amd/csrc/gbp_rjmcmc.h), drawing
+from the same counter-based streams, built on the host restatement rjmcmc.py (which is pinned to the reference's
+chains).  Test infrastructure only."""
+import math
+
+import numpy as np
+
+from geobipy_amd import rjmcmc
+
+M32 = 0xFFFFFFFF
+
+
+def philox(seed, c0, c1, c2, c3):
+    """Philox4x32-10 (Salmon et al. 2011)."""
+    k0, k1 = seed & M32, (seed >> 32) & M32
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    return c0, c1, c2, c3
+
+
+def u53(a, b):
+    return ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0
+
+
+class Rng:
+    def __init__(self, seed, chain, it, stream):
+        self.a, self.n, self.buf = (seed, chain, it, stream), 0, None
+
+    def uniform(self):
+        if self.buf is not None:
+            u, self.buf = self.buf, None
+            return u
+        r = philox(*self.a, self.n)
+        self.n += 1
+        self.buf = u53(r[2], r[3])
+        return u53(r[0], r[1])
+
+    def normal(self):
+        u1, u2 = self.uniform(), self.uniform()
+        return math.sqrt(-2.0 * math.log(1.0 - u1)) * math.cos(2.0 * math.pi * u2)
+
+
+def normal_pair(seed, chain, it, stream, j):
+    r = philox(seed, chain, it, stream, j)
+    rad, ang = math.sqrt(-2.0 * math.log(1.0 - u53(r[0], r[1]))), 2.0 * math.pi * u53(r[2], r[3])
+    return rad * math.cos(ang), rad * math.sin(ang)
+
+
+def propose_error(r, cur, sd, lo, hi):
+    lc, llo, lhi = math.log(cur), math.log(lo), math.log(hi)
+    x = lc + sd * r.normal()
+    tries = 0
+    while not (llo <= x <= lhi):
+        x = lc + sd * r.normal()
+        tries += 1
+        if tries == 10:
+            return cur
+    return math.exp(x)
+
+
+def propose(o, seed, b, it, edges, sigma, rel, add):
+    """k_rj_propose for one chain.  edges: k - 1 interior depths.  Returns (action, idx, val, edges_r, sigma_r, rel_p, add_p)."""
+    r = Rng(seed, b, it, 0)
+    k, K, mw = sigma.size, o["K"], o["min_width"]
+    lo, hi = math.log(o["min_edge"]), math.log(o["max_edge"])
+    action, idx, val = rjmcmc.NONE, 0, 0.0
+    done = False
+    for _ in range(8):
+        if done:
+            break
+        pb = 0.0 if k == K else o["p"][0]
+        pd, pp = (0.0, 0.0) if k == 1 else (o["p"][1], o["p"][2])
+        u = r.uniform() * (pb + pd + pp + o["p"][3])
+        if u < pb:
+            for _t in range(9):
+                depth = math.exp(lo + r.uniform() * (hi - lo))
+                pos = int(np.searchsorted(edges, depth))
+                prev = edges[pos - 1] if pos > 0 else 0.0
+                nxt = edges[pos] if pos < k - 1 else math.inf
+                if depth - prev > mw and nxt - depth > mw:
+                    action, idx, val, done = rjmcmc.INSERT, pos + 1, depth, True
+                    break
+        elif u < pb + pd:
+            idx = min(int(math.floor(r.uniform() * (k - 1))), k - 2) + 1
+            action, done = rjmcmc.DELETE, True
+        elif u < pb + pd + pp:
+            for _t in range(9):
+                i = min(int(math.floor(1.0 + r.uniform() * (k - 1))), k - 1)
+                n = r.normal()
+                dz = (1.0 if n > 0 else (-1.0 if n < 0 else 0.0)) * mw * r.uniform()
+                z = edges.copy()
+                z[i - 1] += dz
+                full = np.r_[0.0, z, np.inf]
+                if np.min(np.diff(full)) > mw and z[0] > o["min_edge"] and z[-1] < o["max_edge"]:
+                    action, idx, val, done = rjmcmc.PERTURB, i, dz, True
+                    break
+        else:
+            done = True
+    full = np.r_[0.0, edges, np.inf]
+    if action == rjmcmc.INSERT:
+        e_r, s_r = np.insert(full, idx, val)[1:-1], np.insert(sigma, idx, sigma[idx - 1])
+    elif action == rjmcmc.DELETE:
+        s_r = np.delete(sigma, idx)
+        s_r[idx - 1] = 0.5 * (sigma[idx - 1] + sigma[idx])
+        e_r = np.delete(full, idx)[1:-1]
+    elif action == rjmcmc.PERTURB:
+        e_r, s_r = edges.copy(), sigma.copy()
+        e_r[idx - 1] += val
+    else:
+        e_r, s_r = edges.copy(), sigma.copy()
+    rel_p = propose_error(r, rel, o["rel_sd"], o["rel_min"], o["rel_max"])
+    add_p = propose_error(r, add, o["add_sd"], o["add_min"], o["add_max"])
+    return action, idx, val, e_r, s_r, rel_p, add_p
+
+
+def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add):
+    """k_rj_newton for one chain: (log_prop, C) with precision = C C'."""
+    k = sigma_r.size
+    std = np.sqrt((rel * data) ** 2 + add ** 2)
+    a = data > 0.0
+    Ja, P = J[a][:, :k], 1.0 / std[a] ** 2
+    op = rjmcmc.model_prior_derivative(vp, edges_r, sigma_r, 2)
+    hess = op + Ja.T @ (P[:, None] * Ja)
+    grad = op @ (np.log(sigma_r) - vp.log_mean) + Ja.T @ (P * (pred[a] - data[a]))
+    C = np.linalg.cholesky(hess)
+    z = np.array([v for j in range(32) for v in normal_pair(seed, b, it, 1, j)])[:k]
+    log_prop = np.log(sigma_r) - o["alpha"] * np.linalg.solve(hess, grad) + np.linalg.solve(C.T, z)
+    return log_prop, C
+
+
+def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, pred_p, data, rel_p, add_p, like_p, prior, like):
+    """k_rj_accept for one chain: (log_ratio, accepted, prior_p)."""
+    rp = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0)
+    ap = rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
+    prop = np.exp(log_prop)
+    prior_p = rjmcmc.model_log_prior(sp, vp, edges_r, prop) + rp.log_prior(rel_p) + ap.log_prior(add_p)
+    dq = 0.0
+    if action in (rjmcmc.INSERT, rjmcmc.DELETE):
+        k = prop.size
+        std = np.sqrt((rel_p * data) ** 2 + add_p ** 2)
+        a = data > 0.0
+        grad = rjmcmc.model_prior_derivative(vp, edges_r, prop, 1) + J_p[a][:, :k].T @ ((pred_p[a] - data[a]) / std[a] ** 2)
+        hess = C @ C.T
+        mean_r = log_prop + o["alpha"] * np.linalg.solve(hess, grad)
+        d1, d2 = np.log(sigma_r) - mean_r, log_prop - np.log(sigma_r)
+        dq = -0.5 * d1 @ hess @ d1 + 0.5 * d2 @ hess @ d2
+        if not np.all(np.abs(mean_r) < 11356.0):        # the reference's long-double exp of the reverse mean over/underflows
+            dq = np.nan
+    log_ratio = (prior_p - prior) + (like_p - like) + dq
+    r = philox(seed, b, it, 2, 0)
+    u = u53(r[0], r[1])
+    with np.errstate(divide="ignore"):
+        return log_ratio, bool(np.log(u) < log_ratio), prior_p

@@ -1,122 +1,265 @@
-"""Device-resident rjMCMC (geobipy_amd/rjmcmc_gpu.py): the deterministic tensor pieces against the host restatement
-rjmcmc.py (which is pinned to the reference's chains), on the CPU; the sampler itself on the GPU."""
+"""Device-resident rjMCMC (geobipy_amd/rjmcmc_gpu.py, csrc/gbp_rjmcmc.h).
+
+CPU tier: the counter-based generator against its published known answers, the batched prior against rjmcmc.py.
+GPU tier: every stage kernel against the host emulation (tests/rj_emul.py = rjmcmc.py + the same random streams);
+state coherence after many steps; the posterior accumulators against a host replay; the ensembles against the
+host sampler that reproduces the reference's chains."""
+import ctypes
+import math
+import os
+
 import numpy as np
 import pytest
 import torch
 
+import rj_emul
 from geobipy_amd import rjmcmc
 from geobipy_amd import rjmcmc_gpu as rg
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K = 12
 
 
-def _random_models(rng, B):
-    ks = rng.integers(1, K, size=B)
-    edges = np.full((B, K - 1), np.inf)
-    sigma = np.ones((B, K))
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert philox_hex(0, (0, 0, 0, 0)) == ("6627e8d5", "e169c58d", "bc57ac4c", "9b00dbd8")
+    assert philox_hex(0xFFFFFFFFFFFFFFFF, (0xFFFFFFFF,) * 4) == ("408f276d", "41c83b0e", "a20bc7c6", "6d5451fd")
+    assert philox_hex(0x299F31D0_A4093822, (0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344)) == ("d16cfe09", "94fdcceb", "5001e420", "24126ea1")
+    r = rj_emul.Rng(7, 3, 11, 0)
+    u = np.array([r.uniform() for _ in range(20000)])
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.003
+    z = np.array([v for j in range(10000) for v in rj_emul.normal_pair(7, 3, 11, 1, j)])
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1.0) < 0.03 and abs(np.mean(z ** 4) - 3.0) < 0.15
+
+
+def philox_hex(seed, ctr):
+    return tuple("%08x" % v for v in rj_emul.philox(seed, *ctr))
+
+
+def _random_models(rng, B, kmax=K - 1, pad=K):
+    ks = rng.integers(1, kmax + 1, size=B)
+    edges = np.full((B, pad), np.inf)
+    sigma = np.ones((B, pad))
     models = []
     for b, k in enumerate(ks):
-        e = np.cumsum(rng.uniform(1.5, 20.0, size=k - 1))
+        e = np.cumsum(rng.uniform(1.5, 14.0, size=k - 1)) + 0.3
         v = 10.0 ** rng.uniform(-3, 0, size=k)
         edges[b, : k - 1], sigma[b, :k] = e, v
         models.append((e, v))
     return ks, edges, sigma, models
 
 
-def test_remap_matches_host():
-    rng = np.random.default_rng(3)
-    B = 200
-    ks, edges, sigma, models = _random_models(rng, B)
-    action = np.zeros(B, dtype=np.int64)
-    index = np.ones(B, dtype=np.int64)
-    value = np.zeros(B)
-    expect = []
-    for b, (e, v) in enumerate(models):
-        k = v.size
-        full = np.r_[0.0, e, np.inf]
-        a = rng.integers(0, 4) if k > 1 else rng.choice([rjmcmc.NONE, rjmcmc.INSERT])
-        if a == rjmcmc.INSERT:
-            d = np.exp(rng.uniform(np.log(1.0), np.log(250.0)))
-            i = int(np.searchsorted(full, d))
-            expect.append((np.insert(full, i, d)[1:-1], np.insert(v, i, v[i - 1])))
-            action[b], index[b], value[b] = a, i, d
-        elif a == rjmcmc.DELETE:
-            i = int(rng.integers(1, k))
-            vv = np.delete(v, i)
-            vv[i - 1] = 0.5 * (v[i - 1] + v[i])
-            expect.append((np.delete(full, i)[1:-1], vv))
-            action[b], index[b] = a, i
-        elif a == rjmcmc.PERTURB:
-            i, dz = int(rng.integers(1, k)), rng.uniform(-1, 1)
-            z = full.copy()
-            z[i] += dz
-            expect.append((z[1:-1], v.copy()))
-            action[b], index[b], value[b] = a, i, dz
-        else:
-            expect.append((e.copy(), v.copy()))
-    t = torch.as_tensor
-    ne, ns, nk = rg.remap(t(action), t(index), t(value), t(edges), t(sigma), t(ks.astype(np.int64)))
-    for b, (e, v) in enumerate(expect):
-        assert int(nk[b]) == v.size
-        assert np.array_equal(ne[b, : v.size - 1].numpy(), e)
-        assert np.array_equal(ns[b, : v.size].numpy(), v)
-        assert np.all(np.isinf(ne[b, v.size - 1:].numpy())) and np.all(ns[b, v.size:].numpy() == 1.0)
-
-
-def test_prior_operator_newton_and_priors_match_host():
+def test_batched_priors_match_host():
     rng = np.random.default_rng(5)
-    B, N = 64, 12
+    B = 64
     ks, edges, sigma, models = _random_models(rng, B)
     vp = rjmcmc.ValuePrior(0.01, 10.0, 1.5, True)
     sp = rjmcmc.StructurePrior(K, 1.0, 300.0, 1.0, [1, 1, 1, 3])
-    J = rng.normal(size=(B, N, K)) * 30.0
-    pred = rng.uniform(50, 500, size=(B, N))
-    data = pred * (1 + 0.05 * rng.normal(size=(B, N)))
-    data[:, 3] = -1.0                                   # an inactive channel
-    std = 0.05 * np.abs(data) + 5.0
     t = torch.as_tensor
-    kt = t(ks.astype(np.int64))
-    op = rg.prior_operator(t(edges), kt, vp.value_precision, vp.gradient_precision)
-    mean_log, hess, H = rg.stochastic_newton(t(edges), t(sigma), kt, t(J), t(pred), t(data), t(std),
-                                             torch.full((B,), float(vp.log_mean), dtype=torch.float64),
-                                             vp.value_precision, vp.gradient_precision, 0.7)
-    lp = rg.model_log_prior(t(edges), t(sigma), kt, K, vp.gradient_precision)
+    lp = rg.model_log_prior(t(edges), t(sigma), t(ks.astype(np.int64)), K, vp.gradient_precision)
     for b, (e, v) in enumerate(models):
-        k = v.size
-        ref_op = rjmcmc.model_prior_derivative(vp, e, v, 2)
-        np.testing.assert_allclose(op[b, :k, :k].numpy(), ref_op, rtol=1e-13, atol=1e-18)
-        assert np.array_equal(op[b, k:, k:].numpy(), np.eye(K - k)) and not op[b, :k, k:].any()
-        m, Href = rjmcmc.stochastic_newton(vp, e, v, J[b][:, :k], pred[b], data[b], std[b], 0.7)
-        np.testing.assert_allclose(H[b, :k, :k].numpy(), Href, rtol=1e-9, atol=1e-15)
-        np.testing.assert_allclose(mean_log[b, :k].numpy(), np.log(m), rtol=1e-9, atol=1e-10)
-        np.testing.assert_allclose(hess[b, :k, :k].numpy() @ Href, np.eye(k), atol=1e-8)
         np.testing.assert_allclose(float(lp[b]), rjmcmc.model_log_prior(sp, vp, e, v), rtol=1e-12)
-
-
-def test_log_uniform_prior():
     x = torch.tensor([0.001, 0.01, 0.5, 0.6], dtype=torch.float64)
     p = rjmcmc.ErrorPrior(0.005, 0.5, 1e-4)
-    got = rg.log_uniform_prior(x, 0.005, 0.5).numpy()
-    for g, xi in zip(got, x.numpy()):
+    for g, xi in zip(rg.log_uniform_prior(x, 0.005, 0.5).numpy(), x.numpy()):
         assert g == p.log_prior(xi) or np.isclose(g, p.log_prior(xi), rtol=1e-14)
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# GPU: the sampler
+# GPU
 # ------------------------------------------------------------------------------------------------------------------
-import os
-
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-
-
-def _chains(B, seed, exact=False, n_it=0):
+def _options():
     from test_rjmcmc import RESOLVE_OPTIONS
+    return {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
+
+
+def _chains(B, seed, exact=False, n_it=0, **kw):
     from geobipy_amd import FdemSystem
     d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
     s = FdemSystem.read(os.path.join(GOLDEN, "resolve.stm"))
-    o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
-    dc = rg.DeviceChains(s, np.full(B, float(d["z"])), np.tile(d["data"], (B, 1)), seed=seed, exact_jacobian=exact, **o)
+    o = _options()
+    o.update(kw.pop("options", {}))
+    dc = rg.DeviceChains(s, np.full(B, float(d["z"])), np.tile(d["data"], (B, 1)), seed=seed, exact_jacobian=exact, **o, **kw)
     return d, s, dc.run(n_it)
+
+
+def _emul_options(dc):
+    o = dc._o
+    return dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge,
+                p=[o.p_birth, o.p_death, o.p_perturb, o.p_none], rel_sd=o.rel_sd, rel_min=o.rel_min, rel_max=o.rel_max,
+                add_sd=o.add_sd, add_min=o.add_min, add_max=o.add_max, alpha=o.alpha)
+
+
+def _host_priors(dc, b):
+    o = dc.o
+    sp = rjmcmc.StructurePrior(dc.K, o["minimum_depth"], o["maximum_depth"], o["minimum_thickness"],
+                               [o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
+                                o["probability_of_no_change"]])
+    vp = rjmcmc.ValuePrior(math.exp(float(dc.log_mean_prior[b])), o["factor"], o["gradient_standard_deviation"], o["solve_gradient"])
+    return sp, vp
+
+
+def _load_random_state(dc, rng, kmax):
+    """Overwrite the chain state with random valid models (and wide error levels so that the error moves get rejected
+    sometimes)."""
+    ks, edges, sigma, models = _random_models(rng, dc.B, kmax=kmax, pad=dc.K)
+    dc.k.copy_(torch.as_tensor(ks.astype(np.int32)))
+    dc.edges.copy_(torch.as_tensor(edges))
+    dc.sigma.copy_(torch.as_tensor(sigma))
+    dc.rel.copy_(torch.as_tensor(rng.uniform(0.0012, 0.4, dc.B)))
+    dc.add.copy_(torch.as_tensor(rng.uniform(3.05, 19.5, dc.B)))
+    return ks, models
+
+
+@pytest.mark.gpu
+def test_device_random_streams_match_the_emulation():
+    from geobipy_amd import _lib
+    n = 64
+    u, z = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+    for seed, chain, it, st in ((0, 0, 0, 0), (12345678901234567, 4100, 77, 1), (2 ** 64 - 1, 65535, 2 ** 31, 2)):
+        _lib.check(_lib.load().gbp_rj_debug_random(seed, chain, it, st, n, u.data_ptr(), z.data_ptr(), None))
+        r = rj_emul.Rng(seed, chain, it & 0xFFFFFFFF, st)
+        assert np.array_equal(u.cpu().numpy(), [r.uniform() for _ in range(n)])
+        ref = [v for j in range(n // 2) for v in rj_emul.normal_pair(seed, chain, it & 0xFFFFFFFF, st, j)]
+        assert np.allclose(z.cpu().numpy(), ref, rtol=1e-14, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_propose_kernel_matches_the_emulation():
+    """Structural move, remapping, layer-bucket masks and error proposals of 2048 chains, two iterations, one of them
+    with the error proposal widths blown up so that the redraw / give-up path is exercised."""
+    from geobipy_amd import _lib
+    _, _, dc = _chains(2048, 99, options=dict(relative_error_proposal_variance=400.0, additive_error_proposal_variance=1.0,
+                                              maximum_depth=150.0))
+    rng = np.random.default_rng(8)
+    ks, models = _load_random_state(dc, rng, kmax=dc.K)
+    eo = _emul_options(dc)
+    seen = set()
+    kept = 0
+    for it in (5, 6):
+        _lib.check(_lib.load().gbp_rj_propose(dc._o, dc._c, it, None))
+        act, k_r = dc.action.cpu().numpy(), dc.k_r.cpu().numpy()
+        e_r, s_r, t_r = dc.edges_r.cpu().numpy(), dc.sigma_r.cpu().numpy(), dc.thk_r.cpu().numpy()
+        rel_p, add_p = dc.rel_p.cpu().numpy(), dc.add_p.cpu().numpy()
+        nl_a, nl_c = dc.nl_a.cpu().numpy(), dc.nl_c.cpu().numpy()
+        rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
+        for b, (e, v) in enumerate(models):
+            a, idx, val, ee, ss, rp, ap = rj_emul.propose(eo, 99, b, it, e, v, rel[b], add[b])
+            assert act[b] == a and k_r[b] == ss.size, (b, act[b], a)
+            assert np.allclose(e_r[b, : ss.size - 1], ee, rtol=1e-14) and np.all(np.isinf(e_r[b, ss.size - 1:]))
+            assert np.array_equal(s_r[b, : ss.size], ss) and np.all(s_r[b, ss.size:] == 1.0)
+            assert np.allclose(t_r[b, : ss.size - 1], np.diff(np.r_[0.0, ee]), rtol=1e-13) and not t_r[b, ss.size - 1:].any()
+            assert np.isclose(rel_p[b], rp, rtol=1e-13) and np.isclose(add_p[b], ap, rtol=1e-13)
+            kept += rp == rel[b]
+            bucket = 1 + (0 if ss.size <= 8 else (1 if ss.size <= 16 else 2))
+            want_a = np.zeros(4, dtype=int)
+            want_c = np.zeros(4, dtype=int)
+            if a != rjmcmc.NONE:
+                want_a[0] = want_a[bucket] = ss.size
+            if a in (rjmcmc.INSERT, rjmcmc.DELETE):
+                want_c[0] = want_c[bucket] = ss.size
+            assert np.array_equal(nl_a[:, b], want_a) and np.array_equal(nl_c[:, b], want_c)
+            seen.add(a)
+    assert seen == {0, 1, 2, 3} and kept > 20          # all four moves, and the give-up path of the error proposal
+
+
+@pytest.mark.gpu
+def test_newton_kernel_matches_the_emulation():
+    from geobipy_amd import _lib
+    _, _, dc = _chains(512, 3)
+    rng = np.random.default_rng(21)
+    ks, models = _load_random_state(dc, rng, kmax=dc.K)
+    B, N, Kp = dc.B, dc.N, dc.K
+    # a remapped model = the state itself; half the chains read the "changed" buffers, half the carried ones
+    dc.edges_r.copy_(dc.edges); dc.sigma_r.copy_(dc.sigma); dc.k_r.copy_(dc.k)
+    action = rng.integers(0, 4, B).astype(np.int32)
+    dc.action.copy_(torch.as_tensor(action))
+    J_a, J_b = rng.normal(size=(B, N, Kp)) * 40.0, rng.normal(size=(B, N, Kp)) * 40.0
+    data = dc.data.cpu().numpy().copy()
+    data[::3, 4] = -1.0                                                      # inactive channels
+    dc.data.copy_(torch.as_tensor(data))
+    p_a, p_b = data * (1 + 0.1 * rng.normal(size=data.shape)), data * (1 + 0.1 * rng.normal(size=data.shape))
+    dc.J.copy_(torch.as_tensor(J_a)); dc.J_r.copy_(torch.as_tensor(J_b))
+    dc.pred.copy_(torch.as_tensor(p_a)); dc.pred_r.copy_(torch.as_tensor(p_b))
+    _lib.check(_lib.load().gbp_rj_newton(dc._o, dc._c, 17, None))
+    lp, sp_, ch = dc.log_prop.cpu().numpy(), dc.sigma_p.cpu().numpy(), dc.chol.cpu().numpy()
+    rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
+    eo = _emul_options(dc)
+    for b, (e, v) in enumerate(models):
+        _, vp = _host_priors(dc, b)
+        k = v.size
+        J, pred = (J_b, p_b) if action[b] else (J_a, p_a)
+        ref_lp, ref_C = rj_emul.newton(eo, 3, b, 17, vp, e, v, J[b], pred[b], data[b], rel[b], add[b])
+        assert np.allclose(np.tril(ch[b, :k, :k]), ref_C, rtol=1e-9, atol=1e-12), b
+        assert np.allclose(lp[b, :k], ref_lp, rtol=1e-8, atol=1e-9), (b, k, lp[b, :k] - ref_lp)
+        assert np.allclose(sp_[b, :k], np.exp(ref_lp), rtol=1e-8) and np.all(sp_[b, k:] == 1.0) and not lp[b, k:].any()
+
+
+@pytest.mark.gpu
+def test_accept_kernel_matches_the_emulation():
+    """Run propose + the remapped-model kernels + newton + the proposal kernels through the library on random states,
+    then check the accept kernel's ratio, decision and state update against the emulation fed with the device's own
+    intermediate buffers."""
+    from geobipy_amd import _lib
+    lib = _lib.load()
+    _, _, dc = _chains(1024, 41, exact=True)
+    rng = np.random.default_rng(2)
+    ks, models = _load_random_state(dc, rng, kmax=10)
+    dc.rel.fill_(0.05); dc.add.fill_(5.0)
+    B, N, Kp, h = dc.B, dc.N, dc.K, dc._h.ptr
+    thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
+    # a coherent carried state: prediction / Jacobian / likelihood / prior of the random models
+    _lib.check(lib.gbp_fdem_forward_loglike(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
+                                            dc.data.data_ptr(), dc.rel.data_ptr(), dc.add.data_ptr(), dc.pred.data_ptr(),
+                                            dc.misfit.data_ptr(), dc.like.data_ptr(), None))
+    _lib.check(lib.gbp_fdem_sensitivity_ex(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
+                                           dc.J.data_ptr(), Kp, 1, None))
+    o = dc.o
+    dc.prior.copy_(rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), Kp, dc.gradient_precision)
+                   + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
+                   + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
+    before = {n: getattr(dc, n).clone() for n in ("k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit")}
+    it = 9
+    dc.iteration = it
+    _lib.check(lib.gbp_rj_propose(dc._o, dc._c, it, None))
+    dc2_state = {n: getattr(dc, n).cpu().numpy().copy() for n in ("action", "k_r", "edges_r", "sigma_r", "rel_p", "add_p")}
+    dc.run(1)                                                   # the same iteration, complete
+    g = lambda n: getattr(dc, n).cpu().numpy()
+    for n, v in dc2_state.items():
+        assert np.array_equal(g(n), v, equal_nan=True), n       # run() proposed exactly what the stage call did
+    action, k_r, e_r, s_r = g("action"), g("k_r"), g("edges_r"), g("sigma_r")
+    log_prop, chol, J_p, pred_p = g("log_prop"), g("chol"), g("J_p"), g("pred_p")
+    rel_p, add_p, like_p, misfit_p, log_ratio = g("rel_p"), g("add_p"), g("like_p"), g("misfit_p"), g("log_ratio")
+    data, n_accepted = g("data"), g("n_accepted")
+    eo = _emul_options(dc)
+    n_acc = n_jump = 0
+    bk = {n: v.cpu().numpy() for n, v in before.items()}
+    for b in range(B):
+        sp, vp = _host_priors(dc, b)
+        k = k_r[b]
+        C = np.tril(chol[b, :k, :k])
+        ref_lr, ref_acc, ref_prior = rj_emul.accept(eo, 41, b, it, sp, vp, action[b], e_r[b, : k - 1], s_r[b, :k], log_prop[b, :k], C,
+                                                    J_p[b], pred_p[b], data[b], rel_p[b], add_p[b], like_p[b], bk["prior"][b],
+                                                    bk["like"][b])
+        assert (np.isclose(log_ratio[b], ref_lr, rtol=1e-7, atol=1e-6, equal_nan=True)
+                or (np.isneginf(ref_lr) and np.isneginf(log_ratio[b]))), (b, action[b], log_ratio[b], ref_lr)
+        margin = abs(ref_lr - np.log(rj_emul.u53(*rj_emul.philox(41, b, it, 2, 0)[:2])))
+        accepted = int(n_accepted[b]) == 1
+        assert accepted == ref_acc or margin < 1e-5
+        n_acc += accepted
+        n_jump += action[b] in (1, 2)
+        if accepted:
+            assert int(dc.k[b]) == k
+            assert np.array_equal(dc.edges[b].cpu().numpy(), e_r[b]) and np.array_equal(dc.sigma[b].cpu().numpy(), g("sigma_p")[b])
+            assert np.array_equal(dc.pred[b].cpu().numpy(), pred_p[b]) and float(dc.like[b]) == like_p[b]
+            assert float(dc.misfit[b]) == misfit_p[b] and np.isclose(float(dc.prior[b]), ref_prior, rtol=1e-12)
+            assert float(dc.rel[b]) == rel_p[b] and float(dc.add[b]) == add_p[b]
+            Jsrc = {0: bk["J"][b], 1: J_p[b], 2: J_p[b], 3: g("J_r")[b]}[int(action[b])]
+            assert np.array_equal(dc.J[b].cpu().numpy(), Jsrc)
+        else:
+            for n in before:
+                assert np.array_equal(getattr(dc, n)[b].cpu().numpy(), bk[n][b], equal_nan=True), (b, n)
+    assert n_acc > 50 and n_jump > 100
 
 
 @pytest.mark.gpu
@@ -131,13 +274,13 @@ def test_device_chains_initialise_like_the_reference():
 
 @pytest.mark.gpu
 def test_device_chains_state_is_coherent_after_many_steps():
-    """After 300 iterations every chain's cached prediction / misfit / likelihood / prior / Jacobian-free state equals
-    a from-scratch evaluation of its current model, and every model satisfies the structural constraints."""
+    """After 300 iterations every chain's cached prediction / misfit / likelihood / prior equals a from-scratch
+    evaluation of its current model, every model satisfies the structural constraints, and the run is reproducible."""
     from geobipy_amd import FdemBatch
     d, s, dc = _chains(256, 11, n_it=300)
     k = dc.k.cpu().numpy()
     e, sig = dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
-    assert k.min() >= 1 and k.max() <= dc.K and len(np.unique(k)) > 3
+    assert k.min() >= 1 and k.max() <= dc.K and len(np.unique(k)) > 2
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).cpu().numpy()
     for b in range(dc.B):
         w = thk[b, : k[b] - 1]
@@ -147,14 +290,45 @@ def test_device_chains_state_is_coherent_after_many_steps():
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
                    relative_error=dc.rel.cpu().numpy(), additive_error=dc.add.cpu().numpy())
     chi2, logl = fb.forward_loglike()
-    pred = fb.predicted
-    assert torch.equal(pred, dc.pred) and torch.equal(chi2, dc.misfit) and torch.equal(logl, dc.like)
+    assert torch.equal(fb.predicted, dc.pred) and torch.equal(chi2, dc.misfit) and torch.equal(logl, dc.like)
     o = dc.o
     prior = (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
              + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
              + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
     assert torch.allclose(prior, dc.prior, rtol=1e-12, atol=0)
     assert int(dc.k_hist.sum()) == 300 * dc.B
+    assert torch.all(dc.best_posterior >= dc.like + dc.prior)
+    _, _, dc2 = _chains(256, 11, n_it=300)
+    for n in ("k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "n_accepted", "k_hist", "edge_hist"):
+        assert torch.equal(getattr(dc, n), getattr(dc2, n)), n
+    _, _, dc3 = _chains(256, 12, n_it=300)
+    assert not torch.equal(dc.sigma, dc3.sigma)
+
+
+@pytest.mark.gpu
+def test_posterior_accumulators_match_a_host_replay():
+    _, _, dc = _chains(16, 4, exact=True, hitmap=True, n_value_bins=50)
+    dc.run(200, accumulate=False)                                # burn-in: nothing is accumulated
+    assert int(dc.k_hist.sum()) == 0 and int(dc.edge_hist.sum()) == 0 and int(dc.hitmap.sum()) == 0
+    B, nz, nv, w, W = dc.B, dc.n_depth_bins, dc.n_value_bins, dc.depth_bin_width, dc.value_half_width
+    k_hist, e_hist, hit = np.zeros((B, dc.K + 1), int), np.zeros((B, nz), int), np.zeros((B, nz, nv), int)
+    zc = (np.arange(nz) + 0.5) * w
+    lmp = dc.log_mean_prior.cpu().numpy()
+    for _ in range(150):
+        dc.step()
+        k, e, s = dc.k.cpu().numpy(), dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
+        for b in range(B):
+            k_hist[b, k[b]] += 1
+            ratio = s[b, 1:k[b]] / s[b, : k[b] - 1]
+            for depth in e[b, : k[b] - 1][(ratio <= 0.5) | (ratio >= 1.5)]:
+                e_hist[b, min(int(depth // w), nz - 1)] += 1
+            layer = np.searchsorted(e[b, : k[b] - 1], zc, side="right")
+            v = (np.log(s[b, layer]) - lmp[b]) / math.log(10.0)
+            bins = np.clip(np.floor((v + W) / (2 * W) * nv).astype(int), 0, nv - 1)
+            hit[b, np.arange(nz), bins] += 1
+    assert np.array_equal(dc.k_hist.cpu().numpy(), k_hist)
+    assert np.array_equal(dc.edge_hist.cpu().numpy(), e_hist) and e_hist.sum() > 0
+    assert np.array_equal(dc.hitmap.cpu().numpy(), hit)
 
 
 @pytest.mark.gpu
