@@ -153,3 +153,49 @@ def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, p
     u = u53(r[0], r[1])
     with np.errstate(divide="ignore"):
         return log_ratio, bool(np.log(u) < log_ratio), prior_p
+
+
+class Chain:
+    """A complete CPU chain with the device sampler's random streams: the three stage emulations above around an engine
+    with forward(edges, values) / sensitivity(edges, values) (the C oracle in the tests).  Carries the same state and
+    posterior accumulators as one row of gbp_rj_chains."""
+
+    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width):
+        self.o, self.seed, self.b, self.engine, self.sp, self.vp, self.data = o, seed, b, engine, sp, vp, data
+        self.edges, self.sigma, self.rel, self.add = np.zeros(0), np.array([sigma0]), rel, add
+        self.pred, self.J = engine.forward(self.edges, self.sigma), engine.sensitivity(self.edges, self.sigma)
+        std = np.sqrt((rel * data) ** 2 + add ** 2)
+        self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
+        rp, ap = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0), rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
+        self.prior = rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + rp.log_prior(rel) + ap.log_prior(add)
+        self.k_hist = np.zeros(o["K"] + 1, dtype=int)
+        self.edge_hist = np.zeros(n_depth_bins, dtype=int)
+        self.w = depth_bin_width
+        self.n_accepted = 0
+        self.trace = []
+
+    def step(self, it):
+        o, d = self.o, self.data
+        action, idx, val, e_r, s_r, rel_p, add_p = propose(o, self.seed, self.b, it, self.edges, self.sigma, self.rel, self.add)
+        if action != rjmcmc.NONE:
+            pred_r, J_r = self.engine.forward(e_r, s_r), self.engine.sensitivity(e_r, s_r)
+        else:
+            pred_r, J_r = self.pred, self.J
+        log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add)
+        prop = np.exp(log_prop)
+        pred_p = self.engine.forward(e_r, prop)
+        misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, np.sqrt((rel_p * d) ** 2 + add_p ** 2))
+        J_p = self.engine.sensitivity(e_r, prop) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
+        log_ratio, acc, prior_p = accept(o, self.seed, self.b, it, self.sp, self.vp, action, e_r, s_r, log_prop, C, J_p, pred_p, d,
+                                         rel_p, add_p, like_p, self.prior, self.like)
+        if acc:
+            self.edges, self.sigma, self.rel, self.add, self.pred = e_r, prop, rel_p, add_p, pred_p
+            self.prior, self.like, self.misfit = prior_p, like_p, misfit_p
+            self.J = J_p if J_p is not None else J_r
+            self.n_accepted += 1
+        self.trace.append((action, acc, self.sigma.size))
+        self.k_hist[self.sigma.size] += 1
+        ratio = self.sigma[1:] / self.sigma[:-1]
+        for depth in self.edges[(ratio <= 0.5) | (ratio >= 1.5)]:
+            self.edge_hist[min(int(depth // self.w), self.edge_hist.size - 1)] += 1
+        return log_ratio

@@ -332,6 +332,44 @@ def test_posterior_accumulators_match_a_host_replay():
 
 
 @pytest.mark.gpu
+def test_device_chains_equal_cpu_chains_with_the_same_seeds():
+    """BASELINE config 5's bar for the device sampler: a CPU implementation (rjmcmc.py pieces + the C oracle's forward
+    and Jacobian) driven by the same counter-based streams walks the same chain -- every move, every accept / reject,
+    and therefore identical layer-count and interface-depth histograms -- for 4 soundings x 400 iterations."""
+    from test_rjmcmc import OracleEngine
+    n_it, B = 400, 4
+    d, s, dc = _chains(B, 2024)
+    eo = _emul_options(dc)
+    rng = np.random.default_rng(6)
+    data = np.tile(d["data"], (B, 1)) * np.r_[1.0, rng.uniform(0.8, 1.3, B - 1)][:, None]
+    dc.data.copy_(torch.as_tensor(data))
+    dc._initialize()
+    sig0 = dc.sigma[:, 0].cpu().numpy()
+    eng = OracleEngine("resolve", float(d["z"]))
+    chains = []
+    for b in range(B):
+        sp, vp = _host_priors(dc, b)
+        chains.append(rj_emul.Chain(eo, 2024, b, eng, sp, vp, data[b], sig0[b], 0.05, 5.0, dc.n_depth_bins, dc.depth_bin_width))
+        assert np.isclose(chains[b].misfit, float(dc.misfit[b]), rtol=1e-9) and np.isclose(chains[b].prior, float(dc.prior[b]), rtol=1e-12)
+    acts, accs, ks = [], [], []
+    prev = dc.n_accepted.cpu().numpy().copy()
+    for it in range(n_it):
+        dc.step()
+        now = dc.n_accepted.cpu().numpy()
+        acts.append(dc.action.cpu().numpy().copy()); accs.append(now - prev); ks.append(dc.k.cpu().numpy().copy())
+        prev = now.copy()
+        for c in chains:
+            c.step(it)
+    acts, accs, ks = np.array(acts), np.array(accs), np.array(ks)
+    for b, c in enumerate(chains):
+        tr = np.array(c.trace)
+        assert np.array_equal(tr[:, 0], acts[:, b]) and np.array_equal(tr[:, 1], accs[:, b]) and np.array_equal(tr[:, 2], ks[:, b]), b
+        assert np.array_equal(c.k_hist, dc.k_hist[b].cpu().numpy()) and np.array_equal(c.edge_hist, dc.edge_hist[b].cpu().numpy())
+        assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-6) and np.allclose(c.sigma, dc.sigma[b, : c.sigma.size].cpu().numpy(), rtol=1e-6)
+    assert accs.sum() > 0.25 * accs.size and len(np.unique(ks)) >= 3 and set(np.unique(acts)) == {0, 1, 2, 3}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exact", [False, True])
 def test_device_chains_sample_like_the_host_chains(exact):
     """The device sampler against the host sampler (rjmcmc.py through BatchedInference -- the code that reproduces
