@@ -3,7 +3,8 @@
 Scope: the 1-D layered-earth FDEM and TDEM forward solves, the FDEM Jacobian and the
 Gaussian data misfit / log-likelihood evaluated at every rjMCMC proposal, behind the reference's
 ``FdemSystem / TdemSystem / Model / FdemDataPoint / TdemDataPoint`` interface, plus batched device-resident
-entry points (``FdemBatch``, ``TdemBatch``).
+entry points (``FdemBatch``, ``TdemBatch``) and the rjMCMC step around them (``Inference1D`` with the reference's random
+streams, ``DeviceChains`` resident on the GPU).
 All arithmetic runs in hand-written HIP kernels (geobipy_amd/csrc); importing the classes works on
 a CPU-only machine, evaluating anything needs the built library and a GPU -- there is no fallback.
 """
@@ -13,7 +14,8 @@ from .datapoint import FdemDataPoint
 from .batch import FdemBatch
 from .tdem import TdemBatch, TdemDataPoint, TdemSystem
 from .inference import BatchedInference, Inference1D
+from .rjmcmc_gpu import DeviceChains
 from . import rjmcmc, synthetic
 
 __all__ = ["CircularLoop", "FdemSystem", "Model", "RectilinearMesh1D", "FdemDataPoint", "FdemBatch", "TdemSystem", "TdemDataPoint", "TdemBatch",
-           "Inference1D", "BatchedInference", "rjmcmc", "synthetic"]
+           "Inference1D", "BatchedInference", "DeviceChains", "rjmcmc", "synthetic"]

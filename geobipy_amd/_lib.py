@@ -23,7 +23,7 @@ class RjOptions(ctypes.Structure):
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
                                                   "value_precision", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
                                                   "add_min", "add_max", "add_sd", "depth_bin_width", "value_half_width")]
-                + [("seed", ctypes.c_uint64)])
+                + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)])
 
 
 RJ_CHAIN_FIELDS = ("data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_cha
     const double* e = c.edges + (size_t)b * K;
     const double* s = c.sigma + (size_t)b * K;
     const int k = c.k[b];
-    Rng r(o.seed, (uint32_t)b, iter, 0);
+    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
     int action = NONE, idx = 0;
     double val = 0.0;
     const double lo = log(o.min_edge), hi = log(o.max_edge), mw = o.min_width;
@@ -263,29 +263,27 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     const double ls = lane < k ? log(sr[lane]) : 0.0;
     if (lane < k) s.v[lane] = ls - lmp;
     __syncthreads();
-    double acc[64];                                              // row `lane` of J'PJ, columns <= lane
+    // row `lane` of J'PJ in column blocks of 8; J[n, j] is a wave-uniform address (scalar loads), J[n, lane] coalesced
+    const int li = min(lane, k - 1);
     double gi = 0.0;
-    // the compiler keeps acc[] in registers only with a static bound; K <= 64
+    for (int n = 0; n < N; ++n) gi += J[(size_t)n * K + li] * s.PR[n];
+    for (int j0 = 0; j0 < k; j0 += 8) {
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < N; ++n) {
+            const double* Jn = J + (size_t)n * K;
+            const double jp = Jn[li] * s.P[n];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) acc[j] = 0.0;
-    for (int n = 0; n < N; ++n) {
-        if (lane < k) s.row[lane] = J[(size_t)n * K + lane];
-        __syncthreads();
-        if (lane < k) {
-            const double ji = s.row[lane], jp = ji * s.P[n];
-            gi += ji * s.PR[n];
-#pragma unroll
-            for (int j = 0; j < 64; ++j)
-                if (j <= lane && j < k) acc[j] += jp * s.row[j];
+            for (int jj = 0; jj < 8; ++jj) acc[jj] += jp * Jn[min(j0 + jj, K - 1)];
         }
-        __syncthreads();
-    }
-    if (lane < k) {
+        if (lane < k) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j)
-            if (j <= lane && j < k) s.A[lane * KS + j] = acc[j] + prior_entry(o, s.t2, k, lane, j);
-        s.g[lane] = gi + prior_apply(o, s.t2, k, lane, s.v);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j <= lane) s.A[lane * KS + j] = acc[jj] + prior_entry(o, s.t2, k, lane, j);
+            }
+        }
     }
+    if (lane < k) s.g[lane] = gi + prior_apply(o, s.t2, k, lane, s.v);
     __syncthreads();
     for (int j = 0; j < k; ++j) {                                // Cholesky, lower, in place
         if (lane == j) {
@@ -307,7 +305,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     chol_solve(s.A, KS, k, lane, s.g, true, true);
     if (lane < 32) {
         double z0, z1;
-        normal_pair(o.seed, (uint32_t)b, iter, 1, (uint32_t)lane, z0, z1);
+        normal_pair(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 1, (uint32_t)lane, z0, z1);
         if (2 * lane < K) s.w[2 * lane] = z0;
         if (2 * lane + 1 < K) s.w[2 * lane + 1] = z1;
     }
@@ -388,7 +386,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     }
     const double like_p = c.like_p[b];
     const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
-    const U4 rr = philox(o.seed, (uint32_t)b, iter, 2, 0);
+    const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
     const bool accept = log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
     __syncthreads();
     if (lane == 0) c.log_ratio[b] = log_ratio;

@@ -58,11 +58,13 @@ class DeviceChains:
     """B rjMCMC chains (one per sounding) resident on one GPU.  ``options``: keys of the reference's options file
     (documentation_source/source/supplementary/options_files/resolve_options).
 
+    ``first_chain``: global index of the block's first sounding -- the random streams are keyed by the global chain
+    index, so a survey produces the same chains on 1 GPU or sharded over 8.
     hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_depth_bins, n_value_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
-                 **options):
+                 first_chain=0, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -106,6 +108,7 @@ class DeviceChains:
         ro.add_sd = math.sqrt(o["additive_error_proposal_variance"])
         ro.depth_bin_width, ro.value_half_width = self.depth_bin_width, self.value_half_width
         ro.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        ro.first_chain = int(first_chain)          # global index of this block's first sounding (sharded surveys)
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)

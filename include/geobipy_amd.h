@@ -205,6 +205,8 @@ typedef struct gbp_rj_options {
     double depth_bin_width;      /* interface histogram / hit-map depth cell                           */
     double value_half_width;     /* hit-map spans log10(sigma / prior mean) in [-w, w]                 */
     uint64_t seed;
+    uint64_t first_chain;        /* global index of chain 0 of this block: the random streams are keyed by
+                                    first_chain + b, so a survey gives the same chains however it is sharded */
 } gbp_rj_options;
 
 typedef struct gbp_rj_chains {

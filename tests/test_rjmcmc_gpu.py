@@ -303,6 +303,10 @@ def test_device_chains_state_is_coherent_after_many_steps():
         assert torch.equal(getattr(dc, n), getattr(dc2, n)), n
     _, _, dc3 = _chains(256, 12, n_it=300)
     assert not torch.equal(dc.sigma, dc3.sigma)
+    # sharding invariance: the second half of the block as its own DeviceChains with first_chain = 128
+    _, _, dc4 = _chains(128, 11, n_it=300, first_chain=128)
+    for n in ("k", "edges", "sigma", "rel", "add", "pred", "like", "n_accepted", "k_hist", "edge_hist"):
+        assert torch.equal(getattr(dc, n)[128:], getattr(dc4, n)), n
 
 
 @pytest.mark.gpu
