@@ -19,7 +19,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 class RjOptions(ctypes.Structure):
     """gbp_rj_options (include/geobipy_amd.h)."""
     _fields_ = ([(n, ctypes.c_int32) for n in ("max_layers", "n_channels", "solve_gradient", "solve_relative_error",
-                                               "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins")]
+                                               "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "forward_waves")]
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
                                                   "value_precision", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
                                                   "add_min", "add_max", "add_sd", "depth_bin_width", "value_half_width")]
@@ -45,6 +45,7 @@ SIGNATURES = {
     "gbp_rj_newton": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
     "gbp_rj_accept": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
+    "gbp_pin_forward_waves": (c_int, [c_int]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gbp_version": (ctypes.c_char_p, []),
     "gbp_last_error": (ctypes.c_char_p, []),

@@ -435,6 +435,9 @@ size_t dyn_lds_bytes(int nw, int Lmax, int F)
 }
 
 // waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches
+thread_local int g_pinned_waves = 0;   // set by gbp_rj_run for the duration of its launches (gbp_rj_options.forward_waves)
+thread_local int g_user_waves = 0;     // gbp_pin_forward_waves
+
 int pick_waves(int B, int F, int Lmax, int max_waves)
 {
     static int forced = -2;
@@ -442,7 +445,7 @@ int pick_waves(int B, int F, int Lmax, int max_waves)
         const char* e = std::getenv("GBP_NW");
         forced = e ? std::atoi(e) : -1;
     }
-    int nw = forced > 0 ? forced : (8192 + B - 1) / B;  // aim for >= 8 waves per SIMD-slot worth of work
+    int nw = g_pinned_waves > 0 ? g_pinned_waves : (g_user_waves > 0 ? g_user_waves : (forced > 0 ? forced : (8192 + B - 1) / B));  // aim for >= 8 waves per SIMD-slot worth of work
     if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;
     while (nw > 1 && dyn_lds_bytes(nw, Lmax, F) > 60000) --nw;

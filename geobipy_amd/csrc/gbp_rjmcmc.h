@@ -525,6 +525,7 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
     if (B == 0) return GBP_OK;
     const int caps[3] = {8 < K ? 8 : K, 16 < K ? 16 : K, K};
     const int nb = K <= 8 ? 1 : (K <= 16 ? 2 : 3);
+    struct Pin { Pin(int w) { g_pinned_waves = w; } ~Pin() { g_pinned_waves = 0; } } pin(o->forward_waves);   // 0: no pin
     for (int it = 0; it < n_iterations; ++it) {
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
@@ -543,6 +544,13 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
                                               caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
         if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
     }
+    return GBP_OK;
+}
+
+gbp_status gbp_pin_forward_waves(int waves)
+{
+    if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
+    g_user_waves = waves;
     return GBP_OK;
 }
 

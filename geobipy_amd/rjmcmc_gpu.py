@@ -59,12 +59,15 @@ class DeviceChains:
     (documentation_source/source/supplementary/options_files/resolve_options).
 
     ``first_chain``: global index of the block's first sounding -- the random streams are keyed by the global chain
-    index, so a survey produces the same chains on 1 GPU or sharded over 8.
+    index, so a survey produces the same chains on 1 GPU or sharded over 8 -- bit for bit as long as ``forward_waves`` pins
+    the forward kernels' waves per workgroup (the default, 4, is also the fastest choice up to ~16k chains per GPU; with 0
+    they adapt it to the block size, which changes the summation order of the Hankel sums in the last bits, and long
+    chains of differently sized blocks drift apart).
     hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_depth_bins, n_value_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
-                 first_chain=0, **options):
+                 first_chain=0, forward_waves=4, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -109,6 +112,7 @@ class DeviceChains:
         ro.depth_bin_width, ro.value_half_width = self.depth_bin_width, self.value_half_width
         ro.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         ro.first_chain = int(first_chain)          # global index of this block's first sounding (sharded surveys)
+        ro.forward_waves = int(forward_waves)
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
@@ -128,7 +132,11 @@ class DeviceChains:
             setattr(rc, name, None if t[name] is None else t[name].data_ptr())
         self._c = rc
         self.iteration = 0
-        self._initialize()
+        _lib.check(_lib.load().gbp_pin_forward_waves(int(forward_waves)))
+        try:
+            self._initialize()
+        finally:
+            _lib.check(_lib.load().gbp_pin_forward_waves(0))
 
     def __getattr__(self, name):              # chain state by the names of gbp_rj_chains
         t = self.__dict__.get("t")

@@ -196,6 +196,9 @@ typedef struct gbp_rj_options {
     int32_t n_channels;          /* N = 2 * nF                                                         */
     int32_t solve_gradient, solve_relative_error, solve_additive_error, exact_jacobian;
     int32_t n_depth_bins, n_value_bins;   /* posterior grids (interface histogram / hit-map)          */
+    int32_t forward_waves;       /* 0: the forward kernels pick their waves per workgroup from the batch size (fastest);
+                                    > 0: fixed, which fixes the summation order of the Hankel sums and so makes the
+                                    chains bit-identical for any sharding of the survey                 */
     double min_edge, max_edge, min_width; /* min_edge already raised to min_width (RectilinearMesh1D.py:358-360) */
     double p_birth, p_death, p_perturb, p_none;
     double value_precision;      /* 1 / ln(1 + factor)^2                                              */
@@ -252,6 +255,9 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
+/* Pin (waves > 0) or release (0) the waves per workgroup of the forward kernels launched from the calling thread;
+ * same meaning as gbp_rj_options.forward_waves, for the forward calls made outside gbp_rj_run (chain initialisation). */
+gbp_status gbp_pin_forward_waves(int waves);
 /* Test hook: n uniforms and n standard normals of stream (chain, iteration, stream_id) as the kernels draw them. */
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);

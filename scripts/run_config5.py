@@ -21,6 +21,7 @@ ap.add_argument("--soundings", type=int, default=8192)
 ap.add_argument("--iterations", type=int, default=10000)
 ap.add_argument("--layers", type=int, default=4, help="layers of the synthetic true models")
 ap.add_argument("--seed", type=int, default=2026)
+ap.add_argument("--forward-waves", type=int, default=4, help="pinned waves per workgroup of the forward kernels (0 = adaptive)")
 ap.add_argument("--reference-jacobian", action="store_true", help="use the reference's Jacobian expression in the proposals")
 args = ap.parse_args()
 rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
@@ -31,7 +32,7 @@ if world > 1:
     backend = os.environ.get("GBP_BENCH_BACKEND", "nccl")
     dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
-from geobipy_amd import DeviceChains, FdemBatch, synthetic
+from geobipy_amd import DeviceChains, FdemBatch, synthetic, _lib
 from geobipy_amd.distributed import SummaryGather, shard
 
 S, n_it = args.soundings, args.iterations
@@ -40,7 +41,9 @@ start, Bloc = shard(S, rank, world)
 # the whole survey is drawn with one seed and sliced, so the workload does not depend on the number of ranks
 nl, sigma_true, thk, height = synthetic.draw_models(S, args.layers, seed=synthetic.SEED + 5)
 sl = slice(start, start + Bloc)
+_lib.check(_lib.load().gbp_pin_forward_waves(args.forward_waves))      # the synthetic data must not depend on the shard size either
 clean = FdemBatch(system, nl[sl], sigma_true[sl], thk[sl], height[sl], device=device).forward().cpu().numpy()
+_lib.check(_lib.load().gbp_pin_forward_waves(0))
 noise = np.random.Generator(np.random.PCG64DXSM(synthetic.SEED + 6)).normal(size=(S, clean.shape[1]))[sl]
 data = clean + noise * np.sqrt((0.05 * clean) ** 2 + 5.0 ** 2)
 options = dict(solve_gradient=True, maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, minimum_thickness=1.0,
@@ -49,7 +52,7 @@ options = dict(solve_gradient=True, maximum_number_of_layers=30, minimum_depth=1
                additive_error_proposal_variance=1e-6, probability_of_birth=1.0 / 6.0, probability_of_death=1.0 / 6.0,
                probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5)
 dc = DeviceChains(system, height[sl], data, seed=args.seed, exact_jacobian=not args.reference_jacobian, first_chain=start,
-                  device=device, **options)
+                  forward_waves=args.forward_waves, device=device, **options)
 m0 = dc.misfit.clone()
 K = dc.K
 gather = SummaryGather(S, 6 + K + 1, device)
