@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-windowed", action="store_true", help="skip the extra opt-in abscissa-window measurement")
+    ap.add_argument("--no-rjmcmc", action="store_true", help="skip the extra full-rjMCMC-step measurement")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -246,6 +247,31 @@ def main():
                                 "max_abs_diff_pred_ppm": float((wb[0].predicted - batches[0].predicted).abs().max()),
                                 "max_abs_diff_logL": float((l_w - l_e).abs().max()),
                                 "note": "opt-in FdemBatch(hankel_eps_ppm=...); the headline value evaluates all 120 abscissae"}
+        if world == 1 and not args.no_rjmcmc:
+            # the caller of the hot path: complete rjMCMC iterations on the first 8192 soundings of the
+            # same batch, every chain resident on the device (gbp_rj_run).  Reported next to the headline, not in it.
+            from geobipy_amd import DeviceChains
+            nrj, n_it = min(Btot, 8192), 300
+            obs_np = obs.cpu().numpy() if torch.is_tensor(obs) else np.asarray(obs)
+            dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=True, device=device,
+                              maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, initial_relative_error=0.05,
+                              minimum_relative_error=0.001, maximum_relative_error=0.5, initial_additive_error=5.0,
+                              minimum_additive_error=3.0, maximum_additive_error=20.0, relative_error_proposal_variance=1e-6,
+                              additive_error_proposal_variance=1e-6, probability_of_birth=1.0 / 6.0,
+                              probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5)
+            dc.run(50)
+            torch.cuda.synchronize(device)
+            tr = time.perf_counter()
+            dc.run(n_it)
+            torch.cuda.synchronize(device)
+            tr = time.perf_counter() - tr
+            sm = dc.summaries().cpu().numpy()
+            line["rjmcmc"] = {"value": nrj * n_it / tr, "unit": "chain-iterations/s", "soundings": nrj, "iterations": n_it,
+                              "ms_per_lockstep_iteration": 1e3 * tr / n_it, "acceptance": float(sm[:, 4].mean()),
+                              "mean_layers": float(sm[:, 3].mean()),
+                              "note": "full birth/death/perturb rjMCMC step (gbp_rj_run): >= 1 fused forward+likelihood, ~0.5 "
+                                      "forward and ~0.7 Jacobian per chain-iteration; reference ~165 iterations/s per core"}
+            del dc
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))
