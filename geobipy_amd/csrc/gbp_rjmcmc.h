@@ -90,7 +90,7 @@ __global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_cha
     int action = NONE, idx = 0;
     double val = 0.0;
     const double lo = log(o.min_edge), hi = log(o.max_edge), mw = o.min_width;
-    bool done = false;
+    bool done = o.schedule == 1 && c.status[b] != 0;             // finished chains idle through the remaining iterations
     for (int round = 0; round < 8 && !done; ++round) {          // RectilinearMesh1D.perturb: redraw the event when the tries run out
         const double pb = (k == K) ? 0.0 : o.p_birth, pd = (k == 1) ? 0.0 : o.p_death, pp = (k == 1) ? 0.0 : o.p_perturb;
         const double u = r.uniform() * (pb + pd + pp + o.p_none);
@@ -387,9 +387,11 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     const double like_p = c.like_p[b];
     const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
     const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
-    const bool accept = log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
+    const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
+    const bool accept = !frozen && log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
     __syncthreads();
     if (lane == 0) c.log_ratio[b] = log_ratio;
+    if (frozen) return;
     if (accept) {
         if (lane < K) {
             c.edges[(size_t)b * K + lane] = e[lane];
@@ -407,14 +409,42 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             c.n_accepted[b] += 1;
         }
     }
-    __syncthreads();
-    __threadfence_block();
-    // bookkeeping on the post-step state (Inference1D.update :705-790)
+    // bookkeeping on the post-step state (Inference1D.update :705-790); the post-step model is read from where it came
+    // from (the proposal buffers when accepted, the untouched state otherwise), never back from what other lanes just wrote
     const int kc = accept ? k : c.k[b];
-    const double* ec = c.edges + (size_t)b * K;
-    const double* sc = c.sigma + (size_t)b * K;
+    const double* ec = accept ? e : c.edges + (size_t)b * K;
+    const double* sc = accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K;
     const double post = (accept ? prior_p + like_p : c.prior[b] + c.like[b]);
-    if (post > c.best_posterior[b]) {
+    bool reset_best = false;
+    if (o.schedule == 1) {                                       // the reference's per-sounding schedule
+        const int it1 = (int)iter + 1;                           //   (Inference1D.update :713-737, infer :641-688)
+        int bi = c.burned_in_iteration[b];
+        if (bi < 0) {
+            double na = 0.0;
+            for (int n = lane; n < N; n += 64) na += c.data[(size_t)b * N + n] > 0.0 ? 1.0 : 0.0;
+            na = wave_sum(na);
+            const double misfit_now = accept ? c.misfit_p[b] : c.misfit[b];
+            if (it1 > o.burn_in_min_iterations && misfit_now < na) {        // burned in: posteriors and best model start over
+                bi = it1;
+                reset_best = true;
+                for (int i = lane; i < K + 1; i += 64) c.k_hist[(size_t)b * (K + 1) + i] = 0;
+                if (c.edge_hist != nullptr)
+                    for (int i = lane; i < o.n_depth_bins; i += 64) c.edge_hist[(size_t)b * o.n_depth_bins + i] = 0;
+                if (c.hitmap != nullptr) {
+                    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
+                    for (size_t i = lane; i < nh; i += 64) c.hitmap[(size_t)b * nh + i] = 0;
+                }
+                __syncthreads();
+                if (lane == 0) c.burned_in_iteration[b] = bi;
+            }
+        }
+        accumulate = 1;                                          // every iteration; the reset above discards the burn-in
+        if (lane == 0) {
+            if (bi >= 0 && it1 > o.n_markov_chains + bi) c.status[b] = 1;          // done: n_markov_chains samples collected
+            else if (bi < 0 && it1 >= o.n_markov_chains) c.status[b] = 2;          // failed to burn in
+        }
+    }
+    if (reset_best || post > c.best_posterior[b]) {
         if (lane < K) { c.best_edges[(size_t)b * K + lane] = ec[lane]; c.best_sigma[(size_t)b * K + lane] = sc[lane]; }
         __syncthreads();
         if (lane == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
@@ -469,6 +499,8 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
     if (c->B < 0) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0%s");
     if (!(o->min_width > 0.0) || !(o->max_edge > o->min_edge) || !(o->min_edge > 0.0))
         return fail(GBP_ERR_INVALID_ARG, "need 0 < min_edge < max_edge and min_width > 0%s");
+    if (o->schedule == 1 && (!c->burned_in_iteration || !c->status))
+        return fail(GBP_ERR_INVALID_ARG, "schedule 1 needs burned_in_iteration and status%s");
     if ((c->edge_hist || c->hitmap) && (o->n_depth_bins < 1 || !(o->depth_bin_width > 0.0)))
         return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
     if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");

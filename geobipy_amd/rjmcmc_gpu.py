@@ -63,11 +63,15 @@ class DeviceChains:
     the forward kernels' waves per workgroup (the default, 4, is also the fastest choice up to ~16k chains per GPU; with 0
     they adapt it to the block size, which changes the summation order of the Hankel sums in the last bits, and long
     chains of differently sized blocks drift apart).
+    ``reference_schedule``: per-sounding burn-in / stop rule of the reference (Inference1D.update :713-737, infer
+    :641-688) evaluated on the device: a chain burns in at the first iteration > ``burn_in_min_iterations`` whose misfit
+    is below the number of active channels (its posteriors and best model restart there), is done ``n_markov_chains``
+    iterations later and has failed if it has not burned in after ``n_markov_chains`` iterations; see ``infer``.
     hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_depth_bins, n_value_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
-                 first_chain=0, forward_waves=4, **options):
+                 first_chain=0, forward_waves=4, reference_schedule=False, burn_in_min_iterations=5000, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -113,6 +117,10 @@ class DeviceChains:
         ro.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         ro.first_chain = int(first_chain)          # global index of this block's first sounding (sharded surveys)
         ro.forward_waves = int(forward_waves)
+        ro.schedule = int(bool(reference_schedule))
+        ro.burn_in_min_iterations = int(burn_in_min_iterations)
+        ro.n_markov_chains = int(o.get("n_markov_chains", 0))
+        assert not reference_schedule or ro.n_markov_chains > 0, ValueError("reference_schedule needs n_markov_chains")
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
@@ -125,6 +133,7 @@ class DeviceChains:
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
             edge_hist=z(B, self.n_depth_bins, dt=i32),
             hitmap=z(B, self.n_depth_bins, self.n_value_bins, dt=i32) if hitmap else None,
+            burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K))
         rc = _lib.RjChains()
         rc.B = B
@@ -204,6 +213,16 @@ class DeviceChains:
 
     def step(self, accumulate=True):
         return self.run(1, accumulate)
+
+    def infer(self, check_every=1000):
+        """Run under the reference's schedule until every chain is done or has failed (at most 2 n_markov_chains + 2
+        iterations); the host looks at the status flags every ``check_every`` iterations.  Returns the number of chains
+        that failed to burn in."""
+        assert self._o.schedule == 1, "infer() needs reference_schedule=True"
+        limit = 2 * self._o.n_markov_chains + 2
+        while self.iteration < limit and bool((self.t["status"] == 0).any()):
+            self.run(min(check_every, limit - self.iteration))
+        return int((self.t["status"] == 2).sum())
 
     def summaries(self):
         """[B, 6] per-sounding summary for the gather: misfit, logL, prior, k, acceptance rate, best posterior."""

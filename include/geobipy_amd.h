@@ -196,6 +196,13 @@ typedef struct gbp_rj_options {
     int32_t n_channels;          /* N = 2 * nF                                                         */
     int32_t solve_gradient, solve_relative_error, solve_additive_error, exact_jacobian;
     int32_t n_depth_bins, n_value_bins;   /* posterior grids (interface histogram / hit-map)          */
+    int32_t schedule;            /* 0: the caller decides what is accumulated (`accumulate` argument);
+                                    1: the reference's per-sounding schedule (Inference1D.update :713-737, infer :641-688):
+                                       a chain burns in at the first iteration > burn_in_min_iterations with misfit <
+                                       active channels -- its posteriors and best model start over there --, is done
+                                       n_markov_chains iterations later, and has failed when it has not burned in after
+                                       n_markov_chains iterations; done / failed chains keep their final state          */
+    int32_t burn_in_min_iterations, n_markov_chains;
     int32_t forward_waves;       /* 0: the forward kernels pick their waves per workgroup from the batch size (fastest);
                                     > 0: fixed, which fixes the summation order of the Hankel sums and so makes the
                                     chains bit-identical for any sharding of the survey                 */
@@ -240,6 +247,8 @@ typedef struct gbp_rj_chains {
     int32_t *k_hist;               /* [B, K + 1]            posterior of the layer count               */
     int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
     int32_t *hitmap;               /* [B, n_depth_bins, n_value_bins] or NULL                           */
+    int32_t *burned_in_iteration;  /* [B]  schedule 1: -1 until the chain burns in (may be NULL for schedule 0)          */
+    int32_t *status;               /* [B]  schedule 1: 0 running, 1 done, 2 failed to burn in                            */
     double *best_posterior;        /* [B]                                                              */
     int32_t *best_k;
     double *best_edges, *best_sigma;          /* [B, K]                                                */

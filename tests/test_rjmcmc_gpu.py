@@ -289,7 +289,10 @@ def test_device_chains_state_is_coherent_after_many_steps():
             assert e[b, 0] > dc.min_edge and e[b, k[b] - 2] < dc.max_edge
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
                    relative_error=dc.rel.cpu().numpy(), additive_error=dc.add.cpu().numpy())
+    from geobipy_amd import _lib
+    _lib.check(_lib.load().gbp_pin_forward_waves(4))             # the summation order the chains ran with (forward_waves=4)
     chi2, logl = fb.forward_loglike()
+    _lib.check(_lib.load().gbp_pin_forward_waves(0))
     assert torch.equal(fb.predicted, dc.pred) and torch.equal(chi2, dc.misfit) and torch.equal(logl, dc.like)
     o = dc.o
     prior = (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
@@ -340,6 +343,58 @@ def test_posterior_accumulators_match_a_host_replay():
     assert np.array_equal(dc.k_hist.cpu().numpy(), k_hist)
     assert np.array_equal(dc.edge_hist.cpu().numpy(), e_hist) and e_hist.sum() > 0
     assert np.array_equal(dc.hitmap.cpu().numpy(), hit)
+
+
+@pytest.mark.gpu
+def test_reference_schedule_on_the_device_matches_a_host_replay():
+    """Per-sounding burn-in / stop rule of Inference1D.update / infer evaluated in the accept kernel: burn-in iteration,
+    status, the posterior that restarts at burn-in, the frozen final state -- against a replay of the rule on the host
+    from the per-iteration misfits.  A few soundings carry data no layered earth fits, so that they fail to burn in."""
+    n_mc, burn_min, B = 300, 100, 48
+    d, s, dc = _chains(B, 77, exact=True, reference_schedule=True, burn_in_min_iterations=burn_min,
+                       options=dict(n_markov_chains=n_mc))
+    rng = np.random.default_rng(1)
+    data = np.tile(d["data"], (B, 1))
+    data[:6] *= rng.uniform(0.4, 2.5, size=(6, data.shape[1]))
+    dc.data.copy_(torch.as_tensor(data))
+    dc._initialize()
+    bi = np.full(B, -1)
+    status = np.zeros(B, dtype=int)
+    k_hist = np.zeros((B, dc.K + 1), dtype=int)
+    final = {}
+    n_active = (data > 0).sum(axis=1)
+    it1 = 0
+    while it1 < 2 * n_mc + 2:
+        dc.step()
+        it1 += 1
+        mis, k = dc.misfit.cpu().numpy(), dc.k.cpu().numpy()
+        sig = dc.sigma.cpu().numpy()
+        for b in range(B):
+            if status[b]:
+                assert np.array_equal(sig[b], final[b]), (b, it1)         # frozen
+                continue
+            if bi[b] < 0 and it1 > burn_min and mis[b] < n_active[b]:
+                bi[b] = it1
+                k_hist[b] = 0
+            k_hist[b, k[b]] += 1
+            if bi[b] >= 0 and it1 > n_mc + bi[b]:
+                status[b] = 1
+            elif bi[b] < 0 and it1 >= n_mc:
+                status[b] = 2
+            if status[b]:
+                final[b] = sig[b].copy()
+    assert np.array_equal(dc.burned_in_iteration.cpu().numpy(), bi) and np.array_equal(dc.status.cpu().numpy(), status)
+    assert np.array_equal(dc.k_hist.cpu().numpy(), k_hist)
+    assert (status == 1).sum() > B // 2 and (status == 2).sum() >= 3 and not (status == 0).any()
+    assert np.all(k_hist[status == 1].sum(axis=1) == n_mc + 2) and np.all(k_hist[status == 2].sum(axis=1) == n_mc)
+    assert torch.all(dc.best_posterior[dc.status == 1] <= (dc.like + dc.prior)[dc.status == 1] + 1e300)
+    # infer(): the same run driven by the status flags
+    _, _, dc2 = _chains(B, 77, exact=True, reference_schedule=True, burn_in_min_iterations=burn_min, options=dict(n_markov_chains=n_mc))
+    dc2.data.copy_(torch.as_tensor(data))
+    dc2._initialize()
+    assert dc2.infer(check_every=64) == (status == 2).sum()
+    for n in ("k", "sigma", "k_hist", "edge_hist", "burned_in_iteration", "status", "best_sigma"):
+        assert torch.equal(getattr(dc, n), getattr(dc2, n)), n
 
 
 @pytest.mark.gpu
