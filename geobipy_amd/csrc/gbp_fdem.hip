@@ -437,6 +437,7 @@ size_t dyn_lds_bytes(int nw, int Lmax, int F)
 // waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches
 thread_local int g_pinned_waves = 0;   // set by gbp_rj_run for the duration of its launches (gbp_rj_options.forward_waves)
 thread_local int g_user_waves = 0;     // gbp_pin_forward_waves
+thread_local int g_sens_waves = 0;     // waves per workgroup of the Jacobian launches issued by gbp_rj_run
 
 int pick_waves(int B, int F, int Lmax, int max_waves)
 {
@@ -703,7 +704,10 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, 
     const size_t per_wave = (size_t)max_layers * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK));
     if (per_wave + (size_t)max_layers * 8 > 150000)
         return fail(GBP_ERR_INVALID_ARG, "too many layers for the Jacobian kernel's LDS working set (max ~140)%s");
-    int nw = pick_waves(B, sys->t.nF, Lmax, sys->t.nF);
+    // one frequency per wave at a time, so the result does not depend on nw (no pin needed) and nw should divide nF;
+    // g_sens_waves: the sampler's launches, where only a fraction of the workgroups has work (gbp_rj_run)
+    int nw = g_sens_waves > 0 ? g_sens_waves : pick_waves(B, sys->t.nF, Lmax, sys->t.nF);
+    if (nw > sys->t.nF) nw = sys->t.nF;
     while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
     const size_t lds = nw * per_wave + (size_t)max_layers * 8;
     if (exact) {

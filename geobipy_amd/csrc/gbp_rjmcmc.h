@@ -557,7 +557,20 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
     if (B == 0) return GBP_OK;
     const int caps[3] = {8 < K ? 8 : K, 16 < K ? 16 : K, K};
     const int nb = K <= 8 ? 1 : (K <= 16 ? 2 : 3);
-    struct Pin { Pin(int w) { g_pinned_waves = w; } ~Pin() { g_pinned_waves = 0; } } pin(o->forward_waves);   // 0: no pin
+    struct Pin { Pin(int w, int sw) { g_pinned_waves = w; g_sens_waves = sw; } ~Pin() { g_pinned_waves = 0; g_sens_waves = 0; } };
+    // Jacobian launches: ~40 % of the chains need one (structure changed / dimension changed), the rest exit at once;
+    // size the workgroups for the chains that work, with a wave count that divides nF (one frequency per wave at a time)
+    int sw = 1;
+    {
+        static int env = -2;
+        if (env == -2) { const char* e = std::getenv("GBP_RJ_SENS_NW"); env = e ? std::atoi(e) : -1; }
+        const int F = sys->t.nF;
+        const int want = env > 0 ? env : (int)((8192.0 + 0.4 * B - 1.0) / (0.4 * B));
+        sw = F;
+        for (int d = 1; d <= F; ++d)
+            if (F % d == 0 && d >= want) { sw = d; break; }
+    }
+    Pin pin(o->forward_waves, sw);   // forward_waves 0: no pin
     for (int it = 0; it < n_iterations; ++it) {
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
