@@ -15,7 +15,7 @@ from .batch import FdemBatch
 from .tdem import TdemBatch, TdemDataPoint, TdemSystem
 from .inference import BatchedInference, Inference1D
 from .rjmcmc_gpu import DeviceChains
-from . import rjmcmc, synthetic
+from . import rjmcmc, survey, synthetic
 
 __all__ = ["CircularLoop", "FdemSystem", "Model", "RectilinearMesh1D", "FdemDataPoint", "FdemBatch", "TdemSystem", "TdemDataPoint", "TdemBatch",
-           "Inference1D", "BatchedInference", "DeviceChains", "rjmcmc", "synthetic"]
+           "Inference1D", "BatchedInference", "DeviceChains", "rjmcmc", "survey", "synthetic"]

@@ -94,7 +94,7 @@ class DeviceChains:
         # posterior grids: the reference's interface-depth grid (RectilinearMesh1D.set_posteriors :1438-1455) and a
         # log10 conductivity axis of +-4 prior standard deviations about the prior mean (Model.set_posteriors)
         self.depth_bin_width = 0.5 * self.min_width
-        self.n_depth_bins = int(math.ceil(1.1 * self.max_edge / self.depth_bin_width))
+        self.n_depth_bins = max(1, np.arange(0.0, 1.1 * self.max_edge, self.depth_bin_width).size - 1)   # cells between the reference's edges
         self.n_value_bins = int(n_value_bins)
         self.value_half_width = 4.0 * math.log(1.0 + o["factor"]) / math.log(10.0)
         ro = _lib.RjOptions()

@@ -1,0 +1,246 @@
+"""Survey-level entry (reduced to what feeds the path): the reference's user inputs -- an options file
+and an FDEM data CSV -- to the posteriors of every sounding, on the GPUs of one node.
+
+Mirrors what the reference's harness does around ``Inference1D`` without its control plane:
+  ``read_options``      inversion/user_parameters.py:31-99 (same keys, same defaults, same required keys)
+  ``FdemData.read_csv`` classes/data/dataset/FdemData.py:620-682 + Data.py:505-528 + pointcloud/Point.py:355-382
+                        (column recognition by header name), one row per sounding
+  ``infer``             inversion/Inference3D.py:518-635: soundings are independent; a rank owns one GPU and a
+                        contiguous block of soundings (base/MPI.py:172-201) and runs all of its chains in lockstep
+                        (``DeviceChains`` under the reference's burn-in / stop schedule); results are gathered on rank 0.
+The reference's HDF5 output (row f-4) is not reproduced: results are numpy arrays (``SurveyResult.save`` -> .npz).
+"""
+import ast
+import os
+
+import numpy as np
+
+from .datapoint import FdemDataPoint
+from .system import FdemSystem
+
+REQUIRED_KEYS = ("data_type", "data_filename", "system_filename", "n_markov_chains", "interactive_plot", "update_plot_every",
+                 "save_png", "save_hdf5", "solve_parameter", "solve_gradient", "maximum_number_of_layers", "minimum_depth",
+                 "maximum_depth", "probability_of_birth", "probability_of_death", "probability_of_perturb",
+                 "probability_of_no_change")
+_DATA_TYPES = ("FdemData", "TdemData", "TempestData", "FdemDataPoint", "TdemDataPoint", "TempestDataPoint")
+
+
+def _value(node):
+    """Literals, arithmetic on literals, lists / tuples, and the data-type names (kept as strings).  The reference
+    exec()s the file (user_parameters.py:83-88); the files it ships need no more than this."""
+    if isinstance(node, ast.Name):
+        if node.id in _DATA_TYPES:
+            return node.id
+        if node.id in ("inf", "nan"):
+            return float(node.id)
+        raise ValueError("unknown name {!r} in options file".format(node.id))
+    if isinstance(node, (ast.List, ast.Tuple)):
+        return [_value(e) for e in node.elts]
+    if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+        v = _value(node.operand)
+        return -v if isinstance(node.op, ast.USub) else v
+    if isinstance(node, ast.BinOp):
+        a, b = _value(node.left), _value(node.right)
+        ops = {ast.Add: lambda: a + b, ast.Sub: lambda: a - b, ast.Mult: lambda: a * b, ast.Div: lambda: a / b,
+               ast.Pow: lambda: a ** b}
+        if type(node.op) not in ops:
+            raise ValueError("unsupported operator in options file")
+        return ops[type(node.op)]()
+    return ast.literal_eval(node)
+
+
+def read_options(filename, **overrides):
+    """dict of the options file's assignments with the reference's defaults filled in and the file names joined to
+    ``data_directory`` (relative directories are taken relative to the options file)."""
+    with open(filename) as f:
+        tree = ast.parse(f.read(), filename=filename)
+    o = {}
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name):
+            o[node.targets[0].id] = _value(node.value)
+    o.update({k: v for k, v in overrides.items() if v is not None})
+    missing = [k for k in REQUIRED_KEYS if k not in o]
+    if missing:
+        raise ValueError("Missing {} from the user parameter file".format(missing))
+    for key, default in (("gradient_standard_deviation", 1.5), ("multiplier", 1.0), ("factor", 10.0), ("covariance_scaling", 1.0)):
+        if o.get(key) is None:
+            o[key] = default
+    o["stochastic_newton"] = not o.get("ignore_likelihood", False)
+    base = o.get("data_directory", "")
+    if not os.path.isabs(base):
+        base = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(filename)), base))
+    join = lambda v: [os.path.join(base, x) for x in v] if isinstance(v, list) else os.path.join(base, v)
+    o["data_filename"], o["system_filename"] = join(o["data_filename"]), join(o["system_filename"])
+    return o
+
+
+class FdemData:
+    """A set of FDEM soundings (classes/data/dataset/FdemData.py): per-sounding location, altitude and the 2 F data
+    channels [in-phase F | quadrature F] in ppm, optional standard deviations."""
+
+    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, std=None):
+        self.system = system if isinstance(system, FdemSystem) else FdemSystem.read(system)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.lineNumber, self.fiducial = f64(lineNumber), f64(fiducial)
+        self.x, self.y, self.z, self.elevation = f64(x), f64(y), f64(z), f64(elevation)
+        self.data = f64(data)
+        self.std = None if std is None else f64(std)
+        assert self.data.shape == (self.nPoints, 2 * self.system.nFrequencies), ValueError(
+            "data must have shape (nPoints, 2 * nFrequencies)")
+
+    @property
+    def nPoints(self):
+        return self.x.size
+
+    @property
+    def nChannels(self):
+        return self.data.shape[1]
+
+    @staticmethod
+    def _csv_channels(header):
+        """Column roles by header name, the reference's rules (case-insensitive)."""
+        roles = dict(line=("line", "linenumber", "line_number"), fid=("fid", "fiducial", "id"), x=("e", "x", "easting"),
+                     y=("n", "y", "northing"), z=("alt", "altitude", "laser", "bheight", "height"),
+                     elev=("dtm", "dem_elev", "dem_np", "topo", "elev", "elevation"))
+        loc, inphase, quad, in_err, quad_err = {}, [], [], [], []
+        for j, name in enumerate(header):
+            c = name.strip().lower()
+            role = next((r for r, names in roles.items() if c in names), None)
+            if role is not None:
+                loc[role] = j
+            elif any(label in c for label in ("cpi", "i_", "in_phase")):
+                (in_err if "err" in c else inphase).append(j)
+            elif any(label in c for label in ("cpq", "q_", "quad")):
+                (quad_err if "err" in c else quad).append(j)
+        if "line" not in loc or "fid" not in loc:
+            raise ValueError("File must contain columns for line and fiducial")
+        if not all(r in loc for r in ("x", "y", "z")):
+            raise ValueError("File must contain columns for easting, northing, height. May also have an elevation column")
+        return loc, inphase + quad, in_err + quad_err
+
+    @classmethod
+    def read_csv(cls, data_filename, system_filename):
+        system = system_filename if isinstance(system_filename, FdemSystem) else FdemSystem.read(system_filename)
+        with open(data_filename) as f:
+            first = f.readline()
+        sep = "," if "," in first else None
+        header = [h for h in (first.strip().split(sep) if sep else first.split())]
+        loc, dcols, ecols = cls._csv_channels(header)
+        if len(dcols) != 2 * system.nFrequencies:
+            raise ValueError("Number of data columns {} in {} does not match 2 * nFrequencies {}".format(
+                len(dcols), data_filename, 2 * system.nFrequencies))
+        table = np.atleast_2d(np.loadtxt(data_filename, delimiter=sep, skiprows=1))
+        col = lambda r: table[:, loc[r]]
+        elev = col("elev") if "elev" in loc else np.zeros(table.shape[0])
+        std = table[:, ecols] if len(ecols) == len(dcols) else None
+        return cls(system, col("line"), col("fid"), col("x"), col("y"), col("z"), elev, table[:, dcols], std)
+
+    def datapoint(self, i):
+        """Sounding i as the per-sounding object (FdemData.datapoint, FdemData.py:447-487)."""
+        return FdemDataPoint(x=self.x[i], y=self.y[i], z=self.z[i], elevation=self.elevation[i], data=self.data[i],
+                             std=None if self.std is None else self.std[i], system=self.system,
+                             lineNumber=self.lineNumber[i], fiducial=self.fiducial[i])
+
+
+class SurveyResult(dict):
+    """Per-sounding results, rows in file order: line, fiducial, x, y, z, elevation, status (1 done, 2 failed to burn
+    in), burned_in_iteration, iterations, acceptance, misfit, relative_error, additive_error, n_layers, best_* (highest
+    posterior model: n_layers, edges, conductivity), layer_count_posterior [S, K + 1], interface_posterior
+    [S, n_depth_bins], depth_bin_width, and -- when the hit map is kept -- mean_log10_conductivity [S, n_depth_bins] and
+    the 5 / 50 / 95 % conductivity percentiles per depth cell."""
+
+    def save(self, filename):
+        np.savez_compressed(filename, **self)
+
+
+def _hitmap_statistics(hitmap, log_mean_prior, half_width):
+    """Mean and percentiles of log10 conductivity per depth cell from the hit map (the reference derives the same from
+    its Histogram2D posterior)."""
+    import torch
+    B, nz, nv = hitmap.shape
+    centres = (torch.arange(nv, dtype=torch.float64, device=hitmap.device) + 0.5) / nv * (2.0 * half_width) - half_width
+    h = hitmap.to(torch.float64)
+    tot = h.sum(dim=2).clamp(min=1.0)
+    shift = (log_mean_prior / np.log(10.0))[:, None]
+    mean = (h * centres).sum(dim=2) / tot + shift
+    cdf = torch.cumsum(h, dim=2) / tot[:, :, None]
+    pct = []
+    for q in (0.05, 0.5, 0.95):
+        idx = (cdf < q).sum(dim=2).clamp(max=nv - 1)
+        pct.append(centres[idx] + shift)
+    return mean, pct
+
+
+def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
+          exact_jacobian=False, data=None, **overrides):
+    """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
+    ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
+    whole survey (and writes ``output`` if given), the other ranks return None.
+
+    ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
+    expression."""
+    import torch
+    import torch.distributed as dist
+    from .distributed import shard
+    from .rjmcmc_gpu import DeviceChains
+
+    o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
+    if o["data_type"] not in ("FdemData", "FdemDataPoint"):
+        raise NotImplementedError("the device sampler handles FDEM data; {} is not supported".format(o["data_type"]))
+    if o.get("solve_height") or o.get("solve_calibration") or o.get("solve_parameter"):
+        raise NotImplementedError("solve_height / solve_calibration / solve_parameter are not supported by the device sampler")
+    ds = data if data is not None else FdemData.read_csv(o["data_filename"], o["system_filename"])
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    start, n = shard(ds.nPoints, rank, world)
+    sl = slice(start, start + n)
+    seed = o.get("seed", 0) if seed is None else seed
+    keys = ("n_markov_chains", "solve_gradient", "solve_relative_error", "solve_additive_error", "maximum_number_of_layers",
+            "minimum_depth", "maximum_depth", "minimum_thickness", "initial_relative_error", "minimum_relative_error",
+            "maximum_relative_error", "initial_additive_error", "minimum_additive_error", "maximum_additive_error",
+            "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",
+            "probability_of_death", "probability_of_perturb", "probability_of_no_change", "factor",
+            "gradient_standard_deviation", "covariance_scaling")
+    dc = DeviceChains(ds.system, ds.z[sl], ds.data[sl], seed=int(seed) % (1 << 64), exact_jacobian=exact_jacobian, device=device,
+                      hitmap=hitmap, first_chain=start, reference_schedule=True, burn_in_min_iterations=burn_in_min_iterations,
+                      **{k: o[k] for k in keys if o.get(k) is not None})
+    dc.infer(check_every=check_every)
+    K = dc.K
+    t = dc.t
+    f64 = lambda x: x.to(torch.float64)
+    cols = [f64(t["status"]), f64(t["burned_in_iteration"]), f64(t["n_accepted"]), t["misfit"], t["rel"], t["add"], f64(t["k"]),
+            f64(t["best_k"]), t["best_posterior"]]
+    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"])]
+    if hitmap:
+        mean, pct = _hitmap_statistics(t["hitmap"], t["log_mean_prior"], dc.value_half_width)
+        blocks += [mean] + pct
+    local = torch.cat(blocks, dim=1).contiguous()
+    if world > 1:                                   # the one exchange of the job: per-sounding result rows to rank 0
+        from .distributed import SummaryGather
+        g = SummaryGather(ds.nPoints, local.shape[1], local.device)
+        rows = g.finish(g.launch(*[local[:, i] for i in range(local.shape[1])]))
+    else:
+        rows = local
+    if rank != 0:
+        return None
+    r = rows.cpu().numpy()
+    nz = dc.n_depth_bins
+    n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
+    ran = np.where(r[:, 0] == 1, r[:, 1] + n_mc + 1, np.where(r[:, 0] == 2, n_mc, dc.iteration)).astype(np.int64)
+    res = SurveyResult(line=ds.lineNumber, fiducial=ds.fiducial, x=ds.x, y=ds.y, z=ds.z, elevation=ds.elevation,
+                       status=r[:, 0].astype(np.int32), burned_in_iteration=r[:, 1].astype(np.int32),
+                       iterations=ran, acceptance=r[:, 2] / np.maximum(1, ran), misfit=r[:, 3],
+                       relative_error=r[:, 4], additive_error=r[:, 5], n_layers=r[:, 6].astype(np.int32),
+                       best_n_layers=r[:, 7].astype(np.int32), best_posterior=r[:, 8], best_edges=r[:, 9:9 + K],
+                       best_conductivity=r[:, 9 + K:9 + 2 * K],
+                       layer_count_posterior=r[:, 9 + 2 * K:10 + 3 * K].astype(np.int64),
+                       interface_posterior=r[:, 10 + 3 * K:10 + 3 * K + nz].astype(np.int64),
+                       depth_bin_width=np.float64(dc.depth_bin_width))
+    if hitmap:
+        c0 = 10 + 3 * K + nz
+        res["mean_log10_conductivity"] = r[:, c0:c0 + nz]
+        for i, q in enumerate(("p05", "p50", "p95")):
+            res["log10_conductivity_" + q] = r[:, c0 + (i + 1) * nz:c0 + (i + 2) * nz]
+    if output is not None:
+        res.save(output)
+    return res
