@@ -4,7 +4,8 @@
 // Three kernels hold the host logic of one iteration of the reference's Inference1D.accept_reject
 // (inversion/Inference1D.py:537-631); between them the forward / Jacobian kernels above are entered with
 // per-chain layer counts of 0 for the chains that do not need them (a workgroup whose sounding has 0 layers exits).
-//   k_rj_propose  one thread per chain: structural move, value remapping, error proposals
+//   k_rj_propose  one wave (small blocks) or one thread (large blocks) per chain: structural move, value remapping,
+//                 error proposals
 //   k_rj_newton   one wave per chain:  Gauss-Newton precision, its Cholesky factor in LDS, mean and sample
 //   k_rj_accept   one wave per chain:  priors, reversible-jump proposal ratio, Metropolis test, state update, posteriors
 #pragma once
@@ -78,32 +79,28 @@ __device__ inline double propose_error(Rng& r, double cur, double sd, double lo,
 
 __device__ inline int bucket_of(int k) { return k <= 8 ? 0 : (k <= 16 ? 1 : 2); }
 
-__global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+// The structural move of one chain (RectilinearMesh1D.perturb :1018-1118).  edge(j): interface j of the current model;
+// below(depth): number of interfaces shallower than depth.
+template <class EdgeAt, class CountBelow>
+__device__ inline void choose_move(const gbp_rj_options& o, Rng& r, int k, bool idle, EdgeAt edge, CountBelow below, int& action,
+                                   int& idx, double& val)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
     const int K = o.max_layers;
-    const double* e = c.edges + (size_t)b * K;
-    const double* s = c.sigma + (size_t)b * K;
-    const int k = c.k[b];
-    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
-    int action = NONE, idx = 0;
-    double val = 0.0;
     const double lo = log(o.min_edge), hi = log(o.max_edge), mw = o.min_width;
-    bool done = o.schedule == 1 && c.status[b] != 0;             // finished chains idle through the remaining iterations
-    for (int round = 0; round < 8 && !done; ++round) {          // RectilinearMesh1D.perturb: redraw the event when the tries run out
+    action = NONE; idx = 0; val = 0.0;
+    bool done = idle;
+    for (int round = 0; round < 8 && !done; ++round) {          // redraw the event when the tries run out
         const double pb = (k == K) ? 0.0 : o.p_birth, pd = (k == 1) ? 0.0 : o.p_death, pp = (k == 1) ? 0.0 : o.p_perturb;
         const double u = r.uniform() * (pb + pd + pp + o.p_none);
         if (u < pb) {                                           // birth (:1061-1081); the reference's 10th try always fails
             for (int t = 0; t < 9; ++t) {
                 const double depth = exp(lo + r.uniform() * (hi - lo));
-                int pos = 0;
-                while (pos < k - 1 && e[pos] < depth) ++pos;
-                const double prev = pos > 0 ? e[pos - 1] : 0.0, next = pos < k - 1 ? e[pos] : INF;
+                const int pos = below(depth);
+                const double prev = pos > 0 ? edge(pos - 1) : 0.0, next = pos < k - 1 ? edge(pos) : INF;
                 if (depth - prev > mw && next - depth > mw) { action = INSERT; idx = pos + 1; val = depth; done = true; break; }
             }
         } else if (u < pb + pd) {                               // death (:1083-1087)
-            int i = (int)floor(r.uniform() * (double)(k - 1));
+            const int i = (int)floor(r.uniform() * (double)(k - 1));
             idx = min(i, k - 2) + 1; action = DELETE; done = true;
         } else if (u < pb + pd + pp) {                          // perturb (:1089-1118)
             for (int t = 0; t < 9; ++t) {
@@ -111,9 +108,9 @@ __global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_cha
                 const double n = r.normal();
                 const double dz = (n > 0.0 ? 1.0 : (n < 0.0 ? -1.0 : 0.0)) * mw * r.uniform();
                 const int ii = i - 1;
-                const double ne = e[ii] + dz;
-                const double prev = ii > 0 ? e[ii - 1] : 0.0, next = ii < k - 2 ? e[ii + 1] : INF;
-                const double first = ii == 0 ? ne : e[0], last = ii == k - 2 ? ne : e[k - 2];
+                const double ne = edge(ii) + dz;
+                const double prev = ii > 0 ? edge(ii - 1) : 0.0, next = ii < k - 2 ? edge(ii + 1) : INF;
+                const double first = ii == 0 ? ne : edge(0), last = ii == k - 2 ? ne : edge(k - 2);
                 if (ne - prev > mw && next - ne > mw && first > o.min_edge && last < o.max_edge) {
                     action = PERTURB; idx = i; val = dz; done = true; break;
                 }
@@ -122,39 +119,101 @@ __global__ __launch_bounds__(128) void k_rj_propose(gbp_rj_options o, gbp_rj_cha
             done = true;
         }
     }
-    // remapped model (Model.perturb_structure: insert copies the layer above, delete averages the merged pair)
-    double* er = c.edges_r + (size_t)b * K;
-    double* sr = c.sigma_r + (size_t)b * K;
-    double* tr = c.thk_r + (size_t)b * K;
-    const int kr = k + (action == INSERT) - (action == DELETE);
-    for (int j = 0; j < K; ++j) {
-        double ev = INF, sv = 1.0;
-        if (action == INSERT) {
-            if (j < kr - 1) ev = j < idx - 1 ? e[j] : (j == idx - 1 ? val : e[j - 1]);
-            if (j < kr) sv = j < idx ? s[j] : s[j - 1];
-        } else if (action == DELETE) {
-            if (j < kr - 1) ev = j < idx - 1 ? e[j] : e[j + 1];
-            if (j < kr) sv = j < idx - 1 ? s[j] : (j == idx - 1 ? 0.5 * (s[idx - 1] + s[idx]) : s[j + 1]);
-        } else {
-            if (j < kr - 1) ev = e[j] + ((action == PERTURB && j == idx - 1) ? val : 0.0);
-            if (j < kr) sv = s[j];
-        }
-        er[j] = ev; sr[j] = sv;
+}
+
+// Remapping rule (Model.perturb_structure: insert copies the layer above, delete averages the merged pair) for entry j,
+// given the entry itself and its neighbours in the current model.
+__device__ inline void remap_entry(int action, int idx, double val, int kr, int j, double e_j, double e_up, double e_dn, double s_j,
+                                   double s_up, double s_dn, double& ev, double& sv)
+{
+    ev = INF; sv = 1.0;
+    if (action == INSERT) {
+        if (j < kr - 1) ev = j < idx - 1 ? e_j : (j == idx - 1 ? val : e_up);
+        if (j < kr) sv = j < idx ? s_j : s_up;
+    } else if (action == DELETE) {
+        if (j < kr - 1) ev = j < idx - 1 ? e_j : e_dn;
+        if (j < kr) sv = j < idx - 1 ? s_j : (j == idx - 1 ? 0.5 * (s_j + s_dn) : s_dn);
+    } else {
+        if (j < kr - 1) ev = e_j + ((action == PERTURB && j == idx - 1) ? val : 0.0);
+        if (j < kr) sv = s_j;
     }
-    for (int j = 0; j < K; ++j) tr[j] = j < kr - 1 ? er[j] - (j > 0 ? er[j - 1] : 0.0) : 0.0;
-    c.action[b] = action;
-    c.k_r[b] = kr;
+}
+
+__device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr)
+{   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-3: by bucket), error proposals
     const int bk = bucket_of(kr);
     const bool jump = action == INSERT || action == DELETE;
-    c.nl_a[b] = action != NONE ? kr : 0;
-    c.nl_c[b] = jump ? kr : 0;
-    for (int i = 0; i < 3; ++i) {
-        c.nl_a[(size_t)(1 + i) * c.B + b] = (action != NONE && bk == i) ? kr : 0;
-        c.nl_c[(size_t)(1 + i) * c.B + b] = (jump && bk == i) ? kr : 0;
+    for (int i = 0; i < 4; ++i) {
+        const bool mine = i == 0 || bk == i - 1;
+        c.nl_a[(size_t)i * c.B + b] = (action != NONE && mine) ? kr : 0;
+        c.nl_c[(size_t)i * c.B + b] = (jump && mine) ? kr : 0;
     }
+    c.action[b] = action;
+    c.k_r[b] = kr;
     // error levels (DataPoint.perturb: relative then additive)
     c.rel_p[b] = o.solve_relative_error ? propose_error(r, c.rel[b], o.rel_sd, o.rel_min, o.rel_max) : c.rel[b];
     c.add_p[b] = o.solve_additive_error ? propose_error(r, c.add[b], o.add_sd, o.add_min, o.add_max) : c.add[b];
+}
+
+// Small blocks of soundings: one wave per chain (4 chains per workgroup).  Lane j holds interface j and layer j, every
+// lane runs the same draws (wave-uniform control flow), neighbour look-ups are cross-lane reads, rows are written coalesced.
+__global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= c.B) return;
+    const int K = o.max_layers;
+    const int k = c.k[b];
+    const double ej = lane < k - 1 ? c.edges[(size_t)b * K + lane] : INF;
+    const double sj = lane < k ? c.sigma[(size_t)b * K + lane] : 1.0;
+    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
+    int action, idx;
+    double val;
+    choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return __shfl(ej, j, 64); },
+                [&](double depth) { return (int)__popcll(__ballot(ej < depth)); }, action, idx, val);
+    const int kr = k + (action == INSERT) - (action == DELETE);
+    const int up = max(lane - 1, 0), dn = min(lane + 1, 63);
+    double ev, sv;
+    remap_entry(action, idx, val, kr, lane, ej, __shfl(ej, up, 64), __shfl(ej, dn, 64), sj, __shfl(sj, up, 64), __shfl(sj, dn, 64), ev, sv);
+    const double ev_up = __shfl(ev, up, 64);
+    if (lane < K) {
+        c.edges_r[(size_t)b * K + lane] = ev;
+        c.sigma_r[(size_t)b * K + lane] = sv;
+        c.thk_r[(size_t)b * K + lane] = lane < kr - 1 ? ev - (lane > 0 ? ev_up : 0.0) : 0.0;
+    }
+    Rng r0 = r;                                                  // every lane continues the same stream; lane 0 writes
+    if (lane == 0) write_move(o, c, r0, b, action, kr);
+}
+
+// Large blocks: one thread per chain (the wave version would spend 64 lanes on every scalar decision).
+__global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B) return;
+    const int K = o.max_layers;
+    const double* __restrict__ e = c.edges + (size_t)b * K;
+    const double* __restrict__ s = c.sigma + (size_t)b * K;
+    const int k = c.k[b];
+    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
+    int action, idx;
+    double val;
+    choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return e[j]; },
+                [&](double depth) { int pos = 0; while (pos < k - 1 && e[pos] < depth) ++pos; return pos; }, action, idx, val);
+    const int kr = k + (action == INSERT) - (action == DELETE);
+    double* __restrict__ er = c.edges_r + (size_t)b * K;
+    double* __restrict__ sr = c.sigma_r + (size_t)b * K;
+    double* __restrict__ tr = c.thk_r + (size_t)b * K;
+    double above = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const int up = max(j - 1, 0), dn = min(j + 1, K - 1);
+        double ev, sv;
+        remap_entry(action, idx, val, kr, j, j < k - 1 ? e[j] : INF, up < k - 1 ? e[up] : INF, dn < k - 1 ? e[dn] : INF,
+                    j < k ? s[j] : 1.0, up < k ? s[up] : 1.0, dn < k ? s[dn] : 1.0, ev, sv);
+        er[j] = ev; sr[j] = sv;
+        tr[j] = j < kr - 1 ? ev - above : 0.0;
+        above = ev;
+    }
+    write_move(o, c, r, b, action, kr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -521,7 +580,12 @@ gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    hipLaunchKernelGGL(rj::k_rj_propose, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+    const char* force = std::getenv("GBP_RJ_PROPOSE");          // test hook: "wave" / "thread"
+    if (force ? force[0] == 'w' : c->B <= 4096)
+        hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+    else
+        hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
+                           (uint32_t)iteration);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

@@ -161,6 +161,21 @@ def test_propose_kernel_matches_the_emulation():
             assert np.array_equal(nl_a[:, b], want_a) and np.array_equal(nl_c[:, b], want_c)
             seen.add(a)
     assert seen == {0, 1, 2, 3} and kept > 20          # all four moves, and the give-up path of the error proposal
+    # the one-thread-per-chain variant used for large blocks writes the same bits
+    names = ("action", "k_r", "nl_a", "nl_c", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p")
+    out = {}
+    for variant in ("wave", "thread"):
+        os.environ["GBP_RJ_PROPOSE"] = variant
+        try:
+            for n in names:
+                getattr(dc, n).fill_(-7)
+            _lib.check(_lib.load().gbp_rj_propose(dc._o, dc._c, 6, None))
+            out[variant] = {n: getattr(dc, n).clone() for n in names}
+        finally:
+            del os.environ["GBP_RJ_PROPOSE"]
+    for n in names:
+        assert torch.equal(out["wave"][n], out["thread"][n]), n
+    assert np.array_equal(out["wave"]["action"].cpu().numpy(), act)
 
 
 @pytest.mark.gpu
