@@ -1,0 +1,69 @@
+"""Command line of the survey driver: ``python -m geobipy_amd options_file output_directory [...]``.
+
+Same positional arguments and switches as the reference's ``geobipy`` command (geobipy/__init__.py:76-243).  Instead of
+``--mpi`` under mpirun, launch one process per GPU with ``python -m torch.distributed.run --nproc-per-node N -m geobipy_amd
+...``: each rank takes a block of soundings and rank 0 writes the results, one ``<line number>.npz`` per flight line.
+"""
+import argparse
+import os
+import shutil
+import sys
+import time
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(prog="geobipy_amd", description="GeoBIPy's rjMCMC inversion of FDEM soundings on MI355X GPUs",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("options_file", help="User options file")
+    p.add_argument("output_directory", help="Output directory for results")
+    p.add_argument("--seed", dest="seed", default=None, help="Seed of the random streams (overrides the options file)")
+    p.add_argument("--index", dest="index", type=int, default=None, help="Invert this data point only.")
+    p.add_argument("--fiducial", dest="fiducial", type=float, default=None, help="Invert this fiducial only (needs --line).")
+    p.add_argument("--line", dest="line_number", type=float, default=None, help="Invert this line (or the fiducial on this line).")
+    p.add_argument("--verbose", dest="verbose", action="store_true", help="Throw warnings as errors.")
+    p.add_argument("--mpi", dest="mpi", action="store_true", help="Accepted for compatibility: ranks come from torch.distributed.run.")
+    p.add_argument("--data_directory", default=None, help="override data_directory in parameter file.")
+    p.add_argument("--data_filename", default=None, help="override data_filename in parameter file")
+    p.add_argument("--exact-jacobian", action="store_true", help="true derivative in the proposals (DESIGN.md 3.4)")
+    p.add_argument("--no-hitmap", action="store_true", help="skip the conductivity-depth hit map")
+    a = p.parse_args(argv)
+    if a.seed is not None:
+        a.seed = int(a.seed)
+    return a
+
+
+def main(argv=None):
+    a = parse(argv)
+    if a.verbose:
+        import warnings
+        warnings.filterwarnings("error")
+    assert os.path.exists(a.options_file), Exception("Cannot find input file {}".format(a.options_file))
+    assert os.path.isdir(a.output_directory), Exception("Make sure the output directory exists {}".format(a.output_directory))
+    import torch
+    import torch.distributed as dist
+    from . import survey
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(os.environ.get("GBP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    if rank == 0:
+        print("Running geobipy_amd on {} GPU process(es)".format(world))
+        print("Using user input file {}".format(a.options_file))
+        print("Output files will be produced at {}".format(a.output_directory))
+        shutil.copy(a.options_file, a.output_directory)            # kept with the results, like the reference does
+    t0 = time.perf_counter()
+    res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
+                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, data_directory=a.data_directory,
+                       data_filename=a.data_filename)
+    if rank == 0:
+        paths = res.save_lines(a.output_directory)
+        done, failed = int((res["status"] == 1).sum()), int((res["status"] == 2).sum())
+        print("{} soundings: {} done, {} failed to burn in; {:.1f} s; wrote {}".format(
+            res["status"].size, done, failed, time.perf_counter() - t0, ", ".join(os.path.basename(q) for q in paths)))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

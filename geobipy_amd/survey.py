@@ -152,6 +152,17 @@ class SurveyResult(dict):
     def save(self, filename):
         np.savez_compressed(filename, **self)
 
+    def save_lines(self, directory):
+        """One file per flight line, ``<line number>.npz`` (the reference writes ``<line number>.h5`` there)."""
+        S = self["line"].size
+        paths = []
+        for ln in np.unique(self["line"]):
+            m = self["line"] == ln
+            part = {k: (v[m] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == S else v) for k, v in self.items()}
+            paths.append(os.path.join(directory, "{}.npz".format(ln)))
+            np.savez_compressed(paths[-1], **part)
+        return paths
+
 
 def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     """Mean and percentiles of log10 conductivity per depth cell from the hit map (the reference derives the same from
@@ -171,12 +182,31 @@ def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     return mean, pct
 
 
+def select_soundings(ds, index=None, fiducial=None, line_number=None):
+    """Row indices chosen by the reference's --index / --fiducial / --line switches (Inference3D.infer_serial :458-500:
+    one data point by position, or by fiducial on a line); all rows when none is given."""
+    if index is not None:
+        assert 0 <= index < ds.nPoints, ValueError("index {} outside the {} data points".format(index, ds.nPoints))
+        return np.array([index])
+    if fiducial is not None:
+        assert line_number is not None, ValueError("--fiducial needs --line")
+        hit = np.nonzero((ds.fiducial == fiducial) & (ds.lineNumber == line_number))[0]
+        assert hit.size > 0, ValueError("fiducial {} not found on line {}".format(fiducial, line_number))
+        return hit[:1]
+    if line_number is not None:
+        hit = np.nonzero(ds.lineNumber == line_number)[0]
+        assert hit.size > 0, ValueError("line {} not found".format(line_number))
+        return hit
+    return np.arange(ds.nPoints)
+
+
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
-          exact_jacobian=False, data=None, **overrides):
+          exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
+    ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
     expression."""
     import torch
@@ -190,6 +220,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     if o.get("solve_height") or o.get("solve_calibration") or o.get("solve_parameter"):
         raise NotImplementedError("solve_height / solve_calibration / solve_parameter are not supported by the device sampler")
     ds = data if data is not None else FdemData.read_csv(o["data_filename"], o["system_filename"])
+    rows = select_soundings(ds, index, fiducial, line_number)
+    if rows.size != ds.nPoints:
+        ds = FdemData(ds.system, ds.lineNumber[rows], ds.fiducial[rows], ds.x[rows], ds.y[rows], ds.z[rows], ds.elevation[rows],
+                      ds.data[rows], None if ds.std is None else ds.std[rows])
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     start, n = shard(ds.nPoints, rank, world)
@@ -201,8 +235,11 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",
             "probability_of_death", "probability_of_perturb", "probability_of_no_change", "factor",
             "gradient_standard_deviation", "covariance_scaling")
+    # chains are keyed by the sounding's row in the data file, so a sounding inverted alone walks the chain it walks in the
+    # full survey
+    assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
     dc = DeviceChains(ds.system, ds.z[sl], ds.data[sl], seed=int(seed) % (1 << 64), exact_jacobian=exact_jacobian, device=device,
-                      hitmap=hitmap, first_chain=start, reference_schedule=True, burn_in_min_iterations=burn_in_min_iterations,
+                      hitmap=hitmap, first_chain=int(rows[0]) + start, reference_schedule=True, burn_in_min_iterations=burn_in_min_iterations,
                       **{k: o[k] for k in keys if o.get(k) is not None})
     dc.infer(check_every=check_every)
     K = dc.K

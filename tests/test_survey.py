@@ -13,7 +13,7 @@ OPTIONS = os.path.join(GOLDEN, "resolve_options_small")
 
 def test_read_options():
     o = survey.read_options(OPTIONS)
-    assert o["data_type"] == "FdemData" and o["n_markov_chains"] == 2000
+    assert o["data_type"] == "FdemData" and o["n_markov_chains"] == 6000
     assert o["probability_of_birth"] == 1.0 / 6.0 and o["probability_of_no_change"] == 0.5
     assert o["factor"] == 10.0 and o["gradient_standard_deviation"] == 1.5 and o["covariance_scaling"] == 1.0 and o["multiplier"] == 1.0
     assert o["stochastic_newton"] is True and o["seed"] == 146100583096709124601953385843316024947
@@ -52,6 +52,37 @@ def test_read_csv_fixture():
     assert dp.nChannels == 12 and np.array_equal(dp.data, ds.data[3]) and dp.z[0] == 30.0 and dp.fiducial == 3.0
 
 
+def test_select_soundings_and_cli_arguments():
+    ds = survey.FdemData.read_csv(os.path.join(GOLDEN, "resolve_glacial_clean.csv"), os.path.join(GOLDEN, "resolve.stm"))
+    assert np.array_equal(survey.select_soundings(ds), np.arange(79))
+    assert np.array_equal(survey.select_soundings(ds, index=7), [7])
+    assert np.array_equal(survey.select_soundings(ds, fiducial=12.0, line_number=0.0), [12])
+    assert survey.select_soundings(ds, line_number=0.0).size == 79
+    with pytest.raises(AssertionError):
+        survey.select_soundings(ds, fiducial=12.0)
+    with pytest.raises(AssertionError):
+        survey.select_soundings(ds, index=79)
+    from geobipy_amd.__main__ import parse
+    a = parse(["opts", "out", "--seed", "12", "--index", "3", "--line", "100.0", "--fiducial", "5", "--mpi"])
+    assert (a.options_file, a.output_directory, a.seed, a.index, a.line_number, a.fiducial, a.mpi) == ("opts", "out", 12, 3, 100.0, 5.0, True)
+
+
+@pytest.mark.gpu
+def test_command_line_single_point_equals_the_survey_run(tmp_path):
+    """python -m geobipy_amd options out --index 5: the sounding inverted alone walks the chain it walks in the full survey
+    (streams keyed by the row in the data file)."""
+    from geobipy_amd.__main__ import main
+    out = tmp_path / "out"
+    out.mkdir()
+    assert main([OPTIONS, str(out), "--index", "5", "--exact-jacobian"]) == 0
+    assert (out / "resolve_options_small").exists() and (out / "0.0.npz").exists()
+    one = np.load(out / "0.0.npz")
+    full = survey.infer(OPTIONS, exact_jacobian=True)
+    assert one["fiducial"].tolist() == [5.0] and one["status"].shape == (1,)
+    for k in ("status", "burned_in_iteration", "misfit", "best_conductivity", "interface_posterior", "mean_log10_conductivity"):
+        assert np.array_equal(one[k][0], full[k][5]), k
+
+
 @pytest.mark.gpu
 def test_invert_the_wedge_survey(tmp_path):
     ds = survey.FdemData.read_csv(os.path.join(GOLDEN, "resolve_glacial_clean.csv"), os.path.join(GOLDEN, "resolve.stm"))
@@ -62,8 +93,8 @@ def test_invert_the_wedge_survey(tmp_path):
     S, K = 79, 30
     assert res["status"].shape == (S,) and set(np.unique(res["status"])) <= {1, 2} and (res["status"] == 1).sum() >= 70
     done = res["status"] == 1
-    assert np.all(res["burned_in_iteration"][done] > 500) and np.all(res["iterations"][done] == res["burned_in_iteration"][done] + 2001)
-    assert np.all(res["layer_count_posterior"][done].sum(axis=1) == 2002)
+    assert np.all(res["burned_in_iteration"][done] > 500) and np.all(res["iterations"][done] == res["burned_in_iteration"][done] + 6001)
+    assert np.all(res["layer_count_posterior"][done].sum(axis=1) == 6002)
     assert np.all((res["acceptance"] > 0.05) & (res["acceptance"] < 0.9)) and np.median(res["misfit"][done]) < 20.0
     assert res["best_edges"].shape == (S, K) and res["interface_posterior"].shape[1] == 440
     # the recovered structure: 0.01 S/m over 0.1 S/m, interface from 5 m (first sounding) to 0.1 m (last), 0.033 S/m below
