@@ -18,7 +18,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 class RjOptions(ctypes.Structure):
     """gbp_rj_options (include/geobipy_amd.h)."""
-    _fields_ = ([(n, ctypes.c_int32) for n in ("max_layers", "n_channels", "solve_gradient", "solve_relative_error",
+    _fields_ = ([(n, ctypes.c_int32) for n in ("max_layers", "n_channels", "solve_gradient", "solve_value", "solve_relative_error",
                                                "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "schedule",
                                                "burn_in_min_iterations", "n_markov_chains", "forward_waves")]
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",

@@ -396,6 +396,12 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     const double lmp = c.log_mean_prior[b];
     // priors of the proposal (Model.probability :533-575: uniform on k, normal on the gradient of ln sigma)
     double prior_p = -log((double)K - 1.0);
+    if (o.solve_value) {                                         // log-normal prior on the values (solve_parameter)
+        double d2 = 0.0;
+        if (lane < k) { const double d = lpv[lane] - lmp; d2 = d * d; }
+        d2 = wave_sum(d2);
+        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * log(o.value_precision) - 0.5 * o.value_precision * d2;
+    }
     if (o.solve_gradient) {
         double g2 = 0.0;
         if (lane < k - 1) { const double g = (lpv[lane + 1] - lpv[lane]) / log(tr[lane]); g2 = g * g; }

@@ -78,11 +78,14 @@ class ValuePrior:
     model/Model.py:727-746): log-normal on the values, mean = best half-space, variance = ln(1 + factor)^2; and a
     normal prior on the vertical gradient of ln(sigma) with standard deviation gradient_standard_deviation."""
 
-    def __init__(self, value_mean, factor=10.0, gradient_std=1.5, solve_gradient=True):
+    def __init__(self, value_mean, factor=10.0, gradient_std=1.5, solve_gradient=True, solve_value=False):
         self.log_mean = np.log(value_mean)
         self.value_precision = 1.0 / np.log(1.0 + factor) ** 2.0
         self.gradient_precision = 1.0 / gradient_std ** 2.0
         self.solve_gradient = solve_gradient
+        # solve_parameter of the options file: the log-normal prior on the values also enters the model probability
+        # (it always shapes the stochastic-Newton step: Inference1D.py:503 sets it regardless)
+        self.solve_value = solve_value
 
 
 def gradient_operator(edges):
@@ -173,11 +176,13 @@ def mvn_logpdf(x, mean, cov):
 
 
 def model_log_prior(sp, vp, edges, values):
-    """Model.probability(solve_value=False, solve_gradient=True) (model/Model.py:533-575): uniform prior on the
+    """Model.probability(solve_value, solve_gradient) (model/Model.py:533-575): uniform prior on the
     number of layers (mesh/RectilinearMesh1D.py:1351-1382; the order-statistics prior on the interfaces is
     commented out in the reference) + normal prior on the vertical gradient of ln sigma (Model.py:213-234)."""
     k = values.size
     lp = -np.log(sp.max_cells - 1.0)
+    if vp.solve_value:
+        lp += mvn_logpdf(np.log(values), np.full(k, vp.log_mean), np.eye(k) / vp.value_precision)
     if not vp.solve_gradient:
         return lp
     if k == 1:   # the reference evaluates a two-layer copy of the half-space: zero gradient

@@ -34,9 +34,15 @@ def layer_widths(edges, k):
     return torch.where(j < (k[:, None] - 1), edges - top, torch.zeros_like(edges))
 
 
-def model_log_prior(edges, sigma, k, max_cells, gradient_precision, solve_gradient=True):
-    """Batched rjmcmc.model_log_prior (Model.probability, model/Model.py:533-575)."""
+def model_log_prior(edges, sigma, k, max_cells, gradient_precision, solve_gradient=True, value_precision=None, log_mean=None):
+    """Batched rjmcmc.model_log_prior (Model.probability, model/Model.py:533-575); the prior on the values is included
+    when ``value_precision`` / ``log_mean`` are given (solve_parameter)."""
     lp = torch.full((sigma.shape[0],), -math.log(max_cells - 1.0), dtype=sigma.dtype, device=sigma.device)
+    if value_precision is not None:
+        j = torch.arange(sigma.shape[1], device=sigma.device)[None, :]
+        d = torch.where(j < k[:, None], torch.log(sigma) - log_mean[:, None], torch.zeros_like(sigma))
+        kk = k.to(sigma.dtype)
+        lp = lp - 0.5 * kk * LOG_2PI + 0.5 * kk * math.log(value_precision) - 0.5 * value_precision * (d * d).sum(dim=1)
     if not solve_gradient:
         return lp
     w = layer_widths(edges, k)[:, :-1]
@@ -100,6 +106,7 @@ class DeviceChains:
         ro = _lib.RjOptions()
         ro.max_layers, ro.n_channels = K, self.N
         ro.solve_gradient = int(bool(o["solve_gradient"]))
+        ro.solve_value = int(bool(o.get("solve_parameter", False)))
         ro.solve_relative_error = int(bool(o.get("solve_relative_error", True)))
         ro.solve_additive_error = int(bool(o.get("solve_additive_error", True)))
         ro.exact_jacobian = int(bool(exact_jacobian))
@@ -190,7 +197,8 @@ class DeviceChains:
                                                 t["like"].data_ptr(), self._stream()))
         _lib.check(lib.gbp_fdem_sensitivity_ex(self._h.ptr, B, K, t["k"].data_ptr(), t["sigma"].data_ptr(), thk.data_ptr(),
                                                t["height"].data_ptr(), t["J"].data_ptr(), 1, self._o.exact_jacobian, self._stream()))
-        prior = model_log_prior(t["edges"], t["sigma"], t["k"].to(torch.int64), K, self.gradient_precision, o["solve_gradient"])
+        prior = model_log_prior(t["edges"], t["sigma"], t["k"].to(torch.int64), K, self.gradient_precision, o["solve_gradient"],
+                                self._o.value_precision if self._o.solve_value else None, t["log_mean_prior"])
         if self._o.solve_relative_error:
             prior = prior + log_uniform_prior(t["rel"], o["minimum_relative_error"], o["maximum_relative_error"])
         if self._o.solve_additive_error:

@@ -217,8 +217,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
     if o["data_type"] not in ("FdemData", "FdemDataPoint"):
         raise NotImplementedError("the device sampler handles FDEM data; {} is not supported".format(o["data_type"]))
-    if o.get("solve_height") or o.get("solve_calibration") or o.get("solve_parameter"):
-        raise NotImplementedError("solve_height / solve_calibration / solve_parameter are not supported by the device sampler")
+    if o.get("solve_calibration"):
+        raise NotImplementedError("solve_calibration is not supported by the device sampler")
+    # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
+    # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- the height stays fixed there too
     ds = data if data is not None else FdemData.read_csv(o["data_filename"], o["system_filename"])
     rows = select_soundings(ds, index, fiducial, line_number)
     if rows.size != ds.nPoints:
@@ -229,7 +231,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     start, n = shard(ds.nPoints, rank, world)
     sl = slice(start, start + n)
     seed = o.get("seed", 0) if seed is None else seed
-    keys = ("n_markov_chains", "solve_gradient", "solve_relative_error", "solve_additive_error", "maximum_number_of_layers",
+    keys = ("n_markov_chains", "solve_gradient", "solve_parameter", "solve_relative_error", "solve_additive_error", "maximum_number_of_layers",
             "minimum_depth", "maximum_depth", "minimum_thickness", "initial_relative_error", "minimum_relative_error",
             "maximum_relative_error", "initial_additive_error", "minimum_additive_error", "maximum_additive_error",
             "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",

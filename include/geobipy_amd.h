@@ -194,7 +194,8 @@ gbp_status gbp_debug_math(int op, int n, const double *x, const double *y, doubl
 typedef struct gbp_rj_options {
     int32_t max_layers;          /* K = maximum_number_of_layers                                      */
     int32_t n_channels;          /* N = 2 * nF                                                         */
-    int32_t solve_gradient, solve_relative_error, solve_additive_error, exact_jacobian;
+    int32_t solve_gradient, solve_value;  /* which model priors enter the probability (solve_gradient / solve_parameter) */
+    int32_t solve_relative_error, solve_additive_error, exact_jacobian;
     int32_t n_depth_bins, n_value_bins;   /* posterior grids (interface histogram / hit-map)          */
     int32_t schedule;            /* 0: the caller decides what is accumulated (`accumulate` argument);
                                     1: the reference's per-sounding schedule (Inference1D.update :713-737, infer :641-688):

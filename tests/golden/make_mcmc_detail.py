@@ -31,7 +31,9 @@ ACTIONS = {"none": 0, "insert": 1, "delete": 2, "perturb": 3}
 def main():
     global N_LONG
     import numpy as np
-    deep = len(sys.argv) > 1 and sys.argv[1] == "deep"   # birth-heavy variant on another sounding -> mcmc_deep.npz
+    deep = len(sys.argv) > 1 and sys.argv[1] in ("deep", "value")   # decisions-only variants on other soundings:
+    value = len(sys.argv) > 1 and sys.argv[1] == "value"            # "deep": birth-heavy -> mcmc_deep.npz; "value": prior on the
+                                                                     # conductivities instead of on their gradient -> mcmc_value.npz
     import_reference()
     from geobipy import FdemData, Inference1D, get_prng
     from geobipy.src.inversion import user_parameters as up
@@ -41,12 +43,16 @@ def main():
     options = up.user_parameters.read(opt_file, data_directory=SUP)
     options["system_filename"] = SUP + "/resolve.stm"
     options.update(n_markov_chains=N_LONG, save_hdf5=False, interactive_plot=True, update_plot_every=100000)
-    if deep:
+    if value:
+        options.update(solve_parameter=True, solve_gradient=False)
+        N_LONG = 1000
+        options["n_markov_chains"] = N_LONG
+    elif deep:
         options.update(probability_of_birth=0.5, probability_of_death=0.1, probability_of_perturb=0.2,
                        probability_of_no_change=0.2)
         N_LONG = 1200
         options["n_markov_chains"] = N_LONG
-    dp = FdemData.read_csv(SUP + "/resolve_glacial.csv", system=options["system_filename"]).datapoint(60 if deep else 30)
+    dp = FdemData.read_csv(SUP + "/resolve_glacial.csv", system=options["system_filename"]).datapoint(45 if value else (60 if deep else 30))
     prng = get_prng(seed=options["seed"])
     inf = Inference1D(prng=prng, world=None, **options)
     inf.initialize(dp)
@@ -163,7 +169,9 @@ def main():
                 "cur_misfit", "cur_J", "cur_pred"]
         out = {k: (v[:1] if k in keep else v) for k, v in out.items()
                if k in keep or k in ("long_accepted", "long_k", "long_misfit", "data", "z", "halfspace", "options")}
-        np.savez_compressed(HERE + "/mcmc_deep.npz", **out)
+        np.savez_compressed(HERE + ("/mcmc_value.npz" if value else "/mcmc_deep.npz"), **out)
+        print("long run: acceptance", out["long_accepted"].mean(), "k max", out["long_k"].max())
+        return
     else:
         np.savez_compressed(HERE + "/mcmc_detail.npz", **out)
     a = out["action"]

@@ -99,11 +99,12 @@ class OracleEngine:
         return np.vstack([J.real, J.imag])
 
 
-def chain_setup(d):   # works for both fixtures: the state of iteration 0 and the options array
+def chain_setup(d, solve_gradient=True, solve_value=False):   # works for all fixtures: the state of iteration 0 and the options array
     from geobipy_amd import rjmcmc
     o = d["options"]
     sp = rjmcmc.StructurePrior(max_cells=o[0], min_edge=o[1], max_edge=o[2], min_width=o[3], probabilities=o[4:8])
-    vp = rjmcmc.ValuePrior(value_mean=d["halfspace"].item(), factor=o[10], gradient_std=o[9])
+    vp = rjmcmc.ValuePrior(value_mean=d["halfspace"].item(), factor=o[10], gradient_std=o[9], solve_gradient=solve_gradient,
+                           solve_value=solve_value)
     rp = rjmcmc.ErrorPrior(o[11], o[12], o[15])
     ap = rjmcmc.ErrorPrior(o[13], o[14], o[16])
     k = int(d["cur_k"][0])
@@ -113,9 +114,9 @@ def chain_setup(d):   # works for both fixtures: the state of iteration 0 and th
     return sp, vp, rp, ap, st, o[8]
 
 
-def run_chain(d, engine, n):
+def run_chain(d, engine, n, **flags):
     from geobipy_amd import rjmcmc
-    sp, vp, rp, ap, st, alpha = chain_setup(d)
+    sp, vp, rp, ap, st, alpha = chain_setup(d, **flags)
     prng = generator_at(d["rng_state"][0])
     acc, ks, mis = [], [], []
     for it in range(n):
@@ -147,6 +148,18 @@ def test_birth_heavy_chain_reproduces_the_reference_decisions():
     assert d["long_k"].max() >= 4
     assert np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
     assert np.allclose(mis, d["long_misfit"], rtol=1e-7)
+
+
+def test_value_prior_chain_reproduces_the_reference_decisions():
+    """A third reference run with solve_parameter = True and solve_gradient = False (prior on the conductivities instead
+    of on their vertical gradient; the stochastic-Newton operator loses its gradient term): 1000 iterations of identical
+    decisions."""
+    d = np.load(os.path.join(GOLDEN, "mcmc_value.npz"))
+    n = d["long_accepted"].size
+    acc, ks, mis, _ = run_chain(dict(d, accepted=d["long_accepted"]), OracleEngine("resolve", float(d["z"])), n,
+                                solve_gradient=False, solve_value=True)
+    assert n == 1000 and np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
+    assert np.allclose(mis, d["long_misfit"], rtol=1e-7) and d["long_accepted"].sum() > 200
 
 
 def test_long_chain_reproduces_the_reference_decisions():

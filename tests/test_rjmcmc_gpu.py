@@ -95,7 +95,8 @@ def _host_priors(dc, b):
     sp = rjmcmc.StructurePrior(dc.K, o["minimum_depth"], o["maximum_depth"], o["minimum_thickness"],
                                [o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
                                 o["probability_of_no_change"]])
-    vp = rjmcmc.ValuePrior(math.exp(float(dc.log_mean_prior[b])), o["factor"], o["gradient_standard_deviation"], o["solve_gradient"])
+    vp = rjmcmc.ValuePrior(math.exp(float(dc.log_mean_prior[b])), o["factor"], o["gradient_standard_deviation"], o["solve_gradient"],
+                           bool(o.get("solve_parameter", False)))
     return sp, vp
 
 
@@ -413,13 +414,14 @@ def test_reference_schedule_on_the_device_matches_a_host_replay():
 
 
 @pytest.mark.gpu
-def test_device_chains_equal_cpu_chains_with_the_same_seeds():
+@pytest.mark.parametrize("priors", [dict(), dict(solve_parameter=True, solve_gradient=False)])
+def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
     """BASELINE config 5's bar for the device sampler: a CPU implementation (rjmcmc.py pieces + the C oracle's forward
     and Jacobian) driven by the same counter-based streams walks the same chain -- every move, every accept / reject,
     and therefore identical layer-count and interface-depth histograms -- for 4 soundings x 400 iterations."""
     from test_rjmcmc import OracleEngine
     n_it, B = 400, 4
-    d, s, dc = _chains(B, 2024)
+    d, s, dc = _chains(B, 2024, options=priors)
     eo = _emul_options(dc)
     rng = np.random.default_rng(6)
     data = np.tile(d["data"], (B, 1)) * np.r_[1.0, rng.uniform(0.8, 1.3, B - 1)][:, None]
