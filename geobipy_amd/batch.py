@@ -127,6 +127,17 @@ class FdemBatch:
                                              self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
         return self.chi2, self.logL
 
+    def fm_dlogc(self, exact=False):
+        """Prediction and Jacobian of every sounding from one pass (FdemDataPoint.fm_dlogc): refreshes ``self.predicted``
+        and returns J[B, 2F, Lmax]."""
+        J = torch.empty((self.B, 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gbp_fdem_fm_dlogc(
+                self._h_exact.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
+                self.height.data_ptr(), self.predicted.data_ptr(), J.data_ptr(), self.Lmax, 1 if exact else 0,
+                _stream_ptr(self.device)))
+        return J
+
     def sensitivity(self, out=None, exact=False, max_layers=None, bucket=True):
         """J[B, 2F, Lmax] = d pred / d ln(sigma) (FdemDataPoint.sensitivity -> nbFdem1dsen).
 

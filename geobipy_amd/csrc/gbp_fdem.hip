@@ -275,7 +275,8 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                                     const int* __restrict__ nlayers,
                                                     const double* __restrict__ sigma,
                                                     const double* __restrict__ thk,
-                                                    const double* __restrict__ height, double* __restrict__ J)
+                                                    const double* __restrict__ height, double* __restrict__ J,
+                                                    double* __restrict__ pred)
 {
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
         constexpr int NG = 8;                          // 8 row groups of 8 layers are summed per evaluation
         for (int m0 = 0; m0 < L; m0 += 8 * NG) {       // (L <= 64: this loop runs once; deeper models re-evaluate)
             double acc_re[NG], acc_im[NG];
+            double fw_re = 0.0, fw_im = 0.0;       // this lane's share of the forward sum (fm_dlogc)
 #pragma unroll
             for (int g = 0; g < NG; ++g) { acc_re[g] = 0.0; acc_im[g] = 0.0; }
             for (int j0 = 0; j0 < ch.npts; j0 += 64) {
@@ -317,8 +319,10 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                     gbp::Point pt = gbp::load_point(pts, npts_total, ch.off + (valid ? j : ch.npts - 1));
                     if (!valid) pt.coef = gbp::mk(0.0, 0.0);
                     const cplx E = gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD);
-                    gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, E * pt.coef, sh_D + lane,
-                                           GBP_SENS_STRIDE);
+                    const cplx t = gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, E * pt.coef, sh_D + lane,
+                                                          GBP_SENS_STRIDE);
+                    fw_re += t.re;
+                    fw_im += t.im;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -333,6 +337,13 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+            if (pred != nullptr && m0 == 0) {      // one wave owns the frequency: fixed summation order for any launch shape
+                const double sr = wave_sum(fw_re), si = wave_sum(fw_im);
+                if (lane == 0) {
+                    pred[(size_t)b * N + f] = ch.g_re * sr - ch.g_im * si;
+                    pred[(size_t)b * N + F + f] = ch.g_re * si + ch.g_im * sr;
+                }
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -696,6 +707,13 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, 
                                    const double* sigma, const double* thk, const double* height, double* J,
                                    int max_layers, int exact, void* stream)
 {
+    return gbp_fdem_fm_dlogc(sys, B, Lmax, nlayers, sigma, thk, height, nullptr, J, max_layers, exact, stream);
+}
+
+gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                             const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                             void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
@@ -714,12 +732,12 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system* sys, int B, int Lmax, 
         if (lds > 48 * 1024)
             GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fdem_sens<true>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
-                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J);
+                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
     } else {
         if (lds > 48 * 1024)
             GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fdem_sens<false>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
-                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J);
+                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
     }
     GBP_HIP(hipGetLastError());
     return GBP_OK;

@@ -120,8 +120,10 @@ GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD
 // multiplied by "accumulate" as the sweep moves up (the reference stores accumulate[] and sens[] for all
 // (layer, frequency, abscissa) and does a prefix product afterwards).  D lives in LDS on the device:
 // element m of this lane is D[m * stride].
+// Returns this point's term of the forward sum, rTE * Q = Q (u0 - Yh_1) / (u0 + Yh_1), which the sweep has at hand
+// (fm_dlogc: prediction and Jacobian of the same model from one pass).
 template <bool EXACT>
-GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restrict__ lay,
+GBP_HD cplx sens_point(const MathCtx& M, double a, int L, const LayerK* __restrict__ lay,
                        const double* __restrict__ t2, cplx u0, cplx Q, cplx* D, int stride)
 {
     const double RSQRT2 = 0.70710678118654752440;
@@ -131,6 +133,7 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
         return mk(f * u.im, f * u.re);
     };
     cplx Y = csqrt_upper2(a, lay[L - 1].b2, lay[L - 1].bc);
+    cplx fwd = mk(0.0, 0.0);
     D[(L - 1) * stride] = ihb_over_u(lay[L - 1].bc, Y);
     for (int k = L - 2; k >= 0; --k) {
         const LayerK lk = lay[k];
@@ -160,6 +163,7 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
             const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
             fac = acc * QQ;
             W = W * QQ;
+            fwd = Q * ((u0 - Y) * i0);
         }
 #pragma unroll 4
         for (int m = k + 1; m < L; ++m) D[m * stride] = D[m * stride] * fac;
@@ -168,7 +172,9 @@ GBP_HD void sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
     if (L == 1) {  // half-space only: no layer loop ran
         const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
         D[0] = D[0] * (Q * ((u0 * (i0 * i0)) * -2.0));
+        fwd = Q * ((u0 - Y) * i0);
     }
+    return fwd;
 }
 
 }  // namespace gbp

@@ -644,11 +644,10 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
     for (int it = 0; it < n_iterations; ++it) {
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
-        // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
-        if ((st = gbp_fdem_forward(sys, B, K, c->nl_a, c->sigma_r, c->thk_r, c->height, c->pred_r, stream)) != GBP_OK) return st;
+        // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
         for (int i = 0; i < nb; ++i)
-            if ((st = gbp_fdem_sensitivity_ex(sys, B, K, c->nl_a + (size_t)(1 + i) * B, c->sigma_r, c->thk_r, c->height, c->J_r,
-                                              caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_fm_dlogc(sys, B, K, c->nl_a + (size_t)(1 + i) * B, c->sigma_r, c->thk_r, c->height, c->pred_r,
+                                        c->J_r, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
         if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
         // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
         if ((st = gbp_fdem_forward_loglike(sys, B, K, c->k_r, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,

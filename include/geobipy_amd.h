@@ -160,6 +160,16 @@ gbp_status gbp_fdem_sensitivity_ex(const gbp_fdem_system *sys, int B, int Lmax, 
                                    const double *sigma, const double *thk, const double *height,
                                    double *J, int max_layers, int exact, void *stream);
 
+/*
+ * Prediction AND Jacobian of the same models from one pass: FdemDataPoint.fm_dlogc (DP/FdemDataPoint.py:547-551,
+ * = forward + sensitivity).  Arguments as gbp_fdem_sensitivity_ex; pred [dev] f64[B, 2*nF] out (may be NULL).
+ * Each frequency's Hankel sum is formed by one wave, so `pred` does not depend on the launch shape; it equals
+ * gbp_fdem_forward's to rounding (different summation order).
+ */
+gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                             const double *sigma, const double *thk, const double *height,
+                             double *pred, double *J, int max_layers, int exact, void *stream);
+
 /* Timing helper for bench.py: average kernel time (ms) of `reps` launches of the fused kernel,
  * measured with hipEvents recorded on `stream` around the launches. */
 gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
@@ -260,7 +270,7 @@ gbp_status gbp_rj_propose(const gbp_rj_options *opt, const gbp_rj_chains *c, int
 gbp_status gbp_rj_newton(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, void *stream);
 gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, int accumulate,
                          void *stream);
-/* ... and n_iterations complete iterations (propose, forward + Jacobian of the remapped models, newton, fused
+/* ... and n_iterations complete iterations (propose, prediction + Jacobian of the remapped models, newton, fused
  * forward + likelihood of the proposals, Jacobian of the jump proposals, accept), all stream-ordered, no host
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,

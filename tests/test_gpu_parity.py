@@ -268,6 +268,41 @@ def test_jacobian_fixtures_of_imported_reference(golden_npz, name):
     assert np.array_equal(b.sensitivity(max_layers=Lmax).cpu().numpy(), J)      # LDS sizing does not change results
 
 
+@pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
+def test_fm_dlogc_prediction_and_jacobian_from_one_pass(golden_npz, name):
+    """gbp_fdem_fm_dlogc (FdemDataPoint.fm_dlogc): the prediction formed inside the Jacobian sweep against the imported
+    reference's predictions (same tolerance as the forward kernel), the Jacobian bit-equal to the Jacobian entry's, soundings
+    with 0 layers untouched."""
+    from geobipy_amd import FdemBatch
+    g, s = golden_npz, product_system(name)
+    Lmax = 32
+    nl, sig, thk, h, pref = [], [], [], [], []
+    for L in [1, 2, 3, 5, 8, 30]:
+        k = f"{name}_L{L}"
+        t = g[k + "/thk"].copy()
+        t[:, -1] = 0.0
+        nl += [L] * t.shape[0]
+        sig.append(pad(g[k + "/sigma"], Lmax, 1.0))
+        thk.append(pad(t, Lmax, 0.0))
+        h.append(g[k + "/height"])
+        pref.append(g[k + "/pred"])
+    cat = np.concatenate
+    b = FdemBatch(s, np.array(nl), cat(sig), cat(thk), cat(h))
+    for exact in (False, True):
+        J = b.fm_dlogc(exact=exact)
+        pred = b.predicted.clone()
+        assert close(pred.cpu().numpy(), cat(pref), PRED_ATOL, PRED_RTOL)
+        assert torch.equal(J, b.sensitivity(exact=exact, bucket=False))
+        assert close(pred.cpu().numpy(), b.forward().cpu().numpy(), 1e-9, 1e-12)
+    skip = np.array(nl)
+    skip[::2] = 0
+    b2 = FdemBatch(s, np.array(nl), cat(sig), cat(thk), cat(h))
+    b2.nlayers.copy_(torch.as_tensor(skip.astype(np.int32)))
+    b2.predicted.fill_(-1.0)
+    J2, J = b2.fm_dlogc(), b.fm_dlogc()
+    assert torch.all(b2.predicted[::2] == -1.0) and torch.equal(b2.predicted[1::2], pred[1::2]) and torch.equal(J2[1::2], J[1::2])
+
+
 def test_jacobian_random_batch_vs_oracle_and_finite_differences():
     from geobipy_amd import FdemBatch, synthetic
     from oracle import fdem_oracle as fo
