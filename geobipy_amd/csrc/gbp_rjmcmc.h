@@ -148,6 +148,7 @@ __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& 
         c.nl_a[(size_t)i * c.B + b] = (action != NONE && mine) ? kr : 0;
         c.nl_c[(size_t)i * c.B + b] = (jump && mine) ? kr : 0;
     }
+    c.nl_b[b] = jump ? 0 : kr;          // jump proposals get their prediction from the Jacobian pass instead
     c.action[b] = action;
     c.k_r[b] = kr;
     // error levels (DataPoint.perturb: relative then additive)
@@ -449,7 +450,26 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         dq = -0.5 * q1 + 0.5 * q2;
         if (__any(bad)) dq = __builtin_nan("");
     }
-    const double like_p = c.like_p[b];
+    double like_p, misfit_p;
+    if (action == INSERT || action == DELETE) {                  // their prediction came with the Jacobian (fm_dlogc): chi^2 / logL here
+        const double* pp = c.pred_p + (size_t)b * N;             //   (same arithmetic as the fused forward kernel's epilogue)
+        const double* ob = c.data + (size_t)b * N;
+        double s2 = 0.0, logdet = 0.0, na = 0.0;
+        for (int i = lane; i < N; i += 64) {
+            const double ov = ob[i];
+            if (ov > 0.0) {
+                const double ro = rel_p * ov, var = ro * ro + add_p * add_p;
+                const double r = (pp[i] - ov) * (1.0 / sqrt(var));
+                s2 += r * r; logdet += log(var); na += 1.0;
+            }
+        }
+        s2 = wave_sum(s2); logdet = wave_sum(logdet); na = wave_sum(na);
+        misfit_p = s2;
+        like_p = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
+    } else {
+        like_p = c.like_p[b];
+        misfit_p = c.misfit_p[b];
+    }
     const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
     const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         }
         if (lane == 0) {
             c.k[b] = k; c.rel[b] = rel_p; c.add[b] = add_p;
-            c.prior[b] = prior_p; c.like[b] = like_p; c.misfit[b] = c.misfit_p[b];
+            c.prior[b] = prior_p; c.like[b] = like_p; c.misfit[b] = misfit_p;
             c.n_accepted[b] += 1;
         }
     }
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             double na = 0.0;
             for (int n = lane; n < N; n += 64) na += c.data[(size_t)b * N + n] > 0.0 ? 1.0 : 0.0;
             na = wave_sum(na);
-            const double misfit_now = accept ? c.misfit_p[b] : c.misfit[b];
+            const double misfit_now = accept ? misfit_p : c.misfit[b];
             if (it1 > o.burn_in_min_iterations && misfit_now < na) {        // burned in: posteriors and best model start over
                 bi = it1;
                 reset_best = true;
@@ -570,7 +590,7 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
         return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
     if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
-                          c->like, c->misfit, c->action, c->k_r, c->nl_a, c->nl_c, c->edges_r, c->sigma_r, c->thk_r, c->rel_p,
+                          c->like, c->misfit, c->action, c->k_r, c->nl_a, c->nl_b, c->nl_c, c->edges_r, c->sigma_r, c->thk_r, c->rel_p,
                           c->add_p, c->pred_r, c->J_r, c->chol, c->log_prop, c->sigma_p, c->pred_p, c->misfit_p, c->like_p,
                           c->J_p, c->log_ratio, c->n_accepted, c->k_hist, c->best_posterior, c->best_k, c->best_edges, c->best_sigma};
     if (c->B > 0)
@@ -650,12 +670,13 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
                                         c->J_r, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
         if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
         // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
-        if ((st = gbp_fdem_forward_loglike(sys, B, K, c->k_r, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
+        //   ... of the proposals that keep their dimension
+        if ((st = gbp_fdem_forward_loglike(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
                                            c->pred_p, c->misfit_p, c->like_p, stream)) != GBP_OK) return st;
-        // Jacobian at the proposals that changed dimension (Model.py:612)
+        //   ... and prediction + Jacobian (Model.py:612) of those that change it; their chi^2 / logL are formed in accept
         for (int i = 0; i < nb; ++i)
-            if ((st = gbp_fdem_sensitivity_ex(sys, B, K, c->nl_c + (size_t)(1 + i) * B, c->sigma_p, c->thk_r, c->height, c->J_p,
-                                              caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_fm_dlogc(sys, B, K, c->nl_c + (size_t)(1 + i) * B, c->sigma_p, c->thk_r, c->height, c->pred_p,
+                                        c->J_p, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
         if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
     }
     return GBP_OK;

@@ -12,7 +12,7 @@ emulation with the same draws, and the ensembles against the host sampler.
 
 ``DeviceChains`` owns the buffers (torch tensors) and hands their addresses to ``gbp_rj_run``, which issues the ten
 launches of one iteration (propose | 3 x prediction + Jacobian of the remapped models | newton | fused forward +
-likelihood of all proposals | 3 x Jacobian of the jump proposals | accept) on the caller's stream without
+likelihood of the proposals that keep their dimension | 3 x prediction + Jacobian of those that change it | accept) on the caller's stream without
 synchronising; nothing crosses PCIe between iterations.
 """
 import math
@@ -135,7 +135,7 @@ class DeviceChains:
         self.t = t = dict(
             data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
-            nl_a=z(4, B, dt=i32), nl_c=z(4, B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
+            nl_a=z(4, B, dt=i32), nl_c=z(4, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
             edge_hist=z(B, self.n_depth_bins, dt=i32),

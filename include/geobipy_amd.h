@@ -246,6 +246,7 @@ typedef struct gbp_rj_chains {
     int32_t *action, *k_r;         /* [B]     0 none, 1 insert, 2 delete, 3 perturb; layers after the move */
     int32_t *nl_a, *nl_c;          /* [4, B]  k_r of the chains needing the phase A / C kernels, else 0: row 0 all,
                                       rows 1-3 split by layer count (<= 8, <= 16, more)                  */
+    int32_t *nl_b;                 /* [B]     k_r of the chains whose proposal keeps its dimension (fused forward), else 0 */
     double *edges_r, *sigma_r, *thk_r;        /* [B, K] remapped model                                 */
     double *rel_p, *add_p;                    /* [B]    proposed errors                                */
     double *pred_r, *J_r;                     /* [B, N], [B, N, K] at the remapped model               */
@@ -271,7 +272,7 @@ gbp_status gbp_rj_newton(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
 gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, int accumulate,
                          void *stream);
 /* ... and n_iterations complete iterations (propose, prediction + Jacobian of the remapped models, newton, fused
- * forward + likelihood of the proposals, Jacobian of the jump proposals, accept), all stream-ordered, no host
+ * forward + likelihood of the proposals that keep their dimension, prediction + Jacobian of those that change it, accept), all stream-ordered, no host
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);

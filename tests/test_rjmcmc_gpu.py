@@ -254,8 +254,11 @@ def test_accept_kernel_matches_the_emulation():
         sp, vp = _host_priors(dc, b)
         k = k_r[b]
         C = np.tril(chol[b, :k, :k])
+        ref_misfit, ref_like = rjmcmc.gauss_loglike(pred_p[b], data[b], np.sqrt((rel_p[b] * data[b]) ** 2 + add_p[b] ** 2))
+        if action[b] in (0, 3):                # proposals that keep their dimension: chi^2 / logL from the fused forward kernel
+            assert np.isclose(like_p[b], ref_like, rtol=1e-12) and np.isclose(misfit_p[b], ref_misfit, rtol=1e-11)
         ref_lr, ref_acc, ref_prior = rj_emul.accept(eo, 41, b, it, sp, vp, action[b], e_r[b, : k - 1], s_r[b, :k], log_prop[b, :k], C,
-                                                    J_p[b], pred_p[b], data[b], rel_p[b], add_p[b], like_p[b], bk["prior"][b],
+                                                    J_p[b], pred_p[b], data[b], rel_p[b], add_p[b], ref_like, bk["prior"][b],
                                                     bk["like"][b])
         assert (np.isclose(log_ratio[b], ref_lr, rtol=1e-7, atol=1e-6, equal_nan=True)
                 or (np.isneginf(ref_lr) and np.isneginf(log_ratio[b]))), (b, action[b], log_ratio[b], ref_lr)
@@ -267,8 +270,8 @@ def test_accept_kernel_matches_the_emulation():
         if accepted:
             assert int(dc.k[b]) == k
             assert np.array_equal(dc.edges[b].cpu().numpy(), e_r[b]) and np.array_equal(dc.sigma[b].cpu().numpy(), g("sigma_p")[b])
-            assert np.array_equal(dc.pred[b].cpu().numpy(), pred_p[b]) and float(dc.like[b]) == like_p[b]
-            assert float(dc.misfit[b]) == misfit_p[b] and np.isclose(float(dc.prior[b]), ref_prior, rtol=1e-12)
+            assert np.array_equal(dc.pred[b].cpu().numpy(), pred_p[b]) and np.isclose(float(dc.like[b]), ref_like, rtol=1e-12)
+            assert np.isclose(float(dc.misfit[b]), ref_misfit, rtol=1e-11) and np.isclose(float(dc.prior[b]), ref_prior, rtol=1e-12)
             assert float(dc.rel[b]) == rel_p[b] and float(dc.add[b]) == add_p[b]
             Jsrc = {0: bk["J"][b], 1: J_p[b], 2: J_p[b], 3: g("J_r")[b]}[int(action[b])]
             assert np.array_equal(dc.J[b].cpu().numpy(), Jsrc)
@@ -309,7 +312,10 @@ def test_device_chains_state_is_coherent_after_many_steps():
     _lib.check(_lib.load().gbp_pin_forward_waves(4))             # the summation order the chains ran with (forward_waves=4)
     chi2, logl = fb.forward_loglike()
     _lib.check(_lib.load().gbp_pin_forward_waves(0))
-    assert torch.equal(fb.predicted, dc.pred) and torch.equal(chi2, dc.misfit) and torch.equal(logl, dc.like)
+    # proposals that keep their dimension get prediction / chi^2 / logL from the fused forward kernel (bit-equal to this
+    # evaluation); the others from the Jacobian pass and the accept kernel (same values, different summation order)
+    assert torch.allclose(fb.predicted, dc.pred, rtol=1e-11, atol=1e-9) and torch.allclose(chi2, dc.misfit, rtol=1e-9)
+    assert torch.allclose(logl, dc.like, rtol=1e-10) and (fb.predicted == dc.pred).all(dim=1).float().mean() > 0.3
     o = dc.o
     prior = (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
              + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
