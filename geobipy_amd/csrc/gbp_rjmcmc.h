@@ -205,14 +205,15 @@ __global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp
     double* __restrict__ sr = c.sigma_r + (size_t)b * K;
     double* __restrict__ tr = c.thk_r + (size_t)b * K;
     double above = 0.0;
+    double e_j = 0 < k - 1 ? e[0] : INF, s_j = 0 < k ? s[0] : 1.0, e_up = e_j, s_up = s_j;   // rolling window over the rows
     for (int j = 0; j < K; ++j) {
-        const int up = max(j - 1, 0), dn = min(j + 1, K - 1);
+        const double e_dn = j + 1 < k - 1 ? e[j + 1] : INF, s_dn = j + 1 < k ? s[j + 1] : 1.0;
         double ev, sv;
-        remap_entry(action, idx, val, kr, j, j < k - 1 ? e[j] : INF, up < k - 1 ? e[up] : INF, dn < k - 1 ? e[dn] : INF,
-                    j < k ? s[j] : 1.0, up < k ? s[up] : 1.0, dn < k ? s[dn] : 1.0, ev, sv);
+        remap_entry(action, idx, val, kr, j, e_j, e_up, j + 1 < K ? e_dn : e_j, s_j, s_up, j + 1 < K ? s_dn : s_j, ev, sv);
         er[j] = ev; sr[j] = sv;
         tr[j] = j < kr - 1 ? ev - above : 0.0;
         above = ev;
+        e_up = e_j; s_up = s_j; e_j = e_dn; s_j = s_dn;
     }
     write_move(o, c, r, b, action, kr);
 }
