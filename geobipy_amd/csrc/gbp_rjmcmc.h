@@ -305,14 +305,16 @@ struct Lds {
     static size_t bytes(int K, int N) { return ((size_t)K * (K + 1) + 5 * (size_t)K + 2 * (size_t)N) * sizeof(double); }
 };
 
-__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int min_k)
 {   // Model.stochastic_newton_perturbation (model/Model.py:368-419): precision = J'PJ + Wm'Wm at the remapped model,
     // mean = ln sigma - alpha * precision^-1 g, sample ~ N(mean, precision^-1) = mean + C^-T z with precision = C C'
+    // One wave per chain; chains with at most min_k layers are left to k_rj_newton8.
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
     const int k = c.k_r[b];
+    if (k <= min_k) return;
     const bool changed = c.action[b] != NONE;
     const double* J = (changed ? c.J_r : c.J) + (size_t)b * N * K;
     const double* pred = (changed ? c.pred_r : c.pred) + (size_t)b * N;
@@ -376,6 +378,125 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
         const double lp = lane < k ? (ls - o.alpha * s.g[lane]) + s.w[lane] : 0.0;
         c.log_prop[(size_t)b * K + lane] = lp;
         c.sigma_p[(size_t)b * K + lane] = lane < k ? exp(lp) : 1.0;
+    }
+}
+
+// The same for chains with at most 8 layers -- the common case -- packed 8 lanes per chain, 8 chains per wave: row i of the
+// 8 x 8 system lives in the registers of lane i of the chain's group, columns of the Cholesky factor are passed around with
+// cross-lane reads (lane j also keeps column j for the transposed solves), so there is no LDS traffic and no barrier in
+// the factorisation or the substitutions.  Rows >= k are identity rows.
+__device__ inline double group_bcast(double v, int base, int j) { return __shfl(v, base + j, 64); }
+
+__global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // P[8][N] | PR[8][N]
+    const int lane = threadIdx.x, slot = lane >> 3, i = lane & 7, base = lane & ~7;
+    const int K = o.max_layers, N = o.n_channels;
+    const int b = blockIdx.x * 8 + slot;
+    int k = b < c.B ? c.k_r[b] : 0;
+    const bool live = k >= 1 && k <= 8;              // deeper chains: k_rj_newton.  No early exit: idle groups still take
+    if (!live) k = 0;                                //   part in the cross-lane reads
+    const size_t bb = live ? (size_t)b : 0;
+    const bool changed = c.action[bb] != NONE;
+    const double* J = (changed ? c.J_r : c.J) + bb * N * K;
+    const double* pred = (changed ? c.pred_r : c.pred) + bb * N;
+    const double* e = c.edges_r + bb * K;
+    double* P = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * 2 * N;
+    double* PR = P + N;
+    {
+        const double rel = c.rel[bb], add = c.add[bb];
+        const double* data = c.data + bb * N;
+        for (int n = i; n < N; n += 8) {
+            const double d = data[n];
+            const bool act = d > 0.0;
+            const double rd = rel * d, w = act ? 1.0 / (rd * rd + add * add) : 0.0;
+            P[n] = w;
+            PR[n] = act ? w * (pred[n] - d) : 0.0;
+        }
+    }
+    double t2 = 0.0;
+    if (i < k - 1 && o.solve_gradient) {
+        const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
+        t2 = o.gradient_precision / (c2c * c2c);
+    }
+    // (cross-lane reads are issued by all lanes -- a lane that sits out of the instruction cannot be read from)
+    const double t2_sh = __shfl(t2, max(lane - 1, 0), 64);
+    const double t2_up = i > 0 ? t2_sh : 0.0;
+    const double lmp = c.log_mean_prior[bb];
+    const double ls = i < k ? log(c.sigma_r[bb * K + i]) : 0.0;
+    const double v = i < k ? ls - lmp : 0.0;
+    const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
+    const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
+    __syncthreads();
+    double arow[8], acol[8];
+    double g = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { arow[j] = 0.0; acol[j] = 0.0; }
+    for (int n = 0; n < N; ++n) {                    // J'PJ and J'P r
+        const double Ji = i < k ? J[(size_t)n * K + i] : 0.0;
+        const double jp = Ji * P[n];
+        g += Ji * PR[n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) arow[j] += jp * group_bcast(Ji, base, j);
+    }
+    {   // + Wm'Wm (tridiagonal), Wm'Wm (ln sigma - ln sigma_ref)
+        const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
+        const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
+        g += diag * v - t2_up * v_up - t2 * v_dn;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j == i) arow[j] += diag;
+            if (j == i - 1) arow[j] -= t2_up;
+            if (i >= k) arow[j] = j == i ? 1.0 : 0.0;
+            if (j >= k && j != i) arow[j] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                    // Cholesky, right-looking
+        const double cjj = sqrt(group_bcast(arow[j], base, j));
+        if (i == j) { arow[j] = cjj; acol[j] = cjj; }
+        else if (i > j) arow[j] = arow[j] / cjj;
+#pragma unroll
+        for (int m = j + 1; m < 8; ++m) {
+            const double cmj = group_bcast(arow[j], base, m);       // C[m][j]
+            if (i == j) acol[m] = cmj;
+            if (i >= m) arow[m] -= arow[j] * cmj;
+        }
+    }
+    if (live && i < k) {
+        double* C = c.chol + bb * K * K + (size_t)i * K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j <= i) C[j] = arow[j];
+    }
+    auto forward = [&](double x) {                   // C y = x
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double yj = group_bcast(x / arow[j], base, j);     // lane j holds C[j][j] in arow[j]
+            if (i == j) x = yj;
+            if (i > j) x -= arow[j] * yj;
+        }
+        return x;
+    };
+    auto backward = [&](double x) {                  // C' y = x
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const double yj = group_bcast(x / acol[j], base, j);     // lane j holds C[j][j] in acol[j]
+            if (i == j) x = yj;
+            if (i < j) x -= acol[j] * yj;                            // C[j][i]
+        }
+        return x;
+    };
+    const double step = backward(forward(g));        // (C C')^-1 g
+    double z0 = 0.0, z1 = 0.0;
+    if (i < 4) normal_pair(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 1, (uint32_t)i, z0, z1);
+    const double za = __shfl(z0, base + (i >> 1), 64), zb = __shfl(z1, base + (i >> 1), 64);
+    const double w = backward((i & 1) ? zb : za);    // C^-T z
+    if (live) {
+        const double lp = i < k ? (ls - o.alpha * step) + w : 0.0;
+        c.log_prop[bb * K + i] = lp;
+        c.sigma_p[bb * K + i] = i < k ? exp(lp) : 1.0;
+        for (int j = i + 8; j < K; j += 8) { c.log_prop[bb * K + j] = 0.0; c.sigma_p[bb * K + j] = 1.0; }
     }
 }
 
@@ -621,8 +742,12 @@ gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
-                       *c, (uint32_t)iteration);
+    // chains with <= 8 layers: packed kernel (8 per wave); the others: one wave each
+    hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                       *o, *c, (uint32_t)iteration);
+    if (o->max_layers > 8)
+        hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+                           *c, (uint32_t)iteration, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
