@@ -368,6 +368,17 @@ def test_posterior_accumulators_match_a_host_replay():
 
 
 @pytest.mark.gpu
+def test_abscissa_window_does_not_change_the_chains():
+    """Opt-in hankel_eps_ppm = 1e-12: predictions and Jacobians move by < 2e-12 ppm, so 300 iterations take the same
+    decisions and end in the same models to 1e-8."""
+    _, _, a = _chains(64, 31, exact=True, n_it=300)
+    _, _, w = _chains(64, 31, exact=True, n_it=300, hankel_eps_ppm=1e-12)
+    assert w._h.npoints < a._h.npoints
+    assert torch.equal(a.k, w.k) and torch.equal(a.n_accepted, w.n_accepted) and torch.equal(a.k_hist, w.k_hist)
+    assert torch.allclose(a.sigma, w.sigma, rtol=1e-8) and torch.allclose(a.misfit, w.misfit, rtol=1e-8)
+
+
+@pytest.mark.gpu
 def test_reference_schedule_on_the_device_matches_a_host_replay():
     """Per-sounding burn-in / stop rule of Inference1D.update / infer evaluated in the accept kernel: burn-in iteration,
     status, the posterior that restarts at burn-in, the frozen final state -- against a replay of the rule on the host
