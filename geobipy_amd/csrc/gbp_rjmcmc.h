@@ -77,7 +77,7 @@ __device__ inline double propose_error(Rng& r, double cur, double sd, double lo,
     return exp(x);
 }
 
-__device__ inline int bucket_of(int k) { return k <= 8 ? 0 : (k <= 16 ? 1 : 2); }
+__device__ inline int bucket_of(int k) { return k <= 8 ? 0 : 1; }
 
 // The structural move of one chain (RectilinearMesh1D.perturb :1018-1118).  edge(j): interface j of the current model;
 // below(depth): number of interfaces shallower than depth.
@@ -140,10 +140,10 @@ __device__ inline void remap_entry(int action, int idx, double val, int kr, int 
 }
 
 __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr)
-{   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-3: by bucket), error proposals
+{   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-2: by bucket), error proposals
     const int bk = bucket_of(kr);
     const bool jump = action == INSERT || action == DELETE;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {
         const bool mine = i == 0 || bk == i - 1;
         c.nl_a[(size_t)i * c.B + b] = (action != NONE && mine) ? kr : 0;
         c.nl_c[(size_t)i * c.B + b] = (jump && mine) ? kr : 0;
@@ -771,8 +771,8 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
     if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
     const int B = c->B, K = o->max_layers;
     if (B == 0) return GBP_OK;
-    const int caps[3] = {8 < K ? 8 : K, 16 < K ? 16 : K, K};
-    const int nb = K <= 8 ? 1 : (K <= 16 ? 2 : 3);
+    const int caps[2] = {8 < K ? 8 : K, K};      // Jacobian launches by layer count: <= 8 (the common case, small LDS
+    const int nb = K <= 8 ? 1 : 2;               //   footprint, high occupancy) and the rest
     struct Pin { Pin(int w, int sw) { g_pinned_waves = w; g_sens_waves = sw; } ~Pin() { g_pinned_waves = 0; g_sens_waves = 0; } };
     // Jacobian launches: ~40 % of the chains need one (structure changed / dimension changed), the rest exit at once;
     // size the workgroups for the chains that work, with a wave count that divides nF (one frequency per wave at a time)

@@ -10,9 +10,9 @@ draw from the same Markov kernel but not the *same* draw as the reference's chai
 ``inference.Inference1D`` / ``BatchedInference`` are for; tests/test_rjmcmc_gpu.py checks the stages against a host
 emulation with the same draws, and the ensembles against the host sampler.
 
-``DeviceChains`` owns the buffers (torch tensors) and hands their addresses to ``gbp_rj_run``, which issues the eleven
-launches of one iteration (propose | 3 x prediction + Jacobian of the remapped models | newton (packed, general) | fused forward +
-likelihood of the proposals that keep their dimension | 3 x prediction + Jacobian of those that change it | accept) on the caller's stream without
+``DeviceChains`` owns the buffers (torch tensors) and hands their addresses to ``gbp_rj_run``, which issues the nine
+launches of one iteration (propose | 2 x prediction + Jacobian of the remapped models | newton (packed, general) | fused forward +
+likelihood of the proposals that keep their dimension | 2 x prediction + Jacobian of those that change it | accept) on the caller's stream without
 synchronising; nothing crosses PCIe between iterations.
 """
 import math
@@ -145,7 +145,7 @@ class DeviceChains:
         self.t = t = dict(
             data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
-            nl_a=z(4, B, dt=i32), nl_c=z(4, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
+            nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
             edge_hist=z(B, self.n_depth_bins, dt=i32),

@@ -244,8 +244,8 @@ typedef struct gbp_rj_chains {
     double *prior, *like, *misfit; /* [B]                                                              */
     /* proposal scratch (written by the step) */
     int32_t *action, *k_r;         /* [B]     0 none, 1 insert, 2 delete, 3 perturb; layers after the move */
-    int32_t *nl_a, *nl_c;          /* [4, B]  k_r of the chains needing the phase A / C kernels, else 0: row 0 all,
-                                      rows 1-3 split by layer count (<= 8, <= 16, more)                  */
+    int32_t *nl_a, *nl_c;          /* [3, B]  k_r of the chains needing the phase A / C kernels, else 0: row 0 all,
+                                      rows 1-2 split by layer count (<= 8, more)                         */
     int32_t *nl_b;                 /* [B]     k_r of the chains whose proposal keeps its dimension (fused forward), else 0 */
     double *edges_r, *sigma_r, *thk_r;        /* [B, K] remapped model                                 */
     double *rel_p, *add_p;                    /* [B]    proposed errors                                */

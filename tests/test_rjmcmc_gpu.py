@@ -152,9 +152,9 @@ def test_propose_kernel_matches_the_emulation():
             assert np.allclose(t_r[b, : ss.size - 1], np.diff(np.r_[0.0, ee]), rtol=1e-13) and not t_r[b, ss.size - 1:].any()
             assert np.isclose(rel_p[b], rp, rtol=1e-13) and np.isclose(add_p[b], ap, rtol=1e-13)
             kept += rp == rel[b]
-            bucket = 1 + (0 if ss.size <= 8 else (1 if ss.size <= 16 else 2))
-            want_a = np.zeros(4, dtype=int)
-            want_c = np.zeros(4, dtype=int)
+            bucket = 1 + (0 if ss.size <= 8 else 1)
+            want_a = np.zeros(3, dtype=int)
+            want_c = np.zeros(3, dtype=int)
             if a != rjmcmc.NONE:
                 want_a[0] = want_a[bucket] = ss.size
             if a in (rjmcmc.INSERT, rjmcmc.DELETE):
