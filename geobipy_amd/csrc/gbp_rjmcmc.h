@@ -506,13 +506,14 @@ __device__ inline double log_uniform_prior(double x, double lo, double hi)
     return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
-{
+__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
+{   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to k_rj_accept8
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
     const int k = c.k_r[b], action = c.action[b];
+    if (max(k, c.k[b]) <= min_k) return;
     const double* e = c.edges_r + (size_t)b * K;
     const double* lpv = c.log_prop + (size_t)b * K;
     const double* tr = c.thk_r + (size_t)b * K;
@@ -679,6 +680,212 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     }
 }
 
+// The same for chains whose current and proposed models have at most 8 layers, packed 8 lanes per chain like k_rj_newton8:
+// the reverse-move algebra runs on the Cholesky factor held in registers (row i and column i on lane i), sums over a
+// chain are 8-lane butterflies, state copies and posterior updates are strided by 8.
+__device__ inline double group_sum8(double v)
+{
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // PR[8][N]
+    const int lane = threadIdx.x, slot = lane >> 3, i = lane & 7, base = lane & ~7;
+    const int K = o.max_layers, N = o.n_channels;
+    const int b = blockIdx.x * 8 + slot;
+    int k = b < c.B ? c.k_r[b] : 0;
+    const int k_prev = b < c.B ? c.k[b] : 0;
+    const bool live = k >= 1 && max(k, k_prev) <= 8;         // no early exit: idle groups still take part in cross-lane reads
+    if (!live) k = 0;
+    const size_t bb = live ? (size_t)b : 0;
+    const int action = live ? c.action[bb] : NONE;
+    const bool jump = action == INSERT || action == DELETE;
+    const bool frozen = o.schedule == 1 && c.status[bb] != 0;
+    const double* e = c.edges_r + bb * K;
+    const double lmp = c.log_mean_prior[bb];
+    const double lpv = i < k ? c.log_prop[bb * K + i] : 0.0;
+    const double lpv_dn = __shfl(lpv, min(lane + 1, 63), 64);
+    // priors of the proposal
+    double prior_p = -log((double)K - 1.0);
+    if (o.solve_value) {
+        const double d = i < k ? lpv - lmp : 0.0;
+        const double d2 = group_sum8(d * d);
+        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * log(o.value_precision) - 0.5 * o.value_precision * d2;
+    }
+    if (o.solve_gradient) {
+        double g = 0.0;
+        if (i < k - 1) g = (lpv_dn - lpv) / log(c.thk_r[bb * K + i]);
+        const double g2 = group_sum8(g * g);
+        const double n = (double)max(1, k - 1);
+        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
+    }
+    const double rel_p = c.rel_p[bb], add_p = c.add_p[bb];
+    if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);
+    if (o.solve_additive_error) prior_p += log_uniform_prior(add_p, o.add_min, o.add_max);
+    // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian
+    double* PR = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * N;
+    double s2 = 0.0, logdet = 0.0, na = 0.0;
+    if (jump) {
+        const double* pp = c.pred_p + bb * N;
+        const double* ob = c.data + bb * N;
+        for (int n = i; n < N; n += 8) {
+            const double ov = ob[n];
+            double pr = 0.0;
+            if (ov > 0.0) {
+                const double ro = rel_p * ov, var = ro * ro + add_p * add_p;
+                const double r = (pp[n] - ov) * (1.0 / sqrt(var));
+                s2 += r * r; logdet += log(var); na += 1.0;
+                pr = (1.0 / var) * (pp[n] - ov);
+            }
+            PR[n] = pr;
+        }
+    }
+    s2 = group_sum8(s2); logdet = group_sum8(logdet); na = group_sum8(na);
+    __syncthreads();
+    // reverse-move proposal density (Model.proposal_probabilities :577-659); executed by every group, used by the jumps
+    double t2 = 0.0;
+    if (i < k - 1 && o.solve_gradient) {
+        const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
+        t2 = o.gradient_precision / (c2c * c2c);
+    }
+    const double t2_sh = __shfl(t2, max(lane - 1, 0), 64);
+    const double t2_up = i > 0 ? t2_sh : 0.0;
+    const double v = i < k ? lpv - lmp : 0.0;
+    const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
+    const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
+    double arow[8], acol[8];
+    const bool row = jump && i < k;
+    {
+        const double* C = c.chol + bb * K * K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            arow[j] = (row && j <= i) ? C[(size_t)i * K + j] : (j == i ? 1.0 : 0.0);
+            acol[j] = (row && j >= i && j < k) ? C[(size_t)j * K + i] : (j == i ? 1.0 : 0.0);
+        }
+    }
+    double grad = 0.0;
+    if (row) {
+        const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
+        const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
+        grad = diag * v - t2_up * v_up - t2 * v_dn;
+        const double* Jp = c.J_p + bb * N * K;
+        for (int n = 0; n < N; ++n) grad += Jp[(size_t)n * K + i] * PR[n];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                    // C y = grad
+        const double yj = group_bcast(grad / arow[j], base, j);
+        if (i == j) grad = yj;
+        if (i > j) grad -= arow[j] * yj;
+    }
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {                   // C' x = y
+        const double yj = group_bcast(grad / acol[j], base, j);
+        if (i == j) grad = yj;
+        if (i < j) grad -= acol[j] * yj;
+    }
+    const double mean_r = lpv + o.alpha * grad;
+    const bool bad = row && !(fabs(mean_r) < 11356.0);
+    const double lrem = row ? log(c.sigma_r[bb * K + i]) : 0.0;
+    const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
+    double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const double d1m = group_bcast(d1, base, m), d2m = group_bcast(d2, base, m);
+        if (m >= i) { a1 += acol[m] * d1m; a2 += acol[m] * d2m; }
+    }
+    const double q1 = group_sum8(row ? a1 * a1 : 0.0), q2 = group_sum8(row ? a2 * a2 : 0.0);
+    const unsigned long long badmask = __ballot(bad);
+    double dq = jump ? -0.5 * q1 + 0.5 * q2 : 0.0;
+    if ((badmask >> base) & 0xFFull) dq = __builtin_nan("");
+    const double misfit_p = jump ? s2 : c.misfit_p[bb];
+    const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : c.like_p[bb];
+    const double prior_c = c.prior[bb], like_c = c.like[bb], best_prev = c.best_posterior[bb];
+    const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
+    const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
+    const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
+    if (live && i == 0) c.log_ratio[bb] = log_ratio;
+    if (!live || frozen) return;                     // (no cross-lane reads below this line)
+    const double misfit_c = c.misfit[bb];
+    if (accept) {
+        for (int j = i; j < K; j += 8) {
+            c.edges[bb * K + j] = e[j];
+            c.sigma[bb * K + j] = c.sigma_p[bb * K + j];
+        }
+        for (int n = i; n < N; n += 8) c.pred[bb * N + n] = c.pred_p[bb * N + n];
+        if (action != NONE) {
+            const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
+            double* Jd = c.J + bb * N * K;
+            for (int q = i; q < N * K; q += 8) Jd[q] = Js[q];
+        }
+        if (i == 0) {
+            c.k[bb] = k; c.rel[bb] = rel_p; c.add[bb] = add_p;
+            c.prior[bb] = prior_p; c.like[bb] = like_p; c.misfit[bb] = misfit_p;
+            c.n_accepted[bb] += 1;
+        }
+    }
+    // bookkeeping on the post-step state (Inference1D.update :705-790)
+    const int kc = accept ? k : k_prev;
+    const double* ec = accept ? e : c.edges + bb * K;
+    const double* sc = accept ? c.sigma_p + bb * K : c.sigma + bb * K;
+    const double post = accept ? prior_p + like_p : prior_c + like_c;
+    bool reset_best = false;
+    if (o.schedule == 1) {
+        const int it1 = (int)iter + 1;
+        int bi = c.burned_in_iteration[bb];
+        if (bi < 0) {
+            double nact = 0.0;
+            for (int n = i; n < N; n += 8) nact += c.data[bb * N + n] > 0.0 ? 1.0 : 0.0;
+            nact = group_sum8(nact);
+            const double misfit_now = accept ? misfit_p : misfit_c;
+            if (it1 > o.burn_in_min_iterations && misfit_now < nact) {
+                bi = it1;
+                reset_best = true;
+                for (int q = i; q < K + 1; q += 8) c.k_hist[bb * (K + 1) + q] = 0;
+                if (c.edge_hist != nullptr)
+                    for (int q = i; q < o.n_depth_bins; q += 8) c.edge_hist[bb * o.n_depth_bins + q] = 0;
+                if (c.hitmap != nullptr) {
+                    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
+                    for (size_t q = i; q < nh; q += 8) c.hitmap[bb * nh + q] = 0;
+                }
+                if (i == 0) c.burned_in_iteration[bb] = bi;
+            }
+        }
+        accumulate = 1;
+        if (i == 0) {
+            if (bi >= 0 && it1 > o.n_markov_chains + bi) c.status[bb] = 1;
+            else if (bi < 0 && it1 >= o.n_markov_chains) c.status[bb] = 2;
+        }
+    }
+    if (reset_best || post > best_prev) {
+        for (int j = i; j < K; j += 8) { c.best_edges[bb * K + j] = ec[j]; c.best_sigma[bb * K + j] = sc[j]; }
+        if (i == 0) { c.best_posterior[bb] = post; c.best_k[bb] = kc; }
+    }
+    if (accumulate) {
+        // (the k_hist row may have been zeroed by other lanes of the group just above: same wave, program order)
+        if (i == 0) c.k_hist[bb * (K + 1) + kc] += 1;
+        if (c.edge_hist != nullptr && i < kc - 1) {
+            const double ratio = sc[i + 1] / sc[i];
+            if (ratio <= 0.5 || ratio >= 1.5) {
+                const int bin = min(max((int)floor(ec[i] / o.depth_bin_width), 0), o.n_depth_bins - 1);
+                atomicAdd(c.edge_hist + bb * o.n_depth_bins + bin, 1);
+            }
+        }
+        if (c.hitmap != nullptr) {
+            const double inv_ln10 = 0.43429448190325182765, W = o.value_half_width;
+            for (int cell = i; cell < o.n_depth_bins; cell += 8) {
+                const double zc = ((double)cell + 0.5) * o.depth_bin_width;
+                int layer = 0;
+                while (layer < kc - 1 && ec[layer] <= zc) ++layer;
+                const double vv = (log(sc[layer]) - lmp) * inv_ln10;
+                const int bin = min(max((int)floor((vv + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
+                c.hitmap[(bb * o.n_depth_bins + cell) * o.n_value_bins + bin] += 1;
+            }
+        }
+    }
+}
+
 __global__ void k_rj_debug_random(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, int n, double* uni, double* nor)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -756,8 +963,11 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
-                       *c, (uint32_t)iteration, accumulate);
+    hipLaunchKernelGGL(rj::k_rj_accept8, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                       *o, *c, (uint32_t)iteration, accumulate);
+    if (o->max_layers > 8)
+        hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+                           *c, (uint32_t)iteration, accumulate, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

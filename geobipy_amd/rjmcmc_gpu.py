@@ -10,9 +10,9 @@ draw from the same Markov kernel but not the *same* draw as the reference's chai
 ``inference.Inference1D`` / ``BatchedInference`` are for; tests/test_rjmcmc_gpu.py checks the stages against a host
 emulation with the same draws, and the ensembles against the host sampler.
 
-``DeviceChains`` owns the buffers (torch tensors) and hands their addresses to ``gbp_rj_run``, which issues the nine
+``DeviceChains`` owns the buffers (torch tensors) and hands their addresses to ``gbp_rj_run``, which issues the ten
 launches of one iteration (propose | 2 x prediction + Jacobian of the remapped models | newton (packed, general) | fused forward +
-likelihood of the proposals that keep their dimension | 2 x prediction + Jacobian of those that change it | accept) on the caller's stream without
+likelihood of the proposals that keep their dimension | 2 x prediction + Jacobian of those that change it | accept (packed, general)) on the caller's stream without
 synchronising; nothing crosses PCIe between iterations.
 """
 import math

@@ -1,5 +1,5 @@
 """Throughput of the device-resident rjMCMC (geobipy_amd/rjmcmc_gpu.py -> gbp_rj_run;
-SURVEY row f-2, BASELINE config 5 shape): B Resolve soundings, all chains advancing in lockstep, nine launches per iteration,
+SURVEY row f-2, BASELINE config 5 shape): B Resolve soundings, all chains advancing in lockstep, ten launches per iteration,
 no host synchronisation between iterations."""
 import os, sys, time
 import numpy as np
