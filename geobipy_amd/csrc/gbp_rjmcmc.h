@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
                 while (layer < kc - 1 && ec[layer] <= zc) ++layer;
                 const double v = (log(sc[layer]) - lmp) * inv_ln10;
                 const int bin = min(max((int)floor((v + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
-                c.hitmap[((size_t)b * o.n_depth_bins + cell) * o.n_value_bins + bin] += 1;
+                c.hitmap[((size_t)b * o.n_value_bins + bin) * o.n_depth_bins + cell] += 1;   // depth fastest: a layer's cells are contiguous
             }
         }
     }
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                 while (layer < kc - 1 && ec[layer] <= zc) ++layer;
                 const double vv = (log(sc[layer]) - lmp) * inv_ln10;
                 const int bin = min(max((int)floor((vv + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
-                c.hitmap[(bb * o.n_depth_bins + cell) * o.n_value_bins + bin] += 1;
+                c.hitmap[(bb * o.n_value_bins + bin) * o.n_depth_bins + cell] += 1;
             }
         }
     }

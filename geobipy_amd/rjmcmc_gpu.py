@@ -77,7 +77,7 @@ class DeviceChains:
     altitude floor ``min_altitude`` (default: the lowest sounding of this block; pass the survey's floor for results that
     do not depend on the sharding) -- 1e-12 keeps 673 of 1200 points of the 10-frequency system and changes predictions and
     Jacobians by < 2e-12 ppm.
-    hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_depth_bins, n_value_bins] (440 KB per
+    hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_value_bins, n_depth_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
@@ -149,7 +149,7 @@ class DeviceChains:
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
             edge_hist=z(B, self.n_depth_bins, dt=i32),
-            hitmap=z(B, self.n_depth_bins, self.n_value_bins, dt=i32) if hitmap else None,
+            hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K))
         rc = _lib.RjChains()

@@ -168,9 +168,9 @@ def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     """Mean and percentiles of log10 conductivity per depth cell from the hit map (the reference derives the same from
     its Histogram2D posterior)."""
     import torch
-    B, nz, nv = hitmap.shape
+    B, nv, nz = hitmap.shape                                      # stored value-major, depth fastest
     centres = (torch.arange(nv, dtype=torch.float64, device=hitmap.device) + 0.5) / nv * (2.0 * half_width) - half_width
-    h = hitmap.to(torch.float64)
+    h = hitmap.transpose(1, 2).to(torch.float64)                  # [B, nz, nv]
     tot = h.sum(dim=2).clamp(min=1.0)
     shift = (log_mean_prior / np.log(10.0))[:, None]
     mean = (h * centres).sum(dim=2) / tot + shift

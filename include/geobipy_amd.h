@@ -258,7 +258,8 @@ typedef struct gbp_rj_chains {
     int64_t *n_accepted;           /* [B]                                                              */
     int32_t *k_hist;               /* [B, K + 1]            posterior of the layer count               */
     int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
-    int32_t *hitmap;               /* [B, n_depth_bins, n_value_bins] or NULL                           */
+    int32_t *hitmap;               /* [B, n_value_bins, n_depth_bins] or NULL (depth fastest: the cells of one layer share a
+                                      value bin, so one iteration updates a few contiguous runs)         */
     int32_t *burned_in_iteration;  /* [B]  schedule 1: -1 until the chain burns in (may be NULL for schedule 0)          */
     int32_t *status;               /* [B]  schedule 1: 0 running, 1 done, 2 failed to burn in                            */
     double *best_posterior;        /* [B]                                                              */

@@ -364,7 +364,7 @@ def test_posterior_accumulators_match_a_host_replay():
             hit[b, np.arange(nz), bins] += 1
     assert np.array_equal(dc.k_hist.cpu().numpy(), k_hist)
     assert np.array_equal(dc.edge_hist.cpu().numpy(), e_hist) and e_hist.sum() > 0
-    assert np.array_equal(dc.hitmap.cpu().numpy(), hit)
+    assert np.array_equal(dc.hitmap.cpu().numpy(), hit.transpose(0, 2, 1))      # stored [B, value, depth]
 
 
 @pytest.mark.gpu
