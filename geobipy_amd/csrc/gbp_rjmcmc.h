@@ -991,7 +991,7 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
         static int env = -2;
         if (env == -2) { const char* e = std::getenv("GBP_RJ_SENS_NW"); env = e ? std::atoi(e) : -1; }
         const int F = sys->t.nF;
-        const int want = env > 0 ? env : (int)((8192.0 + 0.4 * B - 1.0) / (0.4 * B));
+        const int want = env > 0 ? env : (int)((5000.0 + 0.4 * B - 1.0) / (0.4 * B));   // ~5000 working waves (measured optimum)
         sw = F;
         for (int d = 1; d <= F; ++d)
             if (F % d == 0 && d >= want) { sw = d; break; }
