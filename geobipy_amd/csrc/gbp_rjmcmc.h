@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
     if (i < 4) normal_pair(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 1, (uint32_t)i, z0, z1);
     const double za = __shfl(z0, base + (i >> 1), 64), zb = __shfl(z1, base + (i >> 1), 64);
     const double w = backward((i & 1) ? zb : za);    // C^-T z
-    if (live) {
+    if (live && i < K) {                             // (max_layers may be smaller than the group)
         const double lp = i < k ? (ls - o.alpha * step) + w : 0.0;
         c.log_prop[bb * K + i] = lp;
         c.sigma_p[bb * K + i] = i < k ? exp(lp) : 1.0;

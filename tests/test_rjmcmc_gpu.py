@@ -431,7 +431,8 @@ def test_reference_schedule_on_the_device_matches_a_host_replay():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("priors", [dict(), dict(solve_parameter=True, solve_gradient=False)])
+@pytest.mark.parametrize("priors", [dict(), dict(solve_parameter=True, solve_gradient=False),
+                                    dict(maximum_number_of_layers=4, probability_of_birth=0.4)])
 def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
     """BASELINE config 5's bar for the device sampler: a CPU implementation (rjmcmc.py pieces + the C oracle's forward
     and Jacobian) driven by the same counter-based streams walks the same chain -- every move, every accept / reject,
@@ -466,7 +467,8 @@ def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
         assert np.array_equal(tr[:, 0], acts[:, b]) and np.array_equal(tr[:, 1], accs[:, b]) and np.array_equal(tr[:, 2], ks[:, b]), b
         assert np.array_equal(c.k_hist, dc.k_hist[b].cpu().numpy()) and np.array_equal(c.edge_hist, dc.edge_hist[b].cpu().numpy())
         assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-6) and np.allclose(c.sigma, dc.sigma[b, : c.sigma.size].cpu().numpy(), rtol=1e-6)
-    assert accs.sum() > 0.25 * accs.size and len(np.unique(ks)) >= 3 and set(np.unique(acts)) == {0, 1, 2, 3}
+    assert accs.sum() > 0.2 * accs.size and len(np.unique(ks)) >= 3 and set(np.unique(acts)) == {0, 1, 2, 3}
+    assert ks.max() <= dc.K
 
 
 @pytest.mark.gpu
