@@ -331,6 +331,46 @@ def test_device_chains_state_is_coherent_after_many_steps():
 
 
 @pytest.mark.gpu
+def test_deep_chains_stay_coherent():
+    """Chains started from random models with up to 30 layers (the one-wave-per-chain newton / accept kernels and the deep
+    Jacobian bucket): after 60 iterations the carried prediction / misfit / likelihood / prior still describe the carried
+    model, and layers have been both added and removed."""
+    from geobipy_amd import FdemBatch, _lib
+    lib = _lib.load()
+    _, s, dc = _chains(512, 8, exact=True)
+    rng = np.random.default_rng(12)
+    ks0, _ = _load_random_state(dc, rng, kmax=dc.K)
+    dc.rel.fill_(0.05); dc.add.fill_(5.0)
+    B, Kp, h = dc.B, dc.K, dc._h.ptr
+    thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
+    _lib.check(lib.gbp_pin_forward_waves(4))
+    _lib.check(lib.gbp_fdem_forward_loglike(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
+                                            dc.data.data_ptr(), dc.rel.data_ptr(), dc.add.data_ptr(), dc.pred.data_ptr(),
+                                            dc.misfit.data_ptr(), dc.like.data_ptr(), None))
+    _lib.check(lib.gbp_fdem_sensitivity_ex(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
+                                           dc.J.data_ptr(), Kp, 1, None))
+    o = dc.o
+    full_prior = lambda: (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), Kp, dc.gradient_precision)
+                          + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
+                          + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
+    dc.prior.copy_(full_prior())
+    dc.best_posterior.copy_(dc.prior + dc.like)
+    dc.run(60)
+    k = dc.k.cpu().numpy()
+    n_acc = dc.n_accepted.cpu().numpy()
+    print("deep chains:", (k > 8).sum(), "changed k:", (k != ks0).sum(), "accepted moves of deep chains:", n_acc[ks0 > 8].sum())
+    assert (k > 8).sum() > 100 and (k != ks0).sum() > 30 and (k > ks0).any() and (k < ks0).any() and n_acc[ks0 > 8].sum() > 100
+    thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
+    assert torch.all(torch.where(thk > 0, thk, torch.full_like(thk, 9.0)) > dc.min_width)
+    fb = FdemBatch(s, k, dc.sigma.cpu().numpy(), thk.cpu().numpy(), dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
+                   relative_error=dc.rel.cpu().numpy(), additive_error=dc.add.cpu().numpy())
+    chi2, logl = fb.forward_loglike()
+    _lib.check(lib.gbp_pin_forward_waves(0))
+    assert torch.allclose(fb.predicted, dc.pred, rtol=1e-10, atol=1e-8) and torch.allclose(chi2, dc.misfit, rtol=1e-8)
+    assert torch.allclose(logl, dc.like, rtol=1e-9) and torch.allclose(full_prior(), dc.prior, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
 def test_device_chains_do_not_depend_on_the_sharding():
     """The random streams are keyed by the global chain index and forward_waves pins the summation order of the forward
     kernels: a block of 96 soundings run as one DeviceChains or as three shards of 32 gives bit-identical chains."""
