@@ -30,7 +30,7 @@ class RjOptions(ctypes.Structure):
 RJ_CHAIN_FIELDS = ("data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
-                   "hitmap", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")
+                   "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")
 
 
 class RjChains(ctypes.Structure):
@@ -46,6 +46,7 @@ SIGNATURES = {
     "gbp_rj_newton": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
     "gbp_rj_accept": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
+    "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
     "gbp_pin_forward_waves": (c_int, [c_int]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gbp_version": (ctypes.c_char_p, []),

@@ -506,6 +506,24 @@ __device__ inline double log_uniform_prior(double x, double lo, double hi)
     return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
 }
 
+// Conductivity-depth hit map (Model.update_parameter_posterior :819-847): `weight` counts of model (ec, sc, kc) added to one
+// chain's map hm[n_value_bins][n_depth_bins]; W lanes share the depth cells.  The samplers call it when a chain's model
+// changes (with the number of iterations the old model was the current one) instead of once per iteration.
+template <int W>
+__device__ inline void hitmap_add(const gbp_rj_options& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
+                                  int i, int weight)
+{
+    const double inv_ln10 = 0.43429448190325182765, Wd = o.value_half_width;
+    for (int cell = i; cell < o.n_depth_bins; cell += W) {
+        const double zc = ((double)cell + 0.5) * o.depth_bin_width;
+        int layer = 0;
+        while (layer < kc - 1 && ec[layer] <= zc) ++layer;
+        const double v = (log(sc[layer]) - lmp) * inv_ln10;
+        const int bin = min(max((int)floor((v + Wd) / (2.0 * Wd) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
+        hm[(size_t)bin * o.n_depth_bins + cell] += weight;       // depth fastest: a layer's cells are one contiguous run
+    }
+}
+
 __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
 {   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to k_rj_accept8
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -600,6 +618,13 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     __syncthreads();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
+    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
+    int dwell = c.hitmap != nullptr ? c.hit_dwell[b] : 0;        // iterations the current model is still owed to the hit map
+    if (accept && dwell > 0) {                                   // the model changes: settle the old one first
+        hitmap_add<64>(o, c.hitmap + (size_t)b * nh, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, c.k[b], lmp, lane, dwell);
+        dwell = 0;
+        __syncthreads();
+    }
     if (accept) {
         if (lane < K) {
             c.edges[(size_t)b * K + lane] = e[lane];
@@ -624,6 +649,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     const double* sc = accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K;
     const double post = (accept ? prior_p + like_p : c.prior[b] + c.like[b]);
     bool reset_best = false;
+    int finished = 0;
     if (o.schedule == 1) {                                       // the reference's per-sounding schedule
         const int it1 = (int)iter + 1;                           //   (Inference1D.update :713-737, infer :641-688)
         int bi = c.burned_in_iteration[b];
@@ -639,18 +665,16 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
                 if (c.edge_hist != nullptr)
                     for (int i = lane; i < o.n_depth_bins; i += 64) c.edge_hist[(size_t)b * o.n_depth_bins + i] = 0;
                 if (c.hitmap != nullptr) {
-                    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
                     for (size_t i = lane; i < nh; i += 64) c.hitmap[(size_t)b * nh + i] = 0;
+                    dwell = 0;
                 }
                 __syncthreads();
                 if (lane == 0) c.burned_in_iteration[b] = bi;
             }
         }
         accumulate = 1;                                          // every iteration; the reset above discards the burn-in
-        if (lane == 0) {
-            if (bi >= 0 && it1 > o.n_markov_chains + bi) c.status[b] = 1;          // done: n_markov_chains samples collected
-            else if (bi < 0 && it1 >= o.n_markov_chains) c.status[b] = 2;          // failed to burn in
-        }
+        finished = (bi >= 0 && it1 > o.n_markov_chains + bi) ? 1 : ((bi < 0 && it1 >= o.n_markov_chains) ? 2 : 0);
+        if (lane == 0 && finished) c.status[b] = finished;      // 1 done: n_markov_chains samples collected; 2 failed to burn in
     }
     if (reset_best || post > c.best_posterior[b]) {
         if (lane < K) { c.best_edges[(size_t)b * K + lane] = ec[lane]; c.best_sigma[(size_t)b * K + lane] = sc[lane]; }
@@ -666,17 +690,15 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
                 atomicAdd(c.edge_hist + (size_t)b * o.n_depth_bins + bin, 1);
             }
         }
-        if (c.hitmap != nullptr) {                               // conductivity-depth hit map (Model.update_parameter_posterior :819-847)
-            const double inv_ln10 = 0.43429448190325182765, W = o.value_half_width;
-            for (int cell = lane; cell < o.n_depth_bins; cell += 64) {
-                const double zc = ((double)cell + 0.5) * o.depth_bin_width;
-                int layer = 0;
-                while (layer < kc - 1 && ec[layer] <= zc) ++layer;
-                const double v = (log(sc[layer]) - lmp) * inv_ln10;
-                const int bin = min(max((int)floor((v + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
-                c.hitmap[((size_t)b * o.n_value_bins + bin) * o.n_depth_bins + cell] += 1;   // depth fastest: a layer's cells are contiguous
-            }
+    }
+    if (c.hitmap != nullptr) {
+        if (accumulate) dwell += 1;
+        if (finished && dwell > 0) {                             // the chain stops here: settle its last model
+            __syncthreads();
+            hitmap_add<64>(o, c.hitmap + (size_t)b * nh, ec, sc, kc, lmp, lane, dwell);
+            dwell = 0;
         }
+        if (lane == 0) c.hit_dwell[b] = dwell;
     }
 }
 
@@ -687,6 +709,34 @@ __device__ inline double group_sum8(double v)
 {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
     return v;
+}
+
+// hitmap_add for the packed kernel (kc <= 8, 8 lanes per chain): the interface depths and the value bin of every layer
+// are gathered into registers once (cross-lane reads issued by the whole wave), so a depth cell costs a few compares
+// instead of a logarithm and a search through global memory.  Called by all 8 lanes of a group; `on`: the group really adds.
+__device__ inline void hitmap_add8(const gbp_rj_options& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
+                                   int i, int base, int weight, bool on)
+{
+    const double inv_ln10 = 0.43429448190325182765, Wd = o.value_half_width;
+    double my_edge = INF;
+    int my_bin = 0;
+    if (on && i < kc) {
+        const double v = (log(sc[i]) - lmp) * inv_ln10;
+        my_bin = min(max((int)floor((v + Wd) / (2.0 * Wd) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
+        if (i < kc - 1) my_edge = ec[i];
+    }
+    double edge[8];
+    int bin[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { edge[j] = __shfl(my_edge, base + j, 64); bin[j] = __shfl(my_bin, base + j, 64); }
+    if (!on) return;
+    for (int cell = i; cell < o.n_depth_bins; cell += 8) {
+        const double zc = ((double)cell + 0.5) * o.depth_bin_width;
+        int b = bin[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) b = edge[j - 1] <= zc ? bin[j] : b;       // interfaces ascend (+inf beyond the last)
+        hm[(size_t)b * o.n_depth_bins + cell] += weight;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
@@ -806,8 +856,15 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
     const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
-    if (!live || frozen) return;                     // (no cross-lane reads below this line)
+    if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
     const double misfit_c = c.misfit[bb];
+    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
+    int dwell = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
+    if (c.hitmap != nullptr) {                       // the model changes: settle the old one in the hit map first
+        const bool on = accept && dwell > 0;
+        hitmap_add8(o, c.hitmap + bb * nh, c.edges + bb * K, c.sigma + bb * K, k_prev, lmp, i, base, dwell, on);
+        if (on) dwell = 0;
+    }
     if (accept) {
         for (int j = i; j < K; j += 8) {
             c.edges[bb * K + j] = e[j];
@@ -831,6 +888,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     const double* sc = accept ? c.sigma_p + bb * K : c.sigma + bb * K;
     const double post = accept ? prior_p + like_p : prior_c + like_c;
     bool reset_best = false;
+    int finished = 0;
     if (o.schedule == 1) {
         const int it1 = (int)iter + 1;
         int bi = c.burned_in_iteration[bb];
@@ -846,17 +904,15 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                 if (c.edge_hist != nullptr)
                     for (int q = i; q < o.n_depth_bins; q += 8) c.edge_hist[bb * o.n_depth_bins + q] = 0;
                 if (c.hitmap != nullptr) {
-                    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
                     for (size_t q = i; q < nh; q += 8) c.hitmap[bb * nh + q] = 0;
+                    dwell = 0;
                 }
                 if (i == 0) c.burned_in_iteration[bb] = bi;
             }
         }
         accumulate = 1;
-        if (i == 0) {
-            if (bi >= 0 && it1 > o.n_markov_chains + bi) c.status[bb] = 1;
-            else if (bi < 0 && it1 >= o.n_markov_chains) c.status[bb] = 2;
-        }
+        finished = (bi >= 0 && it1 > o.n_markov_chains + bi) ? 1 : ((bi < 0 && it1 >= o.n_markov_chains) ? 2 : 0);
+        if (i == 0 && finished) c.status[bb] = finished;
     }
     if (reset_best || post > best_prev) {
         for (int j = i; j < K; j += 8) { c.best_edges[bb * K + j] = ec[j]; c.best_sigma[bb * K + j] = sc[j]; }
@@ -872,18 +928,28 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                 atomicAdd(c.edge_hist + bb * o.n_depth_bins + bin, 1);
             }
         }
-        if (c.hitmap != nullptr) {
-            const double inv_ln10 = 0.43429448190325182765, W = o.value_half_width;
-            for (int cell = i; cell < o.n_depth_bins; cell += 8) {
-                const double zc = ((double)cell + 0.5) * o.depth_bin_width;
-                int layer = 0;
-                while (layer < kc - 1 && ec[layer] <= zc) ++layer;
-                const double vv = (log(sc[layer]) - lmp) * inv_ln10;
-                const int bin = min(max((int)floor((vv + W) / (2.0 * W) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
-                c.hitmap[(bb * o.n_value_bins + bin) * o.n_depth_bins + cell] += 1;
-            }
-        }
     }
+    if (c.hitmap != nullptr) {
+        if (accumulate) dwell += 1;
+        if (finished && dwell > 0) {                 // (rare: the generic routine, no cross-lane reads)
+            hitmap_add<8>(o, c.hitmap + bb * nh, ec, sc, kc, lmp, i, dwell);
+            dwell = 0;
+        }
+        if (i == 0) c.hit_dwell[bb] = dwell;
+    }
+}
+
+// Settles what the chains' current models are still owed in the hit map (call before reading it).
+__global__ __launch_bounds__(64) void k_rj_flush(gbp_rj_options o, gbp_rj_chains c)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int dwell = c.hit_dwell[b];
+    if (dwell <= 0) return;
+    const int K = o.max_layers;
+    hitmap_add<64>(o, c.hitmap + (size_t)b * o.n_depth_bins * o.n_value_bins, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, c.k[b],
+                   c.log_mean_prior[b], lane, dwell);
+    __syncthreads();
+    if (lane == 0) c.hit_dwell[b] = 0;
 }
 
 __global__ void k_rj_debug_random(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, int n, double* uni, double* nor)
@@ -918,6 +984,7 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
     if ((c->edge_hist || c->hitmap) && (o->n_depth_bins < 1 || !(o->depth_bin_width > 0.0)))
         return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
     if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");
+    if (c->hitmap && !c->hit_dwell) return fail(GBP_ERR_INVALID_ARG, "hitmap needs hit_dwell%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
                           c->like, c->misfit, c->action, c->k_r, c->nl_a, c->nl_b, c->nl_c, c->edges_r, c->sigma_r, c->thk_r, c->rel_p,
                           c->add_p, c->pred_r, c->J_r, c->chol, c->log_prop, c->sigma_p, c->pred_p, c->misfit_p, c->like_p,
@@ -1015,6 +1082,15 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
                                         c->J_p, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
         if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
     }
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_flush_posteriors(const gbp_rj_options* o, const gbp_rj_chains* c, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK || c->B == 0 || !c->hitmap) return st;
+    hipLaunchKernelGGL(rj::k_rj_flush, dim3(c->B), dim3(64), 0, (hipStream_t)stream, *o, *c);
+    GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
 

@@ -150,6 +150,7 @@ class DeviceChains:
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
             edge_hist=z(B, self.n_depth_bins, dt=i32),
             hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
+            hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K))
         rc = _lib.RjChains()
@@ -167,6 +168,10 @@ class DeviceChains:
     def __getattr__(self, name):              # chain state by the names of gbp_rj_chains
         t = self.__dict__.get("t")
         if t is not None and name in t:
+            if name == "hitmap" and t["hitmap"] is not None:
+                # a model enters the hit map with its dwell time when it is replaced; settle the current models first
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.load().gbp_rj_flush_posteriors(self._o, self._c, self._stream()))
             return t[name]
         raise AttributeError(name)
 

@@ -251,7 +251,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             f64(t["best_k"]), t["best_posterior"]]
     blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"])]
     if hitmap:
-        mean, pct = _hitmap_statistics(t["hitmap"], t["log_mean_prior"], dc.value_half_width)
+        mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
         blocks += [mean] + pct
     local = torch.cat(blocks, dim=1).contiguous()
     if world > 1:                                   # the one exchange of the job: per-sounding result rows to rank 0

@@ -260,6 +260,8 @@ typedef struct gbp_rj_chains {
     int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
     int32_t *hitmap;               /* [B, n_value_bins, n_depth_bins] or NULL (depth fastest: the cells of one layer share a
                                       value bin, so one iteration updates a few contiguous runs)         */
+    int32_t *hit_dwell;            /* [B] (with hitmap)  iterations the current model is still owed to the hit map: a model is
+                                      added with its dwell time when it is replaced; gbp_rj_flush_posteriors settles the rest */
     int32_t *burned_in_iteration;  /* [B]  schedule 1: -1 until the chain burns in (may be NULL for schedule 0)          */
     int32_t *status;               /* [B]  schedule 1: 0 running, 1 done, 2 failed to burn in                            */
     double *best_posterior;        /* [B]                                                              */
@@ -277,6 +279,8 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
+/* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
+gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chains *c, void *stream);
 /* Pin (waves > 0) or release (0) the waves per workgroup of the forward kernels launched from the calling thread;
  * same meaning as gbp_rj_options.forward_waves, for the forward calls made outside gbp_rj_run (chain initialisation). */
 gbp_status gbp_pin_forward_waves(int waves);
