@@ -113,6 +113,44 @@ def _load_random_state(dc, rng, kmax):
 
 
 @pytest.mark.gpu
+def test_rj_entries_refuse_bad_arguments():
+    """gbp_rj_* validate what they can on the host: sizes, NULL pointers, the option / buffer combinations."""
+    import copy
+    from geobipy_amd import _lib
+    lib = _lib.load()
+    _, _, dc = _chains(8, 1)
+
+    def status(o=None, c=None, run=True):
+        o, c = o or dc._o, c or dc._c
+        return lib.gbp_rj_run(dc._h.ptr, o, c, 0, 1, 0, None) if run else lib.gbp_rj_propose(o, c, 0, None)
+
+    def opt(**kw):
+        o = _lib.RjOptions.from_buffer_copy(dc._o)
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def chains(**kw):
+        c = _lib.RjChains.from_buffer_copy(dc._c)
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    assert status() == 0
+    for bad in (opt(max_layers=1), opt(max_layers=65), opt(n_channels=0), opt(min_width=0.0), opt(max_edge=0.5),
+                opt(n_channels=10), opt(n_depth_bins=0)):
+        assert status(o=bad) == -1, "GBP_ERR_INVALID_ARG expected"
+        assert b"" != lib.gbp_last_error()
+    for bad in (chains(sigma=None), chains(J_p=None), chains(nl_b=None), chains(B=-1), chains(hitmap=dc.k_hist.data_ptr())):
+        assert status(c=bad) == -1
+    assert lib.gbp_rj_run(None, dc._o, dc._c, 0, 1, 0, None) == -1
+    assert status(o=opt(schedule=1, n_markov_chains=10), c=chains(status=None)) == -1
+    assert status(c=chains(B=0)) == 0                                   # an empty block is fine
+    assert lib.gbp_pin_forward_waves(17) == -1 and lib.gbp_pin_forward_waves(0) == 0
+    assert lib.gbp_rj_flush_posteriors(dc._o, dc._c, None) == 0         # no hit map: nothing to do
+
+
+@pytest.mark.gpu
 def test_device_random_streams_match_the_emulation():
     from geobipy_amd import _lib
     n = 64
