@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
 // abscissa in LDS (row m, column lane, row stride 65 slots so that the row sums below are conflict-free),
 // lane m then sums row m over the 64 abscissae.  J[b, f, m] = Re(g * sum), J[b, F + f, m] = Im(g * sum).
 #define GBP_SENS_STRIDE 65
-template <bool EXACT>
+template <bool EXACT, int NG>   // NG row groups of 8 layers are summed per evaluation: 1 for models of <= 8 layers, else 8
 __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ chan, const double* __restrict__ pts,
                                                     int npts_total, int F, int Lmax, int Lalloc,
                                                     const int* __restrict__ nlayers,
@@ -306,8 +306,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
         // of row m0 + row (consecutive lanes -> consecutive 16-byte slots: conflict-free ds_read_b128), the 8
         // segment partials are combined with three xor-shuffles once per frequency.
         const int row = lane >> 3, seg = lane & 7;
-        constexpr int NG = 8;                          // 8 row groups of 8 layers are summed per evaluation
-        for (int m0 = 0; m0 < L; m0 += 8 * NG) {       // (L <= 64: this loop runs once; deeper models re-evaluate)
+        for (int m0 = 0; m0 < L; m0 += 8 * NG) {       // (runs once for L <= 8 NG; deeper models re-evaluate)
             double acc_re[NG], acc_im[NG];
             double fw_re = 0.0, fw_im = 0.0;       // this lane's share of the forward sum (fm_dlogc)
 #pragma unroll
@@ -728,17 +727,17 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system* sys, int B, int Lmax, const 
     if (nw > sys->t.nF) nw = sys->t.nF;
     while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
     const size_t lds = nw * per_wave + (size_t)max_layers * 8;
-    if (exact) {
-        if (lds > 48 * 1024)
-            GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fdem_sens<true>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
-                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
-    } else {
-        if (lds > 48 * 1024)
-            GBP_HIP(hipFuncSetAttribute((const void*)k_fdem_sens<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fdem_sens<false>, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts,
-                           sys->t.npts, sys->t.nF, Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
-    }
+    auto launch = [&](auto kernel) -> gbp_status {
+        if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
+                           Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
+        return GBP_OK;
+    };
+    // shallow launches (the sampler's common case) use the variant with one row group: 28 fewer VGPRs, one more wave per SIMD
+    const bool shallow = max_layers <= 8;
+    st = exact ? (shallow ? launch(k_fdem_sens<true, 1>) : launch(k_fdem_sens<true, 8>))
+               : (shallow ? launch(k_fdem_sens<false, 1>) : launch(k_fdem_sens<false, 8>));
+    if (st != GBP_OK) return st;
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
