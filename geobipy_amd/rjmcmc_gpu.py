@@ -103,6 +103,9 @@ class DeviceChains:
         self.min_width = float(o["minimum_thickness"])
         self.min_edge = max(float(o["minimum_depth"]), self.min_width)      # RectilinearMesh1D.py:358-360
         self.max_edge = float(o["maximum_depth"])
+        assert self.min_width * self.K < self.max_edge, ValueError(          # RectilinearMesh1D.set_priors :1523
+            "minimum_thickness * maximum_number_of_layers = {} is bigger than maximum_depth {}".format(self.min_width * self.K,
+                                                                                                       self.max_edge))
         self.gradient_precision = 1.0 / o["gradient_standard_deviation"] ** 2
         p = np.array([o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
                       o["probability_of_no_change"]], dtype=np.float64)
