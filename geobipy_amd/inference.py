@@ -84,6 +84,49 @@ def initial_state(engine, data, o):
     return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit)
 
 
+class Posteriors:
+    """The posteriors Inference1D.update accumulates every iteration (Model.update_posteriors, model/Model.py:810-847;
+    RectilinearMesh1D.update_posteriors, mesh/RectilinearMesh1D.py:1595-1610), on the reference's grids
+    (RectilinearMesh1D.set_posteriors :1438-1455, Model.set_posteriors): layer-count histogram, interface-depth histogram
+    (interfaces across which the conductivity changes by more than ``ratio``) and the conductivity-depth hit map
+    ``values[n_value_bins, n_depth_bins]`` on log10(sigma / prior mean) in +-4 prior standard deviations.  Host-side
+    (numpy) twin of the accumulators of the device sampler; the reference's own counts are reproduced bit for bit
+    (tests/test_rjmcmc.py)."""
+
+    def __init__(self, max_cells, max_edge, min_width, value_mean, factor=10.0, n_value_bins=250, ratio=0.5):
+        self.ratio = ratio
+        self.depth_edges = np.arange(0.0, 1.1 * max_edge, 0.5 * min_width)
+        self.depth_centres = 0.5 * (self.depth_edges[:-1] + self.depth_edges[1:])
+        half = 4.0 * np.sqrt(np.log(1.0 + factor) ** 2.0)           # MvNormal.bins(nBins, nStd=4): +- 4 std of ln sigma ...
+        self.value_edges = np.linspace(-half, half, n_value_bins + 1) / np.log(10.0)   # ... on a log10 axis
+        self.relative_to = np.log10(value_mean)
+        self.n_cells = np.zeros(int(max_cells) + 1, dtype=np.int64)
+        self.edges = np.zeros(self.depth_centres.size, dtype=np.int64)
+        self.values = np.zeros((n_value_bins, self.depth_centres.size), dtype=np.int64)
+
+    def reset(self):
+        for a in (self.n_cells, self.edges, self.values):
+            a[:] = 0
+
+    def update(self, edges, values):
+        """``edges``: interior interface depths; ``values``: layer conductivities."""
+        k = values.size
+        self.n_cells[k] += 1
+        if k > 1:
+            r = np.exp(np.diff(np.log(values)))
+            d = edges[(r <= 1.0 - self.ratio) | (r >= 1.0 + self.ratio)]
+            d = d[(d >= self.depth_edges[0]) & (d < self.depth_edges[-1])]           # Histogram.update(trim=True)
+            np.add.at(self.edges, np.searchsorted(self.depth_edges, d, side="right") - 1, 1)
+            # the reference's piecewise-constant interpolation: a ramp of relative width 1e-6 below every interface
+            full = np.r_[0.0, edges, self.depth_edges[-1]]
+            xp = np.kron(full, [1.0, 1.000001])[1:-1]
+            at_centres = np.interp(self.depth_centres, xp, np.kron(values, [1.0, 1.0]))
+        else:
+            at_centres = np.full(self.depth_centres.size, values[0])
+        i0 = np.searchsorted(self.value_edges, np.log10(at_centres) - self.relative_to, side="right") - 1
+        self.values[np.clip(i0, 0, self.values.shape[0] - 1), np.arange(self.depth_centres.size)] += 1
+
+
 class Inference1D:
     """rjMCMC for one FDEM sounding.  ``options``: the keys of the reference's options file
     (documentation_source/source/supplementary/options_files/resolve_options)."""
@@ -108,6 +151,9 @@ class Inference1D:
         self.data_misfit_v[0] = self.state.misfit
         self.acceptance_v = np.zeros(2 * self.n_markov_chains, dtype=np.uint8)
         self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, 0
+        o = self.options
+        self.posteriors = Posteriors(o["maximum_number_of_layers"], o["maximum_depth"], o["minimum_thickness"],
+                                     float(self.halfspace[0]), o["factor"])
 
     # the quantities the reference exposes on its Inference1D
     @property
@@ -138,12 +184,14 @@ class Inference1D:
         return False
 
     def update(self):
-        """Bookkeeping of Inference1D.update (:705-790) that does not need the posterior histograms."""
+        """Bookkeeping of Inference1D.update (:705-790): misfit trace, best model, acceptance, posterior histograms (the
+        burn-in reset of the reference's schedule lives in the device sampler, rjmcmc_gpu.DeviceChains)."""
         self.iteration += 1
         self.data_misfit_v[self.iteration - 1] = self.state.misfit
         if self.posterior > self.best_posterior:
             self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
         self.acceptance_v[self.iteration] = self.accepted
+        self.posteriors.update(self.state.edges, self.state.values)
 
     def infer(self, n_iterations=None):
         for _ in range(self.n_markov_chains if n_iterations is None else n_iterations):

@@ -173,6 +173,18 @@ def main():
         print("long run: acceptance", out["long_accepted"].mean(), "k max", out["long_k"].max())
         return
     else:
+        # the posteriors the reference accumulated over the N_LONG iterations (Inference1D.update -> Model.update_posteriors,
+        # model/Model.py:819-847, mesh/RectilinearMesh1D.py:1595-1610); the chain never burns in on this sounding, so nothing
+        # is reset: layer-count histogram, interface-depth histogram (0.5 m cells to 220 m), conductivity-depth hit map
+        # [250 value cells (log10 relative to the prior mean) x 440 depth cells]
+        m = inf.model
+        hv = m.values.posterior
+        out["post_ncells"] = np.asarray(m.mesh.nCells.posterior.counts, dtype=np.int64)
+        out["post_edges"] = np.asarray(m.mesh.edges.posterior.counts, dtype=np.int64)
+        out["post_values"] = np.asarray(hv.counts, dtype=np.int32)
+        out["post_values_x_edges"] = np.asarray(hv.mesh.x.edges, dtype=float)
+        out["post_values_relative_to"] = np.float64(np.asarray(hv.mesh.x.relative_to).item())
+        out["post_burned_in"] = np.bool_(inf.burned_in)
         np.savez_compressed(HERE + "/mcmc_detail.npz", **out)
     a = out["action"]
     print("long run: acceptance", out["long_accepted"].mean(), "k max", out["long_k"].max())

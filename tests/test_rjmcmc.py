@@ -162,13 +162,31 @@ def test_value_prior_chain_reproduces_the_reference_decisions():
     assert np.allclose(mis, d["long_misfit"], rtol=1e-7) and d["long_accepted"].sum() > 200
 
 
-def test_long_chain_reproduces_the_reference_decisions():
-    """The same without resynchronisation for 3000 iterations (1448 accepted proposals)."""
+def test_long_chain_reproduces_the_reference_decisions_and_posteriors():
+    """The same without resynchronisation for 3000 iterations (1448 accepted proposals), accumulating the posteriors the way
+    Inference1D.update does: the reference's own layer-count histogram, interface-depth histogram and conductivity-depth
+    hit map (1.32 M counts in 250 x 440 cells) are reproduced bit for bit."""
+    from geobipy_amd import rjmcmc
+    from geobipy_amd.inference import Posteriors
     d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
     n = d["long_accepted"].size
-    acc, ks, mis, _ = run_chain(d, OracleEngine("resolve", float(d["z"])), n)
+    eng = OracleEngine("resolve", float(d["z"]))
+    sp, vp, rp, ap, st, alpha = chain_setup(d)
+    o = d["options"]
+    post = Posteriors(o[0], o[2], o[3], d["halfspace"].item(), o[10])
+    assert np.allclose(post.value_edges, d["post_values_x_edges"], rtol=0, atol=1e-14) and np.isclose(post.relative_to, d["post_values_relative_to"], rtol=1e-15)
+    prng = generator_at(d["rng_state"][0])
+    acc, ks, mis = [], [], []
+    for it in range(n):
+        a, st = rjmcmc.accept_reject(prng, st, d["data"], eng, sp, vp, rp, ap, alpha)
+        acc.append(a); ks.append(st.k); mis.append(st.misfit)
+        post.update(st.edges, st.values)
     assert n == 3000 and np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
     assert np.allclose(mis, d["long_misfit"], rtol=1e-8)
+    assert not d["post_burned_in"]
+    assert np.array_equal(post.n_cells, d["post_ncells"])
+    assert np.array_equal(post.edges, d["post_edges"]) and post.edges.sum() == 1947
+    assert np.array_equal(post.values, d["post_values"]) and post.values.sum() == 3000 * 440
 
 
 def test_initial_state_matches_the_reference_initialisation():

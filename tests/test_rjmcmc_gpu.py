@@ -421,28 +421,26 @@ def test_device_chains_do_not_depend_on_the_sharding():
 
 @pytest.mark.gpu
 def test_posterior_accumulators_match_a_host_replay():
-    _, _, dc = _chains(16, 4, exact=True, hitmap=True, n_value_bins=50)
-    dc.run(200, accumulate=False)                                # burn-in: nothing is accumulated
-    assert int(dc.k_hist.sum()) == 0 and int(dc.edge_hist.sum()) == 0 and int(dc.hitmap.sum()) == 0
-    B, nz, nv, w, W = dc.B, dc.n_depth_bins, dc.n_value_bins, dc.depth_bin_width, dc.value_half_width
-    k_hist, e_hist, hit = np.zeros((B, dc.K + 1), int), np.zeros((B, nz), int), np.zeros((B, nz, nv), int)
-    zc = (np.arange(nz) + 0.5) * w
-    lmp = dc.log_mean_prior.cpu().numpy()
-    for _ in range(150):
-        dc.step()
-        k, e, s = dc.k.cpu().numpy(), dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
-        for b in range(B):
-            k_hist[b, k[b]] += 1
-            ratio = s[b, 1:k[b]] / s[b, : k[b] - 1]
-            for depth in e[b, : k[b] - 1][(ratio <= 0.5) | (ratio >= 1.5)]:
-                e_hist[b, min(int(depth // w), nz - 1)] += 1
-            layer = np.searchsorted(e[b, : k[b] - 1], zc, side="right")
-            v = (np.log(s[b, layer]) - lmp[b]) / math.log(10.0)
-            bins = np.clip(np.floor((v + W) / (2 * W) * nv).astype(int), 0, nv - 1)
-            hit[b, np.arange(nz), bins] += 1
-    assert np.array_equal(dc.k_hist.cpu().numpy(), k_hist)
-    assert np.array_equal(dc.edge_hist.cpu().numpy(), e_hist) and e_hist.sum() > 0
-    assert np.array_equal(dc.hitmap.cpu().numpy(), hit.transpose(0, 2, 1))      # stored [B, value, depth]
+    """The device accumulators against inference.Posteriors -- the host rule that reproduces the reference's own posterior
+    counts bit for bit (tests/test_rjmcmc.py) -- fed with the chains' states iteration by iteration: layer-count
+    histogram, interface-depth histogram, conductivity-depth hit map (also the default 250-bin value axis)."""
+    from geobipy_amd.inference import Posteriors
+    for nv in (50, 250):
+        _, _, dc = _chains(16, 4, exact=True, hitmap=True, n_value_bins=nv)
+        dc.run(200, accumulate=False)                            # burn-in: nothing is accumulated
+        assert int(dc.k_hist.sum()) == 0 and int(dc.edge_hist.sum()) == 0 and int(dc.hitmap.sum()) == 0
+        o = dc.o
+        mean = np.exp(dc.log_mean_prior.cpu().numpy())
+        posts = [Posteriors(dc.K, o["maximum_depth"], o["minimum_thickness"], mean[b], o["factor"], n_value_bins=nv) for b in range(dc.B)]
+        assert posts[0].depth_centres.size == dc.n_depth_bins and np.isclose(posts[0].value_edges[-1], dc.value_half_width, rtol=1e-14)
+        for _ in range(150):
+            dc.step()
+            k, e, s = dc.k.cpu().numpy(), dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
+            for b in range(dc.B):
+                posts[b].update(e[b, : k[b] - 1], s[b, : k[b]])
+        assert np.array_equal(dc.k_hist.cpu().numpy(), np.stack([p.n_cells for p in posts]))
+        assert np.array_equal(dc.edge_hist.cpu().numpy(), np.stack([p.edges for p in posts])) and dc.edge_hist.sum() > 0
+        assert np.array_equal(dc.hitmap.cpu().numpy(), np.stack([p.values for p in posts]))    # [B, value, depth] both
 
 
 @pytest.mark.gpu
