@@ -19,7 +19,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 class RjOptions(ctypes.Structure):
     """gbp_rj_options (include/geobipy_amd.h)."""
     _fields_ = ([(n, ctypes.c_int32) for n in ("max_layers", "n_channels", "solve_gradient", "solve_value", "solve_relative_error",
-                                               "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "schedule",
+                                               "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "n_error_bins", "schedule",
                                                "burn_in_min_iterations", "n_markov_chains", "forward_waves")]
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
                                                   "value_precision", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
@@ -30,7 +30,7 @@ class RjOptions(ctypes.Structure):
 RJ_CHAIN_FIELDS = ("data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
-                   "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")
+                   "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")
 
 
 class RjChains(ctypes.Structure):

@@ -506,6 +506,18 @@ __device__ inline double log_uniform_prior(double x, double lo, double hi)
     return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
 }
 
+// Error-level posteriors (DataPoint.set_posteriors :651-694): n_error_bins cells uniform in log10 between the prior bounds.
+__device__ inline void error_hist_add(const gbp_rj_options& o, const gbp_rj_chains& c, size_t b, double rel, double add)
+{
+    if (c.rel_hist == nullptr) return;
+    const double inv_ln10 = 0.43429448190325182765, nb = (double)o.n_error_bins;
+    const double r0 = log(o.rel_min) * inv_ln10, r1 = log(o.rel_max) * inv_ln10, a0 = log(o.add_min) * inv_ln10, a1 = log(o.add_max) * inv_ln10;
+    const int ir = min(max((int)floor((log(rel) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
+    const int ia = min(max((int)floor((log(add) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
+    c.rel_hist[b * o.n_error_bins + ir] += 1;
+    c.add_hist[b * o.n_error_bins + ia] += 1;
+}
+
 // Conductivity-depth hit map (Model.update_parameter_posterior :819-847): `weight` counts of model (ec, sc, kc) added to one
 // chain's map hm[n_value_bins][n_depth_bins]; W lanes share the depth cells.  The samplers call it when a chain's model
 // changes (with the number of iterations the old model was the current one) instead of once per iteration.
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     __syncthreads();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
+    const double rel_c = c.rel[b], add_c = c.add[b];             // (read before the state is overwritten)
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[b] : 0;        // iterations the current model is still owed to the hit map
     if (accept && dwell > 0) {                                   // the model changes: settle the old one first
@@ -662,6 +675,11 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
                 bi = it1;
                 reset_best = true;
                 for (int i = lane; i < K + 1; i += 64) c.k_hist[(size_t)b * (K + 1) + i] = 0;
+                if (c.rel_hist != nullptr)
+                    for (int i = lane; i < o.n_error_bins; i += 64) {
+                        c.rel_hist[(size_t)b * o.n_error_bins + i] = 0;
+                        c.add_hist[(size_t)b * o.n_error_bins + i] = 0;
+                    }
                 if (c.edge_hist != nullptr)
                     for (int i = lane; i < o.n_depth_bins; i += 64) c.edge_hist[(size_t)b * o.n_depth_bins + i] = 0;
                 if (c.hitmap != nullptr) {
@@ -682,7 +700,10 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         if (lane == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
     }
     if (accumulate) {
-        if (lane == 0) c.k_hist[(size_t)b * (K + 1) + kc] += 1;
+        if (lane == 0) {
+            c.k_hist[(size_t)b * (K + 1) + kc] += 1;
+            error_hist_add(o, c, (size_t)b, accept ? rel_p : rel_c, accept ? add_p : add_c);
+        }
         if (c.edge_hist != nullptr && lane < kc - 1) {           // interfaces across which sigma changes by > 50 %
             const double ratio = sc[lane + 1] / sc[lane];        //   (RectilinearMesh1D.update_posteriors :1595-1610)
             if (ratio <= 0.5 || ratio >= 1.5) {
@@ -857,7 +878,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
-    const double misfit_c = c.misfit[bb];
+    const double misfit_c = c.misfit[bb], rel_c = c.rel[bb], add_c = c.add[bb];       // (read before the state is overwritten)
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
     if (c.hitmap != nullptr) {                       // the model changes: settle the old one in the hit map first
@@ -901,6 +922,8 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                 bi = it1;
                 reset_best = true;
                 for (int q = i; q < K + 1; q += 8) c.k_hist[bb * (K + 1) + q] = 0;
+                if (c.rel_hist != nullptr)
+                    for (int q = i; q < o.n_error_bins; q += 8) { c.rel_hist[bb * o.n_error_bins + q] = 0; c.add_hist[bb * o.n_error_bins + q] = 0; }
                 if (c.edge_hist != nullptr)
                     for (int q = i; q < o.n_depth_bins; q += 8) c.edge_hist[bb * o.n_depth_bins + q] = 0;
                 if (c.hitmap != nullptr) {
@@ -920,7 +943,10 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     }
     if (accumulate) {
         // (the k_hist row may have been zeroed by other lanes of the group just above: same wave, program order)
-        if (i == 0) c.k_hist[bb * (K + 1) + kc] += 1;
+        if (i == 0) {
+            c.k_hist[bb * (K + 1) + kc] += 1;
+            error_hist_add(o, c, bb, accept ? rel_p : rel_c, accept ? add_p : add_c);
+        }
         if (c.edge_hist != nullptr && i < kc - 1) {
             const double ratio = sc[i + 1] / sc[i];
             if (ratio <= 0.5 || ratio >= 1.5) {
@@ -985,6 +1011,8 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
         return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
     if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");
     if (c->hitmap && !c->hit_dwell) return fail(GBP_ERR_INVALID_ARG, "hitmap needs hit_dwell%s");
+    if ((c->rel_hist != nullptr) != (c->add_hist != nullptr) || (c->rel_hist && o->n_error_bins < 1))
+        return fail(GBP_ERR_INVALID_ARG, "rel_hist and add_hist come together, with n_error_bins >= 1%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
                           c->like, c->misfit, c->action, c->k_r, c->nl_a, c->nl_b, c->nl_c, c->edges_r, c->sigma_r, c->thk_r, c->rel_p,
                           c->add_p, c->pred_r, c->J_r, c->chol, c->log_prop, c->sigma_p, c->pred_p, c->misfit_p, c->like_p,

@@ -93,8 +93,14 @@ class Posteriors:
     (numpy) twin of the accumulators of the device sampler; the reference's own counts are reproduced bit for bit
     (tests/test_rjmcmc.py)."""
 
-    def __init__(self, max_cells, max_edge, min_width, value_mean, factor=10.0, n_value_bins=250, ratio=0.5):
+    def __init__(self, max_cells, max_edge, min_width, value_mean, factor=10.0, n_value_bins=250, ratio=0.5,
+                 relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99):
         self.ratio = ratio
+        # error levels (DataPoint.set_posteriors :651-694): n_error_bins cells, uniform in log10 between the prior bounds
+        self.rel_edges = None if relative_error_bounds is None else np.linspace(*np.log10(relative_error_bounds), n_error_bins + 1)
+        self.add_edges = None if additive_error_bounds is None else np.linspace(*np.log10(additive_error_bounds), n_error_bins + 1)
+        self.relative_error = np.zeros(n_error_bins, dtype=np.int64)
+        self.additive_error = np.zeros(n_error_bins, dtype=np.int64)
         self.depth_edges = np.arange(0.0, 1.1 * max_edge, 0.5 * min_width)
         self.depth_centres = 0.5 * (self.depth_edges[:-1] + self.depth_edges[1:])
         half = 4.0 * np.sqrt(np.log(1.0 + factor) ** 2.0)           # MvNormal.bins(nBins, nStd=4): +- 4 std of ln sigma ...
@@ -105,11 +111,14 @@ class Posteriors:
         self.values = np.zeros((n_value_bins, self.depth_centres.size), dtype=np.int64)
 
     def reset(self):
-        for a in (self.n_cells, self.edges, self.values):
+        for a in (self.n_cells, self.edges, self.values, self.relative_error, self.additive_error):
             a[:] = 0
 
-    def update(self, edges, values):
-        """``edges``: interior interface depths; ``values``: layer conductivities."""
+    def update(self, edges, values, rel=None, add=None):
+        """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels."""
+        for x, grid, hist in ((rel, self.rel_edges, self.relative_error), (add, self.add_edges, self.additive_error)):
+            if x is not None and grid is not None:
+                hist[np.clip(np.searchsorted(grid, np.log10(x), side="right") - 1, 0, hist.size - 1)] += 1
         k = values.size
         self.n_cells[k] += 1
         if k > 1:
@@ -153,7 +162,9 @@ class Inference1D:
         self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, 0
         o = self.options
         self.posteriors = Posteriors(o["maximum_number_of_layers"], o["maximum_depth"], o["minimum_thickness"],
-                                     float(self.halfspace[0]), o["factor"])
+                                     float(self.halfspace[0]), o["factor"],
+                                     relative_error_bounds=(o["minimum_relative_error"], o["maximum_relative_error"]),
+                                     additive_error_bounds=(o["minimum_additive_error"], o["maximum_additive_error"]))
 
     # the quantities the reference exposes on its Inference1D
     @property
@@ -191,7 +202,7 @@ class Inference1D:
         if self.posterior > self.best_posterior:
             self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
         self.acceptance_v[self.iteration] = self.accepted
-        self.posteriors.update(self.state.edges, self.state.values)
+        self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
 
     def infer(self, n_iterations=None):
         for _ in range(self.n_markov_chains if n_iterations is None else n_iterations):

@@ -124,6 +124,7 @@ class DeviceChains:
         ro.solve_additive_error = int(bool(o.get("solve_additive_error", True)))
         ro.exact_jacobian = int(bool(exact_jacobian))
         ro.n_depth_bins, ro.n_value_bins = self.n_depth_bins, self.n_value_bins
+        ro.n_error_bins = self.n_error_bins = 99                    # DataPoint.set_posteriors: Uniform.bins(nBins=99)
         ro.min_edge, ro.max_edge, ro.min_width = self.min_edge, self.max_edge, self.min_width
         ro.p_birth, ro.p_death, ro.p_perturb, ro.p_none = p
         ro.value_precision = 1.0 / math.log(1.0 + o["factor"]) ** 2
@@ -151,7 +152,7 @@ class DeviceChains:
             nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
-            edge_hist=z(B, self.n_depth_bins, dt=i32),
+            edge_hist=z(B, self.n_depth_bins, dt=i32), rel_hist=z(B, 99, dt=i32), add_hist=z(B, 99, dt=i32),
             hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
             hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),

@@ -249,7 +249,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     f64 = lambda x: x.to(torch.float64)
     cols = [f64(t["status"]), f64(t["burned_in_iteration"]), f64(t["n_accepted"]), t["misfit"], t["rel"], t["add"], f64(t["k"]),
             f64(t["best_k"]), t["best_posterior"]]
-    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"])]
+    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"]), f64(t["rel_hist"]),
+              f64(t["add_hist"])]
     if hitmap:
         mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
         blocks += [mean] + pct
@@ -275,8 +276,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                        layer_count_posterior=r[:, 9 + 2 * K:10 + 3 * K].astype(np.int64),
                        interface_posterior=r[:, 10 + 3 * K:10 + 3 * K + nz].astype(np.int64),
                        depth_bin_width=np.float64(dc.depth_bin_width))
+    ne = dc.n_error_bins
+    c_err = 10 + 3 * K + nz
+    res["relative_error_posterior"] = r[:, c_err:c_err + ne].astype(np.int64)      # ne cells, uniform in log10 between the prior bounds
+    res["additive_error_posterior"] = r[:, c_err + ne:c_err + 2 * ne].astype(np.int64)
     if hitmap:
-        c0 = 10 + 3 * K + nz
+        c0 = 10 + 3 * K + nz + 2 * ne
         res["mean_log10_conductivity"] = r[:, c0:c0 + nz]
         for i, q in enumerate(("p05", "p50", "p95")):
             res["log10_conductivity_" + q] = r[:, c0 + (i + 1) * nz:c0 + (i + 2) * nz]

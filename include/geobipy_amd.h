@@ -207,6 +207,7 @@ typedef struct gbp_rj_options {
     int32_t solve_gradient, solve_value;  /* which model priors enter the probability (solve_gradient / solve_parameter) */
     int32_t solve_relative_error, solve_additive_error, exact_jacobian;
     int32_t n_depth_bins, n_value_bins;   /* posterior grids (interface histogram / hit-map)          */
+    int32_t n_error_bins;        /* cells of the error-level histograms (log10 between the prior bounds; reference: 99) */
     int32_t schedule;            /* 0: the caller decides what is accumulated (`accumulate` argument);
                                     1: the reference's per-sounding schedule (Inference1D.update :713-737, infer :641-688):
                                        a chain burns in at the first iteration > burn_in_min_iterations with misfit <
@@ -258,6 +259,7 @@ typedef struct gbp_rj_chains {
     int64_t *n_accepted;           /* [B]                                                              */
     int32_t *k_hist;               /* [B, K + 1]            posterior of the layer count               */
     int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
+    int32_t *rel_hist, *add_hist;  /* [B, n_error_bins]     posteriors of the error levels (both or neither; may be NULL)     */
     int32_t *hitmap;               /* [B, n_value_bins, n_depth_bins] or NULL (depth fastest: the cells of one layer share a
                                       value bin, so one iteration updates a few contiguous runs)         */
     int32_t *hit_dwell;            /* [B] (with hitmap)  iterations the current model is still owed to the hit map: a model is

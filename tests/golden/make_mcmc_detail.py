@@ -185,6 +185,12 @@ def main():
         out["post_values_x_edges"] = np.asarray(hv.mesh.x.edges, dtype=float)
         out["post_values_relative_to"] = np.float64(np.asarray(hv.mesh.x.relative_to).item())
         out["post_burned_in"] = np.bool_(inf.burned_in)
+        # error-level posteriors (DataPoint.set_posteriors / update_posteriors): 99 cells, uniform in log10 between the prior bounds
+        for name, key in (("relative_error", "post_rel"), ("additive_error", "post_add")):
+            hp = getattr(inf.datapoint, name).posterior
+            hp = hp[0] if isinstance(hp, list) else hp
+            out[key] = np.asarray(hp.counts, dtype=np.int64)
+            out[key + "_edges"] = np.asarray(hp.mesh.edges, dtype=float) + np.asarray(hp.mesh.relative_to, dtype=float).item()
         np.savez_compressed(HERE + "/mcmc_detail.npz", **out)
     a = out["action"]
     print("long run: acceptance", out["long_accepted"].mean(), "k max", out["long_k"].max())

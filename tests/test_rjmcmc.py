@@ -173,20 +173,23 @@ def test_long_chain_reproduces_the_reference_decisions_and_posteriors():
     eng = OracleEngine("resolve", float(d["z"]))
     sp, vp, rp, ap, st, alpha = chain_setup(d)
     o = d["options"]
-    post = Posteriors(o[0], o[2], o[3], d["halfspace"].item(), o[10])
+    post = Posteriors(o[0], o[2], o[3], d["halfspace"].item(), o[10], relative_error_bounds=(o[11], o[12]),
+                      additive_error_bounds=(o[13], o[14]))
+    assert np.allclose(post.rel_edges, d["post_rel_edges"], atol=1e-14) and np.allclose(post.add_edges, d["post_add_edges"], atol=1e-14)
     assert np.allclose(post.value_edges, d["post_values_x_edges"], rtol=0, atol=1e-14) and np.isclose(post.relative_to, d["post_values_relative_to"], rtol=1e-15)
     prng = generator_at(d["rng_state"][0])
     acc, ks, mis = [], [], []
     for it in range(n):
         a, st = rjmcmc.accept_reject(prng, st, d["data"], eng, sp, vp, rp, ap, alpha)
         acc.append(a); ks.append(st.k); mis.append(st.misfit)
-        post.update(st.edges, st.values)
+        post.update(st.edges, st.values, st.rel, st.add)
     assert n == 3000 and np.array_equal(acc, d["long_accepted"]) and np.array_equal(ks, d["long_k"])
     assert np.allclose(mis, d["long_misfit"], rtol=1e-8)
     assert not d["post_burned_in"]
     assert np.array_equal(post.n_cells, d["post_ncells"])
     assert np.array_equal(post.edges, d["post_edges"]) and post.edges.sum() == 1947
     assert np.array_equal(post.values, d["post_values"]) and post.values.sum() == 3000 * 440
+    assert np.array_equal(post.relative_error, d["post_rel"]) and np.array_equal(post.additive_error, d["post_add"])
 
 
 def test_initial_state_matches_the_reference_initialisation():

@@ -431,16 +431,21 @@ def test_posterior_accumulators_match_a_host_replay():
         assert int(dc.k_hist.sum()) == 0 and int(dc.edge_hist.sum()) == 0 and int(dc.hitmap.sum()) == 0
         o = dc.o
         mean = np.exp(dc.log_mean_prior.cpu().numpy())
-        posts = [Posteriors(dc.K, o["maximum_depth"], o["minimum_thickness"], mean[b], o["factor"], n_value_bins=nv) for b in range(dc.B)]
+        posts = [Posteriors(dc.K, o["maximum_depth"], o["minimum_thickness"], mean[b], o["factor"], n_value_bins=nv,
+                            relative_error_bounds=(o["minimum_relative_error"], o["maximum_relative_error"]),
+                            additive_error_bounds=(o["minimum_additive_error"], o["maximum_additive_error"])) for b in range(dc.B)]
         assert posts[0].depth_centres.size == dc.n_depth_bins and np.isclose(posts[0].value_edges[-1], dc.value_half_width, rtol=1e-14)
         for _ in range(150):
             dc.step()
             k, e, s = dc.k.cpu().numpy(), dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
+            rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
             for b in range(dc.B):
-                posts[b].update(e[b, : k[b] - 1], s[b, : k[b]])
+                posts[b].update(e[b, : k[b] - 1], s[b, : k[b]], rel[b], add[b])
         assert np.array_equal(dc.k_hist.cpu().numpy(), np.stack([p.n_cells for p in posts]))
         assert np.array_equal(dc.edge_hist.cpu().numpy(), np.stack([p.edges for p in posts])) and dc.edge_hist.sum() > 0
         assert np.array_equal(dc.hitmap.cpu().numpy(), np.stack([p.values for p in posts]))    # [B, value, depth] both
+        assert np.array_equal(dc.rel_hist.cpu().numpy(), np.stack([p.relative_error for p in posts]))
+        assert np.array_equal(dc.add_hist.cpu().numpy(), np.stack([p.additive_error for p in posts]))
 
 
 @pytest.mark.gpu
