@@ -59,6 +59,19 @@ def measured_traffic(Btot, L, world):
     return d["hbm_fetch_bytes_x2_gfx950_correction"] + d["hbm_write_bytes_raw"]
 
 
+def usable_cores():
+    """Host cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota (the GPU boxes hand a
+    16-CPU quota to a 256-thread host, and oversubscribed OpenMP threads would misstate the baseline)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(system, nl, sigma, thk, height, obs, sample, threads):
     from oracle import fdem_oracle as fo
     osys = fo.OracleSystem(system.frequencies, system.transmitter.orientation, system.transmitter.moment,
@@ -273,7 +286,7 @@ def main():
                                       "forward and ~0.7 Jacobian per chain-iteration; reference ~165 iterations/s per core"}
             del dc
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))
             sigma0 = sig_sets[0]
             rate, dt, (p_ref, c_ref, l_ref) = cpu_baseline(system, nl, sigma0, thk, height, obs, sample, threads)
@@ -290,7 +303,9 @@ def main():
             chi2, logl = batches[0].forward_loglike(want_pred=True)
             torch.cuda.synchronize(device)
             p = batches[0].predicted[:sample].cpu().numpy()
+            r1, d1, _ = cpu_baseline(system, nl, sigma0, thk, height, obs, min(Btot, 2048), 1)   # single thread beside all cores
             line["cpu_baseline"] = {"value": rate, "unit": "evals/s", "cores": threads, "kind": "port",
+                                    "single_thread": {"value": r1, "unit": "evals/s", "sample": f"first {min(Btot, 2048)} soundings, {d1:.1f} s"},
                                     "sample": f"first {sample} soundings of the same batch x {rounds} proposal round(s), C oracle "
                                               f"(oracle/fdem1d_oracle.c, gcc -O2, OpenMP {threads} threads), {dt:.1f} s"}
             line["parity_vs_cpu"] = {"max_abs_pred_ppm": float(np.max(np.abs(p - p_ref))),
