@@ -61,6 +61,15 @@ __device__ inline void normal_pair(uint64_t seed, uint32_t chain, uint32_t iter,
 }
 
 enum { NONE = 0, INSERT = 1, DELETE = 2, PERTURB = 3 };
+
+// Key of chain b's random streams: its global index in the survey, so that the chains do not depend on how the survey is
+// sharded or on the rows of a block being re-packed (chain_id), see gbp_rj_options.first_chain.
+__device__ inline uint32_t chain_key(const gbp_rj_options& o, const gbp_rj_chains& c, int b)
+{
+    return (uint32_t)((c.chain_id != nullptr && b < c.B) ? (uint64_t)c.chain_id[b] : o.first_chain + (uint64_t)b);
+}
+
+
 constexpr double INF = __builtin_huge_val();
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_r
     const int k = c.k[b];
     const double ej = lane < k - 1 ? c.edges[(size_t)b * K + lane] : INF;
     const double sj = lane < k ? c.sigma[(size_t)b * K + lane] : 1.0;
-    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
+    Rng r(o.seed, chain_key(o, c, b), iter, 0);
     int action, idx;
     double val;
     choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return __shfl(ej, j, 64); },
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp
     const double* __restrict__ e = c.edges + (size_t)b * K;
     const double* __restrict__ s = c.sigma + (size_t)b * K;
     const int k = c.k[b];
-    Rng r(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 0);
+    Rng r(o.seed, chain_key(o, c, b), iter, 0);
     int action, idx;
     double val;
     choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return e[j]; },
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     chol_solve(s.A, KS, k, lane, s.g, true, true);
     if (lane < 32) {
         double z0, z1;
-        normal_pair(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 1, (uint32_t)lane, z0, z1);
+        normal_pair(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)lane, z0, z1);
         if (2 * lane < K) s.w[2 * lane] = z0;
         if (2 * lane + 1 < K) s.w[2 * lane + 1] = z1;
     }
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
     };
     const double step = backward(forward(g));        // (C C')^-1 g
     double z0 = 0.0, z1 = 0.0;
-    if (i < 4) normal_pair(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 1, (uint32_t)i, z0, z1);
+    if (i < 4) normal_pair(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)i, z0, z1);
     const double za = __shfl(z0, base + (i >> 1), 64), zb = __shfl(z1, base + (i >> 1), 64);
     const double w = backward((i & 1) ? zb : za);    // C^-T z
     if (live && i < K) {                             // (max_layers may be smaller than the group)
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         misfit_p = c.misfit_p[b];
     }
     const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
-    const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
+    const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
     const bool accept = !frozen && log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
     __syncthreads();
@@ -874,7 +883,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : c.like_p[bb];
     const double prior_c = c.prior[bb], like_c = c.like[bb], best_prev = c.best_posterior[bb];
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
-    const U4 rr = philox(o.seed, (uint32_t)(o.first_chain + (uint64_t)b), iter, 2, 0);
+    const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)

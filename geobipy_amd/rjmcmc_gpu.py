@@ -147,7 +147,7 @@ class DeviceChains:
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
         i32, i64 = torch.int32, torch.int64
         self.t = t = dict(
-            data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
+            chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
             nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
@@ -157,17 +157,21 @@ class DeviceChains:
             hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K))
-        rc = _lib.RjChains()
-        rc.B = B
-        for name in _lib.RJ_CHAIN_FIELDS:
-            setattr(rc, name, None if t[name] is None else t[name].data_ptr())
-        self._c = rc
+        self._bind()
         self.iteration = 0
         _lib.check(_lib.load().gbp_pin_forward_waves(int(forward_waves)))
         try:
             self._initialize()
         finally:
             _lib.check(_lib.load().gbp_pin_forward_waves(0))
+
+    def _bind(self):
+        """(Re)build the gbp_rj_chains struct from the tensors in self.t."""
+        rc = _lib.RjChains()
+        rc.B = int(self.t["k"].shape[0])
+        for name in _lib.RJ_CHAIN_FIELDS:
+            setattr(rc, name, None if self.t[name] is None else self.t[name].data_ptr())
+        self._c = rc
 
     def __getattr__(self, name):              # chain state by the names of gbp_rj_chains
         t = self.__dict__.get("t")
@@ -241,15 +245,52 @@ class DeviceChains:
     def step(self, accumulate=True):
         return self.run(1, accumulate)
 
-    def infer(self, check_every=1000):
+    def infer(self, check_every=1000, compact_below=0.5, min_rows=64):
         """Run under the reference's schedule until every chain is done or has failed (at most 2 n_markov_chains + 2
-        iterations); the host looks at the status flags every ``check_every`` iterations.  Returns the number of chains
-        that failed to burn in."""
+        iterations); the host looks at the status flags every ``check_every`` iterations.  When fewer than
+        ``compact_below`` of the rows are still running, the finished chains are set aside and the block is re-packed
+        (finished chains would otherwise idle through every kernel until the slowest one stops); the chains do not notice --
+        their random streams are keyed by ``chain_id``, not by the row -- and all rows are back in place on return.
+        Returns the number of chains that failed to burn in."""
         assert self._o.schedule == 1, "infer() needs reference_schedule=True"
         limit = 2 * self._o.n_markov_chains + 2
-        while self.iteration < limit and bool((self.t["status"] == 0).any()):
+        full, rows = None, None                   # the set-aside full-size tensors and the global row of each working row
+        while self.iteration < limit:
+            running = self.t["status"] == 0
+            n_run = int(running.sum())
+            if n_run == 0:
+                break
+            n_rows = int(running.numel())
+            if n_rows > min_rows and n_run < compact_below * n_rows:
+                keep = torch.nonzero(running).flatten()
+                if full is None:
+                    full = dict(self.t)
+                    rows = torch.arange(self.B, device=self.device)
+                    if self.t["chain_id"] is None:
+                        full["chain_id"] = torch.arange(self._o.first_chain, self._o.first_chain + self.B, dtype=torch.int64, device=self.device)
+                        self.t["chain_id"] = full["chain_id"]
+                else:
+                    self._scatter(full, rows)
+                rows = rows[keep]
+                self.t = {n: (None if v is None else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
+                          for n, v in self.t.items()}
+                self._bind()
             self.run(min(check_every, limit - self.iteration))
+        if full is not None:
+            self._scatter(full, rows)
+            self.t = full
+            self._bind()
         return int((self.t["status"] == 2).sum())
+
+    def _scatter(self, full, rows):
+        """Working rows -> their places in the full-size tensors."""
+        for n, v in self.t.items():
+            if v is None or full[n] is v:
+                continue
+            if n in ("nl_a", "nl_c"):
+                full[n][:, rows] = v
+            else:
+                full[n][rows] = v
 
     def summaries(self):
         """[B, 6] per-sounding summary for the gather: misfit, logL, prior, k, acceptance rate, best posterior."""

@@ -234,6 +234,7 @@ typedef struct gbp_rj_options {
 typedef struct gbp_rj_chains {
     int32_t B;
     /* per-sounding constants */
+    const int64_t *chain_id;       /* [B] or NULL  global index of each chain (keys its random streams); NULL: first_chain + b */
     const double *data;            /* [B, N]  observed data (<= 0: inactive channel)                   */
     const double *height;          /* [B]                                                              */
     const double *log_mean_prior;  /* [B]     ln of the best half-space conductivity                   */

@@ -506,9 +506,23 @@ def test_reference_schedule_on_the_device_matches_a_host_replay():
     _, _, dc2 = _chains(B, 77, exact=True, reference_schedule=True, burn_in_min_iterations=burn_min, options=dict(n_markov_chains=n_mc))
     dc2.data.copy_(torch.as_tensor(data))
     dc2._initialize()
-    assert dc2.infer(check_every=64) == (status == 2).sum()
+    assert dc2.infer(check_every=64, compact_below=0.0) == (status == 2).sum()
     for n in ("k", "sigma", "k_hist", "edge_hist", "burned_in_iteration", "status", "best_sigma"):
         assert torch.equal(getattr(dc, n), getattr(dc2, n)), n
+    # ... and with the block re-packed whenever chains have finished: the same chains, row for row
+    _, _, dc3 = _chains(B, 77, exact=True, reference_schedule=True, burn_in_min_iterations=burn_min, hitmap=True, n_value_bins=20,
+                        options=dict(n_markov_chains=n_mc))
+    dc3.data.copy_(torch.as_tensor(data))
+    dc3._initialize()
+    sizes = []
+    run0 = dc3.run
+    dc3.run = lambda n, accumulate=True: (sizes.append(dc3._c.B), run0(n, accumulate))[1]
+    assert dc3.infer(check_every=16, compact_below=0.95, min_rows=2) == (status == 2).sum()
+    assert min(sizes) < B // 2 and dc3._c.B == B and dc3.k.shape[0] == B
+    for n in ("k", "edges", "sigma", "rel", "add", "pred", "misfit", "k_hist", "edge_hist", "rel_hist", "burned_in_iteration", "status",
+              "best_sigma", "n_accepted", "data"):
+        assert torch.equal(getattr(dc, n), getattr(dc3, n)), n
+    assert int(dc3.hitmap.sum()) == int(dc3.k_hist.sum()) * dc3.n_depth_bins
 
 
 @pytest.mark.gpu
