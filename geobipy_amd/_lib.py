@@ -22,7 +22,7 @@ class RjOptions(ctypes.Structure):
                                                "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "n_error_bins", "schedule",
                                                "burn_in_min_iterations", "n_markov_chains", "forward_waves")]
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
-                                                  "value_precision", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
+                                                  "value_precision", "value_min", "value_max", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
                                                   "add_min", "add_max", "add_sd", "depth_bin_width", "value_half_width")]
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)])
 

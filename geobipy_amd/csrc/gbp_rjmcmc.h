@@ -572,6 +572,10 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         const double n = (double)max(1, k - 1);
         prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
     }
+    if (o.value_max > 0.0) {                                     // parameter_limits (Model.probability :555-558)
+        const double sp = lane < k ? c.sigma_p[(size_t)b * K + lane] : o.value_min;
+        if (__any(!(sp >= o.value_min && sp <= o.value_max))) prior_p = -INF;
+    }
     const double rel_p = c.rel_p[b], add_p = c.add_p[b];
     if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);
     if (o.solve_additive_error) prior_p += log_uniform_prior(add_p, o.add_min, o.add_max);
@@ -800,6 +804,11 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
         const double g2 = group_sum8(g * g);
         const double n = (double)max(1, k - 1);
         prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
+    }
+    if (o.value_max > 0.0) {                         // parameter_limits (Model.probability :555-558)
+        const double sp = i < k ? c.sigma_p[bb * K + i] : o.value_min;
+        const unsigned long long out = __ballot(!(sp >= o.value_min && sp <= o.value_max));
+        if ((out >> base) & 0xFFull) prior_p = -INF;
     }
     const double rel_p = c.rel_p[bb], add_p = c.add_p[bb];
     if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);

@@ -61,7 +61,7 @@ def _priors_from_options(o, value_mean):
                                [o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
                                 o["probability_of_no_change"]])
     vp = rjmcmc.ValuePrior(value_mean, o["factor"], o["gradient_standard_deviation"], o["solve_gradient"],
-                           bool(o.get("solve_parameter", False)))
+                           bool(o.get("solve_parameter", False)), o.get("parameter_limits"))
     rp = rjmcmc.ErrorPrior(o["minimum_relative_error"], o["maximum_relative_error"], o["relative_error_proposal_variance"])
     ap = rjmcmc.ErrorPrior(o["minimum_additive_error"], o["maximum_additive_error"], o["additive_error_proposal_variance"])
     return sp, vp, rp, ap

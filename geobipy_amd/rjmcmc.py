@@ -78,7 +78,7 @@ class ValuePrior:
     model/Model.py:727-746): log-normal on the values, mean = best half-space, variance = ln(1 + factor)^2; and a
     normal prior on the vertical gradient of ln(sigma) with standard deviation gradient_standard_deviation."""
 
-    def __init__(self, value_mean, factor=10.0, gradient_std=1.5, solve_gradient=True, solve_value=False):
+    def __init__(self, value_mean, factor=10.0, gradient_std=1.5, solve_gradient=True, solve_value=False, limits=None):
         self.log_mean = np.log(value_mean)
         self.value_precision = 1.0 / np.log(1.0 + factor) ** 2.0
         self.gradient_precision = 1.0 / gradient_std ** 2.0
@@ -86,6 +86,9 @@ class ValuePrior:
         # solve_parameter of the options file: the log-normal prior on the values also enters the model probability
         # (it always shapes the stochastic-Newton step: Inference1D.py:503 sets it regardless)
         self.solve_value = solve_value
+        # parameter_limits of the options file: proposals with a conductivity outside [lo, hi] have zero prior probability
+        # (Model.probability :555-558, a log-uniform Distribution used only as a bound)
+        self.limits = None if limits is None else (float(limits[0]), float(limits[1]))
 
 
 def gradient_operator(edges):
@@ -180,6 +183,8 @@ def model_log_prior(sp, vp, edges, values):
     number of layers (mesh/RectilinearMesh1D.py:1351-1382; the order-statistics prior on the interfaces is
     commented out in the reference) + normal prior on the vertical gradient of ln sigma (Model.py:213-234)."""
     k = values.size
+    if vp.limits is not None and (np.any(values < vp.limits[0]) or np.any(values > vp.limits[1])):
+        return -np.inf
     lp = -np.log(sp.max_cells - 1.0)
     if vp.solve_value:
         lp += mvn_logpdf(np.log(values), np.full(k, vp.log_mean), np.eye(k) / vp.value_precision)

@@ -129,6 +129,8 @@ class DeviceChains:
         ro.p_birth, ro.p_death, ro.p_perturb, ro.p_none = p
         ro.value_precision = 1.0 / math.log(1.0 + o["factor"]) ** 2
         ro.gradient_precision = self.gradient_precision
+        lim = o.get("parameter_limits")
+        ro.value_min, ro.value_max = (0.0, 0.0) if lim is None else (float(lim[0]), float(lim[1]))
         ro.alpha = float(o["covariance_scaling"])
         ro.rel_min, ro.rel_max = o["minimum_relative_error"], o["maximum_relative_error"]
         ro.rel_sd = math.sqrt(o["relative_error_proposal_variance"])

@@ -221,6 +221,7 @@ typedef struct gbp_rj_options {
     double min_edge, max_edge, min_width; /* min_edge already raised to min_width (RectilinearMesh1D.py:358-360) */
     double p_birth, p_death, p_perturb, p_none;
     double value_precision;      /* 1 / ln(1 + factor)^2                                              */
+    double value_min, value_max; /* parameter_limits: proposals with a conductivity outside have zero prior; value_max <= 0: none */
     double gradient_precision;   /* 1 / gradient_standard_deviation^2                                 */
     double alpha;                /* covariance_scaling                                                 */
     double rel_min, rel_max, rel_sd, add_min, add_max, add_sd;   /* sd = sqrt(proposal variance)      */

@@ -96,7 +96,7 @@ def _host_priors(dc, b):
                                [o["probability_of_birth"], o["probability_of_death"], o["probability_of_perturb"],
                                 o["probability_of_no_change"]])
     vp = rjmcmc.ValuePrior(math.exp(float(dc.log_mean_prior[b])), o["factor"], o["gradient_standard_deviation"], o["solve_gradient"],
-                           bool(o.get("solve_parameter", False)))
+                           bool(o.get("solve_parameter", False)), o.get("parameter_limits"))
     return sp, vp
 
 
@@ -527,7 +527,8 @@ def test_reference_schedule_on_the_device_matches_a_host_replay():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("priors", [dict(), dict(solve_parameter=True, solve_gradient=False),
-                                    dict(maximum_number_of_layers=4, probability_of_birth=0.4)])
+                                    dict(maximum_number_of_layers=4, probability_of_birth=0.4),
+                                    dict(parameter_limits=[0.02, 0.3])])
 def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
     """BASELINE config 5's bar for the device sampler: a CPU implementation (rjmcmc.py pieces + the C oracle's forward
     and Jacobian) driven by the same counter-based streams walks the same chain -- every move, every accept / reject,
