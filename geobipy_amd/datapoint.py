@@ -222,6 +222,8 @@ class FdemDataPoint:
         return self._sensitivity_matrix
 
     def fm_dlogc(self, mod):
+        """Forward model and Jacobian (FdemDataPoint.py:547-551): the prediction of the fused forward kernel (so that
+        data_misfit / likelihood are ready) and the Jacobian."""
         self.forward(mod)
         self.sensitivity(mod)
 

@@ -156,9 +156,9 @@ class Inference1D:
         self.priors, self.state = initial_state(self.engine, self.data, self.options)
         self.halfspace = self.state.values.copy()
         self.iteration = 0
-        self.data_misfit_v = np.zeros(2 * self.n_markov_chains)
+        self.data_misfit_v = np.zeros(2 * self.n_markov_chains + 2)
         self.data_misfit_v[0] = self.state.misfit
-        self.acceptance_v = np.zeros(2 * self.n_markov_chains, dtype=np.uint8)
+        self.acceptance_v = np.zeros(2 * self.n_markov_chains + 2, dtype=np.uint8)
         self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, 0
         o = self.options
         self.posteriors = Posteriors(o["maximum_number_of_layers"], o["maximum_depth"], o["minimum_thickness"],
@@ -204,11 +204,31 @@ class Inference1D:
         self.acceptance_v[self.iteration] = self.accepted
         self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
 
-    def infer(self, n_iterations=None):
-        for _ in range(self.n_markov_chains if n_iterations is None else n_iterations):
+    def infer(self, n_iterations=None, burn_in_min_iterations=5000):
+        """``n_iterations`` given: that many iterations, every state accumulated.  Otherwise the reference's schedule
+        (Inference1D.infer :633-688 with update :713-737): the chain burns in at the first iteration >
+        ``burn_in_min_iterations`` whose misfit is below the number of active channels -- posteriors and best model restart
+        there --, runs ``n_markov_chains`` more iterations, and fails (returns True, like the reference) if it has not
+        burned in after ``n_markov_chains`` iterations."""
+        if n_iterations is not None:
+            for _ in range(n_iterations):
+                self.accept_reject()
+                self.update()
+            return False
+        n_active = int((self.data > 0.0).sum())
+        self.burned_in, self.burned_in_iteration = False, 0
+        while True:
             self.accept_reject()
             self.update()
-        return self.state
+            if not self.burned_in and self.iteration > burn_in_min_iterations and self.data_misfit < n_active:
+                self.burned_in, self.burned_in_iteration = True, self.iteration
+                self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
+                self.posteriors.reset()
+                self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
+            if self.burned_in and self.iteration > self.n_markov_chains + self.burned_in_iteration:
+                return False
+            if not self.burned_in and self.iteration >= self.n_markov_chains:
+                return True
 
 
 class BatchedInference:

@@ -192,6 +192,35 @@ def test_long_chain_reproduces_the_reference_decisions_and_posteriors():
     assert np.array_equal(post.relative_error, d["post_rel"]) and np.array_equal(post.additive_error, d["post_add"])
 
 
+def test_host_inference1d_follows_the_reference_schedule():
+    """Inference1D.infer() without an iteration count: burn-in at the first iteration > the minimum whose misfit is below
+    the number of active channels, posteriors restarted there, n_markov_chains more iterations; or failure after
+    n_markov_chains iterations without burn-in (the reference's infer() returns True then)."""
+    from numpy.random import Generator, PCG64DXSM
+    from geobipy_amd.inference import Inference1D
+
+    class DP:                        # the attributes Inference1D.initialize reads from a datapoint
+        pass
+    d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
+    eng = OracleEngine("resolve", float(d["z"]))
+    eng.forward_many = lambda models, heights=None: np.stack([eng.forward(e, v) for e, v in models])
+    dp = DP()
+    dp.data, dp.z, dp.system = d["data"], np.r_[float(d["z"])], [None]
+    # wide error bars: the best half-space already fits, the chain burns in as soon as it may
+    o = dict(RESOLVE_OPTIONS, n_markov_chains=120, initial_additive_error=400.0, maximum_additive_error=1000.0)
+    inf = Inference1D(prng=Generator(PCG64DXSM(3)), engine=eng, **o)
+    inf.initialize(dp)
+    assert inf.infer(burn_in_min_iterations=40) is False
+    assert inf.burned_in and inf.burned_in_iteration == 41 and inf.iteration == 41 + 120 + 1
+    assert inf.posteriors.n_cells.sum() == 120 + 2 and inf.posteriors.values.sum() == (120 + 2) * 440
+    assert inf.best_iteration >= 41
+    # the fixture's own error levels: the misfit stays far above 12, no burn-in
+    inf = Inference1D(prng=Generator(PCG64DXSM(3)), engine=eng, **dict(RESOLVE_OPTIONS, n_markov_chains=80))
+    inf.initialize(dp)
+    assert inf.infer(burn_in_min_iterations=10) is True and not inf.burned_in and inf.iteration == 80
+    assert inf.posteriors.n_cells.sum() == 80
+
+
 def test_initial_state_matches_the_reference_initialisation():
     """Inference1D.initialize: best half-space of the 100-point grid, its prior / likelihood / misfit."""
     from geobipy_amd import inference
