@@ -27,7 +27,7 @@ class RjOptions(ctypes.Structure):
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)])
 
 
-RJ_CHAIN_FIELDS = ("chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
+RJ_CHAIN_FIELDS = ("add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
                    "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")
@@ -36,6 +36,11 @@ RJ_CHAIN_FIELDS = ("chain_id", "data", "height", "log_mean_prior", "k", "edges",
 class RjChains(ctypes.Structure):
     """gbp_rj_chains: B and the device pointers in declaration order."""
     _fields_ = [("B", ctypes.c_int32)] + [(n, c_void_p) for n in RJ_CHAIN_FIELDS]
+
+
+class TdOperator(ctypes.Structure):
+    """gbp_td_operator."""
+    _fields_ = [("n_nodal", ctypes.c_int32), ("W", c_void_p), ("nodal", c_void_p), ("J_nodal", c_void_p)]
 
 
 _rj_o, _rj_c = ctypes.POINTER(RjOptions), ctypes.POINTER(RjChains)
@@ -48,6 +53,7 @@ SIGNATURES = {
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
     "gbp_pin_forward_waves": (c_int, [c_int]),
+    "gbp_rj_run_td": (c_int, [c_void_p, ctypes.POINTER(TdOperator), _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gbp_version": (ctypes.c_char_p, []),
     "gbp_last_error": (ctypes.c_char_p, []),

@@ -265,12 +265,16 @@ __device__ inline double prior_entry(const gbp_rj_options& o, const double* t2, 
 }
 
 // data weights with the error levels (rel, add): P = active / std^2, PR = P * (pred - data)  (DataPoint.py:268-282, 340-349)
-__device__ inline void data_weights(const double* data, const double* pred, double rel, double add, int N, int lane, double* P, double* PR)
+// per-channel additive error: add * add_scale[n] (TdemDataPoint.std :361-365: sqrt(1e-3 / t) per gate); NULL = 1 (FDEM)
+__device__ inline double add_at(const double* add_scale, double add, int n) { return add_scale != nullptr ? add * add_scale[n] : add; }
+
+__device__ inline void data_weights(const double* data, const double* pred, double rel, double add, const double* add_scale, int N,
+                                    int lane, double* P, double* PR)
 {
     for (int n = lane; n < N; n += 64) {
         const double d = data[n];
         const bool act = d > 0.0;
-        const double rd = rel * d, w = act ? 1.0 / (rd * rd + add * add) : 0.0;
+        const double rd = rel * d, an = add_at(add_scale, add, n), w = act ? 1.0 / (rd * rd + an * an) : 0.0;
         P[n] = w;
         PR[n] = act ? w * (pred[n] - d) : 0.0;
     }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     const double* pred = (changed ? c.pred_r : c.pred) + (size_t)b * N;
     const double* e = c.edges_r + (size_t)b * K;
     const double* sr = c.sigma_r + (size_t)b * K;
-    data_weights(c.data + (size_t)b * N, pred, c.rel[b], c.add[b], N, lane, s.P, s.PR);
+    data_weights(c.data + (size_t)b * N, pred, c.rel[b], c.add[b], c.add_scale, N, lane, s.P, s.PR);
     prior_t2(o, e, k, lane, s.t2);
     const double lmp = c.log_mean_prior[b];
     const double ls = lane < k ? log(sr[lane]) : 0.0;
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
         for (int n = i; n < N; n += 8) {
             const double d = data[n];
             const bool act = d > 0.0;
-            const double rd = rel * d, w = act ? 1.0 / (rd * rd + add * add) : 0.0;
+            const double rd = rel * d, an = add_at(c.add_scale, add, n), w = act ? 1.0 / (rd * rd + an * an) : 0.0;
             P[n] = w;
             PR[n] = act ? w * (pred[n] - d) : 0.0;
         }
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     if (action == INSERT || action == DELETE) {                  // Model.proposal_probabilities (model/Model.py:577-659)
         const double* Jp = c.J_p + (size_t)b * N * K;
         const double* C = c.chol + (size_t)b * K * K;
-        data_weights(c.data + (size_t)b * N, c.pred_p + (size_t)b * N, rel_p, add_p, N, lane, s.P, s.PR);
+        data_weights(c.data + (size_t)b * N, c.pred_p + (size_t)b * N, rel_p, add_p, c.add_scale, N, lane, s.P, s.PR);
         prior_t2(o, e, k, lane, s.t2);
         if (lane < k) {
             for (int j = 0; j <= lane; ++j) s.A[lane * KS + j] = C[(size_t)lane * K + j];
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         for (int i = lane; i < N; i += 64) {
             const double ov = ob[i];
             if (ov > 0.0) {
-                const double ro = rel_p * ov, var = ro * ro + add_p * add_p;
+                const double ro = rel_p * ov, an = add_at(c.add_scale, add_p, i), var = ro * ro + an * an;
                 const double r = (pp[i] - ov) * (1.0 / sqrt(var));
                 s2 += r * r; logdet += log(var); na += 1.0;
             }
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
             const double ov = ob[n];
             double pr = 0.0;
             if (ov > 0.0) {
-                const double ro = rel_p * ov, var = ro * ro + add_p * add_p;
+                const double ro = rel_p * ov, an = add_at(c.add_scale, add_p, n), var = ro * ro + an * an;
                 const double r = (pp[n] - ov) * (1.0 / sqrt(var));
                 s2 += r * r; logdet += log(var); na += 1.0;
                 pr = (1.0 / var) * (pp[n] - ov);
@@ -1009,6 +1013,65 @@ __global__ void k_rj_debug_random(uint64_t seed, uint32_t chain, uint32_t iter, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Time-domain data (TdemDataPoint): the frequency-domain kernels produce the nodal spectrum of a sounding, a constant
+// matrix turns it into window values (geobipy_amd/tdem.py: windows = nodal @ W).  One workgroup per sounding; soundings
+// with 0 layers are skipped like everywhere else.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+__global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int N, const int* __restrict__ nl, const double* __restrict__ W,
+                                                 const double* __restrict__ nodal, const double* __restrict__ J_nodal,
+                                                 double* __restrict__ pred, double* __restrict__ J)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // nodal[n_nodal] | J_nodal[n_nodal][k]
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int k = nl[b];
+    if (k <= 0) return;
+    double* sn = reinterpret_cast<double*>(sh_dyn);
+    double* sj = sn + n_nodal;
+    for (int m = lane; m < n_nodal; m += 64) sn[m] = nodal[(size_t)b * n_nodal + m];
+    if (WITH_J)
+        for (int q = lane; q < n_nodal * k; q += 64) sj[q] = J_nodal[((size_t)b * n_nodal + q / k) * K + q % k];
+    __syncthreads();
+    for (int g = lane; g < N; g += 64) {
+        double acc = 0.0;
+        for (int m = 0; m < n_nodal; ++m) acc += sn[m] * W[(size_t)m * N + g];
+        pred[(size_t)b * N + g] = acc;
+        if (WITH_J) {
+            for (int l = 0; l < k; ++l) {
+                double a = 0.0;
+                for (int m = 0; m < n_nodal; ++m) a += sj[m * k + l] * W[(size_t)m * N + g];
+                J[((size_t)b * N + g) * K + l] = a;
+            }
+            for (int l = k; l < K; ++l) J[((size_t)b * N + g) * K + l] = 0.0;
+        }
+    }
+}
+
+// chi^2 / logL with the per-channel additive scale, for the soundings with nl > 0 (one wave per sounding)
+__global__ __launch_bounds__(64) void k_td_loglike(int B, int N, const int* __restrict__ nl, const double* __restrict__ pred,
+                                                   const double* __restrict__ obs, const double* __restrict__ rel,
+                                                   const double* __restrict__ add, const double* __restrict__ add_scale,
+                                                   double* __restrict__ chi2, double* __restrict__ logL)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (nl[b] <= 0) return;
+    double s2 = 0.0, logdet = 0.0, na = 0.0;
+    for (int i = lane; i < N; i += 64) {
+        const double ov = obs[(size_t)b * N + i];
+        if (ov > 0.0) {
+            const double ro = rel[b] * ov, an = add_at(add_scale, add[b], i), var = ro * ro + an * an;
+            const double r = (pred[(size_t)b * N + i] - ov) * (1.0 / sqrt(var));
+            s2 += r * r; logdet += log(var); na += 1.0;
+        }
+    }
+    s2 = wave_sum(s2); logdet = wave_sum(logdet); na = wave_sum(na);
+    if (lane == 0) {
+        chi2[b] = s2;
+        logL[b] = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
+    }
+}
+
 }  // namespace rj
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1088,10 +1151,21 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
 gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
                       int n_iterations, int accumulate, void* stream)
 {
+    return gbp_rj_run_td(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, stream);
+}
+
+gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
+                         int64_t first_iteration, int n_iterations, int accumulate, void* stream)
+{
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK) return st;
     if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
-    if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
+    if (td == nullptr) {
+        if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
+    } else {
+        if (td->n_nodal != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_nodal must be 2 * nF of the system%s");
+        if (!td->W || !td->nodal || !td->J_nodal) return fail(GBP_ERR_INVALID_ARG, "NULL pointer in gbp_td_operator%s");
+    }
     const int B = c->B, K = o->max_layers;
     if (B == 0) return GBP_OK;
     const int caps[2] = {8 < K ? 8 : K, K};      // Jacobian launches by layer count: <= 8 (the common case, small LDS
@@ -1110,22 +1184,48 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
             if (F % d == 0 && d >= want) { sw = d; break; }
     }
     Pin pin(o->forward_waves, sw);   // forward_waves 0: no pin
+    const int N = o->n_channels;
+    auto td_apply = [&](const int32_t* nl, bool with_j, double* pred, double* J) -> gbp_status {   // nodal -> windows
+        const size_t lds = ((size_t)td->n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
+        if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");
+        if (with_j)
+            hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, td->n_nodal, N, nl, td->W,
+                               td->nodal, td->J_nodal, pred, J);
+        else
+            hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, td->n_nodal, N, nl, td->W,
+                               td->nodal, td->J_nodal, pred, J);
+        GBP_HIP(hipGetLastError());
+        return GBP_OK;
+    };
+    // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
+    auto fm_dlogc = [&](const int32_t* nl, const double* sigma, double* pred, double* J) -> gbp_status {
+        for (int i = 0; i < nb; ++i) {
+            gbp_status s2 = gbp_fdem_fm_dlogc(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
+                                              td ? td->J_nodal : J, caps[i], o->exact_jacobian, stream);
+            if (s2 != GBP_OK) return s2;
+        }
+        return td ? td_apply(nl, true, pred, J) : GBP_OK;
+    };
     for (int it = 0; it < n_iterations; ++it) {
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
         // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
-        for (int i = 0; i < nb; ++i)
-            if ((st = gbp_fdem_fm_dlogc(sys, B, K, c->nl_a + (size_t)(1 + i) * B, c->sigma_r, c->thk_r, c->height, c->pred_r,
-                                        c->J_r, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->pred_r, c->J_r)) != GBP_OK) return st;
         if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
         // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
         //   ... of the proposals that keep their dimension
-        if ((st = gbp_fdem_forward_loglike(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
-                                           c->pred_p, c->misfit_p, c->like_p, stream)) != GBP_OK) return st;
+        if (td == nullptr) {
+            if ((st = gbp_fdem_forward_loglike(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
+                                               c->pred_p, c->misfit_p, c->like_p, stream)) != GBP_OK) return st;
+        } else {
+            if ((st = gbp_fdem_forward(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, stream)) != GBP_OK) return st;
+            if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr)) != GBP_OK) return st;
+            hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, c->nl_b, c->pred_p, c->data, c->rel_p,
+                               c->add_p, c->add_scale, c->misfit_p, c->like_p);
+            GBP_HIP(hipGetLastError());
+        }
         //   ... and prediction + Jacobian (Model.py:612) of those that change it; their chi^2 / logL are formed in accept
-        for (int i = 0; i < nb; ++i)
-            if ((st = gbp_fdem_fm_dlogc(sys, B, K, c->nl_c + (size_t)(1 + i) * B, c->sigma_p, c->thk_r, c->height, c->pred_p,
-                                        c->J_p, caps[i], o->exact_jacobian, stream)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_c, c->sigma_p, c->pred_p, c->J_p)) != GBP_OK) return st;
         if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
     }
     return GBP_OK;

@@ -82,7 +82,7 @@ class DeviceChains:
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=4, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=0.0,
-                 min_altitude=None, **options):
+                 min_altitude=None, add_scale=None, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -149,7 +149,7 @@ class DeviceChains:
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
         i32, i64 = torch.int32, torch.int64
         self.t = t = dict(
-            chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
+            add_scale=None if add_scale is None else f64(add_scale), chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
             nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
@@ -190,7 +190,7 @@ class DeviceChains:
 
     # -- Inference1D.initialize (:353-464): best half-space, its forward / Jacobian, prior and likelihood ----------------
     def _initialize(self):
-        o, B, K, t, lib = self.o, self.B, self.K, self.t, _lib.load()
+        o, B, K, t = self.o, self.B, self.K, self.t
         t["rel"].fill_(float(o["initial_relative_error"]))
         t["add"].fill_(float(o["initial_additive_error"]))
         grid = torch.logspace(-4.0, 4.0, 100, dtype=torch.float64, device=self.device)
@@ -206,9 +206,7 @@ class DeviceChains:
             chi2 = torch.empty(n, dtype=torch.float64, device=self.device)
             logl = torch.empty_like(chi2)
             hh, dd, rr, aa, thk = rep(t["height"]), rep(t["data"]), rep(t["rel"]), rep(t["add"]), torch.zeros_like(sig)
-            _lib.check(lib.gbp_fdem_forward_loglike(self._h.ptr, n, K, k1.data_ptr(), sig.data_ptr(), thk.data_ptr(), hh.data_ptr(),
-                                                    dd.data_ptr(), rr.data_ptr(), aa.data_ptr(), None, chi2.data_ptr(),
-                                                    logl.data_ptr(), self._stream()))
+            self._eval_loglike(k1, sig, thk, hh, dd, rr, aa, None, chi2, logl)
             best[s0:s0 + nb] = torch.argmin(chi2.view(nb, 100), dim=1)
         t["k"].fill_(1)
         t["sigma"].fill_(1.0)
@@ -216,12 +214,8 @@ class DeviceChains:
         t["edges"].fill_(float("inf"))
         t["log_mean_prior"].copy_(torch.log(t["sigma"][:, 0]))
         thk = torch.zeros_like(t["sigma"])
-        _lib.check(lib.gbp_fdem_forward_loglike(self._h.ptr, B, K, t["k"].data_ptr(), t["sigma"].data_ptr(), thk.data_ptr(),
-                                                t["height"].data_ptr(), t["data"].data_ptr(), t["rel"].data_ptr(),
-                                                t["add"].data_ptr(), t["pred"].data_ptr(), t["misfit"].data_ptr(),
-                                                t["like"].data_ptr(), self._stream()))
-        _lib.check(lib.gbp_fdem_sensitivity_ex(self._h.ptr, B, K, t["k"].data_ptr(), t["sigma"].data_ptr(), thk.data_ptr(),
-                                               t["height"].data_ptr(), t["J"].data_ptr(), 1, self._o.exact_jacobian, self._stream()))
+        self._eval_loglike(t["k"], t["sigma"], thk, t["height"], t["data"], t["rel"], t["add"], t["pred"], t["misfit"], t["like"])
+        self._eval_jacobian(t["k"], t["sigma"], thk, t["height"], t["J"], 1)
         prior = model_log_prior(t["edges"], t["sigma"], t["k"].to(torch.int64), K, self.gradient_precision, o["solve_gradient"],
                                 self._o.value_precision if self._o.solve_value else None, t["log_mean_prior"])
         if self._o.solve_relative_error:
@@ -234,13 +228,26 @@ class DeviceChains:
         t["best_edges"].copy_(t["edges"])
         t["best_k"].copy_(t["k"])
 
+    # the two evaluations the initialisation needs, through the same entries the sampler uses (overridden for time-domain data)
+    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
+        _lib.check(_lib.load().gbp_fdem_forward_loglike(
+            self._h.ptr, k.numel(), self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(), data.data_ptr(),
+            rel.data_ptr(), add.data_ptr(), None if pred is None else pred.data_ptr(), chi2.data_ptr(), logl.data_ptr(), self._stream()))
+
+    def _eval_jacobian(self, k, sigma, thk, height, J, max_layers):
+        _lib.check(_lib.load().gbp_fdem_sensitivity_ex(self._h.ptr, k.numel(), self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
+                                                       height.data_ptr(), J.data_ptr(), int(max_layers), self._o.exact_jacobian,
+                                                       self._stream()))
+
+    def _launch(self, n, accumulate):
+        _lib.check(_lib.load().gbp_rj_run(self._h.ptr, self._o, self._c, self.iteration, int(n), int(bool(accumulate)), self._stream()))
+
     # -- sampling ------------------------------------------------------------------------------------------------------
     def run(self, n, accumulate=True):
         """n iterations of every chain (asynchronous: returns once the launches are queued)."""
         if n > 0:
             with torch.cuda.device(self.device):
-                _lib.check(_lib.load().gbp_rj_run(self._h.ptr, self._o, self._c, self.iteration, int(n), int(bool(accumulate)),
-                                                  self._stream()))
+                self._launch(n, accumulate)
             self.iteration += int(n)
         return self
 
@@ -274,7 +281,7 @@ class DeviceChains:
                 else:
                     self._scatter(full, rows)
                 rows = rows[keep]
-                self.t = {n: (None if v is None else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
+                self.t = {n: (v if v is None or n == "add_scale" else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
                           for n, v in self.t.items()}
                 self._bind()
             self.run(min(check_every, limit - self.iteration))

@@ -32,6 +32,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .rjmcmc_gpu import DeviceChains
 from .filters import W0_J0_120, W1_J1_140, base_abscissae
 
 MU0 = 4.0e-7 * np.pi
@@ -373,6 +374,74 @@ class TdemBatch:
                                                  self.logL.data_ptr(),
                                                  torch.cuda.current_stream(self.device).cuda_stream))
         return self.chi2, self.logL
+
+
+class TdemDeviceChains(DeviceChains):
+    """Device-resident rjMCMC (rjmcmc_gpu.DeviceChains) for time-domain soundings of ONE system (one moment): the sampler's
+    frequency-domain launches run on the system's spline nodes and ``gbp_rj_run_td`` turns nodal spectra (and their
+    Jacobians) into window values with the constant time-domain operator W.  Error model: TdemDataPoint.std
+    (data/datapoint/TdemDataPoint.py:361-365), one relative and one additive level, the additive one scaled by
+    sqrt(1e-3 / t) per gate.  The Jacobian is the exact derivative (GA-AEM's is, too).  Parity is unpinned like the rest of
+    the TDEM path; the sampler logic itself is the FDEM-pinned one."""
+
+    def __init__(self, system, heights, data, offset, **kw):
+        assert isinstance(system, TdemSystem), TypeError("system must be a geobipy_amd.TdemSystem")
+        self.td_system, self._offset = system, tuple(float(v) for v in offset)
+        nc, n = system.n_components, system.node_frequencies().size
+        W = system.time_operator()
+        Wb = np.zeros((2 * nc * n, nc * system.nwindows))          # block-diagonal over components, as in TdemBatch
+        for c in range(nc):
+            Wb[c * n:(c + 1) * n, c * system.nwindows:(c + 1) * system.nwindows] = W[:n]
+            Wb[nc * n + c * n: nc * n + (c + 1) * n, c * system.nwindows:(c + 1) * system.nwindows] = W[n:]
+        self._W_host, self._td_struct = Wb, None
+        add_scale = np.sqrt(1e-3 / np.tile(system.off_time, nc))
+        outer = self
+
+        class _Handle:                    # what DeviceChains asks of an acquisition system
+            def handle(self_inner):
+                if getattr(outer, "_raw", None) is None:
+                    outer._raw = _RawHandle(*system.hankel_tables(*outer._offset))
+                return outer._raw
+        kw.pop("exact_jacobian", None)
+        kw.pop("hankel_eps_ppm", None)
+        super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=add_scale, **kw)
+
+    def _td(self):
+        if self._td_struct is None:
+            dev = self.device
+            self._W = torch.as_tensor(self._W_host, dtype=torch.float64).to(dev).contiguous()
+            nn = self._W.shape[0]
+            self._nodal = torch.empty((self.B, nn), dtype=torch.float64, device=dev)
+            self._J_nodal = torch.empty((self.B, nn, self.K), dtype=torch.float64, device=dev)
+            td = _lib.TdOperator()
+            td.n_nodal, td.W, td.nodal, td.J_nodal = nn, self._W.data_ptr(), self._nodal.data_ptr(), self._J_nodal.data_ptr()
+            self._td_struct = td
+        return self._td_struct
+
+    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
+        self._td()
+        lib, n = _lib.load(), k.numel()
+        nodal = torch.empty((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
+        _lib.check(lib.gbp_fdem_forward(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
+                                        nodal.data_ptr(), self._stream()))
+        p = torch.matmul(nodal, self._W)
+        sd = torch.sqrt((rel[:, None] * data) ** 2 + (add[:, None] * self.t["add_scale"][None, :]) ** 2).contiguous()
+        _lib.check(lib.gbp_gauss_loglike_std(n, p.shape[1], p.data_ptr(), data.data_ptr(), sd.data_ptr(), chi2.data_ptr(),
+                                             logl.data_ptr(), self._stream()))
+        if pred is not None:
+            pred.copy_(p)
+
+    def _eval_jacobian(self, k, sigma, thk, height, J, max_layers):
+        self._td()
+        n = k.numel()
+        Jn = torch.empty((n, self._W.shape[0], self.K), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().gbp_fdem_sensitivity_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
+                                                       height.data_ptr(), Jn.data_ptr(), int(max_layers), 1, self._stream()))
+        J.copy_(torch.einsum("bfl,fw->bwl", Jn, self._W))
+
+    def _launch(self, n, accumulate):
+        _lib.check(_lib.load().gbp_rj_run_td(self._h.ptr, self._td(), self._o, self._c, self.iteration, int(n), int(bool(accumulate)),
+                                             self._stream()))
 
 
 class TdemDataPoint:

@@ -234,7 +234,9 @@ typedef struct gbp_rj_options {
 
 typedef struct gbp_rj_chains {
     int32_t B;
-    /* per-sounding constants */
+    /* constants */
+    const double *add_scale;       /* [N] or NULL  per-channel factor of the additive error: std^2 = (rel d)^2 + (add * add_scale)^2
+                                      (TdemDataPoint.std, data/datapoint/TdemDataPoint.py:361-365: sqrt(1e-3 / t)); NULL = 1 (FDEM) */
     const int64_t *chain_id;       /* [B] or NULL  global index of each chain (keys its random streams); NULL: first_chain + b */
     const double *data;            /* [B, N]  observed data (<= 0: inactive channel)                   */
     const double *height;          /* [B]                                                              */
@@ -283,6 +285,20 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
+/*
+ * The same for time-domain data of ONE system (TdemDataPoint with a single moment): `sys` is the frequency-domain handle of
+ * the system's spline nodes (gbp_hankel_system_create_raw), and a constant matrix turns the nodal spectrum into window
+ * values, windows = nodal @ W (geobipy_amd/tdem.py; replaces gatdaem1d's forwardmodel / derivative, TD/tdem1d.py:89-154).
+ * opt->n_channels = the number of windows; chains->add_scale carries the time-dependent additive error.
+ */
+typedef struct gbp_td_operator {
+    int32_t n_nodal;        /* rows of W = 2 * nF of `sys`                                                   */
+    const double *W;        /* [dev] f64[n_nodal, n_channels], row-major                                      */
+    double *nodal;          /* [dev] scratch f64[B, n_nodal]                                                  */
+    double *J_nodal;        /* [dev] scratch f64[B, n_nodal, K]                                               */
+} gbp_td_operator;
+gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, const gbp_rj_options *opt,
+                         const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
 gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chains *c, void *stream);
 /* Pin (waves > 0) or release (0) the waves per workgroup of the forward kernels launched from the calling thread;

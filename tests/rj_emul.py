@@ -115,10 +115,10 @@ def propose(o, seed, b, it, edges, sigma, rel, add):
     return action, idx, val, e_r, s_r, rel_p, add_p
 
 
-def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add):
+def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_scale=1.0):
     """k_rj_newton for one chain: (log_prop, C) with precision = C C'."""
     k = sigma_r.size
-    std = np.sqrt((rel * data) ** 2 + add ** 2)
+    std = np.sqrt((rel * data) ** 2 + (add * add_scale) ** 2)
     a = data > 0.0
     Ja, P = J[a][:, :k], 1.0 / std[a] ** 2
     op = rjmcmc.model_prior_derivative(vp, edges_r, sigma_r, 2)
@@ -130,7 +130,8 @@ def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add):
     return log_prop, C
 
 
-def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, pred_p, data, rel_p, add_p, like_p, prior, like):
+def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, pred_p, data, rel_p, add_p, like_p, prior, like,
+           add_scale=1.0):
     """k_rj_accept for one chain: (log_ratio, accepted, prior_p)."""
     rp = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0)
     ap = rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
@@ -139,7 +140,7 @@ def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, p
     dq = 0.0
     if action in (rjmcmc.INSERT, rjmcmc.DELETE):
         k = prop.size
-        std = np.sqrt((rel_p * data) ** 2 + add_p ** 2)
+        std = np.sqrt((rel_p * data) ** 2 + (add_p * add_scale) ** 2)
         a = data > 0.0
         grad = rjmcmc.model_prior_derivative(vp, edges_r, prop, 1) + J_p[a][:, :k].T @ ((pred_p[a] - data[a]) / std[a] ** 2)
         hess = C @ C.T
@@ -160,11 +161,12 @@ class Chain:
     with forward(edges, values) / sensitivity(edges, values) (the C oracle in the tests).  Carries the same state and
     posterior accumulators as one row of gbp_rj_chains."""
 
-    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width):
+    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0):
         self.o, self.seed, self.b, self.engine, self.sp, self.vp, self.data = o, seed, b, engine, sp, vp, data
+        self.add_scale = add_scale
         self.edges, self.sigma, self.rel, self.add = np.zeros(0), np.array([sigma0]), rel, add
         self.pred, self.J = engine.forward(self.edges, self.sigma), engine.sensitivity(self.edges, self.sigma)
-        std = np.sqrt((rel * data) ** 2 + add ** 2)
+        std = np.sqrt((rel * data) ** 2 + (add * add_scale) ** 2)
         self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
         rp, ap = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0), rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
         self.prior = rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + rp.log_prior(rel) + ap.log_prior(add)
@@ -181,13 +183,13 @@ class Chain:
             pred_r, J_r = self.engine.forward(e_r, s_r), self.engine.sensitivity(e_r, s_r)
         else:
             pred_r, J_r = self.pred, self.J
-        log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add)
+        log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add, self.add_scale)
         prop = np.exp(log_prop)
         pred_p = self.engine.forward(e_r, prop)
-        misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, np.sqrt((rel_p * d) ** 2 + add_p ** 2))
+        misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, np.sqrt((rel_p * d) ** 2 + (add_p * self.add_scale) ** 2))
         J_p = self.engine.sensitivity(e_r, prop) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
         log_ratio, acc, prior_p = accept(o, self.seed, self.b, it, self.sp, self.vp, action, e_r, s_r, log_prop, C, J_p, pred_p, d,
-                                         rel_p, add_p, like_p, self.prior, self.like)
+                                         rel_p, add_p, like_p, self.prior, self.like, self.add_scale)
         if acc:
             self.edges, self.sigma, self.rel, self.add, self.pred = e_r, prop, rel_p, add_p, pred_p
             self.prior, self.like, self.misfit = prior_p, like_p, misfit_p
