@@ -733,10 +733,10 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system* sys, int B, int Lmax, const 
                            Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
         return GBP_OK;
     };
-    // shallow launches (the sampler's common case) use the variant with one row group: 28 fewer VGPRs, one more wave per SIMD
-    const bool shallow = max_layers <= 8;
-    st = exact ? (shallow ? launch(k_fdem_sens<true, 1>) : launch(k_fdem_sens<true, 8>))
-               : (shallow ? launch(k_fdem_sens<false, 1>) : launch(k_fdem_sens<false, 8>));
+    // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs
+    const int ng = max_layers <= 8 ? 1 : (max_layers <= 16 ? 2 : 8);
+    if (exact) st = ng == 1 ? launch(k_fdem_sens<true, 1>) : (ng == 2 ? launch(k_fdem_sens<true, 2>) : launch(k_fdem_sens<true, 8>));
+    else st = ng == 1 ? launch(k_fdem_sens<false, 1>) : (ng == 2 ? launch(k_fdem_sens<false, 2>) : launch(k_fdem_sens<false, 8>));
     if (st != GBP_OK) return st;
     GBP_HIP(hipGetLastError());
     return GBP_OK;
