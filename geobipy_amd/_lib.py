@@ -22,12 +22,14 @@ class RjOptions(ctypes.Structure):
                                                "solve_additive_error", "exact_jacobian", "n_depth_bins", "n_value_bins", "n_error_bins", "schedule",
                                                "burn_in_min_iterations", "n_markov_chains", "forward_waves")]
                 + [(n, ctypes.c_double) for n in ("min_edge", "max_edge", "min_width", "p_birth", "p_death", "p_perturb", "p_none",
-                                                  "value_precision", "value_min", "value_max", "gradient_precision", "alpha", "rel_min", "rel_max", "rel_sd",
-                                                  "add_min", "add_max", "add_sd", "depth_bin_width", "value_half_width")]
+                                                  "value_precision", "value_min", "value_max", "gradient_precision", "alpha")]
+                + [("n_rel_groups", ctypes.c_int32), ("n_add_groups", ctypes.c_int32)]
+                + [(n, ctypes.c_double * 4) for n in ("rel_min", "rel_max", "rel_sd", "add_min", "add_max", "add_sd")]
+                + [("depth_bin_width", ctypes.c_double), ("value_half_width", ctypes.c_double)]
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)])
 
 
-RJ_CHAIN_FIELDS = ("add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
+RJ_CHAIN_FIELDS = ("rel_group", "add_group", "add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
                    "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma")

@@ -73,17 +73,60 @@ __device__ inline uint32_t chain_key(const gbp_rj_options& o, const gbp_rj_chain
 constexpr double INF = __builtin_huge_val();
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
-__device__ inline double propose_error(Rng& r, double cur, double sd, double lo, double hi)
-{   // StatArray.propose(imposePrior=True, log=True), statistics/StatArray.py:578-638: redraw while outside the prior,
-    // give up (keep the current value) at the 10th redraw
-    const double lc = log(cur), llo = log(lo), lhi = log(hi);
-    double x = lc + sd * r.normal();
-    int tries = 0;
-    while (!(x >= llo && x <= lhi)) {
-        x = lc + sd * r.normal();
-        if (++tries == 10) return cur;
+// Error levels of one chain: up to 4 relative and 4 additive groups (TDEM: one relative level per system x component, one
+// additive level per system, DataPoint.py:268-282 / TdemDataPoint.py:361-365; FDEM with one system: one of each).
+struct Levels { double rel[4], add[4]; };
+
+__device__ inline Levels load_levels(const gbp_rj_options& o, const double* rel, const double* add, size_t b)
+{
+    Levels e;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        e.rel[g] = g < o.n_rel_groups ? rel[b * o.n_rel_groups + g] : 1.0;
+        e.add[g] = g < o.n_add_groups ? add[b * o.n_add_groups + g] : 1.0;
     }
-    return exp(x);
+    return e;
+}
+
+__device__ inline double pick4(const double* v, int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); }
+
+// variance of channel n with datum d: (rel_g d)^2 + (add_g' add_scale_n)^2
+__device__ inline double variance_at(const gbp_rj_chains& c, const Levels& e, double d, int n)
+{
+    const double rd = pick4(e.rel, c.rel_group != nullptr ? c.rel_group[n] : 0) * d;
+    double an = pick4(e.add, c.add_group != nullptr ? c.add_group[n] : 0);
+    if (c.add_scale != nullptr) an *= c.add_scale[n];
+    return rd * rd + an * an;
+}
+
+// Joint proposal of the G levels of one kind (StatArray.propose with a multivariate log-normal proposal of diagonal
+// covariance, statistics/StatArray.py:578-638): all are redrawn while any is outside its prior; the current values are
+// kept at the 10th redraw.
+__device__ inline void propose_levels(Rng& r, const double* cur, int G, const double* sd, const double* lo, const double* hi, double* out)
+{
+    double x[4];
+    bool ok;
+    auto draw = [&]() {
+        ok = true;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < G) {
+                x[g] = log(cur[g]) + sd[g] * r.normal();
+                ok = ok && x[g] >= log(lo[g]) && x[g] <= log(hi[g]);
+            }
+    };
+    draw();
+    int tries = 0;
+    while (!ok) {
+        draw();
+        if (++tries == 10) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) out[g] = cur[g];
+            return;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g] = g < G ? exp(x[g]) : cur[g];
 }
 
 __device__ inline int bucket_of(int k) { return k <= 8 ? 0 : 1; }
@@ -161,8 +204,15 @@ __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& 
     c.action[b] = action;
     c.k_r[b] = kr;
     // error levels (DataPoint.perturb: relative then additive)
-    c.rel_p[b] = o.solve_relative_error ? propose_error(r, c.rel[b], o.rel_sd, o.rel_min, o.rel_max) : c.rel[b];
-    c.add_p[b] = o.solve_additive_error ? propose_error(r, c.add[b], o.add_sd, o.add_min, o.add_max) : c.add[b];
+    const Levels cur = load_levels(o, c.rel, c.add, (size_t)b);
+    Levels out = cur;
+    if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.rel_min, o.rel_max, out.rel);
+    if (o.solve_additive_error) propose_levels(r, cur.add, o.n_add_groups, o.add_sd, o.add_min, o.add_max, out.add);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < o.n_rel_groups) c.rel_p[(size_t)b * o.n_rel_groups + g] = out.rel[g];
+        if (g < o.n_add_groups) c.add_p[(size_t)b * o.n_add_groups + g] = out.add[g];
+    }
 }
 
 // Small blocks of soundings: one wave per chain (4 chains per workgroup).  Lane j holds interface j and layer j, every
@@ -265,16 +315,14 @@ __device__ inline double prior_entry(const gbp_rj_options& o, const double* t2, 
 }
 
 // data weights with the error levels (rel, add): P = active / std^2, PR = P * (pred - data)  (DataPoint.py:268-282, 340-349)
-// per-channel additive error: add * add_scale[n] (TdemDataPoint.std :361-365: sqrt(1e-3 / t) per gate); NULL = 1 (FDEM)
-__device__ inline double add_at(const double* add_scale, double add, int n) { return add_scale != nullptr ? add * add_scale[n] : add; }
-
-__device__ inline void data_weights(const double* data, const double* pred, double rel, double add, const double* add_scale, int N,
-                                    int lane, double* P, double* PR)
+// (variance_at: relative level of the channel's group, additive level of its group times add_scale[n] -- TdemDataPoint.std)
+__device__ inline void data_weights(const gbp_rj_chains& c, const double* data, const double* pred, const Levels& e, int N, int lane,
+                                    int stride, double* P, double* PR)
 {
-    for (int n = lane; n < N; n += 64) {
+    for (int n = lane; n < N; n += stride) {
         const double d = data[n];
         const bool act = d > 0.0;
-        const double rd = rel * d, an = add_at(add_scale, add, n), w = act ? 1.0 / (rd * rd + an * an) : 0.0;
+        const double w = act ? 1.0 / variance_at(c, e, d, n) : 0.0;
         P[n] = w;
         PR[n] = act ? w * (pred[n] - d) : 0.0;
     }
@@ -333,7 +381,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     const double* pred = (changed ? c.pred_r : c.pred) + (size_t)b * N;
     const double* e = c.edges_r + (size_t)b * K;
     const double* sr = c.sigma_r + (size_t)b * K;
-    data_weights(c.data + (size_t)b * N, pred, c.rel[b], c.add[b], c.add_scale, N, lane, s.P, s.PR);
+    data_weights(c, c.data + (size_t)b * N, pred, load_levels(o, c.rel, c.add, (size_t)b), N, lane, 64, s.P, s.PR);
     prior_t2(o, e, k, lane, s.t2);
     const double lmp = c.log_mean_prior[b];
     const double ls = lane < k ? log(sr[lane]) : 0.0;
@@ -416,17 +464,7 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
     const double* e = c.edges_r + bb * K;
     double* P = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * 2 * N;
     double* PR = P + N;
-    {
-        const double rel = c.rel[bb], add = c.add[bb];
-        const double* data = c.data + bb * N;
-        for (int n = i; n < N; n += 8) {
-            const double d = data[n];
-            const bool act = d > 0.0;
-            const double rd = rel * d, an = add_at(c.add_scale, add, n), w = act ? 1.0 / (rd * rd + an * an) : 0.0;
-            P[n] = w;
-            PR[n] = act ? w * (pred[n] - d) : 0.0;
-        }
-    }
+    data_weights(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, 8, P, PR);
     double t2 = 0.0;
     if (i < k - 1 && o.solve_gradient) {
         const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
@@ -519,17 +557,37 @@ __device__ inline double log_uniform_prior(double x, double lo, double hi)
     return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
 }
 
+__device__ inline double levels_log_prior(const double* x, int G, const double* lo, const double* hi)
+{
+    double p = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (g < G) p += log_uniform_prior(x[g], lo[g], hi[g]);
+    return p;
+}
+
 // Error-level posteriors (DataPoint.set_posteriors :651-694): n_error_bins cells uniform in log10 between the prior bounds.
-__device__ inline void error_hist_add(const gbp_rj_options& o, const gbp_rj_chains& c, size_t b, double rel, double add)
+__device__ inline void error_hist_add(const gbp_rj_options& o, const gbp_rj_chains& c, size_t b, const Levels& e)
 {
     if (c.rel_hist == nullptr) return;
     const double inv_ln10 = 0.43429448190325182765, nb = (double)o.n_error_bins;
-    const double r0 = log(o.rel_min) * inv_ln10, r1 = log(o.rel_max) * inv_ln10, a0 = log(o.add_min) * inv_ln10, a1 = log(o.add_max) * inv_ln10;
-    const int ir = min(max((int)floor((log(rel) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
-    const int ia = min(max((int)floor((log(add) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
-    c.rel_hist[b * o.n_error_bins + ir] += 1;
-    c.add_hist[b * o.n_error_bins + ia] += 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g < o.n_rel_groups) {
+            const double r0 = log(o.rel_min[g]) * inv_ln10, r1 = log(o.rel_max[g]) * inv_ln10;
+            const int ir = min(max((int)floor((log(e.rel[g]) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
+            c.rel_hist[(b * o.n_rel_groups + g) * o.n_error_bins + ir] += 1;
+        }
+        if (g < o.n_add_groups) {
+            const double a0 = log(o.add_min[g]) * inv_ln10, a1 = log(o.add_max[g]) * inv_ln10;
+            const int ia = min(max((int)floor((log(e.add[g]) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
+            c.add_hist[(b * o.n_add_groups + g) * o.n_error_bins + ia] += 1;
+        }
+    }
 }
+
+// sum over the groups of the log-uniform priors of one kind of level
+__device__ inline double levels_log_prior(const double* x, int G, const double* lo, const double* hi);
 
 // Conductivity-depth hit map (Model.update_parameter_posterior :819-847): `weight` counts of model (ec, sc, kc) added to one
 // chain's map hm[n_value_bins][n_depth_bins]; W lanes share the depth cells.  The samplers call it when a chain's model
@@ -580,14 +638,14 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         const double sp = lane < k ? c.sigma_p[(size_t)b * K + lane] : o.value_min;
         if (__any(!(sp >= o.value_min && sp <= o.value_max))) prior_p = -INF;
     }
-    const double rel_p = c.rel_p[b], add_p = c.add_p[b];
-    if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);
-    if (o.solve_additive_error) prior_p += log_uniform_prior(add_p, o.add_min, o.add_max);
+    const Levels lev_p = load_levels(o, c.rel_p, c.add_p, (size_t)b);
+    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.rel_min, o.rel_max);
+    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.add_min, o.add_max);
     double dq = 0.0;
     if (action == INSERT || action == DELETE) {                  // Model.proposal_probabilities (model/Model.py:577-659)
         const double* Jp = c.J_p + (size_t)b * N * K;
         const double* C = c.chol + (size_t)b * K * K;
-        data_weights(c.data + (size_t)b * N, c.pred_p + (size_t)b * N, rel_p, add_p, c.add_scale, N, lane, s.P, s.PR);
+        data_weights(c, c.data + (size_t)b * N, c.pred_p + (size_t)b * N, lev_p, N, lane, 64, s.P, s.PR);
         prior_t2(o, e, k, lane, s.t2);
         if (lane < k) {
             for (int j = 0; j <= lane; ++j) s.A[lane * KS + j] = C[(size_t)lane * K + j];
@@ -628,7 +686,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         for (int i = lane; i < N; i += 64) {
             const double ov = ob[i];
             if (ov > 0.0) {
-                const double ro = rel_p * ov, an = add_at(c.add_scale, add_p, i), var = ro * ro + an * an;
+                const double var = variance_at(c, lev_p, ov, i);
                 const double r = (pp[i] - ov) * (1.0 / sqrt(var));
                 s2 += r * r; logdet += log(var); na += 1.0;
             }
@@ -647,7 +705,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     __syncthreads();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
-    const double rel_c = c.rel[b], add_c = c.add[b];             // (read before the state is overwritten)
+    const Levels lev_c = load_levels(o, c.rel, c.add, (size_t)b);  // (read before the state is overwritten)
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[b] : 0;        // iterations the current model is still owed to the hit map
     if (accept && dwell > 0) {                                   // the model changes: settle the old one first
@@ -667,7 +725,12 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             for (int i = lane; i < N * K; i += 64) Jd[i] = Js[i];
         }
         if (lane == 0) {
-            c.k[b] = k; c.rel[b] = rel_p; c.add[b] = add_p;
+            c.k[b] = k;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < o.n_rel_groups) c.rel[(size_t)b * o.n_rel_groups + g] = lev_p.rel[g];
+                if (g < o.n_add_groups) c.add[(size_t)b * o.n_add_groups + g] = lev_p.add[g];
+            }
             c.prior[b] = prior_p; c.like[b] = like_p; c.misfit[b] = misfit_p;
             c.n_accepted[b] += 1;
         }
@@ -692,11 +755,10 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
                 bi = it1;
                 reset_best = true;
                 for (int i = lane; i < K + 1; i += 64) c.k_hist[(size_t)b * (K + 1) + i] = 0;
-                if (c.rel_hist != nullptr)
-                    for (int i = lane; i < o.n_error_bins; i += 64) {
-                        c.rel_hist[(size_t)b * o.n_error_bins + i] = 0;
-                        c.add_hist[(size_t)b * o.n_error_bins + i] = 0;
-                    }
+                if (c.rel_hist != nullptr) {
+                    for (int i = lane; i < o.n_rel_groups * o.n_error_bins; i += 64) c.rel_hist[(size_t)b * o.n_rel_groups * o.n_error_bins + i] = 0;
+                    for (int i = lane; i < o.n_add_groups * o.n_error_bins; i += 64) c.add_hist[(size_t)b * o.n_add_groups * o.n_error_bins + i] = 0;
+                }
                 if (c.edge_hist != nullptr)
                     for (int i = lane; i < o.n_depth_bins; i += 64) c.edge_hist[(size_t)b * o.n_depth_bins + i] = 0;
                 if (c.hitmap != nullptr) {
@@ -719,7 +781,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     if (accumulate) {
         if (lane == 0) {
             c.k_hist[(size_t)b * (K + 1) + kc] += 1;
-            error_hist_add(o, c, (size_t)b, accept ? rel_p : rel_c, accept ? add_p : add_c);
+            error_hist_add(o, c, (size_t)b, accept ? lev_p : lev_c);
         }
         if (c.edge_hist != nullptr && lane < kc - 1) {           // interfaces across which sigma changes by > 50 %
             const double ratio = sc[lane + 1] / sc[lane];        //   (RectilinearMesh1D.update_posteriors :1595-1610)
@@ -814,9 +876,9 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
         const unsigned long long out = __ballot(!(sp >= o.value_min && sp <= o.value_max));
         if ((out >> base) & 0xFFull) prior_p = -INF;
     }
-    const double rel_p = c.rel_p[bb], add_p = c.add_p[bb];
-    if (o.solve_relative_error) prior_p += log_uniform_prior(rel_p, o.rel_min, o.rel_max);
-    if (o.solve_additive_error) prior_p += log_uniform_prior(add_p, o.add_min, o.add_max);
+    const Levels lev_p = load_levels(o, c.rel_p, c.add_p, bb);
+    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.rel_min, o.rel_max);
+    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.add_min, o.add_max);
     // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian
     double* PR = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * N;
     double s2 = 0.0, logdet = 0.0, na = 0.0;
@@ -827,7 +889,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
             const double ov = ob[n];
             double pr = 0.0;
             if (ov > 0.0) {
-                const double ro = rel_p * ov, an = add_at(c.add_scale, add_p, n), var = ro * ro + an * an;
+                const double var = variance_at(c, lev_p, ov, n);
                 const double r = (pp[n] - ov) * (1.0 / sqrt(var));
                 s2 += r * r; logdet += log(var); na += 1.0;
                 pr = (1.0 / var) * (pp[n] - ov);
@@ -900,7 +962,8 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
     const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
-    const double misfit_c = c.misfit[bb], rel_c = c.rel[bb], add_c = c.add[bb];       // (read before the state is overwritten)
+    const double misfit_c = c.misfit[bb];
+    const Levels lev_c = load_levels(o, c.rel, c.add, bb);       // (read before the state is overwritten)
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
     if (c.hitmap != nullptr) {                       // the model changes: settle the old one in the hit map first
@@ -920,7 +983,12 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
             for (int q = i; q < N * K; q += 8) Jd[q] = Js[q];
         }
         if (i == 0) {
-            c.k[bb] = k; c.rel[bb] = rel_p; c.add[bb] = add_p;
+            c.k[bb] = k;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < o.n_rel_groups) c.rel[bb * o.n_rel_groups + g] = lev_p.rel[g];
+                if (g < o.n_add_groups) c.add[bb * o.n_add_groups + g] = lev_p.add[g];
+            }
             c.prior[bb] = prior_p; c.like[bb] = like_p; c.misfit[bb] = misfit_p;
             c.n_accepted[bb] += 1;
         }
@@ -944,8 +1012,10 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                 bi = it1;
                 reset_best = true;
                 for (int q = i; q < K + 1; q += 8) c.k_hist[bb * (K + 1) + q] = 0;
-                if (c.rel_hist != nullptr)
-                    for (int q = i; q < o.n_error_bins; q += 8) { c.rel_hist[bb * o.n_error_bins + q] = 0; c.add_hist[bb * o.n_error_bins + q] = 0; }
+                if (c.rel_hist != nullptr) {
+                    for (int q = i; q < o.n_rel_groups * o.n_error_bins; q += 8) c.rel_hist[bb * o.n_rel_groups * o.n_error_bins + q] = 0;
+                    for (int q = i; q < o.n_add_groups * o.n_error_bins; q += 8) c.add_hist[bb * o.n_add_groups * o.n_error_bins + q] = 0;
+                }
                 if (c.edge_hist != nullptr)
                     for (int q = i; q < o.n_depth_bins; q += 8) c.edge_hist[bb * o.n_depth_bins + q] = 0;
                 if (c.hitmap != nullptr) {
@@ -967,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
         // (the k_hist row may have been zeroed by other lanes of the group just above: same wave, program order)
         if (i == 0) {
             c.k_hist[bb * (K + 1) + kc] += 1;
-            error_hist_add(o, c, bb, accept ? rel_p : rel_c, accept ? add_p : add_c);
+            error_hist_add(o, c, bb, accept ? lev_p : lev_c);
         }
         if (c.edge_hist != nullptr && i < kc - 1) {
             const double ratio = sc[i + 1] / sc[i];
@@ -1049,18 +1119,20 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
 }
 
 // chi^2 / logL with the per-channel additive scale, for the soundings with nl > 0 (one wave per sounding)
-__global__ __launch_bounds__(64) void k_td_loglike(int B, int N, const int* __restrict__ nl, const double* __restrict__ pred,
-                                                   const double* __restrict__ obs, const double* __restrict__ rel,
-                                                   const double* __restrict__ add, const double* __restrict__ add_scale,
-                                                   double* __restrict__ chi2, double* __restrict__ logL)
+__global__ __launch_bounds__(64) void k_td_loglike(gbp_rj_options o, gbp_rj_chains c, const int* __restrict__ nl,
+                                                   const double* __restrict__ pred, const double* __restrict__ rel,
+                                                   const double* __restrict__ add, double* __restrict__ chi2,
+                                                   double* __restrict__ logL)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x, N = o.n_channels;
     if (nl[b] <= 0) return;
+    const Levels e = load_levels(o, rel, add, (size_t)b);
+    const double* obs = c.data;
     double s2 = 0.0, logdet = 0.0, na = 0.0;
     for (int i = lane; i < N; i += 64) {
         const double ov = obs[(size_t)b * N + i];
         if (ov > 0.0) {
-            const double ro = rel[b] * ov, an = add_at(add_scale, add[b], i), var = ro * ro + an * an;
+            const double var = variance_at(c, e, ov, i);
             const double r = (pred[(size_t)b * N + i] - ov) * (1.0 / sqrt(var));
             s2 += r * r; logdet += log(var); na += 1.0;
         }
@@ -1092,6 +1164,8 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
         return fail(GBP_ERR_INVALID_ARG, "posterior depth grid is empty%s");
     if (c->hitmap && (o->n_value_bins < 1 || !(o->value_half_width > 0.0))) return fail(GBP_ERR_INVALID_ARG, "hit-map value grid is empty%s");
     if (c->hitmap && !c->hit_dwell) return fail(GBP_ERR_INVALID_ARG, "hitmap needs hit_dwell%s");
+    if (o->n_rel_groups < 1 || o->n_rel_groups > 4 || o->n_add_groups < 1 || o->n_add_groups > 4)
+        return fail(GBP_ERR_INVALID_ARG, "n_rel_groups / n_add_groups must be in [1, 4]%s");
     if ((c->rel_hist != nullptr) != (c->add_hist != nullptr) || (c->rel_hist && o->n_error_bins < 1))
         return fail(GBP_ERR_INVALID_ARG, "rel_hist and add_hist come together, with n_error_bins >= 1%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
@@ -1162,6 +1236,8 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (td == nullptr) {
         if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
+        if (o->n_rel_groups != 1 || o->n_add_groups != 1)
+            return fail(GBP_ERR_INVALID_ARG, "frequency-domain data: one relative and one additive error level%s");
     } else {
         if (td->n_nodal != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_nodal must be 2 * nF of the system%s");
         if (!td->W || !td->nodal || !td->J_nodal) return fail(GBP_ERR_INVALID_ARG, "NULL pointer in gbp_td_operator%s");
@@ -1220,8 +1296,8 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
         } else {
             if ((st = gbp_fdem_forward(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr)) != GBP_OK) return st;
-            hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, B, N, c->nl_b, c->pred_p, c->data, c->rel_p,
-                               c->add_p, c->add_scale, c->misfit_p, c->like_p);
+            hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, *o, *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
+                               c->misfit_p, c->like_p);
             GBP_HIP(hipGetLastError());
         }
         //   ... and prediction + Jacobian (Model.py:612) of those that change it; their chi^2 / logL are formed in accept

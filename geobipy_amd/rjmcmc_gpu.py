@@ -15,6 +15,7 @@ launches of one iteration (propose | 2 x prediction + Jacobian of the remapped m
 likelihood of the proposals that keep their dimension | 2 x prediction + Jacobian of those that change it | accept (packed, general)) on the caller's stream without
 synchronising; nothing crosses PCIe between iterations.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -82,7 +83,7 @@ class DeviceChains:
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=4, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=0.0,
-                 min_altitude=None, add_scale=None, **options):
+                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -132,10 +133,20 @@ class DeviceChains:
         lim = o.get("parameter_limits")
         ro.value_min, ro.value_max = (0.0, 0.0) if lim is None else (float(lim[0]), float(lim[1]))
         ro.alpha = float(o["covariance_scaling"])
-        ro.rel_min, ro.rel_max = o["minimum_relative_error"], o["maximum_relative_error"]
-        ro.rel_sd = math.sqrt(o["relative_error_proposal_variance"])
-        ro.add_min, ro.add_max = o["minimum_additive_error"], o["maximum_additive_error"]
-        ro.add_sd = math.sqrt(o["additive_error_proposal_variance"])
+        # error levels: one of each for frequency-domain data; time-domain data have one relative level per system x
+        # component and one additive level per system (options given as lists, as in the reference's skytem / tempest files)
+        vec = lambda key, n: np.broadcast_to(np.atleast_1d(np.asarray(o[key], dtype=np.float64)), (n,)).copy()
+        self.n_rel_groups = Gr = 1 if rel_group is None else int(np.max(rel_group)) + 1
+        self.n_add_groups = Ga = 1 if add_group is None else int(np.max(add_group)) + 1
+        ro.n_rel_groups, ro.n_add_groups = Gr, Ga
+        for name, key, n, f in (("rel_min", "minimum_relative_error", Gr, None), ("rel_max", "maximum_relative_error", Gr, None),
+                                ("rel_sd", "relative_error_proposal_variance", Gr, np.sqrt), ("add_min", "minimum_additive_error", Ga, None),
+                                ("add_max", "maximum_additive_error", Ga, None), ("add_sd", "additive_error_proposal_variance", Ga, np.sqrt)):
+            v = vec(key, n)
+            setattr(ro, name, (ctypes.c_double * 4)(*(list(f(v) if f else v) + [1.0] * (4 - n))))
+        self._rel0, self._add0 = vec("initial_relative_error", Gr), vec("initial_additive_error", Ga)
+        self._bounds = dict(rel=(vec("minimum_relative_error", Gr), vec("maximum_relative_error", Gr)),
+                            add=(vec("minimum_additive_error", Ga), vec("maximum_additive_error", Ga)))
         ro.depth_bin_width, ro.value_half_width = self.depth_bin_width, self.value_half_width
         ro.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         ro.first_chain = int(first_chain)          # global index of this block's first sounding (sharded surveys)
@@ -148,13 +159,15 @@ class DeviceChains:
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
         i32, i64 = torch.int32, torch.int64
+        i32v = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev).contiguous()
         self.t = t = dict(
-            add_scale=None if add_scale is None else f64(add_scale), chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B), add=z(B),
+            rel_group=i32v(rel_group), add_group=i32v(add_group),
+            add_scale=None if add_scale is None else f64(add_scale), chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B, Gr), add=z(B, Ga),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
-            nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B), add_p=z(B),
+            nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B, Gr), add_p=z(B, Ga),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),
             like_p=z(B), J_p=z(B, N, K), log_ratio=z(B), n_accepted=z(B, dt=i64), k_hist=z(B, K + 1, dt=i32),
-            edge_hist=z(B, self.n_depth_bins, dt=i32), rel_hist=z(B, 99, dt=i32), add_hist=z(B, 99, dt=i32),
+            edge_hist=z(B, self.n_depth_bins, dt=i32), rel_hist=z(B, Gr, 99, dt=i32), add_hist=z(B, Ga, 99, dt=i32),
             hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
             hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
@@ -191,8 +204,8 @@ class DeviceChains:
     # -- Inference1D.initialize (:353-464): best half-space, its forward / Jacobian, prior and likelihood ----------------
     def _initialize(self):
         o, B, K, t = self.o, self.B, self.K, self.t
-        t["rel"].fill_(float(o["initial_relative_error"]))
-        t["add"].fill_(float(o["initial_additive_error"]))
+        t["rel"].copy_(torch.as_tensor(self._rel0, device=self.device)[None, :].expand_as(t["rel"]))
+        t["add"].copy_(torch.as_tensor(self._add0, device=self.device)[None, :].expand_as(t["add"]))
         grid = torch.logspace(-4.0, 4.0, 100, dtype=torch.float64, device=self.device)
         best = torch.zeros(B, dtype=torch.int64, device=self.device)
         chunk = max(1, min(B, (1 << 22) // 100))                      # B x 100 half-space forwards, in slabs
@@ -219,9 +232,11 @@ class DeviceChains:
         prior = model_log_prior(t["edges"], t["sigma"], t["k"].to(torch.int64), K, self.gradient_precision, o["solve_gradient"],
                                 self._o.value_precision if self._o.solve_value else None, t["log_mean_prior"])
         if self._o.solve_relative_error:
-            prior = prior + log_uniform_prior(t["rel"], o["minimum_relative_error"], o["maximum_relative_error"])
+            prior = prior + sum(log_uniform_prior(t["rel"][:, g], self._bounds["rel"][0][g], self._bounds["rel"][1][g])
+                                for g in range(self.n_rel_groups))
         if self._o.solve_additive_error:
-            prior = prior + log_uniform_prior(t["add"], o["minimum_additive_error"], o["maximum_additive_error"])
+            prior = prior + sum(log_uniform_prior(t["add"][:, g], self._bounds["add"][0][g], self._bounds["add"][1][g])
+                                for g in range(self.n_add_groups))
         t["prior"].copy_(prior)
         t["best_posterior"].copy_(t["like"] + t["prior"])
         t["best_sigma"].copy_(t["sigma"])
@@ -281,7 +296,7 @@ class DeviceChains:
                 else:
                     self._scatter(full, rows)
                 rows = rows[keep]
-                self.t = {n: (v if v is None or n == "add_scale" else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
+                self.t = {n: (v if v is None or n in ("add_scale", "rel_group", "add_group") else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
                           for n, v in self.t.items()}
                 self._bind()
             self.run(min(check_every, limit - self.iteration))

@@ -247,10 +247,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     K = dc.K
     t = dc.t
     f64 = lambda x: x.to(torch.float64)
-    cols = [f64(t["status"]), f64(t["burned_in_iteration"]), f64(t["n_accepted"]), t["misfit"], t["rel"], t["add"], f64(t["k"]),
+    cols = [f64(t["status"]), f64(t["burned_in_iteration"]), f64(t["n_accepted"]), t["misfit"], t["rel"][:, 0], t["add"][:, 0], f64(t["k"]),
             f64(t["best_k"]), t["best_posterior"]]
-    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"]), f64(t["rel_hist"]),
-              f64(t["add_hist"])]
+    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"]), f64(t["rel_hist"][:, 0]),
+              f64(t["add_hist"][:, 0])]
     if hitmap:
         mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
         blocks += [mean] + pct

@@ -425,7 +425,9 @@ class TdemDeviceChains(DeviceChains):
         _lib.check(lib.gbp_fdem_forward(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
                                         nodal.data_ptr(), self._stream()))
         p = torch.matmul(nodal, self._W)
-        sd = torch.sqrt((rel[:, None] * data) ** 2 + (add[:, None] * self.t["add_scale"][None, :]) ** 2).contiguous()
+        rg = self.t["rel_group"].long() if self.t["rel_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
+        ag = self.t["add_group"].long() if self.t["add_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
+        sd = torch.sqrt((rel[:, rg] * data) ** 2 + (add[:, ag] * self.t["add_scale"][None, :]) ** 2).contiguous()
         _lib.check(lib.gbp_gauss_loglike_std(n, p.shape[1], p.data_ptr(), data.data_ptr(), sd.data_ptr(), chi2.data_ptr(),
                                              logl.data_ptr(), self._stream()))
         if pred is not None:

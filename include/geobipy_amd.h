@@ -224,7 +224,10 @@ typedef struct gbp_rj_options {
     double value_min, value_max; /* parameter_limits: proposals with a conductivity outside have zero prior; value_max <= 0: none */
     double gradient_precision;   /* 1 / gradient_standard_deviation^2                                 */
     double alpha;                /* covariance_scaling                                                 */
-    double rel_min, rel_max, rel_sd, add_min, add_max, add_sd;   /* sd = sqrt(proposal variance)      */
+    int32_t n_rel_groups, n_add_groups;   /* error levels per sounding, 1..4 each: one relative level per system x component and
+                                             one additive level per system (DataPoint.py:268-282, TdemDataPoint.py:361-365);
+                                             frequency-domain data with one system: 1 and 1                              */
+    double rel_min[4], rel_max[4], rel_sd[4], add_min[4], add_max[4], add_sd[4];   /* per group; sd = sqrt(proposal variance) */
     double depth_bin_width;      /* interface histogram / hit-map depth cell                           */
     double value_half_width;     /* hit-map spans log10(sigma / prior mean) in [-w, w]                 */
     uint64_t seed;
@@ -235,6 +238,7 @@ typedef struct gbp_rj_options {
 typedef struct gbp_rj_chains {
     int32_t B;
     /* constants */
+    const int32_t *rel_group, *add_group;   /* [N] or NULL  group of each channel's relative / additive level; NULL = 0 */
     const double *add_scale;       /* [N] or NULL  per-channel factor of the additive error: std^2 = (rel d)^2 + (add * add_scale)^2
                                       (TdemDataPoint.std, data/datapoint/TdemDataPoint.py:361-365: sqrt(1e-3 / t)); NULL = 1 (FDEM) */
     const int64_t *chain_id;       /* [B] or NULL  global index of each chain (keys its random streams); NULL: first_chain + b */
@@ -244,7 +248,7 @@ typedef struct gbp_rj_chains {
     /* chain state */
     int32_t *k;                    /* [B]     layers                                                   */
     double *edges, *sigma;         /* [B, K]  interface depths (k - 1 used, +inf padded), conductivities (1 padded) */
-    double *rel, *add;             /* [B]                                                              */
+    double *rel, *add;             /* [B, n_rel_groups], [B, n_add_groups]  error levels                                  */
     double *pred, *J;              /* [B, N], [B, N, K]  carried prediction / Jacobian                  */
     double *prior, *like, *misfit; /* [B]                                                              */
     /* proposal scratch (written by the step) */
@@ -253,7 +257,7 @@ typedef struct gbp_rj_chains {
                                       rows 1-2 split by layer count (<= 8, more)                         */
     int32_t *nl_b;                 /* [B]     k_r of the chains whose proposal keeps its dimension (fused forward), else 0 */
     double *edges_r, *sigma_r, *thk_r;        /* [B, K] remapped model                                 */
-    double *rel_p, *add_p;                    /* [B]    proposed errors                                */
+    double *rel_p, *add_p;                    /* [B, n_*_groups]  proposed error levels              */
     double *pred_r, *J_r;                     /* [B, N], [B, N, K] at the remapped model               */
     double *chol;                             /* [B, K, K] lower Cholesky factor of the proposal precision */
     double *log_prop, *sigma_p;               /* [B, K] proposed ln sigma, sigma                       */
@@ -263,7 +267,7 @@ typedef struct gbp_rj_chains {
     int64_t *n_accepted;           /* [B]                                                              */
     int32_t *k_hist;               /* [B, K + 1]            posterior of the layer count               */
     int32_t *edge_hist;            /* [B, n_depth_bins]     interfaces with a conductivity contrast > 50 % */
-    int32_t *rel_hist, *add_hist;  /* [B, n_error_bins]     posteriors of the error levels (both or neither; may be NULL)     */
+    int32_t *rel_hist, *add_hist;  /* [B, n_*_groups, n_error_bins]  posteriors of the error levels (both or neither; may be NULL) */
     int32_t *hitmap;               /* [B, n_value_bins, n_depth_bins] or NULL (depth fastest: the cells of one layer share a
                                       value bin, so one iteration updates a few contiguous runs)         */
     int32_t *hit_dwell;            /* [B] (with hitmap)  iterations the current model is still owed to the hit map: a model is

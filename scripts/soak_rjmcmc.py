@@ -33,15 +33,15 @@ for name, system, height, data, exact in cases:
     thk_ = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
     ok &= bool((torch.where(thk_ > 0, thk_, torch.full_like(thk_, 9.0)) > dc.min_width).all()) and k.min() >= 1 and k.max() <= dc.K
     _lib.check(_lib.load().gbp_pin_forward_waves(4))
-    fb = FdemBatch(system, k, dc.sigma.cpu().numpy(), thk_.cpu().numpy(), height, data=data, relative_error=dc.rel.cpu().numpy(),
-                   additive_error=dc.add.cpu().numpy())
+    fb = FdemBatch(system, k, dc.sigma.cpu().numpy(), thk_.cpu().numpy(), height, data=data, relative_error=dc.rel[:, 0].cpu().numpy(),
+                   additive_error=dc.add[:, 0].cpu().numpy())
     chi2, logl = fb.forward_loglike()
     _lib.check(_lib.load().gbp_pin_forward_waves(0))
     ok &= bool(torch.allclose(fb.predicted, dc.pred, rtol=1e-9, atol=1e-7)) and bool(torch.allclose(chi2, dc.misfit, rtol=1e-7))
     kh = dc.k_hist.cpu().numpy().sum(axis=1)
     expect = np.where(st == 1, n_mc + 2, n_mc)
     ok &= bool(np.array_equal(kh, expect)) and bool(np.array_equal(dc.hitmap.sum(dim=(1, 2)).cpu().numpy(), kh * dc.n_depth_bins))
-    ok &= bool(np.array_equal(dc.rel_hist.sum(dim=1).cpu().numpy(), kh)) and not (st == 0).any()
+    ok &= bool(np.array_equal(dc.rel_hist.sum(dim=(1, 2)).cpu().numpy(), kh)) and not (st == 0).any()
     it_total = np.where(st == 1, bi + n_mc + 1, n_mc).sum()
     print(f"{name}: B={B} n_markov_chains={n_mc}: {dt:.1f} s ({it_total/dt/1e6:.1f} M chain-iterations/s incl. idle rows), done {int((st==1).sum())}, "
           f"failed to burn in {failed}, median burn-in iteration {int(np.median(bi[st==1])) if (st==1).any() else -1}, mean k {k.mean():.2f}, max k {k.max()}, "

@@ -86,8 +86,8 @@ def _chains(B, seed, exact=False, n_it=0, **kw):
 def _emul_options(dc):
     o = dc._o
     return dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge,
-                p=[o.p_birth, o.p_death, o.p_perturb, o.p_none], rel_sd=o.rel_sd, rel_min=o.rel_min, rel_max=o.rel_max,
-                add_sd=o.add_sd, add_min=o.add_min, add_max=o.add_max, alpha=o.alpha)
+                p=[o.p_birth, o.p_death, o.p_perturb, o.p_none], rel_sd=o.rel_sd[0], rel_min=o.rel_min[0], rel_max=o.rel_max[0],
+                add_sd=o.add_sd[0], add_min=o.add_min[0], add_max=o.add_max[0], alpha=o.alpha)
 
 
 def _host_priors(dc, b):
@@ -107,8 +107,8 @@ def _load_random_state(dc, rng, kmax):
     dc.k.copy_(torch.as_tensor(ks.astype(np.int32)))
     dc.edges.copy_(torch.as_tensor(edges))
     dc.sigma.copy_(torch.as_tensor(sigma))
-    dc.rel.copy_(torch.as_tensor(rng.uniform(0.0012, 0.4, dc.B)))
-    dc.add.copy_(torch.as_tensor(rng.uniform(3.05, 19.5, dc.B)))
+    dc.rel[:, 0] = torch.as_tensor(rng.uniform(0.0012, 0.4, dc.B))
+    dc.add[:, 0] = torch.as_tensor(rng.uniform(3.05, 19.5, dc.B))
     return ks, models
 
 
@@ -179,9 +179,9 @@ def test_propose_kernel_matches_the_emulation():
         _lib.check(_lib.load().gbp_rj_propose(dc._o, dc._c, it, None))
         act, k_r = dc.action.cpu().numpy(), dc.k_r.cpu().numpy()
         e_r, s_r, t_r = dc.edges_r.cpu().numpy(), dc.sigma_r.cpu().numpy(), dc.thk_r.cpu().numpy()
-        rel_p, add_p = dc.rel_p.cpu().numpy(), dc.add_p.cpu().numpy()
+        rel_p, add_p = dc.rel_p[:, 0].cpu().numpy(), dc.add_p[:, 0].cpu().numpy()
         nl_a, nl_c = dc.nl_a.cpu().numpy(), dc.nl_c.cpu().numpy()
-        rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
+        rel, add = dc.rel[:, 0].cpu().numpy(), dc.add[:, 0].cpu().numpy()
         for b, (e, v) in enumerate(models):
             a, idx, val, ee, ss, rp, ap = rj_emul.propose(eo, 99, b, it, e, v, rel[b], add[b])
             assert act[b] == a and k_r[b] == ss.size, (b, act[b], a)
@@ -237,7 +237,7 @@ def test_newton_kernel_matches_the_emulation():
     dc.pred.copy_(torch.as_tensor(p_a)); dc.pred_r.copy_(torch.as_tensor(p_b))
     _lib.check(_lib.load().gbp_rj_newton(dc._o, dc._c, 17, None))
     lp, sp_, ch = dc.log_prop.cpu().numpy(), dc.sigma_p.cpu().numpy(), dc.chol.cpu().numpy()
-    rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
+    rel, add = dc.rel[:, 0].cpu().numpy(), dc.add[:, 0].cpu().numpy()
     eo = _emul_options(dc)
     for b, (e, v) in enumerate(models):
         _, vp = _host_priors(dc, b)
@@ -270,8 +270,8 @@ def test_accept_kernel_matches_the_emulation():
                                            dc.J.data_ptr(), Kp, 1, None))
     o = dc.o
     dc.prior.copy_(rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), Kp, dc.gradient_precision)
-                   + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
-                   + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
+                   + rg.log_uniform_prior(dc.rel[:, 0], o["minimum_relative_error"], o["maximum_relative_error"])
+                   + rg.log_uniform_prior(dc.add[:, 0], o["minimum_additive_error"], o["maximum_additive_error"]))
     before = {n: getattr(dc, n).clone() for n in ("k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit")}
     it = 9
     dc.iteration = it
@@ -283,7 +283,7 @@ def test_accept_kernel_matches_the_emulation():
         assert np.array_equal(g(n), v, equal_nan=True), n       # run() proposed exactly what the stage call did
     action, k_r, e_r, s_r = g("action"), g("k_r"), g("edges_r"), g("sigma_r")
     log_prop, chol, J_p, pred_p = g("log_prop"), g("chol"), g("J_p"), g("pred_p")
-    rel_p, add_p, like_p, misfit_p, log_ratio = g("rel_p"), g("add_p"), g("like_p"), g("misfit_p"), g("log_ratio")
+    rel_p, add_p, like_p, misfit_p, log_ratio = g("rel_p")[:, 0], g("add_p")[:, 0], g("like_p"), g("misfit_p"), g("log_ratio")
     data, n_accepted = g("data"), g("n_accepted")
     eo = _emul_options(dc)
     n_acc = n_jump = 0
@@ -310,7 +310,7 @@ def test_accept_kernel_matches_the_emulation():
             assert np.array_equal(dc.edges[b].cpu().numpy(), e_r[b]) and np.array_equal(dc.sigma[b].cpu().numpy(), g("sigma_p")[b])
             assert np.array_equal(dc.pred[b].cpu().numpy(), pred_p[b]) and np.isclose(float(dc.like[b]), ref_like, rtol=1e-12)
             assert np.isclose(float(dc.misfit[b]), ref_misfit, rtol=1e-11) and np.isclose(float(dc.prior[b]), ref_prior, rtol=1e-12)
-            assert float(dc.rel[b]) == rel_p[b] and float(dc.add[b]) == add_p[b]
+            assert float(dc.rel[b, 0]) == rel_p[b] and float(dc.add[b, 0]) == add_p[b]
             Jsrc = {0: bk["J"][b], 1: J_p[b], 2: J_p[b], 3: g("J_r")[b]}[int(action[b])]
             assert np.array_equal(dc.J[b].cpu().numpy(), Jsrc)
         else:
@@ -345,7 +345,7 @@ def test_device_chains_state_is_coherent_after_many_steps():
         if k[b] > 1:
             assert e[b, 0] > dc.min_edge and e[b, k[b] - 2] < dc.max_edge
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
-                   relative_error=dc.rel.cpu().numpy(), additive_error=dc.add.cpu().numpy())
+                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy())
     from geobipy_amd import _lib
     _lib.check(_lib.load().gbp_pin_forward_waves(4))             # the summation order the chains ran with (forward_waves=4)
     chi2, logl = fb.forward_loglike()
@@ -356,8 +356,8 @@ def test_device_chains_state_is_coherent_after_many_steps():
     assert torch.allclose(logl, dc.like, rtol=1e-10) and (fb.predicted == dc.pred).all(dim=1).float().mean() > 0.3
     o = dc.o
     prior = (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
-             + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
-             + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
+             + rg.log_uniform_prior(dc.rel[:, 0], o["minimum_relative_error"], o["maximum_relative_error"])
+             + rg.log_uniform_prior(dc.add[:, 0], o["minimum_additive_error"], o["maximum_additive_error"]))
     assert torch.allclose(prior, dc.prior, rtol=1e-12, atol=0)
     assert int(dc.k_hist.sum()) == 300 * dc.B
     assert torch.all(dc.best_posterior >= dc.like + dc.prior)
@@ -389,8 +389,8 @@ def test_deep_chains_stay_coherent():
                                            dc.J.data_ptr(), Kp, 1, None))
     o = dc.o
     full_prior = lambda: (rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), Kp, dc.gradient_precision)
-                          + rg.log_uniform_prior(dc.rel, o["minimum_relative_error"], o["maximum_relative_error"])
-                          + rg.log_uniform_prior(dc.add, o["minimum_additive_error"], o["maximum_additive_error"]))
+                          + rg.log_uniform_prior(dc.rel[:, 0], o["minimum_relative_error"], o["maximum_relative_error"])
+                          + rg.log_uniform_prior(dc.add[:, 0], o["minimum_additive_error"], o["maximum_additive_error"]))
     dc.prior.copy_(full_prior())
     dc.best_posterior.copy_(dc.prior + dc.like)
     dc.run(60)
@@ -401,7 +401,7 @@ def test_deep_chains_stay_coherent():
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
     assert torch.all(torch.where(thk > 0, thk, torch.full_like(thk, 9.0)) > dc.min_width)
     fb = FdemBatch(s, k, dc.sigma.cpu().numpy(), thk.cpu().numpy(), dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
-                   relative_error=dc.rel.cpu().numpy(), additive_error=dc.add.cpu().numpy())
+                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy())
     chi2, logl = fb.forward_loglike()
     _lib.check(lib.gbp_pin_forward_waves(0))
     assert torch.allclose(fb.predicted, dc.pred, rtol=1e-10, atol=1e-8) and torch.allclose(chi2, dc.misfit, rtol=1e-8)
@@ -438,14 +438,14 @@ def test_posterior_accumulators_match_a_host_replay():
         for _ in range(150):
             dc.step()
             k, e, s = dc.k.cpu().numpy(), dc.edges.cpu().numpy(), dc.sigma.cpu().numpy()
-            rel, add = dc.rel.cpu().numpy(), dc.add.cpu().numpy()
+            rel, add = dc.rel[:, 0].cpu().numpy(), dc.add[:, 0].cpu().numpy()
             for b in range(dc.B):
                 posts[b].update(e[b, : k[b] - 1], s[b, : k[b]], rel[b], add[b])
         assert np.array_equal(dc.k_hist.cpu().numpy(), np.stack([p.n_cells for p in posts]))
         assert np.array_equal(dc.edge_hist.cpu().numpy(), np.stack([p.edges for p in posts])) and dc.edge_hist.sum() > 0
         assert np.array_equal(dc.hitmap.cpu().numpy(), np.stack([p.values for p in posts]))    # [B, value, depth] both
-        assert np.array_equal(dc.rel_hist.cpu().numpy(), np.stack([p.relative_error for p in posts]))
-        assert np.array_equal(dc.add_hist.cpu().numpy(), np.stack([p.additive_error for p in posts]))
+        assert np.array_equal(dc.rel_hist[:, 0].cpu().numpy(), np.stack([p.relative_error for p in posts]))
+        assert np.array_equal(dc.add_hist[:, 0].cpu().numpy(), np.stack([p.additive_error for p in posts]))
 
 
 @pytest.mark.gpu

@@ -68,7 +68,8 @@ def test_tdem_chains_equal_cpu_chains_with_the_same_seeds():
 
     o = dc._o
     eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
-              rel_sd=o.rel_sd, rel_min=o.rel_min, rel_max=o.rel_max, add_sd=o.add_sd, add_min=o.add_min, add_max=o.add_max, alpha=o.alpha)
+              rel_sd=o.rel_sd[0], rel_min=o.rel_min[0], rel_max=o.rel_max[0], add_sd=o.add_sd[0], add_min=o.add_min[0], add_max=o.add_max[0],
+              alpha=o.alpha)
     sig0 = dc.sigma[:, 0].cpu().numpy()
     chains = []
     for b in range(B):
@@ -103,8 +104,8 @@ def test_tdem_chains_fit_synthetic_soundings_and_stay_coherent():
     dc.run(1500)
     k = dc.k.cpu().numpy()
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
-    tb = TdemBatch(s, k, dc.sigma.cpu().numpy(), thk.cpu().numpy(), h, OFFSET, data=data, relative_error=dc.rel.cpu().numpy()[:, None],
-                   additive_error=dc.add.cpu().numpy()[:, None])
+    tb = TdemBatch(s, k, dc.sigma.cpu().numpy(), thk.cpu().numpy(), h, OFFSET, data=data, relative_error=dc.rel.cpu().numpy(),
+                   additive_error=dc.add.cpu().numpy())
     chi2, logl = tb.forward_loglike()
     assert torch.allclose(tb.predicted, dc.pred, rtol=1e-8, atol=0) and torch.allclose(chi2, dc.misfit, rtol=1e-7)
     assert torch.allclose(logl, dc.like, rtol=1e-9)
