@@ -377,34 +377,54 @@ class TdemBatch:
 
 
 class TdemDeviceChains(DeviceChains):
-    """Device-resident rjMCMC (rjmcmc_gpu.DeviceChains) for time-domain soundings of ONE system (one moment): the sampler's
-    frequency-domain launches run on the system's spline nodes and ``gbp_rj_run_td`` turns nodal spectra (and their
-    Jacobians) into window values with the constant time-domain operator W.  Error model: TdemDataPoint.std
-    (data/datapoint/TdemDataPoint.py:361-365), one relative and one additive level, the additive one scaled by
-    sqrt(1e-3 / t) per gate.  The Jacobian is the exact derivative (GA-AEM's is, too).  Parity is unpinned like the rest of
-    the TDEM path; the sampler logic itself is the FDEM-pinned one."""
+    """Device-resident rjMCMC (rjmcmc_gpu.DeviceChains) for time-domain soundings: one system or the systems of a
+    multi-moment acquisition (e.g. SkyTEM high + low moment), sharing one transmitter-receiver geometry.
 
-    def __init__(self, system, heights, data, offset, **kw):
-        assert isinstance(system, TdemSystem), TypeError("system must be a geobipy_amd.TdemSystem")
-        self.td_system, self._offset = system, tuple(float(v) for v in offset)
-        nc, n = system.n_components, system.node_frequencies().size
-        W = system.time_operator()
-        Wb = np.zeros((2 * nc * n, nc * system.nwindows))          # block-diagonal over components, as in TdemBatch
-        for c in range(nc):
-            Wb[c * n:(c + 1) * n, c * system.nwindows:(c + 1) * system.nwindows] = W[:n]
-            Wb[nc * n + c * n: nc * n + (c + 1) * n, c * system.nwindows:(c + 1) * system.nwindows] = W[n:]
-        self._W_host, self._td_struct = Wb, None
-        add_scale = np.sqrt(1e-3 / np.tile(system.off_time, nc))
+    The systems' spline nodes are merged into ONE frequency-domain handle (all (system, component, node) triples are
+    "frequencies" of the sampler's forward / Jacobian launches) and ``gbp_rj_run_td`` turns the nodal spectra -- and their
+    Jacobians -- into the windows of all systems with one block matrix W.  Error model: TdemDataPoint.std
+    (data/datapoint/TdemDataPoint.py:361-365): a relative level per (system, component), an additive level per system
+    scaled by sqrt(1e-3 / t) per gate; the error options may be scalars or lists per level like in the reference's
+    skytem / tempest options files.  Channel layout = TdemBatch's (system 0: component x then z windows, system 1 ...).
+    The Jacobian is the exact derivative (GA-AEM's is, too).  Parity is unpinned like the rest of the TDEM path (DESIGN.md
+    3.7); the sampler logic itself is the FDEM-pinned one."""
+
+    def __init__(self, systems, heights, data, offset, **kw):
+        systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
+        assert all(isinstance(s, TdemSystem) for s in systems), TypeError("systems must be geobipy_amd.TdemSystem objects")
+        self.td_systems, self._offset = systems, tuple(float(v) for v in offset)
+        nf = [s.n_components * s.node_frequencies().size for s in systems]          # "frequencies" per system
+        nw = [s.n_components * s.nwindows for s in systems]
+        nF, N = sum(nf), sum(nw)
+        assert nF <= 128, ValueError("the merged systems have {} spline nodes x components (limit 128)".format(nF))
+        Wm = np.zeros((2 * nF, N))
+        rel_group, add_group, add_scale = [], [], []
+        f0 = c0 = g0 = 0
+        for i, s in enumerate(systems):
+            nc, n = s.n_components, s.node_frequencies().size
+            W = s.time_operator()
+            for c in range(nc):          # block-diagonal over components; nodal layout [Re(all frequencies) | Im(all frequencies)]
+                cols = slice(c0 + c * s.nwindows, c0 + (c + 1) * s.nwindows)
+                Wm[f0 + c * n:f0 + (c + 1) * n, cols] = W[:n]
+                Wm[nF + f0 + c * n:nF + f0 + (c + 1) * n, cols] = W[n:]
+                rel_group += [g0 + c] * s.nwindows
+            add_group += [i] * nw[i]
+            add_scale += list(np.sqrt(1e-3 / np.tile(s.off_time, nc)))
+            f0, c0, g0 = f0 + nf[i], c0 + nw[i], g0 + nc
+        self._W_host, self._td_struct = Wm, None
         outer = self
 
         class _Handle:                    # what DeviceChains asks of an acquisition system
             def handle(self_inner):
                 if getattr(outer, "_raw", None) is None:
-                    outer._raw = _RawHandle(*system.hankel_tables(*outer._offset))
+                    parts = [s.hankel_tables(*outer._offset) for s in systems]
+                    cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p[j] for p in parts], axis=ax))
+                    outer._raw = _RawHandle(cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1))
                 return outer._raw
         kw.pop("exact_jacobian", None)
         kw.pop("hankel_eps_ppm", None)
-        super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=add_scale, **kw)
+        super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=np.asarray(add_scale),
+                         rel_group=np.asarray(rel_group, dtype=np.int32), add_group=np.asarray(add_group, dtype=np.int32), **kw)
 
     def _td(self):
         if self._td_struct is None:

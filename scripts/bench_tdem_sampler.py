@@ -7,7 +7,7 @@ import warnings; warnings.filterwarnings("ignore")
 from geobipy_amd.tdem import TdemDeviceChains
 from test_tdem_sampler import _survey, OFFSET
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192").split(",")]:
-    s, h, data, scale, opts = _survey(B, seed=2)
+    s, h, data, scale, opts, _ = _survey(B, seed=2, stm=tuple(os.environ.get("TD_STM", "SkytemLM.stm").split(",")))
     dc = TdemDeviceChains(s, h, data, OFFSET, seed=1, **opts)
     m0 = float(dc.misfit.median())
     dc.run(100); torch.cuda.synchronize()

@@ -60,6 +60,35 @@ def propose_error(r, cur, sd, lo, hi):
     return math.exp(x)
 
 
+def propose_levels(r, cur, sd, lo, hi):
+    """Joint proposal of the levels of one kind (scalars or vectors): all are redrawn while any is outside its prior."""
+    scalar = np.ndim(cur) == 0
+    cur, sd, lo, hi = (np.atleast_1d(np.asarray(v, dtype=float)) for v in (cur, sd, lo, hi))
+    draw = lambda: np.array([math.log(c) + s_ * r.normal() for c, s_ in zip(cur, sd)])
+    ok = lambda x: bool(np.all((x >= np.log(lo)) & (x <= np.log(hi))))
+    x = draw()
+    tries = 0
+    while not ok(x):
+        x = draw()
+        tries += 1
+        if tries == 10:
+            return cur.item() if scalar else cur.copy()
+    out = np.array([math.exp(v) for v in x])
+    return out.item() if scalar else out
+
+
+def channel_std(data, rel, add, add_scale=1.0, groups=None):
+    """sqrt((rel_g d)^2 + (add_g' add_scale)^2) per channel; groups = (rel_group, add_group) channel -> level maps."""
+    if groups is not None:
+        rel, add = np.asarray(rel)[groups[0]], np.asarray(add)[groups[1]]
+    return np.sqrt((rel * data) ** 2 + (add * add_scale) ** 2)
+
+
+def levels_log_prior(x, lo, hi):
+    x, lo, hi = (np.atleast_1d(np.asarray(v, dtype=float)) for v in (x, lo, hi))
+    return float(sum(rjmcmc.ErrorPrior(l, h, 1.0).log_prior(v) for v, l, h in zip(x, lo, hi)))
+
+
 def propose(o, seed, b, it, edges, sigma, rel, add):
     """k_rj_propose for one chain.  edges: k - 1 interior depths.  Returns (action, idx, val, edges_r, sigma_r, rel_p, add_p)."""
     r = Rng(seed, b, it, 0)
@@ -110,15 +139,15 @@ def propose(o, seed, b, it, edges, sigma, rel, add):
         e_r[idx - 1] += val
     else:
         e_r, s_r = edges.copy(), sigma.copy()
-    rel_p = propose_error(r, rel, o["rel_sd"], o["rel_min"], o["rel_max"])
-    add_p = propose_error(r, add, o["add_sd"], o["add_min"], o["add_max"])
+    rel_p = propose_levels(r, rel, o["rel_sd"], o["rel_min"], o["rel_max"])
+    add_p = propose_levels(r, add, o["add_sd"], o["add_min"], o["add_max"])
     return action, idx, val, e_r, s_r, rel_p, add_p
 
 
-def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_scale=1.0):
+def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_scale=1.0, groups=None):
     """k_rj_newton for one chain: (log_prop, C) with precision = C C'."""
     k = sigma_r.size
-    std = np.sqrt((rel * data) ** 2 + (add * add_scale) ** 2)
+    std = channel_std(data, rel, add, add_scale, groups)
     a = data > 0.0
     Ja, P = J[a][:, :k], 1.0 / std[a] ** 2
     op = rjmcmc.model_prior_derivative(vp, edges_r, sigma_r, 2)
@@ -131,16 +160,15 @@ def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_sc
 
 
 def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, pred_p, data, rel_p, add_p, like_p, prior, like,
-           add_scale=1.0):
+           add_scale=1.0, groups=None):
     """k_rj_accept for one chain: (log_ratio, accepted, prior_p)."""
-    rp = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0)
-    ap = rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
     prop = np.exp(log_prop)
-    prior_p = rjmcmc.model_log_prior(sp, vp, edges_r, prop) + rp.log_prior(rel_p) + ap.log_prior(add_p)
+    prior_p = (rjmcmc.model_log_prior(sp, vp, edges_r, prop) + levels_log_prior(rel_p, o["rel_min"], o["rel_max"])
+               + levels_log_prior(add_p, o["add_min"], o["add_max"]))
     dq = 0.0
     if action in (rjmcmc.INSERT, rjmcmc.DELETE):
         k = prop.size
-        std = np.sqrt((rel_p * data) ** 2 + (add_p * add_scale) ** 2)
+        std = channel_std(data, rel_p, add_p, add_scale, groups)
         a = data > 0.0
         grad = rjmcmc.model_prior_derivative(vp, edges_r, prop, 1) + J_p[a][:, :k].T @ ((pred_p[a] - data[a]) / std[a] ** 2)
         hess = C @ C.T
@@ -161,15 +189,15 @@ class Chain:
     with forward(edges, values) / sensitivity(edges, values) (the C oracle in the tests).  Carries the same state and
     posterior accumulators as one row of gbp_rj_chains."""
 
-    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0):
+    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0, groups=None):
         self.o, self.seed, self.b, self.engine, self.sp, self.vp, self.data = o, seed, b, engine, sp, vp, data
-        self.add_scale = add_scale
+        self.add_scale, self.groups = add_scale, groups
         self.edges, self.sigma, self.rel, self.add = np.zeros(0), np.array([sigma0]), rel, add
         self.pred, self.J = engine.forward(self.edges, self.sigma), engine.sensitivity(self.edges, self.sigma)
-        std = np.sqrt((rel * data) ** 2 + (add * add_scale) ** 2)
+        std = channel_std(data, rel, add, add_scale, groups)
         self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
-        rp, ap = rjmcmc.ErrorPrior(o["rel_min"], o["rel_max"], 1.0), rjmcmc.ErrorPrior(o["add_min"], o["add_max"], 1.0)
-        self.prior = rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + rp.log_prior(rel) + ap.log_prior(add)
+        self.prior = (rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + levels_log_prior(rel, o["rel_min"], o["rel_max"])
+                      + levels_log_prior(add, o["add_min"], o["add_max"]))
         self.k_hist = np.zeros(o["K"] + 1, dtype=int)
         self.edge_hist = np.zeros(n_depth_bins, dtype=int)
         self.w = depth_bin_width
@@ -183,13 +211,13 @@ class Chain:
             pred_r, J_r = self.engine.forward(e_r, s_r), self.engine.sensitivity(e_r, s_r)
         else:
             pred_r, J_r = self.pred, self.J
-        log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add, self.add_scale)
+        log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add, self.add_scale, self.groups)
         prop = np.exp(log_prop)
         pred_p = self.engine.forward(e_r, prop)
-        misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, np.sqrt((rel_p * d) ** 2 + (add_p * self.add_scale) ** 2))
+        misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, channel_std(d, rel_p, add_p, self.add_scale, self.groups))
         J_p = self.engine.sensitivity(e_r, prop) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
         log_ratio, acc, prior_p = accept(o, self.seed, self.b, it, self.sp, self.vp, action, e_r, s_r, log_prop, C, J_p, pred_p, d,
-                                         rel_p, add_p, like_p, self.prior, self.like, self.add_scale)
+                                         rel_p, add_p, like_p, self.prior, self.like, self.add_scale, self.groups)
         if acc:
             self.edges, self.sigma, self.rel, self.add, self.pred = e_r, prop, rel_p, add_p, pred_p
             self.prior, self.like, self.misfit = prior_p, like_p, misfit_p

@@ -24,31 +24,49 @@ OPTIONS = dict(solve_gradient=True, maximum_number_of_layers=20, minimum_depth=1
                probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5, covariance_scaling=0.5)
 
 
-def _survey(B, seed=0):
+def _survey(B, seed=0, stm=("SkytemLM.stm",)):
+    """Synthetic 3-layer soundings for the given systems; returns (systems, heights, data, add_scale, options, groups)."""
     from geobipy_amd.tdem import TdemBatch, TdemSystem
-    s = TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))
+    systems = [TdemSystem(os.path.join(GOLDEN, f)) for f in stm]
     rng = np.random.default_rng(seed)
     K = 20
     sig, thk = np.ones((B, K)), np.zeros((B, K))
     sig[:, :3] = np.c_[10.0 ** rng.uniform(-2.5, -1.5, B), 10.0 ** rng.uniform(-1.2, -0.5, B), 10.0 ** rng.uniform(-2.5, -1.5, B)]
     thk[:, :2] = np.c_[rng.uniform(8, 25, B), rng.uniform(10, 40, B)]
     h = rng.uniform(30.0, 40.0, B)
-    clean = TdemBatch(s, np.full(B, 3), sig, thk, h, OFFSET).forward().cpu().numpy()
-    scale = np.sqrt(1e-3 / np.tile(s.off_time, s.n_components))
-    add0 = 0.02 * np.abs(clean).min(axis=1).mean() / scale.min()          # additive level: a few % of the smallest gate
-    std = np.sqrt((0.05 * clean) ** 2 + (add0 * scale) ** 2)
+    clean = TdemBatch(systems, np.full(B, 3), sig, thk, h, OFFSET).forward().cpu().numpy()
+    scale, add0, add_group, rel_group = [], [], [], []
+    col = g = 0
+    for i, s in enumerate(systems):
+        n = s.n_components * s.nwindows
+        sc = np.sqrt(1e-3 / np.tile(s.off_time, s.n_components))
+        add0.append(0.02 * np.abs(clean[:, col:col + n]).min(axis=1).mean() / sc.min())   # a few % of the system's smallest gate
+        scale += list(sc)
+        add_group += [i] * n
+        for c in range(s.n_components):
+            rel_group += [g + c] * s.nwindows
+        col, g = col + n, g + s.n_components
+    scale, add0, groups = np.array(scale), np.array(add0), (np.array(rel_group), np.array(add_group))
+    std = np.sqrt((0.05 * clean) ** 2 + (add0[groups[1]] * scale) ** 2)
     data = clean + rng.normal(size=clean.shape) * std
-    opts = dict(OPTIONS, initial_additive_error=add0, minimum_additive_error=add0 / 30.0, maximum_additive_error=add0 * 30.0)
-    return s, h, data, scale, opts
+    one = len(systems) == 1
+    opts = dict(OPTIONS, initial_additive_error=add0.item() if one else list(add0),
+                minimum_additive_error=(add0 / 30.0).item() if one else list(add0 / 30.0),
+                maximum_additive_error=(add0 * 30.0).item() if one else list(add0 * 30.0))
+    return (systems[0] if one else systems), h, data, scale, opts, groups
 
 
-def test_tdem_chains_equal_cpu_chains_with_the_same_seeds():
+@pytest.mark.parametrize("stm", [("SkytemLM.stm",), ("SkytemHM.stm", "SkytemLM.stm")])
+def test_tdem_chains_equal_cpu_chains_with_the_same_seeds(stm):
+    """One moment (one relative, one additive level) and the two SkyTEM moments together (merged frequency-domain handle,
+    two relative and two additive levels proposed jointly)."""
     from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
-    B, n_it = 3, 250
-    s, h, data, scale, opts = _survey(B, seed=3)
+    B, n_it = 3, 250 if len(stm) == 1 else 150
+    s, h, data, scale, opts, groups = _survey(B, seed=3, stm=stm)
     assert np.all(data > 0)
     dc = TdemDeviceChains(s, h, data, OFFSET, seed=77, **opts)
-    assert np.allclose(dc.add_scale.cpu().numpy(), scale)
+    assert np.allclose(dc.add_scale.cpu().numpy(), scale) and np.array_equal(dc.rel_group.cpu().numpy(), groups[0])
+    assert dc.n_rel_groups == len(stm) and dc.n_add_groups == len(stm)
 
     class Engine:                       # TDEM forward / Jacobian of one sounding through TdemBatch (B = 1)
         def __init__(self, z):
@@ -66,17 +84,19 @@ def test_tdem_chains_equal_cpu_chains_with_the_same_seeds():
         def sensitivity(self, e, v):
             return self._batch(e, v).sensitivity().cpu().numpy()[0][:, : v.size].copy()
 
-    o = dc._o
+    o, G = dc._o, len(stm)
     eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
-              rel_sd=o.rel_sd[0], rel_min=o.rel_min[0], rel_max=o.rel_max[0], add_sd=o.add_sd[0], add_min=o.add_min[0], add_max=o.add_max[0],
-              alpha=o.alpha)
+              rel_sd=np.array(o.rel_sd[:G]), rel_min=np.array(o.rel_min[:G]), rel_max=np.array(o.rel_max[:G]),
+              add_sd=np.array(o.add_sd[:G]), add_min=np.array(o.add_min[:G]), add_max=np.array(o.add_max[:G]), alpha=o.alpha)
     sig0 = dc.sigma[:, 0].cpu().numpy()
     chains = []
     for b in range(B):
         sp = rjmcmc.StructurePrior(dc.K, opts["minimum_depth"], opts["maximum_depth"], opts["minimum_thickness"], eo["p"])
         vp = rjmcmc.ValuePrior(sig0[b], 10.0, 1.5, True)
-        chains.append(rj_emul.Chain(eo, 77, b, Engine(h[b]), sp, vp, data[b], sig0[b], opts["initial_relative_error"],
-                                    opts["initial_additive_error"], dc.n_depth_bins, dc.depth_bin_width, add_scale=scale))
+        rel0 = np.broadcast_to(np.atleast_1d(opts["initial_relative_error"]), (G,)).astype(float)
+        add0 = np.atleast_1d(np.asarray(opts["initial_additive_error"], dtype=float))
+        chains.append(rj_emul.Chain(eo, 77, b, Engine(h[b]), sp, vp, data[b], sig0[b], rel0, add0, dc.n_depth_bins, dc.depth_bin_width,
+                                    add_scale=scale, groups=groups))
         assert np.isclose(chains[b].misfit, float(dc.misfit[b]), rtol=1e-8) and np.isclose(chains[b].prior, float(dc.prior[b]), rtol=1e-12)
     acts, accs, ks = [], [], []
     prev = dc.n_accepted.cpu().numpy().copy()
@@ -95,10 +115,11 @@ def test_tdem_chains_equal_cpu_chains_with_the_same_seeds():
     assert accs.sum() > 0.15 * accs.size and set(np.unique(acts)) == {0, 1, 2, 3}
 
 
-def test_tdem_chains_fit_synthetic_soundings_and_stay_coherent():
+@pytest.mark.parametrize("stm", [("SkytemLM.stm",), ("SkytemHM.stm", "SkytemLM.stm")])
+def test_tdem_chains_fit_synthetic_soundings_and_stay_coherent(stm):
     from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
     B = 256
-    s, h, data, scale, opts = _survey(B, seed=5)
+    s, h, data, scale, opts, groups = _survey(B, seed=5, stm=stm)
     dc = TdemDeviceChains(s, h, data, OFFSET, seed=1, **opts)
     m0 = dc.misfit.clone()
     dc.run(1500)
