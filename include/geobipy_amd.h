@@ -290,10 +290,11 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /*
- * The same for time-domain data of ONE system (TdemDataPoint with a single moment): `sys` is the frequency-domain handle of
- * the system's spline nodes (gbp_hankel_system_create_raw), and a constant matrix turns the nodal spectrum into window
- * values, windows = nodal @ W (geobipy_amd/tdem.py; replaces gatdaem1d's forwardmodel / derivative, TD/tdem1d.py:89-154).
- * opt->n_channels = the number of windows; chains->add_scale carries the time-dependent additive error.
+ * The same for time-domain data (TdemDataPoint): `sys` is the frequency-domain handle of the spline nodes of the system --
+ * or of all systems of a multi-moment acquisition merged into one (gbp_hankel_system_create_raw) --, and a constant block
+ * matrix turns the nodal spectrum into window values, windows = nodal @ W (geobipy_amd/tdem.py; replaces gatdaem1d's
+ * forwardmodel / derivative, TD/tdem1d.py:89-154).  opt->n_channels = the number of windows; chains->add_scale carries the
+ * time-dependent additive error, rel_group / add_group the level of each channel.
  */
 typedef struct gbp_td_operator {
     int32_t n_nodal;        /* rows of W = 2 * nF of `sys`                                                   */
