@@ -24,7 +24,7 @@ OPTIONS = dict(solve_gradient=True, maximum_number_of_layers=20, minimum_depth=1
                probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5, covariance_scaling=0.5)
 
 
-def _survey(B, seed=0, stm=("SkytemLM.stm",)):
+def _survey(B, seed=0, stm=("SkytemLM.stm",), offset=None, alt=(30.0, 40.0)):
     """Synthetic 3-layer soundings for the given systems; returns (systems, heights, data, add_scale, options, groups)."""
     from geobipy_amd.tdem import TdemBatch, TdemSystem
     systems = [TdemSystem(os.path.join(GOLDEN, f)) for f in stm]
@@ -33,14 +33,15 @@ def _survey(B, seed=0, stm=("SkytemLM.stm",)):
     sig, thk = np.ones((B, K)), np.zeros((B, K))
     sig[:, :3] = np.c_[10.0 ** rng.uniform(-2.5, -1.5, B), 10.0 ** rng.uniform(-1.2, -0.5, B), 10.0 ** rng.uniform(-2.5, -1.5, B)]
     thk[:, :2] = np.c_[rng.uniform(8, 25, B), rng.uniform(10, 40, B)]
-    h = rng.uniform(30.0, 40.0, B)
-    clean = TdemBatch(systems, np.full(B, 3), sig, thk, h, OFFSET).forward().cpu().numpy()
+    offset = OFFSET if offset is None else offset
+    h = rng.uniform(alt[0], alt[1], B)
+    clean = TdemBatch(systems, np.full(B, 3), sig, thk, h, offset).forward().cpu().numpy()
     scale, add0, add_group, rel_group = [], [], [], []
     col = g = 0
     for i, s in enumerate(systems):
         n = s.n_components * s.nwindows
         sc = np.sqrt(1e-3 / np.tile(s.off_time, s.n_components))
-        add0.append(0.02 * np.abs(clean[:, col:col + n]).min(axis=1).mean() / sc.min())   # a few % of the system's smallest gate
+        add0.append(0.02 * np.abs(clean[:, col:col + n]).min(axis=1).mean() / sc.min() + 1e-30)   # a few % of the system's smallest gate
         scale += list(sc)
         add_group += [i] * n
         for c in range(s.n_components):
@@ -113,6 +114,64 @@ def test_tdem_chains_equal_cpu_chains_with_the_same_seeds(stm):
         assert np.array_equal(tr[:, 0], acts[:, b]) and np.array_equal(tr[:, 1], accs[:, b]) and np.array_equal(tr[:, 2], ks[:, b]), b
         assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-5)
     assert accs.sum() > 0.15 * accs.size and set(np.unique(acts)) == {0, 1, 2, 3}
+
+
+def test_tempest_two_components_one_system():
+    """Tempest: x and z components of one system -> two relative levels, one additive level (n_rel_groups != n_add_groups);
+    the device chain equals the CPU chain with the same seeds."""
+    from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
+    off = (-107.0, 0.0, -45.0)
+    B, n_it = 2, 120
+    s, h, data, scale, opts, groups = _survey(B, seed=9, stm=("tempest.stm",), offset=off, alt=(115.0, 125.0))
+    data = np.abs(data)                                  # (inline component changes sign; keep every channel active)
+    opts = dict(opts, initial_relative_error=[0.05, 0.05], minimum_relative_error=[0.005, 0.005], maximum_relative_error=[0.5, 0.5],
+                relative_error_proposal_variance=[1e-6, 1e-6])
+    dc = TdemDeviceChains(s, h, data, off, seed=5, **opts)
+    assert dc.n_rel_groups == 2 and dc.n_add_groups == 1 and dc.rel.shape == (B, 2) and dc.add.shape == (B, 1)
+
+    class Engine:
+        def __init__(self, z):
+            self.z = z
+
+        def _batch(self, e, v):
+            sg, th = np.ones((1, 20)), np.zeros((1, 20))
+            sg[0, : v.size], th[0, : v.size - 1] = v, np.diff(np.r_[0.0, e])
+            return TdemBatch(s, np.array([v.size]), sg, th, np.array([self.z]), off)
+
+        def forward(self, e, v):
+            return self._batch(e, v).forward().cpu().numpy()[0].copy()
+
+        def sensitivity(self, e, v):
+            return self._batch(e, v).sensitivity().cpu().numpy()[0][:, : v.size].copy()
+
+    o = dc._o
+    eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
+              rel_sd=np.array(o.rel_sd[:2]), rel_min=np.array(o.rel_min[:2]), rel_max=np.array(o.rel_max[:2]),
+              add_sd=np.array(o.add_sd[:1]), add_min=np.array(o.add_min[:1]), add_max=np.array(o.add_max[:1]), alpha=o.alpha)
+    sig0 = dc.sigma[:, 0].cpu().numpy()
+    chains = []
+    for b in range(B):
+        sp = rjmcmc.StructurePrior(dc.K, opts["minimum_depth"], opts["maximum_depth"], opts["minimum_thickness"], eo["p"])
+        vp = rjmcmc.ValuePrior(sig0[b], 10.0, 1.5, True)
+        chains.append(rj_emul.Chain(eo, 5, b, Engine(h[b]), sp, vp, data[b], sig0[b], np.array([0.05, 0.05]),
+                                    np.atleast_1d(np.asarray(opts["initial_additive_error"], dtype=float)), dc.n_depth_bins,
+                                    dc.depth_bin_width, add_scale=scale, groups=groups))
+        assert np.isclose(chains[b].misfit, float(dc.misfit[b]), rtol=1e-8)
+    acc = []
+    prev = dc.n_accepted.cpu().numpy().copy()
+    for it in range(n_it):
+        dc.step()
+        now = dc.n_accepted.cpu().numpy()
+        acc.append(now - prev)
+        prev = now.copy()
+        for c in chains:
+            c.step(it)
+    acc = np.array(acc)
+    for b, c in enumerate(chains):
+        tr = np.array(c.trace)
+        assert np.array_equal(tr[:, 1], acc[:, b]) and tr[-1, 2] == int(dc.k[b])
+        assert np.allclose(c.rel, dc.rel[b].cpu().numpy(), rtol=1e-9) and np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-5)
+    assert acc.sum() > 10
 
 
 @pytest.mark.parametrize("stm", [("SkytemLM.stm",), ("SkytemHM.stm", "SkytemLM.stm")])
