@@ -1,10 +1,11 @@
 """Survey-level entry (reduced to what feeds the path): the reference's user inputs -- an options file
-and an FDEM data CSV -- to the posteriors of every sounding, on the GPUs of one node.
+and an FDEM or TDEM data CSV -- to the posteriors of every sounding, on the GPUs of one node.
 
 Mirrors what the reference's harness does around ``Inference1D`` without its control plane:
   ``read_options``      inversion/user_parameters.py:31-99 (same keys, same defaults, same required keys)
   ``FdemData.read_csv`` classes/data/dataset/FdemData.py:620-682 + Data.py:505-528 + pointcloud/Point.py:355-382
                         (column recognition by header name), one row per sounding
+  ``TdemData.read_csv`` classes/data/dataset/TdemData.py (columns S<system><component>_time_<t>, txrx_d{x,y,z})
   ``infer``             inversion/Inference3D.py:518-635: soundings are independent; a rank owns one GPU and a
                         contiguous block of soundings (base/MPI.py:172-201) and runs all of its chains in lockstep
                         (``DeviceChains`` under the reference's burn-in / stop schedule); results are gathered on rank 0.
@@ -135,11 +136,66 @@ class FdemData:
         std = table[:, ecols] if len(ecols) == len(dcols) else None
         return cls(system, col("line"), col("fid"), col("x"), col("y"), col("z"), elev, table[:, dcols], std)
 
+    def subset(self, rows):
+        return FdemData(self.system, self.lineNumber[rows], self.fiducial[rows], self.x[rows], self.y[rows], self.z[rows],
+                        self.elevation[rows], self.data[rows], None if self.std is None else self.std[rows])
+
     def datapoint(self, i):
         """Sounding i as the per-sounding object (FdemData.datapoint, FdemData.py:447-487)."""
         return FdemDataPoint(x=self.x[i], y=self.y[i], z=self.z[i], elevation=self.elevation[i], data=self.data[i],
                              std=None if self.std is None else self.std[i], system=self.system,
                              lineNumber=self.lineNumber[i], fiducial=self.fiducial[i])
+
+
+class TdemData:
+    """A set of time-domain soundings (classes/data/dataset/TdemData.py): location, altitude, transmitter-receiver offset and
+    the window data of every system, columns ``S<system><component>_time_<t>`` of the reference's CSV files in file order
+    (system 0 component X then Z windows, system 1 ...), which is TdemBatch's channel layout.  The device sampler shares one
+    transmitter-receiver offset over a block, so the offsets of the file must be constant; attitude angles must be zero."""
+
+    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset):
+        from .tdem import TdemSystem
+        systems = [system] if isinstance(system, (str, TdemSystem)) else list(system)
+        self.system = [s if isinstance(s, TdemSystem) else TdemSystem(s) for s in systems]
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.lineNumber, self.fiducial = f64(lineNumber), f64(fiducial)
+        self.x, self.y, self.z, self.elevation = f64(x), f64(y), f64(z), f64(elevation)
+        self.data, self.offset = f64(data), tuple(float(v) for v in offset)
+        n = sum(s.n_components * s.nwindows for s in self.system)
+        assert self.data.shape == (self.nPoints, n), ValueError("data must have shape (nPoints, {})".format(n))
+
+    @property
+    def nPoints(self):
+        return self.x.size
+
+    @property
+    def nChannels(self):
+        return self.data.shape[1]
+
+    @classmethod
+    def read_csv(cls, data_filename, system_filename):
+        with open(data_filename) as f:
+            header = [h.strip() for h in f.readline().strip().split(",")]
+        low = [h.lower() for h in header]
+        find = lambda names: next(j for j, h in enumerate(low) if h in names)
+        roles = dict(line=("line", "linenumber", "line_number"), fid=("fid", "fiducial", "id"), x=("e", "x", "easting"),
+                     y=("n", "y", "northing"), z=("alt", "altitude", "laser", "bheight", "height"))
+        idx = {r: find(names) for r, names in roles.items()}
+        elev = next((j for j, h in enumerate(low) if h in ("dtm", "dem_elev", "dem_np", "topo", "elev", "elevation")), None)
+        dcols = [j for j, h in enumerate(low) if "_time_" in h and h[0] == "s"]
+        table = np.atleast_2d(np.loadtxt(data_filename, delimiter=",", skiprows=1))
+        off = [table[:, low.index(k)] for k in ("txrx_dx", "txrx_dy", "txrx_dz")]
+        assert all(np.all(v == v[0]) for v in off), NotImplementedError("the transmitter-receiver offset must be the same for every sounding")
+        for k in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"):
+            if k in low:
+                assert not np.any(table[:, low.index(k)]), NotImplementedError("attitude angles are not supported (level flight)")
+        c = lambda r: table[:, idx[r]]
+        return cls(system_filename, c("line"), c("fid"), c("x"), c("y"), c("z"),
+                   table[:, elev] if elev is not None else np.zeros(table.shape[0]), table[:, dcols], [v[0] for v in off])
+
+    def subset(self, rows):
+        return TdemData(self.system, self.lineNumber[rows], self.fiducial[rows], self.x[rows], self.y[rows], self.z[rows],
+                        self.elevation[rows], self.data[rows], self.offset)
 
 
 class SurveyResult(dict):
@@ -215,17 +271,22 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     from .rjmcmc_gpu import DeviceChains
 
     o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
-    if o["data_type"] not in ("FdemData", "FdemDataPoint"):
-        raise NotImplementedError("the device sampler handles FDEM data; {} is not supported".format(o["data_type"]))
+    time_domain = o["data_type"] in ("TdemData", "TdemDataPoint")
+    if not time_domain and o["data_type"] not in ("FdemData", "FdemDataPoint"):
+        raise NotImplementedError("the device sampler handles FdemData and TdemData; {} is not supported".format(o["data_type"]))
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
     # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
     # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- the height stays fixed there too
-    ds = data if data is not None else FdemData.read_csv(o["data_filename"], o["system_filename"])
+    if data is not None:
+        ds = data
+    elif time_domain:
+        ds = TdemData.read_csv(o["data_filename"], o["system_filename"])
+    else:
+        ds = FdemData.read_csv(o["data_filename"], o["system_filename"])
     rows = select_soundings(ds, index, fiducial, line_number)
     if rows.size != ds.nPoints:
-        ds = FdemData(ds.system, ds.lineNumber[rows], ds.fiducial[rows], ds.x[rows], ds.y[rows], ds.z[rows], ds.elevation[rows],
-                      ds.data[rows], None if ds.std is None else ds.std[rows])
+        ds = ds.subset(rows)
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     start, n = shard(ds.nPoints, rank, world)
@@ -240,51 +301,57 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     # chains are keyed by the sounding's row in the data file, so a sounding inverted alone walks the chain it walks in the
     # full survey
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
-    dc = DeviceChains(ds.system, ds.z[sl], ds.data[sl], seed=int(seed) % (1 << 64), exact_jacobian=exact_jacobian, device=device,
-                      hitmap=hitmap, first_chain=int(rows[0]) + start, reference_schedule=True, burn_in_min_iterations=burn_in_min_iterations,
-                      **{k: o[k] for k in keys if o.get(k) is not None})
+    common = dict(seed=int(seed) % (1 << 64), device=device, hitmap=hitmap, first_chain=int(rows[0]) + start, reference_schedule=True,
+                  burn_in_min_iterations=burn_in_min_iterations, **{k: o[k] for k in keys if o.get(k) is not None})
+    if time_domain:
+        from .tdem import TdemDeviceChains
+        dc = TdemDeviceChains(ds.system, ds.z[sl], ds.data[sl], ds.offset, **common)
+    else:
+        dc = DeviceChains(ds.system, ds.z[sl], ds.data[sl], exact_jacobian=exact_jacobian, **common)
     dc.infer(check_every=check_every)
-    K = dc.K
-    t = dc.t
+    K, nz, ne, t = dc.K, dc.n_depth_bins, dc.n_error_bins, dc.t
     f64 = lambda x: x.to(torch.float64)
-    cols = [f64(t["status"]), f64(t["burned_in_iteration"]), f64(t["n_accepted"]), t["misfit"], t["rel"][:, 0], t["add"][:, 0], f64(t["k"]),
-            f64(t["best_k"]), t["best_posterior"]]
-    blocks = [torch.stack(cols, dim=1), t["best_edges"], t["best_sigma"], f64(t["k_hist"]), f64(t["edge_hist"]), f64(t["rel_hist"][:, 0]),
-              f64(t["add_hist"][:, 0])]
+    col = lambda x: f64(x)[:, None]
+    named = [("status", col(t["status"])), ("burned_in_iteration", col(t["burned_in_iteration"])), ("n_accepted", col(t["n_accepted"])),
+             ("misfit", col(t["misfit"])), ("relative_error", t["rel"]), ("additive_error", t["add"]), ("n_layers", col(t["k"])),
+             ("best_n_layers", col(t["best_k"])), ("best_posterior", col(t["best_posterior"])), ("best_edges", t["best_edges"]),
+             ("best_conductivity", t["best_sigma"]), ("layer_count_posterior", f64(t["k_hist"])),
+             ("interface_posterior", f64(t["edge_hist"])), ("relative_error_posterior", f64(t["rel_hist"]).flatten(1)),
+             ("additive_error_posterior", f64(t["add_hist"]).flatten(1))]
     if hitmap:
         mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
-        blocks += [mean] + pct
-    local = torch.cat(blocks, dim=1).contiguous()
+        named += [("mean_log10_conductivity", mean)] + [("log10_conductivity_" + q, p) for q, p in zip(("p05", "p50", "p95"), pct)]
+    local = torch.cat([v for _, v in named], dim=1).contiguous()
     if world > 1:                                   # the one exchange of the job: per-sounding result rows to rank 0
         from .distributed import SummaryGather
         g = SummaryGather(ds.nPoints, local.shape[1], local.device)
-        rows = g.finish(g.launch(*[local[:, i] for i in range(local.shape[1])]))
+        gathered = g.finish(g.launch(*[local[:, i] for i in range(local.shape[1])]))
     else:
-        rows = local
+        gathered = local
     if rank != 0:
         return None
-    r = rows.cpu().numpy()
-    nz = dc.n_depth_bins
-    n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
-    ran = np.where(r[:, 0] == 1, r[:, 1] + n_mc + 1, np.where(r[:, 0] == 2, n_mc, dc.iteration)).astype(np.int64)
+    r = gathered.cpu().numpy()
     res = SurveyResult(line=ds.lineNumber, fiducial=ds.fiducial, x=ds.x, y=ds.y, z=ds.z, elevation=ds.elevation,
-                       status=r[:, 0].astype(np.int32), burned_in_iteration=r[:, 1].astype(np.int32),
-                       iterations=ran, acceptance=r[:, 2] / np.maximum(1, ran), misfit=r[:, 3],
-                       relative_error=r[:, 4], additive_error=r[:, 5], n_layers=r[:, 6].astype(np.int32),
-                       best_n_layers=r[:, 7].astype(np.int32), best_posterior=r[:, 8], best_edges=r[:, 9:9 + K],
-                       best_conductivity=r[:, 9 + K:9 + 2 * K],
-                       layer_count_posterior=r[:, 9 + 2 * K:10 + 3 * K].astype(np.int64),
-                       interface_posterior=r[:, 10 + 3 * K:10 + 3 * K + nz].astype(np.int64),
                        depth_bin_width=np.float64(dc.depth_bin_width))
-    ne = dc.n_error_bins
-    c_err = 10 + 3 * K + nz
-    res["relative_error_posterior"] = r[:, c_err:c_err + ne].astype(np.int64)      # ne cells, uniform in log10 between the prior bounds
-    res["additive_error_posterior"] = r[:, c_err + ne:c_err + 2 * ne].astype(np.int64)
-    if hitmap:
-        c0 = 10 + 3 * K + nz + 2 * ne
-        res["mean_log10_conductivity"] = r[:, c0:c0 + nz]
-        for i, q in enumerate(("p05", "p50", "p95")):
-            res["log10_conductivity_" + q] = r[:, c0 + (i + 1) * nz:c0 + (i + 2) * nz]
+    c0 = 0
+    ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
+            "relative_error_posterior", "additive_error_posterior")
+    for name, v in named:
+        w = v.shape[1]
+        block = r[:, c0:c0 + w]
+        c0 += w
+        if name in ints:
+            block = block.astype(np.int64)
+        res[name] = block[:, 0] if w == 1 else block
+    for name, G in (("relative_error_posterior", dc.n_rel_groups), ("additive_error_posterior", dc.n_add_groups)):
+        if G > 1:                                   # [S, groups, cells]; ne cells, uniform in log10 between the prior bounds
+            res[name] = res[name].reshape(-1, G, ne)
+    n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
+    ran = np.where(res["status"] == 1, res["burned_in_iteration"] + n_mc + 1, np.where(res["status"] == 2, n_mc, dc.iteration))
+    res["iterations"] = ran.astype(np.int64)
+    res["acceptance"] = res.pop("n_accepted") / np.maximum(1, ran)
+    for k_ in ("status", "burned_in_iteration", "n_layers", "best_n_layers"):
+        res[k_] = res[k_].astype(np.int32)
     if output is not None:
         res.save(output)
     return res

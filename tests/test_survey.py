@@ -67,6 +67,38 @@ def test_select_soundings_and_cli_arguments():
     assert (a.options_file, a.output_directory, a.seed, a.index, a.line_number, a.fiducial, a.mpi) == ("opts", "out", 12, 3, 100.0, 5.0, True)
 
 
+def test_read_time_domain_csv_and_options():
+    o = survey.read_options(os.path.join(GOLDEN, "skytem_options_small"))
+    assert o["data_type"] == "TdemData" and o["initial_additive_error"] == [2e-14, 2e-13] and o["minimum_thickness"] is None
+    assert [os.path.basename(f) for f in o["system_filename"]] == ["SkytemHM.stm", "SkytemLM.stm"]
+    ds = survey.TdemData.read_csv(o["data_filename"], o["system_filename"])
+    raw = np.loadtxt(o["data_filename"], delimiter=",", skiprows=1)
+    assert ds.nPoints == 79 and ds.nChannels == 45 and ds.offset == (-13.0, 0.0, 2.0) and np.all(ds.z == 30.0)
+    assert np.array_equal(ds.data, raw[:, 15:60]) and len(ds.system) == 2 and ds.system[0].nwindows == 26
+    sub = ds.subset(np.array([3, 4]))
+    assert sub.nPoints == 2 and np.array_equal(sub.data, raw[3:5, 15:60]) and sub.offset == ds.offset
+
+
+@pytest.mark.gpu
+def test_invert_a_time_domain_survey():
+    """The reference's SkyTEM example shape: two moments, per-system error levels from the options file; clean wedge data
+    with 5 % + additive noise.  Most soundings burn in and end near chi^2 = number of gates."""
+    o = survey.read_options(os.path.join(GOLDEN, "skytem_options_small"))
+    ds = survey.TdemData.read_csv(o["data_filename"], o["system_filename"])
+    rng = np.random.default_rng(2)
+    scale = np.r_[np.sqrt(1e-3 / ds.system[0].off_time), np.sqrt(1e-3 / ds.system[1].off_time)]
+    add = np.r_[np.full(26, 2e-14), np.full(19, 2e-13)] * scale
+    ds.data[:] = ds.data + rng.normal(size=ds.data.shape) * np.sqrt((0.05 * ds.data) ** 2 + add ** 2)
+    res = survey.infer(os.path.join(GOLDEN, "skytem_options_small"), data=ds, burn_in_min_iterations=1000, check_every=500)
+    S = 79
+    assert res["status"].shape == (S,) and (res["status"] == 1).sum() >= 45
+    done = res["status"] == 1
+    print("time-domain survey: done", done.sum(), "median misfit (45 gates)", np.median(res["misfit"][done]), "mean layers", res["n_layers"].mean())
+    assert np.median(res["misfit"][done]) < 70.0 and np.median(res["misfit"]) < 90.0
+    assert res["relative_error"].shape == (S, 2) and res["additive_error_posterior"].shape == (S, 2, 99)
+    assert np.all(res["layer_count_posterior"][done].sum(axis=1) == 3002) and res["mean_log10_conductivity"].shape == (S, res["interface_posterior"].shape[1])
+
+
 @pytest.mark.gpu
 def test_command_line_single_point_equals_the_survey_run(tmp_path):
     """python -m geobipy_amd options out --index 5: the sounding inverted alone walks the chain it walks in the full survey
