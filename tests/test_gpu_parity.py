@@ -390,3 +390,21 @@ def test_jacobian_bucketing_by_layer_count_is_transparent():
     _, sig, thk, h = synthetic.draw_models(B, Lmax, seed=13)
     b = FdemBatch(s, nl, sig, thk, h)
     assert torch.equal(b.sensitivity(bucket=True), b.sensitivity(bucket=False))
+
+
+def test_gpu_against_the_analytic_half_space_solution():
+    """The kernel on the surface of homogeneous half-spaces (altitude 0, no exponential damping of the filter terms) against
+    the closed form (filter accuracy) and against the oracle (parity bar)."""
+    from test_oracle_golden import analytic_halfspace_zz_ppm
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    ps, osys = synthetic.syn10_system(), oracle_system("syn10")
+    sig = np.array([1e-3, 1e-2, 1e-1, 1.0])
+    b = FdemBatch(ps, np.ones(4, dtype=np.int32), sig[:, None], np.zeros((4, 1)), np.zeros(4))
+    p = b.forward().cpu().numpy()
+    F = ps.nFrequencies
+    for i, (s_, tol) in enumerate(zip(sig, (1e-2, 5e-3, 2e-3, 5e-4))):
+        ana = analytic_halfspace_zz_ppm(ps.frequencies, s_, 7.9)
+        assert np.max(np.abs(p[i, :F] + 1j * p[i, F:] - ana) / np.abs(ana)) < tol
+        ref = fo.predicted_data(osys, np.array([s_]), np.array([np.inf]), 0.0)
+        assert close(p[i], ref, PRED_ATOL, PRED_RTOL)

@@ -77,3 +77,30 @@ def test_filter_tables_identical_in_product_and_oracle():
     assert np.array_equal(filters.W0_J0_120, gs_filters.W0_J0_120)
     assert np.array_equal(filters.W1_J1_140, gs_filters.W1_J1_140)
     assert filters.W0_J0_120.size == 120 and filters.W1_J1_140.size == 140
+
+
+def analytic_halfspace_zz_ppm(frequencies, sigma, r):
+    """Closed form for a vertical magnetic dipole and a vertical receiver on the surface of a homogeneous half-space
+    (quasi-static; Ward & Hohmann 1988, eq. 4.56): Hz = m / (2 pi k^2 r^5) [9 - (9 + 9ikr - 4 k^2 r^2 - i k^3 r^3) e^{-ikr}],
+    k^2 = -i w mu0 sigma; free space Hz0 = -m / (4 pi r^3); response in ppm of the primary."""
+    w = 2.0 * np.pi * np.asarray(frequencies)
+    k = np.sqrt(-1j * w * 4e-7 * np.pi * sigma)
+    k = np.where((-1j * k).real > 0, -k, k)                 # the root for which e^{-ikr} decays
+    ikr = 1j * k * r
+    hz = (9.0 - (9.0 + 9.0 * ikr - 4.0 * (k * r) ** 2 - 1j * (k * r) ** 3) * np.exp(-ikr)) / (2.0 * np.pi * k ** 2 * r ** 5)
+    h0 = -1.0 / (4.0 * np.pi * r ** 3)
+    return 1e6 * (hz - h0) / h0
+
+
+def test_oracle_against_the_analytic_half_space_solution():
+    """Physics known answer, independent of the reference: on the surface of a half-space (the hardest case for the digital
+    filters -- no exponential damping) the restated algorithm agrees with the closed form to the filters' own accuracy."""
+    from conftest import oracle_system
+    from geobipy_amd import synthetic
+    from oracle import fdem_oracle as fo
+    s, ps = oracle_system("syn10"), synthetic.syn10_system()
+    F = ps.nFrequencies
+    for sigma, tol in ((1e-3, 1e-2), (1e-2, 5e-3), (1e-1, 2e-3), (1.0, 5e-4)):
+        p = fo.predicted_data(s, np.array([sigma]), np.array([np.inf]), 0.0)
+        num, ana = p[:F] + 1j * p[F:], analytic_halfspace_zz_ppm(ps.frequencies, sigma, 7.9)
+        assert np.max(np.abs(num - ana) / np.abs(ana)) < tol, sigma
