@@ -177,3 +177,58 @@ def test_tdem_sensitivity_vs_finite_differences():
         fd = (TdemBatch(systems, nl, sp, thk, h, SKYTEM_OFFSET).forward().cpu().numpy()
               - TdemBatch(systems, nl, sm, thk, h, SKYTEM_OFFSET).forward().cpu().numpy()) / (2 * eps)
         assert np.all(np.abs(J[:, :, m] - fd) <= 1e-6 * scale)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# physics known answer, independent of gatdaem1d: step-off transient of a vertical dipole on a half-space
+# ------------------------------------------------------------------------------------------------------------------
+def analytic_stepoff_windows(stm, sigma, r, base_frequency=25.0):
+    """Window averages of d b_z / dt at offset r on the surface of a homogeneous half-space after a unit vertical magnetic
+    dipole is switched off (Ward & Hohmann 1988, eq. 4.70), for the periodic bipolar waveform of tests/golden/
+    ideal_stepoff.stm: 100 us linear turn-on at -10 ms, 1 us linear turn-off at 0, alternating polarity every half period."""
+    from scipy.special import erf
+    mu0 = 4e-7 * np.pi
+
+    def a(t):
+        x = np.sqrt(mu0 * sigma / (4.0 * t)) * r
+        return -(9.0 * erf(x) - (2.0 * x / np.sqrt(np.pi)) * (9.0 + 6.0 * x ** 2 + 4.0 * x ** 4) * np.exp(-x ** 2)) / (2.0 * np.pi * sigma * r ** 5)
+    half = 0.5 / base_frequency
+    out = []
+    for t1, t2 in stm["windows"]:
+        tt = np.linspace(t1, t2, 401)
+        tot = np.zeros_like(tt)
+        for tau in np.linspace(0.0, 1e-6, 21):
+            tot += a(tt - tau) / 21.0
+        for h in range(200):
+            pol = (-1.0) ** h
+            if h > 0:
+                tot += pol * a(tt + half * h)
+            for tau in np.linspace(half / 2 - 1e-4, half / 2, 11):
+                tot -= pol * a(tt + half * h + tau) / 11.0
+        out.append(np.trapezoid(tot, tt) / (t2 - t1))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("r,sigma,tol", [(30.0, 0.1, 0.015), (30.0, 1.0, 0.005), (100.0, 0.01, 0.015), (100.0, 0.1, 0.005)])
+def test_oracle_against_the_analytic_stepoff_transient(r, sigma, tol):
+    """The whole time-domain pipeline (frequency-domain kernel at the spline nodes, waveform spectrum, inverse FFT, window
+    averaging) against a closed-form transient: sign, units and amplitude, to a few 1e-3 of the largest gate (receiver on
+    the surface: no exponential damping of the filter terms)."""
+    from oracle import tdem_oracle as to
+    stm = to.parse_stm(os.path.join(GOLDEN, "ideal_stepoff.stm"))
+    ana = analytic_stepoff_windows(stm, sigma, r)
+    v = to.forward(stm, [sigma], [], 0.0, r, 0.0, 0.0)
+    assert np.max(np.abs(v - ana)) < tol * np.abs(ana).max()
+
+
+@pytest.mark.gpu
+def test_gpu_tdem_against_the_analytic_stepoff_transient():
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    from oracle import tdem_oracle as to
+    s = TdemSystem(os.path.join(GOLDEN, "ideal_stepoff.stm"))
+    stm = to.parse_stm(os.path.join(GOLDEN, "ideal_stepoff.stm"))
+    for r, sigma, tol in [(30.0, 1.0, 0.005), (100.0, 0.1, 0.005), (100.0, 0.01, 0.015)]:
+        b = TdemBatch(s, np.array([1]), np.array([[sigma]]), np.zeros((1, 1)), np.array([0.0]), (r, 0.0, 0.0))
+        v = b.forward().cpu().numpy()[0]
+        ana = analytic_stepoff_windows(stm, sigma, r)
+        assert np.max(np.abs(v - ana)) < tol * np.abs(ana).max(), (r, sigma)
