@@ -217,13 +217,17 @@ class TdemSystem:
         fn = self.node_frequencies()
         npts, wmu, hd0, g, cols = [], [], [], [], []
         for comp in self._components:
+            on_axis = r == 0.0                                     # J0(0) = 1: the loop's own J1(lam a) is the filter kernel
+            if on_axis and not a > 0.0:
+                raise ValueError("a receiver on the axis needs a finite ModellingLoopRadius")
             if comp == "z":
-                lam, w = l0 / rs, W0_J0_120 / rs
-                if r == 0.0:                                       # J0(0) = 1: plain integral via the filter at scale rs
-                    raise NotImplementedError("coincident-axis receiver needs r > 0")
+                lam, w = (l1 / a, W1_J1_140 / a) if on_axis else (l0 / rs, W0_J0_120 / rs)
             else:
-                lam, w = l1 / rs, W1_J1_140 / rs * (-dx / r)
-            src = lam * j1(lam * a) / (2.0 * np.pi * a) if a > 0.0 else lam * lam / (4.0 * np.pi)
+                lam, w = l1 / rs, W1_J1_140 / rs * ((-dx / r) if r > 0.0 else 0.0)
+            if on_axis and comp == "z":
+                src = lam / (2.0 * np.pi * a)
+            else:
+                src = lam * j1(lam * a) / (2.0 * np.pi * a) if a > 0.0 else lam * lam / (4.0 * np.pi)
             coef = src * w * self.scaling[comp]
             for f in fn:
                 npts.append(lam.size)

@@ -66,6 +66,13 @@ def secondary_fields(stm, sig, thk, alt, dx, dy, dz, freqs):
     l0, l1 = base_abscissae()
     hz, hx = np.empty(len(freqs), complex), np.empty(len(freqs), complex)
     H = 2.0 * alt + dz
+    if r == 0.0:                         # receiver on the loop axis: J0(0) = 1, the J1(lam a) of the loop is the filter kernel
+        assert a > 0.0, "coincident dipoles have no finite response"
+        lam = l1 / a
+        for i, f in enumerate(freqs):
+            hz[i] = np.sum(rte(lam, 2 * np.pi * f, sig, thk) * np.exp(-lam * H) * lam / (2 * np.pi * a) * W1_J1_140) / a
+            hx[i] = 0.0
+        return hz, hx
     for i, f in enumerate(freqs):
         for which, lam, w in (("z", l0 / r, W0_J0_120), ("x", l1 / r, W1_J1_140)):
             R = rte(lam, 2 * np.pi * f, sig, thk)

@@ -182,29 +182,36 @@ def test_tdem_sensitivity_vs_finite_differences():
 # ------------------------------------------------------------------------------------------------------------------
 # physics known answer, independent of gatdaem1d: step-off transient of a vertical dipole on a half-space
 # ------------------------------------------------------------------------------------------------------------------
-def analytic_stepoff_windows(stm, sigma, r, base_frequency=25.0):
-    """Window averages of d b_z / dt at offset r on the surface of a homogeneous half-space after a unit vertical magnetic
-    dipole is switched off (Ward & Hohmann 1988, eq. 4.70), for the periodic bipolar waveform of tests/golden/
-    ideal_stepoff.stm: 100 us linear turn-on at -10 ms, 1 us linear turn-off at 0, alternating polarity every half period."""
+def analytic_stepoff_windows(stm, sigma, r=None, a=None, base_frequency=25.0):
+    """Window averages of d b_z / dt on the surface of a homogeneous half-space after a unit-moment vertical source is
+    switched off (Ward & Hohmann 1988): a vertical magnetic dipole seen at offset r (d/dt of eq. 4.69a:
+    + m / (2 pi sigma r^5) [9 erf(x) - 2x/sqrt(pi) (9 + 6x^2 + 4x^4) e^{-x^2}], x = theta r), or a circular loop of radius a
+    seen at its centre (eq. 4.98: - I / (sigma a^3) [3 erf(x) - 2/sqrt(pi) x (3 + 2x^2) e^{-x^2}], x = theta a, I = 1 / (pi a^2));
+    theta = sqrt(mu0 sigma / 4t).  Summed over the periodic bipolar waveform of tests/golden/ideal_*.stm: 100 us linear
+    turn-on at -10 ms, 1 us linear turn-off at 0, alternating polarity every half period."""
     from scipy.special import erf
     mu0 = 4e-7 * np.pi
 
-    def a(t):
-        x = np.sqrt(mu0 * sigma / (4.0 * t)) * r
-        return -(9.0 * erf(x) - (2.0 * x / np.sqrt(np.pi)) * (9.0 + 6.0 * x ** 2 + 4.0 * x ** 4) * np.exp(-x ** 2)) / (2.0 * np.pi * sigma * r ** 5)
+    def step(t):
+        theta = np.sqrt(mu0 * sigma / (4.0 * t))
+        if r is not None:
+            x = theta * r
+            return (9.0 * erf(x) - (2.0 * x / np.sqrt(np.pi)) * (9.0 + 6.0 * x ** 2 + 4.0 * x ** 4) * np.exp(-x ** 2)) / (2.0 * np.pi * sigma * r ** 5)
+        x = theta * a
+        return -(3.0 * erf(x) - (2.0 / np.sqrt(np.pi)) * x * (3.0 + 2.0 * x ** 2) * np.exp(-x ** 2)) / (np.pi * a ** 2 * sigma * a ** 3)
     half = 0.5 / base_frequency
     out = []
     for t1, t2 in stm["windows"]:
         tt = np.linspace(t1, t2, 401)
         tot = np.zeros_like(tt)
         for tau in np.linspace(0.0, 1e-6, 21):
-            tot += a(tt - tau) / 21.0
+            tot += step(tt - tau) / 21.0
         for h in range(200):
             pol = (-1.0) ** h
             if h > 0:
-                tot += pol * a(tt + half * h)
+                tot += pol * step(tt + half * h)
             for tau in np.linspace(half / 2 - 1e-4, half / 2, 11):
-                tot -= pol * a(tt + half * h + tau) / 11.0
+                tot -= pol * step(tt + half * h + tau) / 11.0
         out.append(np.trapezoid(tot, tt) / (t2 - t1))
     return np.array(out)
 
@@ -216,9 +223,19 @@ def test_oracle_against_the_analytic_stepoff_transient(r, sigma, tol):
     the surface: no exponential damping of the filter terms)."""
     from oracle import tdem_oracle as to
     stm = to.parse_stm(os.path.join(GOLDEN, "ideal_stepoff.stm"))
-    ana = analytic_stepoff_windows(stm, sigma, r)
+    ana = analytic_stepoff_windows(stm, sigma, r=r)
     v = to.forward(stm, [sigma], [], 0.0, r, 0.0, 0.0)
-    assert np.max(np.abs(v - ana)) < tol * np.abs(ana).max()
+    assert np.max(np.abs(v + ana)) < tol * np.abs(ana).max()       # the reference's Z output is -d b_z / dt (TdemDataPoint.py:1013-1015)
+
+
+@pytest.mark.parametrize("sigma,tol", [(0.1, 0.02), (1.0, 0.005)])
+def test_oracle_against_the_analytic_central_loop_transient(sigma, tol):
+    """Finite loop source (ModellingLoopRadius), receiver at its centre."""
+    from oracle import tdem_oracle as to
+    stm = to.parse_stm(os.path.join(GOLDEN, "ideal_central_loop.stm"))
+    ana = analytic_stepoff_windows(stm, sigma, a=20.0)
+    v = to.forward(stm, [sigma], [], 0.0, 0.0, 0.0, 0.0)
+    assert np.max(np.abs(v + ana)) < tol * np.abs(ana).max()
 
 
 @pytest.mark.gpu
@@ -230,5 +247,12 @@ def test_gpu_tdem_against_the_analytic_stepoff_transient():
     for r, sigma, tol in [(30.0, 1.0, 0.005), (100.0, 0.1, 0.005), (100.0, 0.01, 0.015)]:
         b = TdemBatch(s, np.array([1]), np.array([[sigma]]), np.zeros((1, 1)), np.array([0.0]), (r, 0.0, 0.0))
         v = b.forward().cpu().numpy()[0]
-        ana = analytic_stepoff_windows(stm, sigma, r)
-        assert np.max(np.abs(v - ana)) < tol * np.abs(ana).max(), (r, sigma)
+        ana = analytic_stepoff_windows(stm, sigma, r=r)
+        assert np.max(np.abs(v + ana)) < tol * np.abs(ana).max(), (r, sigma)
+    s2 = TdemSystem(os.path.join(GOLDEN, "ideal_central_loop.stm"))
+    stm2 = to.parse_stm(os.path.join(GOLDEN, "ideal_central_loop.stm"))
+    for sigma, tol in [(0.1, 0.02), (1.0, 0.005)]:
+        b = TdemBatch(s2, np.array([1]), np.array([[sigma]]), np.zeros((1, 1)), np.array([0.0]), (0.0, 0.0, 0.0))
+        v = b.forward().cpu().numpy()[0]
+        ana = analytic_stepoff_windows(stm2, sigma, a=20.0)
+        assert np.max(np.abs(v + ana)) < tol * np.abs(ana).max(), ("central loop", sigma)
