@@ -607,6 +607,80 @@ __device__ inline void hitmap_add(const gbp_rj_options& o, int32_t* hm, const do
     }
 }
 
+__device__ inline double group_sum8(double v)
+{
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// Bookkeeping on the post-step state of one chain (Inference1D.update :705-790, infer :641-688), shared by the W lanes that
+// own the chain (64: one wave per chain; 8: packed).  The post-step model (ec, sc, kc) is passed from where it came from
+// (the proposal buffers when accepted, the untouched state otherwise), never read back from what other lanes just wrote;
+// all lanes of a chain sit in one wave, so program order is the only ordering needed between them.
+template <int W>
+__device__ inline void bookkeeping(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
+                                   int kc, const double* ec, const double* sc, double post, double best_prev, double misfit_now,
+                                   const Levels& lev, double lmp, int dwell)
+{
+    const int K = o.max_layers, N = o.n_channels;
+    const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
+    bool reset_best = false;
+    int finished = 0;
+    if (o.schedule == 1) {                                       // the reference's per-sounding schedule
+        const int it1 = (int)iter + 1;
+        int bi = c.burned_in_iteration[b];
+        if (bi < 0) {
+            double na = 0.0;
+            for (int n = i; n < N; n += W) na += c.data[b * N + n] > 0.0 ? 1.0 : 0.0;
+            na = W == 64 ? wave_sum(na) : group_sum8(na);
+            if (it1 > o.burn_in_min_iterations && misfit_now < na) {        // burned in: posteriors and best model start over
+                bi = it1;
+                reset_best = true;
+                for (int q = i; q < K + 1; q += W) c.k_hist[b * (K + 1) + q] = 0;
+                if (c.rel_hist != nullptr) {
+                    for (int q = i; q < o.n_rel_groups * o.n_error_bins; q += W) c.rel_hist[b * o.n_rel_groups * o.n_error_bins + q] = 0;
+                    for (int q = i; q < o.n_add_groups * o.n_error_bins; q += W) c.add_hist[b * o.n_add_groups * o.n_error_bins + q] = 0;
+                }
+                if (c.edge_hist != nullptr)
+                    for (int q = i; q < o.n_depth_bins; q += W) c.edge_hist[b * o.n_depth_bins + q] = 0;
+                if (c.hitmap != nullptr) {
+                    for (size_t q = i; q < nh; q += W) c.hitmap[b * nh + q] = 0;
+                    dwell = 0;
+                }
+                if (i == 0) c.burned_in_iteration[b] = bi;
+            }
+        }
+        accumulate = 1;                                          // every iteration; the reset above discards the burn-in
+        finished = (bi >= 0 && it1 > o.n_markov_chains + bi) ? 1 : ((bi < 0 && it1 >= o.n_markov_chains) ? 2 : 0);
+        if (i == 0 && finished) c.status[b] = finished;         // 1 done: n_markov_chains samples collected; 2 failed to burn in
+    }
+    if (reset_best || post > best_prev) {
+        for (int j = i; j < K; j += W) { c.best_edges[b * K + j] = ec[j]; c.best_sigma[b * K + j] = sc[j]; }
+        if (i == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
+    }
+    if (accumulate) {
+        if (i == 0) {
+            c.k_hist[b * (K + 1) + kc] += 1;
+            error_hist_add(o, c, b, lev);
+        }
+        if (c.edge_hist != nullptr && i < kc - 1) {              // interfaces across which sigma changes by > 50 %
+            const double ratio = sc[i + 1] / sc[i];              //   (RectilinearMesh1D.update_posteriors :1595-1610)
+            if (ratio <= 0.5 || ratio >= 1.5) {
+                const int bin = min(max((int)floor(ec[i] / o.depth_bin_width), 0), o.n_depth_bins - 1);
+                atomicAdd(c.edge_hist + b * o.n_depth_bins + bin, 1);
+            }
+        }
+    }
+    if (c.hitmap != nullptr) {
+        if (accumulate) dwell += 1;
+        if (finished && dwell > 0) {                             // the chain stops here: settle its last model
+            hitmap_add<W>(o, c.hitmap + b * nh, ec, sc, kc, lmp, i, dwell);
+            dwell = 0;
+        }
+        if (i == 0) c.hit_dwell[b] = dwell;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
 {   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to k_rj_accept8
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -698,7 +772,9 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
         like_p = c.like_p[b];
         misfit_p = c.misfit_p[b];
     }
-    const double log_ratio = (prior_p - c.prior[b]) + (like_p - c.like[b]) + dq;
+    const int k_prev = c.k[b];                                   // (the carried state, read before it is overwritten)
+    const double prior_c = c.prior[b], like_c = c.like[b], misfit_c = c.misfit[b], best_prev = c.best_posterior[b];
+    const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
     const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
     const bool accept = !frozen && log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
@@ -709,7 +785,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[b] : 0;        // iterations the current model is still owed to the hit map
     if (accept && dwell > 0) {                                   // the model changes: settle the old one first
-        hitmap_add<64>(o, c.hitmap + (size_t)b * nh, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, c.k[b], lmp, lane, dwell);
+        hitmap_add<64>(o, c.hitmap + (size_t)b * nh, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, k_prev, lmp, lane, dwell);
         dwell = 0;
         __syncthreads();
     }
@@ -735,82 +811,14 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             c.n_accepted[b] += 1;
         }
     }
-    // bookkeeping on the post-step state (Inference1D.update :705-790); the post-step model is read from where it came
-    // from (the proposal buffers when accepted, the untouched state otherwise), never back from what other lanes just wrote
-    const int kc = accept ? k : c.k[b];
-    const double* ec = accept ? e : c.edges + (size_t)b * K;
-    const double* sc = accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K;
-    const double post = (accept ? prior_p + like_p : c.prior[b] + c.like[b]);
-    bool reset_best = false;
-    int finished = 0;
-    if (o.schedule == 1) {                                       // the reference's per-sounding schedule
-        const int it1 = (int)iter + 1;                           //   (Inference1D.update :713-737, infer :641-688)
-        int bi = c.burned_in_iteration[b];
-        if (bi < 0) {
-            double na = 0.0;
-            for (int n = lane; n < N; n += 64) na += c.data[(size_t)b * N + n] > 0.0 ? 1.0 : 0.0;
-            na = wave_sum(na);
-            const double misfit_now = accept ? misfit_p : c.misfit[b];
-            if (it1 > o.burn_in_min_iterations && misfit_now < na) {        // burned in: posteriors and best model start over
-                bi = it1;
-                reset_best = true;
-                for (int i = lane; i < K + 1; i += 64) c.k_hist[(size_t)b * (K + 1) + i] = 0;
-                if (c.rel_hist != nullptr) {
-                    for (int i = lane; i < o.n_rel_groups * o.n_error_bins; i += 64) c.rel_hist[(size_t)b * o.n_rel_groups * o.n_error_bins + i] = 0;
-                    for (int i = lane; i < o.n_add_groups * o.n_error_bins; i += 64) c.add_hist[(size_t)b * o.n_add_groups * o.n_error_bins + i] = 0;
-                }
-                if (c.edge_hist != nullptr)
-                    for (int i = lane; i < o.n_depth_bins; i += 64) c.edge_hist[(size_t)b * o.n_depth_bins + i] = 0;
-                if (c.hitmap != nullptr) {
-                    for (size_t i = lane; i < nh; i += 64) c.hitmap[(size_t)b * nh + i] = 0;
-                    dwell = 0;
-                }
-                __syncthreads();
-                if (lane == 0) c.burned_in_iteration[b] = bi;
-            }
-        }
-        accumulate = 1;                                          // every iteration; the reset above discards the burn-in
-        finished = (bi >= 0 && it1 > o.n_markov_chains + bi) ? 1 : ((bi < 0 && it1 >= o.n_markov_chains) ? 2 : 0);
-        if (lane == 0 && finished) c.status[b] = finished;      // 1 done: n_markov_chains samples collected; 2 failed to burn in
-    }
-    if (reset_best || post > c.best_posterior[b]) {
-        if (lane < K) { c.best_edges[(size_t)b * K + lane] = ec[lane]; c.best_sigma[(size_t)b * K + lane] = sc[lane]; }
-        __syncthreads();
-        if (lane == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
-    }
-    if (accumulate) {
-        if (lane == 0) {
-            c.k_hist[(size_t)b * (K + 1) + kc] += 1;
-            error_hist_add(o, c, (size_t)b, accept ? lev_p : lev_c);
-        }
-        if (c.edge_hist != nullptr && lane < kc - 1) {           // interfaces across which sigma changes by > 50 %
-            const double ratio = sc[lane + 1] / sc[lane];        //   (RectilinearMesh1D.update_posteriors :1595-1610)
-            if (ratio <= 0.5 || ratio >= 1.5) {
-                const int bin = min(max((int)floor(ec[lane] / o.depth_bin_width), 0), o.n_depth_bins - 1);
-                atomicAdd(c.edge_hist + (size_t)b * o.n_depth_bins + bin, 1);
-            }
-        }
-    }
-    if (c.hitmap != nullptr) {
-        if (accumulate) dwell += 1;
-        if (finished && dwell > 0) {                             // the chain stops here: settle its last model
-            __syncthreads();
-            hitmap_add<64>(o, c.hitmap + (size_t)b * nh, ec, sc, kc, lmp, lane, dwell);
-            dwell = 0;
-        }
-        if (lane == 0) c.hit_dwell[b] = dwell;
-    }
+    bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
+                    accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
+                    accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
 }
 
 // The same for chains whose current and proposed models have at most 8 layers, packed 8 lanes per chain like k_rj_newton8:
 // the reverse-move algebra runs on the Cholesky factor held in registers (row i and column i on lane i), sums over a
 // chain are 8-lane butterflies, state copies and posterior updates are strided by 8.
-__device__ inline double group_sum8(double v)
-{
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-    return v;
-}
-
 // hitmap_add for the packed kernel (kc <= 8, 8 lanes per chain): the interface depths and the value bin of every layer
 // are gathered into registers once (cross-lane reads issued by the whole wave), so a depth cell costs a few compares
 // instead of a logarithm and a search through global memory.  Called by all 8 lanes of a group; `on`: the group really adds.
@@ -993,68 +1001,9 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
             c.n_accepted[bb] += 1;
         }
     }
-    // bookkeeping on the post-step state (Inference1D.update :705-790)
-    const int kc = accept ? k : k_prev;
-    const double* ec = accept ? e : c.edges + bb * K;
-    const double* sc = accept ? c.sigma_p + bb * K : c.sigma + bb * K;
-    const double post = accept ? prior_p + like_p : prior_c + like_c;
-    bool reset_best = false;
-    int finished = 0;
-    if (o.schedule == 1) {
-        const int it1 = (int)iter + 1;
-        int bi = c.burned_in_iteration[bb];
-        if (bi < 0) {
-            double nact = 0.0;
-            for (int n = i; n < N; n += 8) nact += c.data[bb * N + n] > 0.0 ? 1.0 : 0.0;
-            nact = group_sum8(nact);
-            const double misfit_now = accept ? misfit_p : misfit_c;
-            if (it1 > o.burn_in_min_iterations && misfit_now < nact) {
-                bi = it1;
-                reset_best = true;
-                for (int q = i; q < K + 1; q += 8) c.k_hist[bb * (K + 1) + q] = 0;
-                if (c.rel_hist != nullptr) {
-                    for (int q = i; q < o.n_rel_groups * o.n_error_bins; q += 8) c.rel_hist[bb * o.n_rel_groups * o.n_error_bins + q] = 0;
-                    for (int q = i; q < o.n_add_groups * o.n_error_bins; q += 8) c.add_hist[bb * o.n_add_groups * o.n_error_bins + q] = 0;
-                }
-                if (c.edge_hist != nullptr)
-                    for (int q = i; q < o.n_depth_bins; q += 8) c.edge_hist[bb * o.n_depth_bins + q] = 0;
-                if (c.hitmap != nullptr) {
-                    for (size_t q = i; q < nh; q += 8) c.hitmap[bb * nh + q] = 0;
-                    dwell = 0;
-                }
-                if (i == 0) c.burned_in_iteration[bb] = bi;
-            }
-        }
-        accumulate = 1;
-        finished = (bi >= 0 && it1 > o.n_markov_chains + bi) ? 1 : ((bi < 0 && it1 >= o.n_markov_chains) ? 2 : 0);
-        if (i == 0 && finished) c.status[bb] = finished;
-    }
-    if (reset_best || post > best_prev) {
-        for (int j = i; j < K; j += 8) { c.best_edges[bb * K + j] = ec[j]; c.best_sigma[bb * K + j] = sc[j]; }
-        if (i == 0) { c.best_posterior[bb] = post; c.best_k[bb] = kc; }
-    }
-    if (accumulate) {
-        // (the k_hist row may have been zeroed by other lanes of the group just above: same wave, program order)
-        if (i == 0) {
-            c.k_hist[bb * (K + 1) + kc] += 1;
-            error_hist_add(o, c, bb, accept ? lev_p : lev_c);
-        }
-        if (c.edge_hist != nullptr && i < kc - 1) {
-            const double ratio = sc[i + 1] / sc[i];
-            if (ratio <= 0.5 || ratio >= 1.5) {
-                const int bin = min(max((int)floor(ec[i] / o.depth_bin_width), 0), o.n_depth_bins - 1);
-                atomicAdd(c.edge_hist + bb * o.n_depth_bins + bin, 1);
-            }
-        }
-    }
-    if (c.hitmap != nullptr) {
-        if (accumulate) dwell += 1;
-        if (finished && dwell > 0) {                 // (rare: the generic routine, no cross-lane reads)
-            hitmap_add<8>(o, c.hitmap + bb * nh, ec, sc, kc, lmp, i, dwell);
-            dwell = 0;
-        }
-        if (i == 0) c.hit_dwell[bb] = dwell;
-    }
+    bookkeeping<8>(o, c, iter, accumulate, bb, i, accept ? k : k_prev, accept ? e : c.edges + bb * K,
+                   accept ? c.sigma_p + bb * K : c.sigma + bb * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
+                   accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
 }
 
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
