@@ -10,6 +10,7 @@
 //   Hankel sum = wave64 butterfly reduction; chi^2 / logdet = second wave reduction over channels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -456,7 +457,11 @@ int pick_waves(int B, int F, int Lmax, int max_waves)
         const char* e = std::getenv("GBP_NW");
         forced = e ? std::atoi(e) : -1;
     }
-    int nw = g_pinned_waves > 0 ? g_pinned_waves : (g_user_waves > 0 ? g_user_waves : (forced > 0 ? forced : (8192 + B - 1) / B));  // aim for >= 8 waves per SIMD-slot worth of work
+    // measured (scripts/sweep_waves.py, 10 frequencies x 8 layers): one wave per sounding is best once every SIMD has a
+    // queue of soundings (B >= 49152); below that 4 waves per sounding balance the tail better (+2..6 %), and small
+    // batches need 8192 / B waves to fill the chip at all
+    const int heuristic = B >= 49152 ? 1 : std::max(4, (8192 + B - 1) / B);
+    int nw = g_pinned_waves > 0 ? g_pinned_waves : (g_user_waves > 0 ? g_user_waves : (forced > 0 ? forced : heuristic));
     if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;
     while (nw > 1 && dyn_lds_bytes(nw, Lmax, F) > 60000) --nw;
