@@ -149,10 +149,7 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
             pt = gbp::load_point(pts, P, j);
         }
         cplx num, den;
-        if (__any(pt.a < 0.0))   // (wave-uniform) lambda^2 below the displacement-current term omega^2 mu0 eps0 somewhere
-            gbp::rte_num_den<true>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
-        else
-            gbp::rte_num_den<false>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
+        gbp::rte_num_den(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
         const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
         if (has_next) {
             acc_cr += in_next ? 0.0 : t.re;

@@ -116,9 +116,6 @@ GBP_HD double rcp(double x)
 // principal sqrt(a + i b) for b > 0 (b = omega mu0 sigma in an earth layer), given the per-layer
 // constants b2 = b^2 and bc = b / sqrt(2) (wave-uniform, precomputed once per layer and frequency):
 //   m = |a + i b|,  s2 = m + |a| = 2 s,  sqrt(s) = sqrt(s2)/sqrt(2),  b/(2 sqrt(s)) = bc / sqrt(s2)
-// ANY_SIGN = false: the caller knows a >= 0 (no displacement-current term, or an abscissa above it) and saves the two
-// 64-bit selects; the forward kernel takes that branch for the passes whose 64 abscissae all qualify.
-template <bool ANY_SIGN = true>
 GBP_HD cplx csqrt_upper2(double a, double b2, double bc)
 {
     const double RSQRT2 = 0.70710678118654752440;
@@ -127,7 +124,6 @@ GBP_HD cplx csqrt_upper2(double a, double b2, double bc)
     sqrt_rsqrt(m + __builtin_fabs(a), g2, y2);
     double g = g2 * RSQRT2;
     double o = bc * y2;
-    if (!ANY_SIGN) return mk(g, o);
     return (a >= 0.0) ? mk(g, o) : mk(o, g);
 }
 GBP_HD cplx csqrt_upper(double a, double b) { return csqrt_upper2(a, b * b, b * 0.70710678118654752440); }
