@@ -47,6 +47,19 @@ struct gbp_fdem_system {
     gbp::SystemTables t;      // host copy (channels, H0, point tables)
     Channel* d_chan = nullptr;
     double* d_pts = nullptr;  // SoA, GBP_PT_FIELDS arrays of [npts] (gbp_fdem_point.h)
+    // Soundings whose layers all have sigma >= sigma_direct take the kernels' csqrt_upper2<DIRECT> branch: for every
+    // frequency f and abscissa with a = lambda^2 - omega^2 mu0 eps0 < 0,  -a <= wmu_f sigma / 4, i.e. b^2 >= 16 a^2.
+    // (= 4 omega_max eps0, 2.9e-5 S/m at 130 kHz; 0 for tables without a displacement-current term)
+    double sigma_direct = 0.0;
+    void set_sigma_direct()
+    {
+        sigma_direct = 0.0;
+        for (const Channel& ch : t.chan)
+            for (int j = 0; j < ch.npts; ++j) {
+                const double a = t.soa[(size_t)ch.off + j];   // field 0 of the SoA = a
+                if (a < 0.0) sigma_direct = std::max(sigma_direct, -a / (0.25 * ch.wmu));
+            }
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -88,6 +101,18 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Smallest conductivity of the sounding (wave-uniform, returned in SGPRs; each wave of the workgroup evaluates it).
+__device__ __forceinline__ double wave_min_sigma(const double* __restrict__ sig, int L, int lane)
+{
+    double v = 1.7976931348623157e308;
+    for (int k = lane; k < L; k += 64) v = fmin(v, sig[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Per-frequency layer constants of this sounding -> LDS (lanes k < L), then a wave barrier.
 __device__ __forceinline__ void setup_layers(gbp::LayerK* lay, double wmu, const double* __restrict__ sig, int L,
                                              int lane)
@@ -106,6 +131,7 @@ __device__ __forceinline__ void setup_layers(gbp::LayerK* lay, double wmu, const
 // A pass may straddle two frequencies ("cur" below the boundary lane, "next" above it): each lane picks its
 // frequency's layer constants (two LDS slots) and altitude term, and accumulates into acc_c / acc_n; when a
 // frequency completes (or the range ends) the wave reduces and stores the partial sum in sh_part[f].
+template <bool DIRECT>   // csqrt_upper2<DIRECT> is valid for every layer and abscissa of this sounding (gbp_fdem_system::sigma_direct)
 __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Channel* __restrict__ chan,
                                                const double* __restrict__ pts, int P, int F, int L,
                                                const double* __restrict__ sig, const double* sh_t2,
@@ -149,7 +175,7 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
             pt = gbp::load_point(pts, P, j);
         }
         cplx num, den;
-        gbp::rte_num_den(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
+        gbp::rte_num_den<DIRECT>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
         const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
         if (has_next) {
             acc_cr += in_next ? 0.0 : t.re;
@@ -220,7 +246,8 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
                                                        const double* __restrict__ obs,
                                                        const double* __restrict__ rel,
                                                        const double* __restrict__ add, double* __restrict__ pred,
-                                                       double* __restrict__ chi2, double* __restrict__ logL)
+                                                       double* __restrict__ chi2, double* __restrict__ logL,
+                                                       double sigma_direct)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
@@ -234,6 +261,8 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform): none of its outputs are written
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
+    // every layer conductive enough for the select-free complex sqrt (all but displacement-current dominated models)
+    const bool direct = wave_min_sigma(sig, L, lane) >= sigma_direct;   // workgroup-uniform
     gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
     cplx* sh_part_all = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
     double* sh_t2 = reinterpret_cast<double*>(sh_part_all + (size_t)nwaves * F);
@@ -245,8 +274,12 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const int per = (npass + nwaves - 1) / nwaves;
     const int p0 = wave * per;
     const int p1 = min(npass, p0 + per);
-    forward_passes(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
-                   sh_part_all + (size_t)wave * F);
+    if (direct)
+        forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
+                             sh_part_all + (size_t)wave * F);
+    else
+        forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
+                              sh_part_all + (size_t)wave * F);
     __syncthreads();
 
     // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum over waves (fixed order: deterministic)
@@ -524,6 +557,7 @@ gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t* tid, const dou
     if (rc != GBP_OK) { delete s; return fail(rc, "%s", msg); }
     if (eps_ppm > 0.0 && !(min_altitude >= 0.0)) { delete s; return fail(GBP_ERR_INVALID_ARG, "min_altitude must be >= 0%s"); }
     gbp::window_system_tables(&s->t, eps_ppm, min_altitude);
+    s->set_sigma_direct();
     const std::vector<double>& soa = s->t.soa;
 
     hipError_t e = hipMalloc((void**)&s->d_chan, sizeof(Channel) * nF);
@@ -565,6 +599,7 @@ gbp_status gbp_hankel_system_create_raw(int nF, const int32_t* npts, const doubl
     }
     t.npts = P;
     t.soa.assign(tables, tables + (size_t)GBP_PT_FIELDS * P);
+    s->set_sigma_direct();
     const std::vector<double>& soa = t.soa;
     hipError_t e = hipMalloc((void**)&s->d_chan, sizeof(Channel) * nF);
     if (e == hipSuccess) e = hipMalloc((void**)&s->d_pts, sizeof(double) * soa.size());
@@ -618,7 +653,7 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system* sys, int B, int Lmax, const i
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
-                       nullptr, pred, nullptr, nullptr);
+                       nullptr, pred, nullptr, nullptr, sys->sigma_direct);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -661,7 +696,7 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax,
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
-                       chi2, logL);
+                       chi2, logL, sys->sigma_direct);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

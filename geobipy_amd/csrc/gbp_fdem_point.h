@@ -64,15 +64,16 @@ struct alignas(16) LayerK {
 
 // rTE numerator / denominator for one point.  a = lambda^2 - w2me; lay[k], t2[k] = -2 thk[k] for the
 // sounding's L layers (t2[L-1] is never read -- the reference passes inf there).
+template <bool DIRECT = false>   // see csqrt_upper2
 GBP_HD void rte_num_den(const MathCtx& M, double a, int L, const LayerK* __restrict__ lay,
                         const double* __restrict__ t2, cplx u0, cplx& num, cplx& den)
 {
-    cplx N = csqrt_upper2(a, lay[L - 1].b2, lay[L - 1].bc);  // basement: Yh_L = u_L
+    cplx N = csqrt_upper2<DIRECT>(a, lay[L - 1].b2, lay[L - 1].bc);  // basement: Yh_L = u_L
     cplx D = mk(1.0, 0.0);
     for (int k = L - 2; k >= 0; --k) {
         const LayerK lk = lay[k];
         const double tk = t2[k];
-        cplx u = csqrt_upper2(a, lk.b2, lk.bc);
+        cplx u = csqrt_upper2<DIRECT>(a, lk.b2, lk.bc);
         cplx e = cexp_neg(M, tk * u.re, tk * u.im);
         cplx uD = u * D;
         cplx A = uD + N, B = uD - N;

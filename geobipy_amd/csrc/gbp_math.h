@@ -116,11 +116,20 @@ GBP_HD double rcp(double x)
 // principal sqrt(a + i b) for b > 0 (b = omega mu0 sigma in an earth layer), given the per-layer
 // constants b2 = b^2 and bc = b / sqrt(2) (wave-uniform, precomputed once per layer and frequency):
 //   m = |a + i b|,  s2 = m + |a| = 2 s,  sqrt(s) = sqrt(s2)/sqrt(2),  b/(2 sqrt(s)) = bc / sqrt(s2)
+// DIRECT = true is for callers that know a >= 0, or a < 0 with b^2 >= 16 a^2 (a = lambda^2 - omega^2 mu0 eps0 is negative
+// only below the displacement-current term, where |a| is far smaller than b in any conducting layer): then m + a keeps
+// at least 3/4 of m, re = sqrt((m + a)/2) loses less than half a bit, and the branch swap -- two 64-bit selects per layer
+// of the recursion -- is not needed.
+template <bool DIRECT = false>
 GBP_HD cplx csqrt_upper2(double a, double b2, double bc)
 {
     const double RSQRT2 = 0.70710678118654752440;
     double m = sqrt_fast(__builtin_fma(a, a, b2));
     double g2, y2;
+    if (DIRECT) {
+        sqrt_rsqrt(m + a, g2, y2);
+        return mk(g2 * RSQRT2, bc * y2);
+    }
     sqrt_rsqrt(m + __builtin_fabs(a), g2, y2);
     double g = g2 * RSQRT2;
     double o = bc * y2;
