@@ -627,7 +627,7 @@ __device__ inline void bookkeeping(const gbp_rj_options& o, const gbp_rj_chains&
     bool reset_best = false;
     int finished = 0;
     if (o.schedule == 1) {                                       // the reference's per-sounding schedule
-        const int it1 = (int)iter + 1;
+        const int it1 = (int)iter + 1 - (c.iteration0 != nullptr ? c.iteration0[b] : 0);   // counted from the chain's (re)start
         int bi = c.burned_in_iteration[b];
         if (bi < 0) {
             double na = 0.0;

@@ -147,6 +147,7 @@ class Inference1D:
         self.options.update({k: v for k, v in options.items() if v is not None})
         self.n_markov_chains = int(self.options.get("n_markov_chains", 100000))
         self.iteration, self.accepted = 0, False
+        self.on_update = None                      # optional callback(self) after every update of infer()'s schedule
 
     def initialize(self, datapoint):
         """``datapoint``: geobipy_amd.FdemDataPoint (its data, altitude and system are used)."""
@@ -206,17 +207,23 @@ class Inference1D:
 
     def infer(self, n_iterations=None, burn_in_min_iterations=5000):
         """``n_iterations`` given: that many iterations, every state accumulated.  Otherwise the reference's schedule
-        (Inference1D.infer :633-688 with update :713-737): the chain burns in at the first iteration >
+        (Inference1D.infer :633-688 with update :713-781): the chain burns in at the first iteration >
         ``burn_in_min_iterations`` whose misfit is below the number of active channels -- posteriors and best model restart
         there --, runs ``n_markov_chains`` more iterations, and fails (returns True, like the reference) if it has not
-        burned in after ``n_markov_chains`` iterations."""
+        burned in after ``n_markov_chains`` iterations.  A chain that has not burned in and accepted nothing over
+        ``reset_limit`` consecutive windows of ``update_plot_every`` iterations starts over from its initial state
+        (the random stream goes on); the third restart arms the reference's (inert) variance limiters and restarts once
+        more, and the third restart after that gives the sounding up (returns True)."""
         if n_iterations is not None:
             for _ in range(n_iterations):
                 self.accept_reject()
                 self.update()
             return False
         n_active = int((self.data > 0.0).sum())
+        window = int(self.options.get("update_plot_every") or 5000)
+        reset_limit = int(self.options.get("reset_limit") or 1)
         self.burned_in, self.burned_in_iteration = False, 0
+        self.n_resets, self.n_zero_acceptance, limited = 0, 0, False
         while True:
             self.accept_reject()
             self.update()
@@ -225,10 +232,37 @@ class Inference1D:
                 self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
                 self.posteriors.reset()
                 self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
+            if window > 1 and self.iteration % window == 0 and not self.burned_in:                    # update :764-776
+                # the reference's window: the flags it stored at indices [iteration - window, iteration), i.e. without this step's
+                if self.acceptance_v[max(self.iteration - window, 0):self.iteration].sum() == 0:
+                    self.n_zero_acceptance += 1
+                    if self.n_zero_acceptance == reset_limit:
+                        self.reset()
+                        self.n_zero_acceptance = 0
+                else:
+                    self.n_zero_acceptance = 0
+            if self.on_update is not None:         # (where the reference's update() returns)
+                self.on_update(self)
             if self.burned_in and self.iteration > self.n_markov_chains + self.burned_in_iteration:
                 return False
             if not self.burned_in and self.iteration >= self.n_markov_chains:
                 return True
+            if self.n_resets == 3 and not self.burned_in:                                             # infer :665-678
+                if limited:
+                    return True
+                limited, self.n_resets = True, 0
+                self.reset()
+
+    def reset(self):
+        """Inference1D.reset (:984-999): back to the initial state of this sounding; the random stream is not rewound."""
+        self.n_resets += 1
+        self.priors, self.state = initial_state(self.engine, self.data, self.options)
+        self.iteration = 0
+        self.data_misfit_v[:] = 0.0
+        self.data_misfit_v[0] = self.state.misfit
+        self.acceptance_v[:] = 0
+        self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, 0
+        self.posteriors.reset()
 
 
 class BatchedInference:

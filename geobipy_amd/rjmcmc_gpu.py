@@ -171,7 +171,7 @@ class DeviceChains:
             hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
             hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
-            best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K))
+            best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K), iteration0=z(B, dt=i32))
         self._bind()
         self.iteration = 0
         _lib.check(_lib.load().gbp_pin_forward_waves(int(forward_waves)))
@@ -242,6 +242,12 @@ class DeviceChains:
         t["best_sigma"].copy_(t["sigma"])
         t["best_edges"].copy_(t["edges"])
         t["best_k"].copy_(t["k"])
+        # host-side bookkeeping of infer()'s restarts (not part of gbp_rj_chains; re-packed with the rest): the state the
+        # chains start from and the reference's counters _n_zero_acceptance / _n_resets / "limiters armed"
+        zi = lambda dt: torch.zeros(B, dtype=dt, device=self.device)
+        t.update(init_sigma=t["sigma"][:, 0].clone(), init_pred=t["pred"].clone(), init_J0=t["J"][:, :, 0].clone(),
+                 init_prior=t["prior"].clone(), init_like=t["like"].clone(), init_misfit=t["misfit"].clone(),
+                 acc_mark=zi(torch.int64), n_zero=zi(torch.int32), n_resets=zi(torch.int32), limited=zi(torch.int32))
 
     # the two evaluations the initialisation needs, through the same entries the sampler uses (overridden for time-domain data)
     def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
@@ -270,14 +276,23 @@ class DeviceChains:
         return self.run(1, accumulate)
 
     def infer(self, check_every=1000, compact_below=0.5, min_rows=64):
-        """Run under the reference's schedule until every chain is done or has failed (at most 2 n_markov_chains + 2
-        iterations); the host looks at the status flags every ``check_every`` iterations.  When fewer than
-        ``compact_below`` of the rows are still running, the finished chains are set aside and the block is re-packed
-        (finished chains would otherwise idle through every kernel until the slowest one stops); the chains do not notice --
-        their random streams are keyed by ``chain_id``, not by the row -- and all rows are back in place on return.
-        Returns the number of chains that failed to burn in."""
+        """Run under the reference's schedule until every chain is done or has failed; the host looks at the status flags
+        every ``check_every`` iterations.  When fewer than ``compact_below`` of the rows are still running, the finished
+        chains are set aside and the block is re-packed (finished chains would otherwise idle through every kernel until
+        the slowest one stops); the chains do not notice -- their random streams are keyed by ``chain_id``, not by the
+        row -- and all rows are back in place on return.
+
+        Restarts (Inference1D.update :764-776, infer :665-678, reset :984-999): a chain that has not burned in and accepted
+        nothing over ``reset_limit`` consecutive windows of ``update_plot_every`` iterations goes back to its initial state
+        and its schedule starts over (the random streams go on: they are indexed by the lockstep iteration); the third
+        restart arms the reference's (inert) variance limiters and restarts once more, the third after that gives the
+        sounding up.  Windows are the reference's: the decisions of updates (m-1) W ... m W - 1, looked at after update m W.
+        Returns the number of chains that failed."""
         assert self._o.schedule == 1, "infer() needs reference_schedule=True"
-        limit = 2 * self._o.n_markov_chains + 2
+        window = int(self.o.get("update_plot_every") or 5000)
+        reset_limit = int(self.o.get("reset_limit") or 1)
+        restarts = window > 1
+        limit = 8 * self._o.n_markov_chains + 2 if restarts else 2 * self._o.n_markov_chains + 2
         full, rows = None, None                   # the set-aside full-size tensors and the global row of each working row
         while self.iteration < limit:
             running = self.t["status"] == 0
@@ -299,12 +314,63 @@ class DeviceChains:
                 self.t = {n: (v if v is None or n in ("add_scale", "rel_group", "add_group") else (v[:, keep] if n in ("nl_a", "nl_c") else v[keep]).contiguous())
                           for n, v in self.t.items()}
                 self._bind()
-            self.run(min(check_every, limit - self.iteration))
+                running = self.t["status"] == 0
+            n = min(check_every, limit - self.iteration)
+            if restarts:
+                pos = self.iteration % window
+                if pos == window - 1:             # the update that closes the window: decide on the counts before it
+                    snap = self.t["n_accepted"].clone()
+                    self.run(1)
+                    self._restart_stuck_chains(running, snap, reset_limit)
+                    continue
+                n = min(n, window - 1 - pos)
+            self.run(n)
         if full is not None:
             self._scatter(full, rows)
             self.t = full
             self._bind()
         return int((self.t["status"] == 2).sum())
+
+    def _restart_stuck_chains(self, was_running, snap, reset_limit):
+        """The reference's end-of-window test for the chains that were running before this iteration (see infer)."""
+        t = self.t
+        cand = was_running & (t["burned_in_iteration"] < 0)
+        zero = cand & (snap == t["acc_mark"])
+        t["acc_mark"].copy_(snap)
+        t["n_zero"].copy_(torch.where(zero, t["n_zero"] + 1, torch.where(cand, torch.zeros_like(t["n_zero"]), t["n_zero"])))
+        reset = zero & (t["n_zero"] >= reset_limit)
+        if not bool(reset.any()):
+            return
+        n_res = t["n_resets"] + reset.to(torch.int32)
+        third = reset & (n_res == 3)
+        give_up = third & (t["limited"] != 0)
+        rearm = third & (t["limited"] == 0)                       # limiters armed: _n_resets = 0, reset() again -> 1
+        t["n_resets"].copy_(torch.where(rearm, torch.ones_like(n_res), n_res))
+        t["limited"].copy_(torch.where(rearm, torch.ones_like(t["limited"]), t["limited"]))
+        r = torch.nonzero(reset).flatten()
+        rel0 = torch.as_tensor(self._rel0, device=self.device)
+        add0 = torch.as_tensor(self._add0, device=self.device)
+        t["k"][r] = 1
+        t["sigma"][r] = 1.0
+        t["sigma"][r, 0] = t["init_sigma"][r]
+        t["edges"][r] = float("inf")
+        t["rel"][r] = rel0
+        t["add"][r] = add0
+        t["pred"][r] = t["init_pred"][r]
+        t["J"][r] = 0.0
+        t["J"][r, :, 0] = t["init_J0"][r]
+        for name in ("prior", "like", "misfit"):
+            t[name][r] = t["init_" + name][r]
+        for name in ("n_accepted", "acc_mark", "n_zero", "k_hist", "edge_hist", "rel_hist", "add_hist", "hitmap", "hit_dwell"):
+            if t.get(name) is not None:
+                t[name][r] = 0
+        t["burned_in_iteration"][r] = -1
+        t["iteration0"][r] = self.iteration
+        t["best_posterior"][r] = t["init_like"][r] + t["init_prior"][r]
+        t["best_k"][r] = 1
+        t["best_sigma"][r] = t["sigma"][r]
+        t["best_edges"][r] = float("inf")
+        t["status"].copy_(torch.where(give_up, torch.full_like(t["status"], 2), torch.where(reset, torch.zeros_like(t["status"]), t["status"])))
 
     def _scatter(self, full, rows):
         """Working rows -> their places in the full-size tensors."""

@@ -277,6 +277,9 @@ typedef struct gbp_rj_chains {
     double *best_posterior;        /* [B]                                                              */
     int32_t *best_k;
     double *best_edges, *best_sigma;          /* [B, K]                                                */
+    int32_t *iteration0;           /* [B] or NULL (= 0)  schedule 1: the iteration at which the chain (re)started -- the schedule
+                                      counts from there (Inference1D.reset :984-999 restarts a chain that accepted nothing over a
+                                      whole window; the host does the restart between calls, rjmcmc_gpu.DeviceChains.infer) */
 } gbp_rj_chains;
 
 /* The three host-logic stages of one iteration, exposed separately for the tests ... */

@@ -221,6 +221,36 @@ def test_host_inference1d_follows_the_reference_schedule():
     assert inf.posteriors.n_cells.sum() == 80
 
 
+def test_host_inference1d_restarts_and_gives_up_like_the_reference():
+    """The reference's own infer() on chains that cannot move (parameter_limits pinned to the starting value) and on one that
+    can, with short acceptance windows (tests/golden/make_mcmc_reset.py): a window without an accepted step restarts the
+    chain, the third restart arms the limiters and restarts again, the third after that gives up -- iteration counter,
+    decisions and both counters after every update, the number of updates and the return value."""
+    from geobipy_amd.inference import Inference1D
+
+    class DP:
+        pass
+    r = np.load(os.path.join(GOLDEN, "mcmc_reset.npz"))
+    d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
+    eng = OracleEngine("resolve", float(d["z"]))
+    eng.forward_many = lambda models, heights=None: np.stack([eng.forward(e, v) for e, v in models])
+    dp = DP()
+    dp.data, dp.z, dp.system = d["data"], np.r_[float(d["z"])], [None]
+    for name in ("stuck1", "stuck2", "free", "short"):
+        window, reset_limit, n_mc, pinned, failed, updates, n_resets = (int(x) for x in r[name + "_meta"])
+        o = dict(RESOLVE_OPTIONS, n_markov_chains=n_mc, update_plot_every=window, reset_limit=reset_limit)
+        if pinned:
+            o["parameter_limits"] = r[name + "_limits"]
+        inf = Inference1D(prng=generator_at(d["rng_state"][0]), engine=eng, **o)      # same seed, same sounding as the fixture
+        inf.initialize(dp)
+        rows = []
+        inf.on_update = lambda s: rows.append((s.iteration, int(s.accepted), s.n_resets, s.n_zero_acceptance, int(s.burned_in)))
+        assert inf.infer() is bool(failed), name
+        assert np.array_equal(np.array(rows), r[name + "_trace"]), name
+        assert inf.n_resets == n_resets and len(rows) == updates, name
+    assert np.array_equal(r["free_trace"][:, 1], d["long_accepted"][:150].astype(np.int64))  # (the unpinned run is the detail fixture's chain)
+
+
 def test_initial_state_matches_the_reference_initialisation():
     """Inference1D.initialize: best half-space of the 100-point grid, its prior / likelihood / misfit."""
     from geobipy_amd import inference

@@ -603,3 +603,35 @@ def test_device_chains_sample_like_the_host_chains(exact):
     assert abs(k_d.mean() - k_h.mean()) < 0.25
     assert np.abs(hist(k_d) - hist(k_h)).max() < 0.06
     assert abs(np.median(mis_d) - np.median(mis_h)) < 0.1 * np.median(mis_h)
+
+
+@pytest.mark.gpu
+def test_stuck_chains_restart_and_give_up_like_the_reference():
+    """infer() with the reference's restart rule (tests/golden/mcmc_reset.npz holds the reference's own runs): chains pinned to
+    their starting value by parameter_limits accept nothing, restart after every ``reset_limit`` windows and are given up
+    after the fifth restart -- the same update counts as the reference's infer(); chains that move are not touched: their
+    run equals the run without the rule, row for row."""
+    r = np.load(os.path.join(GOLDEN, "mcmc_reset.npz"))
+    B = 24
+    for name in ("stuck1", "stuck2", "short"):
+        window, reset_limit, n_mc, pinned, failed, updates, n_resets = (int(x) for x in r[name + "_meta"])
+        s0 = float(np.sqrt(np.prod(r[name + "_limits"])))     # the fixture's band is 1e-4 wide: narrow enough for the reference's
+        d, s, dc = _chains(B, 5, exact=True, reference_schedule=True,                # one chain, not for 24 chains x 100 proposals
+                           options=dict(n_markov_chains=n_mc, update_plot_every=window, reset_limit=reset_limit,
+                                        parameter_limits=[s0 * (1.0 - 1e-9), s0 * (1.0 + 1e-9)]))
+        start = {n: getattr(dc, n).clone() for n in ("sigma", "pred", "prior", "like")}
+        assert dc.infer(check_every=7) == B and dc.iteration == updates, name
+        assert torch.all(dc.status == 2) and torch.all(dc.n_resets == n_resets) and torch.all(dc.limited == 1)
+        assert torch.all(dc.n_accepted == 0) and torch.all(dc.k == 1) and torch.all(dc.iteration0 == updates)
+        for n, v in start.items():                                    # back at the initial state after the last restart
+            assert torch.equal(getattr(dc, n), v), n
+        assert int(dc.k_hist.sum()) == 0
+    # chains that move: windows of 20 iterations never pass without an accepted step
+    kw = dict(exact=True, reference_schedule=True, burn_in_min_iterations=40)
+    wide = dict(n_markov_chains=120, initial_additive_error=400.0, maximum_additive_error=1000.0)   # loose data: high acceptance
+    _, _, a = _chains(B, 6, options=dict(wide, update_plot_every=20), **kw)
+    _, _, b = _chains(B, 6, options=dict(wide, update_plot_every=1), **kw)                    # 1: rule off (as in the reference)
+    assert a.infer(check_every=50) == b.infer(check_every=50)
+    assert torch.all(a.n_resets == 0) and torch.all(a.iteration0 == 0)
+    for n in ("k", "sigma", "k_hist", "edge_hist", "burned_in_iteration", "status", "best_sigma", "n_accepted"):
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
