@@ -297,7 +297,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             "maximum_relative_error", "initial_additive_error", "minimum_additive_error", "maximum_additive_error",
             "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",
             "probability_of_death", "probability_of_perturb", "probability_of_no_change", "factor",
-            "gradient_standard_deviation", "covariance_scaling", "parameter_limits")
+            "gradient_standard_deviation", "covariance_scaling", "parameter_limits", "update_plot_every", "reset_limit")
     # chains are keyed by the sounding's row in the data file, so a sounding inverted alone walks the chain it walks in the
     # full survey
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
