@@ -39,11 +39,13 @@ for name, system, height, data, exact in cases:
     _lib.check(_lib.load().gbp_pin_forward_waves(0))
     ok &= bool(torch.allclose(fb.predicted, dc.pred, rtol=1e-9, atol=1e-7)) and bool(torch.allclose(chi2, dc.misfit, rtol=1e-7))
     kh = dc.k_hist.cpu().numpy().sum(axis=1)
-    expect = np.where(st == 1, n_mc + 2, n_mc)
+    gave_up = ((dc.limited == 1) & (dc.n_resets == 3)).cpu().numpy()          # restarted five times without a single accepted step
+    restarted = int((dc.iteration0 > 0).sum())
+    expect = np.where(st == 1, n_mc + 2, np.where(gave_up, 0, n_mc))
     ok &= bool(np.array_equal(kh, expect)) and bool(np.array_equal(dc.hitmap.sum(dim=(1, 2)).cpu().numpy(), kh * dc.n_depth_bins))
     ok &= bool(np.array_equal(dc.rel_hist.sum(dim=(1, 2)).cpu().numpy(), kh)) and not (st == 0).any()
     it_total = np.where(st == 1, bi + n_mc + 1, n_mc).sum()
     print(f"{name}: B={B} n_markov_chains={n_mc}: {dt:.1f} s ({it_total/dt/1e6:.1f} M chain-iterations/s incl. idle rows), done {int((st==1).sum())}, "
-          f"failed to burn in {failed}, median burn-in iteration {int(np.median(bi[st==1])) if (st==1).any() else -1}, mean k {k.mean():.2f}, max k {k.max()}, "
+          f"failed {failed} (given up after restarts {int(gave_up.sum())}), restarted {restarted}, median burn-in iteration {int(np.median(bi[st==1])) if (st==1).any() else -1}, mean k {k.mean():.2f}, max k {k.max()}, "
           f"median misfit {np.median(dc.misfit.cpu().numpy()):.1f}; invariants {'OK' if ok else 'VIOLATED'}", flush=True)
     del dc; torch.cuda.empty_cache()
