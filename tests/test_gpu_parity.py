@@ -168,6 +168,32 @@ def test_ragged_layers_padding_and_order_independence():
     assert np.array_equal(p4, p1)
 
 
+def test_both_branches_of_the_complex_square_root_in_one_launch():
+    """Soundings whose layers all conduct above 4 omega_max eps0 (2.9e-5 S/m at 130 kHz) take the select-free complex
+    square root, the others the general one (the kernel decides per sounding); both against the oracle, including
+    conductivities right at the threshold and layers where displacement currents dominate."""
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    B, L = 600, 6
+    rng = np.random.default_rng(17)
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=41)
+    thr = 4.0 * 2.0 * np.pi * 129550.0 * 8.8541878128e-12
+    sig[np.arange(200), rng.integers(0, L, 200)] = np.exp(rng.uniform(np.log(1e-7), np.log(2e-5), 200))   # general branch
+    sig[200:300, 2] = thr * rng.uniform(0.98, 1.02, 100)                                             # at the threshold
+    sig[300:400] = np.exp(rng.uniform(np.log(3e-5), np.log(3e-4), (100, L)))                         # direct branch, poor conductors
+    h[::3] = rng.uniform(0.5, 5.0, h[::3].size)
+    b = FdemBatch(s, nl, sig, thk, h)
+    p = b.forward().cpu().numpy()
+    J = b.sensitivity().cpu().numpy()
+    p_ref, _, _ = fo.forward_loglike_batch(oracle_system("syn10"), nl, sig, thk, h, np.ones_like(p), np.full(B, 0.05), np.full(B, 5.0),
+                                           nthreads=0)
+    assert np.isfinite(p).all() and close(p, p_ref, PRED_ATOL, PRED_RTOL)
+    for i in (0, 150, 250, 350, 500):
+        Jo = fo.sensitivity(oracle_system("syn10"), sig[i], thk[i], h[i])
+        assert close(J[i], np.vstack([Jo.real, Jo.imag]), PRED_ATOL, 10 * PRED_RTOL), i
+
+
 def test_full_size_properties():
     """BASELINE full size (65 536 x 10 freq x 8 layers): size-independent properties instead of the oracle.
     (a) splitting a layer in two with equal conductivity leaves the response unchanged;
