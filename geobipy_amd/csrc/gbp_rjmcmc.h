@@ -1134,8 +1134,10 @@ gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    const char* force = std::getenv("GBP_RJ_PROPOSE");          // test hook: "wave" / "thread"
-    if (force ? force[0] == 'w' : c->B <= 4096)
+    // one thread per chain is the faster variant at every block size measured (256 ... 65536 chains); the cooperative
+    // one-wave-per-chain kernel is kept as an independent implementation of the same draws (test hook: GBP_RJ_PROPOSE=wave)
+    const char* force = std::getenv("GBP_RJ_PROPOSE");
+    if (force && force[0] == 'w')
         hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
     else
         hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
