@@ -26,6 +26,8 @@ def parse(argv=None):
     p.add_argument("--data_filename", default=None, help="override data_filename in parameter file")
     p.add_argument("--exact-jacobian", action="store_true", help="true derivative in the proposals (DESIGN.md 3.4)")
     p.add_argument("--no-hitmap", action="store_true", help="skip the conductivity-depth hit map")
+    p.add_argument("--hankel-eps", type=float, default=0.0,
+                   help="opt-in accuracy budget of the Hankel-filter abscissa window (ppm for frequency-domain data, relative for time-domain data)")
     a = p.parse_args(argv)
     if a.seed is not None:
         a.seed = int(a.seed)
@@ -53,7 +55,7 @@ def main(argv=None):
         shutil.copy(a.options_file, a.output_directory)            # kept with the results, like the reference does
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
-                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, data_directory=a.data_directory,
+                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, data_directory=a.data_directory,
                        data_filename=a.data_filename)
     if rank == 0:
         paths = res.save_lines(a.output_directory)

@@ -111,6 +111,44 @@ def test_gpu_tdem_vs_oracle_and_reference_csv(model):
 
 
 @pytest.mark.gpu
+def test_gpu_tdem_abscissa_window():
+    """Opt-in window of the Hankel filter (TdemSystem.hankel_tables(eps=...)): 64 of the 120 / 140 abscissae at the survey
+    altitudes, window values and their Jacobian within the budget of the exact sum -- SkyTEM (two moments, 30 m) and
+    TEMPEST (120 m, x and z components), soundings at and above the altitude floor."""
+    torch = pytest.importorskip("torch")
+    from geobipy_amd import synthetic
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    B, L = 300, 5
+    nl, sig, thk, _ = synthetic.draw_models(B, L, seed=9)
+    rng = np.random.default_rng(3)
+    for names, off, floor in ((("SkytemHM.stm", "SkytemLM.stm"), SKYTEM_OFFSET, 30.0), (("tempest.stm",), TEMPEST_OFFSET, 120.0)):
+        systems = [TdemSystem(os.path.join(GOLDEN, n)) for n in names]
+        h = floor + rng.uniform(0.0, 20.0, B)
+        h[0] = floor
+        exact = TdemBatch(systems, nl, sig, thk, h, off)
+        win = TdemBatch(systems, nl, sig, thk, h, off, hankel_eps=1e-12, min_altitude=floor)
+        n_exact, n_win = lib_points(exact), lib_points(win)
+        assert n_win < 0.6 * n_exact
+        pe, pw = exact.forward().clone(), win.forward().clone()
+        top = pe.abs().max(dim=1, keepdim=True).values
+        assert float(((pe - pw).abs() / top).max()) < 1e-11
+        Je, Jw = exact.sensitivity().clone(), win.sensitivity().clone()
+        assert float((Je - Jw).abs().max() / Je.abs().max()) < 1e-9
+    with pytest.raises(AssertionError):
+        TdemBatch(systems, nl, sig, thk, h, off, hankel_eps=1e-12, min_altitude=floor + 50.0)
+
+
+def lib_points(batch):
+    import ctypes
+    from geobipy_amd import _lib
+    n, tot = ctypes.c_int(0), 0
+    for h in batch._h:
+        _lib.check(_lib.load().gbp_fdem_system_npoints(h.ptr, ctypes.byref(n)))
+        tot += n.value
+    return tot
+
+
+@pytest.mark.gpu
 def test_gpu_tdem_likelihood_and_config4_shape():
     """BASELINE config 4 shape: 16 384 soundings x 6 layers (SkyTEM low moment, 19 gates + high moment, 26 gates)."""
     torch = pytest.importorskip("torch")
