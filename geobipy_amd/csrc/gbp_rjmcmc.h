@@ -986,9 +986,12 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
         }
         for (int n = i; n < N; n += 8) c.pred[bb * N + n] = c.pred_p[bb * N + n];
         if (action != NONE) {
+            // (columns 0..7 only: both models have at most 8 layers, and the columns beyond are zero in c.J already --
+            //  the one-wave kernel, which hands such chains over, copies whole rows)
             const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
             double* Jd = c.J + bb * N * K;
-            for (int q = i; q < N * K; q += 8) Jd[q] = Js[q];
+            if (i < K)
+                for (int n = 0; n < N; ++n) Jd[(size_t)n * K + i] = Js[(size_t)n * K + i];
         }
         if (i == 0) {
             c.k[bb] = k;
