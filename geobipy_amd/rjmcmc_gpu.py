@@ -67,7 +67,8 @@ class DeviceChains:
 
     ``first_chain``: global index of the block's first sounding -- the random streams are keyed by the global chain
     index, so a survey produces the same chains on 1 GPU or sharded over 8 -- bit for bit as long as ``forward_waves`` pins
-    the forward kernels' waves per workgroup (the default, 4, is also the fastest choice up to ~16k chains per GPU; with 0
+    the forward kernels' waves per workgroup (the default, 2, is the best single choice from 8k to 64k chains per GPU --
+    4 is 3 % faster at 2k chains, 1 is 1 % faster at 64k; with 0
     they adapt it to the block size, which changes the summation order of the Hankel sums in the last bits, and long
     chains of differently sized blocks drift apart).
     ``reference_schedule``: per-sounding burn-in / stop rule of the reference (Inference1D.update :713-737, infer
@@ -82,7 +83,7 @@ class DeviceChains:
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
-                 first_chain=0, forward_waves=4, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=0.0,
+                 first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=0.0,
                  min_altitude=None, add_scale=None, rel_group=None, add_group=None, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)

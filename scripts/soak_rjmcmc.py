@@ -32,7 +32,7 @@ for name, system, height, data, exact in cases:
     ok = all(bool(torch.isfinite(getattr(dc, n)).all()) for n in ("sigma", "rel", "add", "pred", "misfit", "like", "prior", "best_sigma"))
     thk_ = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
     ok &= bool((torch.where(thk_ > 0, thk_, torch.full_like(thk_, 9.0)) > dc.min_width).all()) and k.min() >= 1 and k.max() <= dc.K
-    _lib.check(_lib.load().gbp_pin_forward_waves(4))
+    _lib.check(_lib.load().gbp_pin_forward_waves(dc._o.forward_waves))
     fb = FdemBatch(system, k, dc.sigma.cpu().numpy(), thk_.cpu().numpy(), height, data=data, relative_error=dc.rel[:, 0].cpu().numpy(),
                    additive_error=dc.add[:, 0].cpu().numpy())
     chi2, logl = fb.forward_loglike()

@@ -42,7 +42,7 @@ def test_cpp_host_runs_the_sampler_through_the_c_abi(tmp_path):
     data = np.tile(d["data"], (B, 1)) * rng.uniform(0.8, 1.3, B)[:, None]
     height = rng.uniform(25.0, 40.0, B)
     o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
-    dc = DeviceChains(s, height, data, seed=seed, exact_jacobian=True, **o)
+    dc = DeviceChains(s, height, data, seed=seed, exact_jacobian=True, forward_waves=4, **o)      # host_demo.cpp pins 4
     sigma0 = dc.sigma[:, 0].cpu().numpy().copy()
     pred0, chi0, like0 = dc.pred.cpu().numpy().copy(), dc.misfit.cpu().numpy().copy(), dc.like.cpu().numpy().copy()
     dc.run(n_it)

@@ -347,7 +347,7 @@ def test_device_chains_state_is_coherent_after_many_steps():
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
                    relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy())
     from geobipy_amd import _lib
-    _lib.check(_lib.load().gbp_pin_forward_waves(4))             # the summation order the chains ran with (forward_waves=4)
+    _lib.check(_lib.load().gbp_pin_forward_waves(dc._o.forward_waves))   # the summation order the chains ran with
     chi2, logl = fb.forward_loglike()
     _lib.check(_lib.load().gbp_pin_forward_waves(0))
     # proposals that keep their dimension get prediction / chi^2 / logL from the fused forward kernel (bit-equal to this
@@ -381,7 +381,7 @@ def test_deep_chains_stay_coherent():
     dc.rel.fill_(0.05); dc.add.fill_(5.0)
     B, Kp, h = dc.B, dc.K, dc._h.ptr
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
-    _lib.check(lib.gbp_pin_forward_waves(4))
+    _lib.check(lib.gbp_pin_forward_waves(dc._o.forward_waves))
     _lib.check(lib.gbp_fdem_forward_loglike(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
                                             dc.data.data_ptr(), dc.rel.data_ptr(), dc.add.data_ptr(), dc.pred.data_ptr(),
                                             dc.misfit.data_ptr(), dc.like.data_ptr(), None))
