@@ -1202,16 +1202,21 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     const int nb = K <= 8 ? 1 : 2;               //   footprint, high occupancy) and the rest
     struct Pin { Pin(int w, int sw) { g_pinned_waves = w; g_sens_waves = sw; } ~Pin() { g_pinned_waves = 0; g_sens_waves = 0; } };
     // Jacobian launches: ~40 % of the chains need one (structure changed / dimension changed), the rest exit at once;
-    // size the workgroups for the chains that work, with a wave count that divides nF (one frequency per wave at a time)
+    // size the workgroups for the chains that work, with a wave count that divides nF (one frequency per wave at a time).
+    // Measured optimum (6 frequencies): 6 waves up to 4 k chains, 3 at 8 k, 2 at 16 k, 1 from 32 k (36 frequencies: 18 at 1 k
+    // chains): ~7 500 working waves for small blocks, growing to ~15 000.
     int sw = 1;
     {
         static int env = -2;
         if (env == -2) { const char* e = std::getenv("GBP_RJ_SENS_NW"); env = e ? std::atoi(e) : -1; }
         const int F = sys->t.nF;
-        const int want = env > 0 ? env : (int)((5000.0 + 0.4 * B - 1.0) / (0.4 * B));   // ~5000 working waves (measured optimum)
-        sw = F;
-        for (int d = 1; d <= F; ++d)
-            if (F % d == 0 && d >= want) { sw = d; break; }
+        const double want = env > 0 ? (double)env : 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
+        double best = 1e300;
+        for (int d = 1; d <= F; ++d) {
+            if (F % d != 0) continue;
+            const double miss = std::fabs(std::log((double)d / want));
+            if (miss < best) { best = miss; sw = d; }
+        }
     }
     Pin pin(o->forward_waves, sw);   // forward_waves 0: no pin
     const int N = o->n_channels;
