@@ -1230,12 +1230,8 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
         if (env == -2) { const char* e = std::getenv("GBP_RJ_SENS_NW"); env = e ? std::atoi(e) : -1; }
         const int F = sys->t.nF;
         const double want = env > 0 ? (double)env : 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
-        double best = 1e300;
-        for (int d = 1; d <= F; ++d) {
-            if (F % d != 0) continue;
-            const double miss = std::fabs(std::log((double)d / want));
-            if (miss < best) { best = miss; sw = d; }
-        }
+        for (int d = 1; d <= F; ++d)                    // the largest divisor of nF not (much) above the target
+            if (F % d == 0 && (double)d <= 1.15 * want) sw = d;
     }
     Pin pin(o->forward_waves, sw);   // forward_waves 0: no pin
     const int N = o->n_channels;
