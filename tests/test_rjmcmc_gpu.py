@@ -420,6 +420,20 @@ def test_device_chains_do_not_depend_on_the_sharding():
 
 
 @pytest.mark.gpu
+def test_large_blocks_fork_the_proposal_evaluations_without_changing_the_chains():
+    """From ~32 k chains on, gbp_rj_run evaluates the dimension-changing proposals on a side stream next to the fused forward
+    kernel (disjoint chains, disjoint rows).  A block of 33 000 chains -- forked -- against the same chains run as two
+    shards below the threshold -- one stream: bit-identical states."""
+    B, half = 33000, 16500
+    _, _, whole = _chains(B, 21, n_it=40)
+    for first in (0, half):
+        _, _, part = _chains(half, 21, n_it=40, first_chain=first)
+        for n in ("k", "edges", "sigma", "rel", "add", "pred", "J", "like", "prior", "n_accepted", "k_hist", "best_sigma"):
+            assert torch.equal(getattr(whole, n)[first:first + half], getattr(part, n)), (first, n)
+    assert int(whole.n_accepted.sum()) > B
+
+
+@pytest.mark.gpu
 def test_posterior_accumulators_match_a_host_replay():
     """The device accumulators against inference.Posteriors -- the host rule that reproduces the reference's own posterior
     counts bit for bit (tests/test_rjmcmc.py) -- fed with the chains' states iteration by iteration: layer-count
