@@ -208,6 +208,24 @@ class SurveyResult(dict):
     def save(self, filename):
         np.savez_compressed(filename, **self)
 
+    @classmethod
+    def load(cls, filename):
+        """A result written by ``save`` / ``save_lines`` (scalars come back as Python scalars)."""
+        with np.load(filename, allow_pickle=False) as f:
+            return cls({k: (f[k].item() if f[k].ndim == 0 else f[k]) for k in f.files})
+
+    @classmethod
+    def load_lines(cls, directory):
+        """The per-line files of ``save_lines`` put back together, lines in ascending order (rows keep their order within a line)."""
+        names = sorted((n for n in os.listdir(directory) if n.endswith(".npz")), key=lambda n: float(n[:-4]))
+        parts = [cls.load(os.path.join(directory, n)) for n in names]
+        S = [p["line"].size for p in parts]
+        out = cls()
+        for k, v in parts[0].items():
+            per_row = isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == S[0]
+            out[k] = np.concatenate([p[k] for p in parts], axis=0) if per_row else v
+        return out
+
     def save_lines(self, directory):
         """One file per flight line, ``<line number>.npz`` (the reference writes ``<line number>.h5`` there)."""
         S = self["line"].size

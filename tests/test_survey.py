@@ -151,3 +151,25 @@ def test_invert_the_wedge_survey(tmp_path):
     # same seed, same survey -> same result
     res2 = survey.infer(OPTIONS, data=ds, burn_in_min_iterations=500, check_every=1000, exact_jacobian=True)
     assert np.array_equal(res2["interface_posterior"], res["interface_posterior"]) and np.array_equal(res2["misfit"], res["misfit"])
+
+
+def test_survey_result_round_trip(tmp_path):
+    """save / load and save_lines / load_lines of a SurveyResult (no GPU needed)."""
+    rng = np.random.default_rng(0)
+    S = 7
+    res = survey.SurveyResult(line=np.array([30.0, 10.0, 10.0, 30.0, 20.0, 10.0, 20.0]), fiducial=np.arange(S, dtype=float),
+                              status=rng.integers(1, 3, S), best_edges=rng.uniform(size=(S, 5)), depth_bin_width=0.5,
+                              layer_count_posterior=rng.integers(0, 9, (S, 6)))
+    res.save(str(tmp_path / "all.npz"))
+    back = survey.SurveyResult.load(str(tmp_path / "all.npz"))
+    assert set(back) == set(res) and back["depth_bin_width"] == 0.5
+    for k in res:
+        assert np.array_equal(np.asarray(back[k]), np.asarray(res[k])), k
+    paths = res.save_lines(str(tmp_path))
+    assert sorted(os.path.basename(p) for p in paths) == ["10.0.npz", "20.0.npz", "30.0.npz"]
+    os.remove(str(tmp_path / "all.npz"))
+    lines = survey.SurveyResult.load_lines(str(tmp_path))
+    order = np.argsort(res["line"], kind="stable")
+    for k in ("line", "fiducial", "status", "best_edges", "layer_count_posterior"):
+        assert np.array_equal(lines[k], res[k][order]), k
+    assert lines["depth_bin_width"] == 0.5
