@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-windowed", action="store_true", help="skip the extra opt-in abscissa-window measurement")
     ap.add_argument("--no-rjmcmc", action="store_true", help="skip the extra full-rjMCMC-step measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra Jacobian and time-domain measurements")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -285,6 +286,37 @@ def main():
                               "note": "full birth/death/perturb rjMCMC step (gbp_rj_run): >= 1 fused forward+likelihood, ~0.5 "
                                       "forward and ~0.7 Jacobian per chain-iteration; reference ~165 iterations/s per core"}
             del dc
+        if world == 1 and not args.no_extras:
+            # the rows either side of the headline path, measured in the same run and reported next to it: the Jacobian
+            # kernel on the same batch, and the time-domain path (rows 13-14, BASELINE config 4 shape)
+            def per_call(fn, n):
+                fn(); torch.cuda.synchronize(device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record(); torch.cuda.synchronize(device)
+                return e0.elapsed_time(e1) / n
+            Jbuf = batches[0].sensitivity()
+            ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 10)
+            line["jacobian"] = {"value": Btot / ms * 1e3, "unit": "Jacobians/s", "ms_per_launch": ms, "soundings": Btot,
+                                "note": "d pred / d ln sigma [2F x L] of the same batch (gbp_fdem_sensitivity, reference expression)"}
+            del Jbuf
+            golden = os.path.join(ROOT, "tests", "golden")
+            stm = [os.path.join(golden, n) for n in ("SkytemHM.stm", "SkytemLM.stm")]
+            if all(os.path.exists(f) for f in stm):
+                from geobipy_amd.tdem import TdemBatch, TdemSystem
+                Bt, Lt = 16384, 6
+                nlt, sgt, tht, ht = synthetic.draw_models(Bt, Lt, seed=synthetic.SEED + 4)
+                td = {}
+                for key, kw in (("exact", {}), ("windowed", dict(hankel_eps=1e-12, min_altitude=25.0))):
+                    tb = TdemBatch([TdemSystem(f) for f in stm], nlt, sgt, tht, ht, (-13.0, 0.0, 2.0), device=device, **kw)
+                    td[key] = Bt / per_call(tb.forward, 10) * 1e3
+                    del tb
+                line["tdem"] = {"value": td["exact"], "unit": "evals/s", "windowed_value": td["windowed"], "soundings": Bt, "layers": Lt,
+                                "gates": 45, "note": "BASELINE config 4 shape: SkyTEM high + low moment (26 + 19 gates), 72 spline nodes x 120 "
+                                                     "abscissae through the same forward kernel, then one fp64 GEMM; windowed_value: opt-in "
+                                                     "abscissa window (TdemBatch(hankel_eps=1e-12)); parity of the TDEM path is unpinned (DESIGN 3.7)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))

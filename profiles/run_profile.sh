@@ -7,7 +7,7 @@
 # 4. PMC pass C: SQ issue/wait counters    -> gpurun_out/prof/<tag>/pmc_sq
 # PMC passes never combine with --sys-trace etc. (gpurun refuses that); they use --kernel-trace only.
 TAG=${1:-r1}; shift
-ARGS=${@:-"--steps 20 --warmup 3 --no-cpu-baseline --no-windowed --no-rjmcmc"}
+ARGS=${@:-"--steps 20 --warmup 3 --no-cpu-baseline --no-windowed --no-rjmcmc --no-extras"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof/$TAG
 mkdir -p $OUT
