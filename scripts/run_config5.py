@@ -21,7 +21,7 @@ ap.add_argument("--soundings", type=int, default=8192)
 ap.add_argument("--iterations", type=int, default=10000)
 ap.add_argument("--layers", type=int, default=4, help="layers of the synthetic true models")
 ap.add_argument("--seed", type=int, default=2026)
-ap.add_argument("--forward-waves", type=int, default=4, help="pinned waves per workgroup of the forward kernels (0 = adaptive)")
+ap.add_argument("--forward-waves", type=int, default=2, help="pinned waves per workgroup of the forward kernels (0 = adaptive)")
 ap.add_argument("--hankel-eps-ppm", type=float, default=0.0, help="opt-in abscissa window (0 = all 120 / 140 abscissae)")
 ap.add_argument("--reference-jacobian", action="store_true", help="use the reference's Jacobian expression in the proposals")
 args = ap.parse_args()
