@@ -79,7 +79,12 @@ class TdemSystem:
     ``gatdaem1d.TDAEMSystem`` / system/TdemSystem_GAAEM.py: ``windows.centre``, ``nwindows``,
     ``loopRadius()``, ``waveform``, ``components``, ``off_time``)."""
 
-    def __init__(self, system_filename, nodes_per_decade=8):
+    def __init__(self, system_filename, nodes_per_decade=None, nodes_below_base=1, boxcar_tolerance=1.0e-7):
+        """``nodes_per_decade`` defaults to the file's ``FrequenciesPerDecade`` (GA-AEM's spline-node density; 5 when the
+        block is absent); the nodes sit at BaseFrequency * 10^(i / nodes_per_decade), ``nodes_below_base`` of them below
+        the base frequency.  ``boxcar_tolerance`` (seconds): a sample belongs to a Boxcar window when it lies within the
+        window widened by this much -- the rule, grid phase and density are what the discretisation study
+        (scripts/tdem_study/) found to reproduce the reference's known-answer files."""
         d = read_stm(system_filename)
         self.filename = system_filename
         self.base_frequency = float(d["BaseFrequency"])
@@ -98,7 +103,13 @@ class TdemSystem:
         self.scaling = {c: float(d.get(c.upper() + "OutputScaling", 0.0)) for c in "xyz"}
         self._components = [c for c in "xyz" if self.scaling[c] != 0.0]
         assert "y" not in self._components, NotImplementedError("Y component output is not supported")
-        self.nodes_per_decade = nodes_per_decade
+        self.frequencies_per_decade = float(d.get("FrequenciesPerDecade", 5))
+        # GA-AEM's Hankel quadrature size; this implementation evaluates the same integrals with the 120 / 140-point
+        # digital filters of the FDEM path (difference < 2e-5 of the largest gate, scripts/tdem_study/README.md)
+        self.hankel_abscissae = int(float(d.get("NumberOfAbsiccaInHankelTransformEvaluation", 21)))
+        self.nodes_per_decade = self.frequencies_per_decade if nodes_per_decade is None else float(nodes_per_decade)
+        self.nodes_below_base = int(nodes_below_base)
+        self.boxcar_tolerance = float(boxcar_tolerance)
         self.off_time = self.windows.centre
         self._op = None
 
@@ -128,11 +139,11 @@ class TdemSystem:
         return int(round(self.sample_frequency / self.base_frequency))
 
     def node_frequencies(self):
-        """Spline nodes: log-spaced from half the base frequency (keeps the spline end condition away from the
-        first harmonic) to just above Nyquist."""
-        lo, hi = np.log10(0.5 * self.base_frequency), np.log10(1.1 * 0.5 * self.sample_frequency)
-        n = int(np.ceil((hi - lo) * self.nodes_per_decade)) + 1
-        return 10.0 ** np.linspace(lo, hi, n)
+        """Spline nodes BaseFrequency * 10^(i / nodes_per_decade), i = -nodes_below_base ... until Nyquist is covered
+        (the .stm ``ForwardModelling`` block's ``FrequenciesPerDecade``)."""
+        fpd = self.nodes_per_decade
+        n = int(np.ceil(np.log10(0.5 * self.sample_frequency / self.base_frequency) * fpd - 1e-9)) + 1
+        return self.base_frequency * 10.0 ** ((np.arange(n + self.nodes_below_base) - self.nodes_below_base) / fpd)
 
     def digitised_current(self):
         """One period of the transmitter current sampled at the digitising frequency; a table that spans
@@ -167,7 +178,7 @@ class TdemSystem:
                 np.add.at(A[w], i0, wq * (1.0 - fr) / (b - a))
                 np.add.at(A[w], i0 + 1, wq * fr / (b - a))
             else:
-                m = (t >= a) & (t <= b)
+                m = (t >= a - self.boxcar_tolerance) & (t <= b + self.boxcar_tolerance)
                 A[w, m] = 1.0 / m.sum()
         return A
 
@@ -185,7 +196,7 @@ class TdemSystem:
         I = np.fft.rfft(cur)
         fk = np.arange(N // 2 + 1) * self.base_frequency
         S = np.zeros((fk.size, n))
-        S[1:] = CubicSpline(np.log(fn), np.eye(n), bc_type="natural")(np.log(np.clip(fk[1:], fn[0], fn[-1])))
+        S[1:] = CubicSpline(np.log10(fn), np.eye(n), bc_type="natural")(np.log10(np.clip(fk[1:], fn[0], fn[-1])))
         fac = np.full(fk.size, MU0 * self.moment, dtype=complex)
         if self.output_type.lower().startswith("db"):
             fac = fac * (-1j * 2.0 * np.pi * fk)                 # receiver voltage convention: -dB/dt
@@ -383,16 +394,24 @@ class TdemBatch:
 
     def std(self):
         """TdemDataPoint.std (data/datapoint/TdemDataPoint.py:361-365):
-        sigma_i^2 = (rel_sys * d_i)^2 + (add_sys * sqrt(1e-3 / t_i))^2, rel/add one value per system."""
+        sigma_i^2 = (rel_{sys,comp} * d_i)^2 + (add_sys * sqrt(1e-3 / t_i))^2 -- ``relative_error[B, sum_i n_components_i]``
+        holds one level per (system, component) in the reference's order ``(i * n_components) + j``; ``additive_error[B,
+        n_systems]`` one per system.  A ``relative_error`` with one column per SYSTEM is accepted for single-component
+        systems only (where the two layouts coincide)."""
+        n_groups = sum(s.n_components for s in self.systems)
+        assert self.relative_error.shape[1] == n_groups, ValueError(
+            "relative_error needs one level per (system, component): {} columns, got {}".format(n_groups, self.relative_error.shape[1]))
+        assert self.additive_error.shape[1] == len(self.systems), ValueError("additive_error needs one level per system")
         out = torch.empty_like(self.data)
-        col = 0
+        col = g = 0
         for i, s in enumerate(self.systems):
-            n = s.n_components * s.nwindows
-            t = torch.as_tensor(np.tile(s.off_time, s.n_components), dtype=torch.float64, device=self.device)
-            rel = self.relative_error[:, i:i + 1]
-            add = self.additive_error[:, i:i + 1]
-            out[:, col:col + n] = torch.sqrt((rel * self.data[:, col:col + n]) ** 2 + (add * torch.sqrt(1e-3 / t)) ** 2)
-            col += n
+            t = torch.as_tensor(s.off_time, dtype=torch.float64, device=self.device)
+            add = self.additive_error[:, i:i + 1] * torch.sqrt(1e-3 / t)
+            for j in range(s.n_components):
+                rel = self.relative_error[:, g:g + 1]
+                out[:, col:col + s.nwindows] = torch.sqrt((rel * self.data[:, col:col + s.nwindows]) ** 2 + add ** 2)
+                col += s.nwindows
+                g += 1
         return out
 
     def forward_loglike(self):
@@ -525,7 +544,7 @@ class TdemDataPoint:
         n = self.nChannels
         self._data = np.zeros(n) if data is None else np.asarray(data, dtype=np.float64).copy()
         self._predictedData = np.zeros(n) if predictedData is None else np.asarray(predictedData, np.float64).copy()
-        self._relative_error = np.full(self.nSystems, 0.01)
+        self._relative_error = np.full(self.n_error_groups, 0.01)      # one per (system, component), TdemDataPoint.py:362
         self._additive_error = np.zeros(self.nSystems)
         self.units = r"$\\frac{V}{m^{2}}$"
 
@@ -536,6 +555,10 @@ class TdemDataPoint:
     @property
     def nChannels(self):
         return int(sum(s.n_components * s.nwindows for s in self.system))
+
+    @property
+    def n_error_groups(self):
+        return int(sum(s.n_components for s in self.system))
 
     @property
     def data(self):
@@ -554,7 +577,8 @@ class TdemDataPoint:
     @relative_error.setter
     def relative_error(self, values):
         v = np.atleast_1d(np.asarray(values, dtype=np.float64))
-        assert v.size == self.nSystems and np.all(v > 0.0), ValueError("relative_error must be > 0, one per system")
+        assert v.size == self.n_error_groups and np.all(v > 0.0), ValueError(
+            "relative_error must be > 0, one per (system, component) in the order (i * n_components) + j")
         self._relative_error = v.copy()
 
     @property

@@ -52,11 +52,19 @@ def rte(lam, omega, sig, thk):
     return (lam - Y) / (lam + Y)
 
 
-def node_frequencies(stm, per_decade=8):
+BOXCAR_TOLERANCE = 1.0e-7      # seconds; see scripts/tdem_study/README.md (inferred from tempest_*_clean.csv gates 7, 8)
+
+
+def node_frequencies(stm, per_decade=None, below_base=1):
+    """f0 * 10^(i / FrequenciesPerDecade), i = -below_base ... up to the first node at or above Nyquist."""
     f0, fs = float(stm["BaseFrequency"]), float(stm["WaveformDigitisingFrequency"])
-    lo, hi = np.log10(0.5 * f0), np.log10(1.1 * 0.5 * fs)
-    n = int(np.ceil((hi - lo) * per_decade)) + 1
-    return 10.0 ** np.linspace(lo, hi, n)
+    fpd = float(stm.get("FrequenciesPerDecade", 5)) if per_decade is None else float(per_decade)
+    out, i = [], -below_base
+    while True:
+        out.append(f0 * 10.0 ** (i / fpd))
+        if i >= 0 and out[-1] >= 0.5 * fs * (1.0 - 1e-12):
+            return np.array(out)
+        i += 1
 
 
 def secondary_fields(stm, sig, thk, alt, dx, dy, dz, freqs):
@@ -85,7 +93,7 @@ def secondary_fields(stm, sig, thk, alt, dx, dy, dz, freqs):
     return hz, hx
 
 
-def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=8):
+def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=None):
     """Window values in the reference's channel order (x windows then z windows, only scaled components)."""
     f0, fs = float(stm["BaseFrequency"]), float(stm["WaveformDigitisingFrequency"])
     N = int(round(fs / f0))
@@ -112,9 +120,9 @@ def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=8):
         scale = float(stm.get(comp + "OutputScaling", 0.0))
         if scale == 0.0:
             continue
-        lf = np.log(np.clip(fk[1:], fn[0], fn[-1]))
+        lf = np.log10(np.clip(fk[1:], fn[0], fn[-1]))
         Hk = np.zeros(fk.size, complex)
-        Hk[1:] = CubicSpline(np.log(fn), H.real, bc_type="natural")(lf) + 1j * CubicSpline(np.log(fn), H.imag, bc_type="natural")(lf)
+        Hk[1:] = CubicSpline(np.log10(fn), H.real, bc_type="natural")(lf) + 1j * CubicSpline(np.log10(fn), H.imag, bc_type="natural")(lf)
         spec = I * fac * Hk * scale
         spec[0] = 0.0
         r = np.fft.irfft(spec, N)
@@ -123,6 +131,6 @@ def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=8):
                 q = np.linspace(a, b, 257)
                 out.append(np.trapezoid(np.interp(q, t, r), q) / (b - a))
             else:
-                m = (t >= a) & (t <= b)
+                m = (t >= a - BOXCAR_TOLERANCE) & (t <= b + BOXCAR_TOLERANCE)
                 out.append(r[m].mean())
     return np.array(out)

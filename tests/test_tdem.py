@@ -1,12 +1,16 @@
-"""TDEM path (BASELINE config 4).  PARITY UNPINNED: the reference's arithmetic is in
-the absent third-party gatdaem1d; the only pins are the reference's CSV known answers
-(tests/test_synthetic_data.py:32-65 of the reference), which carry gatdaem1d's own quadrature / spline noise.
+"""TDEM path (BASELINE config 4).  The reference's arithmetic is in the absent third-party gatdaem1d;
+the pins are the reference's CSV known answers (tests/test_synthetic_data.py:32-65 of the reference; all 6 x 79 rows, both
+SkyTEM moments and Tempest X / Z), reproduced with the discretisation the .stm ``ForwardModelling`` block prescribes
+(``FrequenciesPerDecade`` spline nodes at BaseFrequency * 10^(i / fpd), natural cubic spline in log10 f) -- see the
+resolution study scripts/tdem_study/README.md for how each choice was found and what floor remains.
 
-Bars used here (measured):
-  * vs the reference CSVs: <= 1 % on gates with |value| >= 1e-2 of the sounding's largest gate and
-    <= 5 % on gates >= 1e-3 of it (measured worst cases 0.8 % and 4.4 %, medians 0.2-0.4 %; the worst is
-    always Tempest's last gate, whose window ends 5 us before the next current reversal; the late,
-    near-noise gates of fast-decaying models carry gatdaem1d's own numerical noise and are not compared);
+Bars, on EVERY gate of every sounding (no gate is left out; ``peak`` = largest |gate| of that sounding and component):
+  * Tempest (B field, boxcar windows):   |d| <= 1e-3 |ref| + 7e-5 peak   (measured need: 5.3e-5 / 6.6e-5 for X / Z)
+  * SkyTEM  (dB/dt, area-under-curve):   |d| <= 1e-2 |ref| + 3e-5 peak   (measured need: 2.6e-5 / 4.6e-6 for HM / LM)
+    and over the gates >= 1e-2 of the peak: median |d/ref| <= 1e-3, 99th percentile <= 5.5e-3
+    (measured 5.8e-4 / 4.8e-3 HM, 7.2e-4 / 5.0e-3 LM).  The SkyTEM residual is a per-gate, sub-sample window placement of
+    gatdaem1d itself (two numbers per gate explain 120 soundings to 0.02 - 0.3 permil, scripts/tdem_study/window_jitter.txt),
+    amplified by the steepness of the decay; it is not reproduced, it bounds the bar.
   * GPU path vs the numpy oracle (same pipeline, independent code): <= 1e-8 relative to the largest gate.
 """
 import os
@@ -26,12 +30,13 @@ def wedge_thk(i):
     return [ZW[i], ZD[i] - ZW[i]]
 
 
-def within_bar(val, ref):
-    """1 % on gates >= 1e-2 of the largest gate, 5 % on gates >= 1e-3 of it."""
-    rel = np.abs(val / ref - 1.0)
-    big = np.abs(ref) >= 1e-2 * np.abs(ref).max()
-    mid = np.abs(ref) >= 1e-3 * np.abs(ref).max()
-    return bool(np.all(rel[big] <= 0.01) and np.all(rel[mid] <= 0.05))
+BARS = {"skytem": (1.0e-2, 3.0e-5), "tempest": (1.0e-3, 7.0e-5)}     # (rtol, atol / peak), every gate
+
+
+def within_bar(val, ref, family):
+    """|val - ref| <= rtol |ref| + atol * peak on ALL gates of one sounding and component."""
+    rtol, atol = BARS[family]
+    return bool(np.all(np.abs(val - ref) <= rtol * np.abs(ref) + atol * np.abs(ref).max()))
 
 
 def load(fam, model):
@@ -47,10 +52,10 @@ def test_oracle_vs_reference_csv(model):
         v = np.r_[to.forward(hm, WEDGE_CONDUCTIVITY[model], wedge_thk(i), 30.0, *SKYTEM_OFFSET),
                   to.forward(lm, WEDGE_CONDUCTIVITY[model], wedge_thk(i), 30.0, *SKYTEM_OFFSET)]
         for ref, val in [(sk[i, 15:41], v[:26]), (sk[i, 41:60], v[26:])]:
-            assert within_bar(val, ref), (model, i)
+            assert within_bar(val, ref, "skytem"), (model, i)
         v = to.forward(te, WEDGE_CONDUCTIVITY[model], wedge_thk(i), 120.0, *TEMPEST_OFFSET)
         for ref, val in [(tp[i, 17:32], v[:15]), (tp[i, 32:47], v[15:])]:
-            assert within_bar(val, ref), (model, i)
+            assert within_bar(val, ref, "tempest"), (model, i)
 
 
 def test_system_file_and_time_operator_on_host():
@@ -76,6 +81,8 @@ def test_system_file_and_time_operator_on_host():
         assert np.all(np.abs(out - ref) <= 1e-9 * np.abs(ref).max())
     s = TdemSystem(os.path.join(GOLDEN, "SkytemHM.stm"))
     assert s.loopRadius() == 10.416 and s.components == ["z"] and s.n_samples == 16384
+    assert s.frequencies_per_decade == 5.0 and s.hankel_abscissae == 21 and s.node_frequencies().size == 22
+    assert abs(s.node_frequencies()[1] - 30.0) < 1e-12 and TdemSystem(os.path.join(GOLDEN, "tempest.stm")).frequencies_per_decade == 6.0
     assert s.lowpass == [(300000.0, 1), (210000.0, 2)]
     bx, bz = TdemSystem(os.path.join(GOLDEN, "tempest.stm")).primary_field(*TEMPEST_OFFSET)
     tp = load("tempest", "glacial")
@@ -83,7 +90,7 @@ def test_system_file_and_time_operator_on_host():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["glacial", "resistive_basement", "coastal_salt_water", "ice_over_salt_water"])
+@pytest.mark.parametrize("model", sorted(WEDGE_CONDUCTIVITY))
 def test_gpu_tdem_vs_oracle_and_reference_csv(model):
     torch = pytest.importorskip("torch")
     assert torch.cuda.is_available()
@@ -97,10 +104,14 @@ def test_gpu_tdem_vs_oracle_and_reference_csv(model):
                     TEMPEST_OFFSET)
     ps, pt = sky.forward().cpu().numpy(), tem.forward().cpu().numpy()
     sk, tp = load("skytem", model), load("tempest", model)
-    for ref, val in [(sk[:, 15:41], ps[:, :26]), (sk[:, 41:60], ps[:, 26:]), (tp[:, 17:32], pt[:, :15]),
-                     (tp[:, 32:47], pt[:, 15:])]:
+    for fam, ref, val in [("skytem", sk[:, 15:41], ps[:, :26]), ("skytem", sk[:, 41:60], ps[:, 26:]),
+                          ("tempest", tp[:, 17:32], pt[:, :15]), ("tempest", tp[:, 32:47], pt[:, 15:])]:
         for i in range(79):
-            assert within_bar(val[i], ref[i]), (model, i)
+            assert within_bar(val[i], ref[i], fam), (model, i)
+        if fam == "skytem":           # statistical bar on the gates with signal, all 79 rows of this earth type
+            m = np.abs(ref) >= 1e-2 * np.abs(ref).max(axis=1, keepdims=True)
+            rel = np.abs(val / ref - 1.0)[m]
+            assert np.median(rel) <= 1.0e-3 and np.percentile(rel, 99) <= 5.5e-3, (model, np.median(rel), np.percentile(rel, 99))
     stm = {n: to.parse_stm(os.path.join(GOLDEN, n)) for n in ["SkytemHM.stm", "SkytemLM.stm", "tempest.stm"]}
     for i in [0, 40, 78]:
         o = np.r_[to.forward(stm["SkytemHM.stm"], sig[i], thk[i, :2], 30.0, *SKYTEM_OFFSET),
@@ -185,7 +196,7 @@ def test_tdem_datapoint_interface():
     dp.additive_error = [1e-15, 1e-14]
     mod = Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 50.0, 75.0, np.inf]), values=np.asarray(WEDGE_CONDUCTIVITY["glacial"]))
     dp.forward(mod)
-    assert within_bar(dp.predictedData[:26], sk[0, 15:41]) and within_bar(dp.predictedData[26:], sk[0, 41:60])
+    assert within_bar(dp.predictedData[:26], sk[0, 15:41], "skytem") and within_bar(dp.predictedData[26:], sk[0, 41:60], "skytem")
     t = np.r_[dp.system[0].off_time, dp.system[1].off_time]
     add = np.r_[np.full(26, 1e-15), np.full(19, 1e-14)]
     sd = np.sqrt((0.03 * dp.data) ** 2 + (add * np.sqrt(1e-3 / t)) ** 2)       # TdemDataPoint.py:361-365
@@ -193,6 +204,34 @@ def test_tdem_datapoint_interface():
     chi2 = np.sum(((dp.predictedData - dp.data) / sd) ** 2)
     assert np.isclose(dp.data_misfit(), chi2, rtol=1e-9)
     assert np.isclose(dp.likelihood(log=True), -0.5 * 45 * np.log(2 * np.pi) - np.sum(np.log(sd)) - 0.5 * chi2, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_tempest_std_has_a_relative_level_per_component():
+    """TdemDataPoint.std (TdemDataPoint.py:361-365): relative_error[(i * n_components) + j] -- Tempest has X and Z, so two
+    relative levels and one additive level; both the batch and the data point use that layout."""
+    torch = pytest.importorskip("torch")
+    from geobipy_amd import CircularLoop, TdemDataPoint
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    tp = load("tempest", "glacial")
+    s = TdemSystem(os.path.join(GOLDEN, "tempest.stm"))
+    data = tp[:8, 17:47]
+    rel, add = np.tile([0.02, 0.07], (8, 1)), np.full((8, 1), 0.011)
+    b = TdemBatch(s, np.full(8, 1), np.full((8, 1), 0.01), np.zeros((8, 1)), np.full(8, 120.0), TEMPEST_OFFSET, data=data,
+                  relative_error=rel, additive_error=add)
+    t = s.off_time
+    ref = np.sqrt((np.r_[np.full(15, 0.02), np.full(15, 0.07)] * data) ** 2 + (0.011 * np.sqrt(1e-3 / np.r_[t, t])) ** 2)
+    assert np.allclose(b.std().cpu().numpy(), ref, rtol=1e-13)
+    with pytest.raises(AssertionError):
+        TdemBatch(s, np.full(8, 1), np.full((8, 1), 0.01), np.zeros((8, 1)), np.full(8, 120.0), TEMPEST_OFFSET, data=data,
+                  relative_error=np.full((8, 1), 0.02), additive_error=add).std()
+    tx = CircularLoop(x=[0.0], y=[0.0], z=[120.0], orientation=["z"], radius=[1.0])
+    rx = CircularLoop(x=[-107.0], y=[0.0], z=[75.0], orientation=["z"], radius=[1.0])
+    dp = TdemDataPoint(z=120.0, data=data[0], system=[s], transmitter_loop=tx, receiver_loop=rx)
+    dp.relative_error, dp.additive_error = [0.02, 0.07], [0.011]
+    assert np.allclose(dp.std, ref[0], rtol=1e-13)
+    with pytest.raises(AssertionError):
+        dp.relative_error = [0.02]
 
 
 @pytest.mark.gpu
