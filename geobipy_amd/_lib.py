@@ -55,7 +55,6 @@ SIGNATURES = {
     "gbp_rj_accept": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
-    "gbp_pin_forward_waves": (c_int, [c_int]),
     "gbp_rj_run_td": (c_int, [c_void_p, ctypes.POINTER(TdOperator), _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gbp_version": (ctypes.c_char_p, []),
@@ -70,14 +69,18 @@ SIGNATURES = {
     "gbp_fdem_system_nfreq": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "gbp_fdem_system_h0": (c_int, [c_void_p, c_double_p]),
     "gbp_fdem_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "gbp_fdem_forward_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
+    "gbp_fdem_validate": (c_int, [c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike_std": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_fdem_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
+    "gbp_fdem_forward_loglike_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_int, c_void_p]),
     "gbp_fdem_sensitivity": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_fdem_sensitivity_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "gbp_fdem_fm_dlogc": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "gbp_fdem_fm_dlogc_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
     "gbp_debug_math": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
-    "gbp_fdem_time_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p, c_int,
+    "gbp_bench_time_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p, c_int,
                                                                                         ctypes.POINTER(ctypes.c_float)]),
 }
 

@@ -39,12 +39,16 @@ class FdemBatch:
     """
 
     def __init__(self, system, nlayers, sigma, thk, height, data=None, relative_error=None, additive_error=None,
-                 device=None, hankel_eps_ppm=0.0):
+                 device=None, hankel_eps_ppm=0.0, waves=0):
         if not torch.cuda.is_available():
             raise _lib.NativeLibraryError("FdemBatch needs a HIP device (torch.cuda.is_available() is False); "
                                           "there is no CPU fallback")
         _lib.load()
         self.system = system
+        # waves per workgroup of the forward kernels: 0 = chosen from the batch size; 1..16 fixes the summation order of the
+        # Hankel sums, i.e. makes the values independent of how the soundings are batched (gbp_fdem_forward_ex)
+        self.waves = int(waves)
+        assert 0 <= self.waves <= 16, ValueError("waves must be in [0, 16]")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.device):
             self._h_exact = system.handle()
@@ -77,20 +81,28 @@ class FdemBatch:
         self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
 
     def validate(self):
-        """Host-side input checks the reference does with asserts (FD/fdem1d.py:29) plus sigma, thk > 0."""
-        nl = self.nlayers.cpu().numpy()
-        assert nl.min() >= 1 and nl.max() <= self.Lmax, ValueError("nlayers out of range")
-        mask = torch.arange(self.Lmax, device=self.device)[None, :] < self.nlayers[:, None]
-        assert bool((self.sigma[mask] > 0).all()), ValueError("conductivity must be > 0")
-        tmask = torch.arange(self.Lmax, device=self.device)[None, :] < (self.nlayers[:, None] - 1)
-        assert bool((self.thk[tmask] > 0).all()), ValueError("thickness must be > 0")
-        assert bool((self.height >= 0).all()), ValueError("Sensor altitude must be above the top of the model")
+        """The reference's host asserts (FD/fdem1d.py:29, DP/FdemDataPoint.py:541) plus sigma, thk > 0, evaluated on the
+        device by ``gbp_fdem_validate`` (one small launch + one sync); raises for the first kind of bad row found."""
+        st = self.status(with_outputs=False)
+        bad = int((st != 0).sum().item())
+        if bad:
+            bits = int(torch.bitwise_or(st[st != 0][0], torch.zeros((), dtype=torch.int32, device=self.device)).item())
+            msg = [m for b, m in ((1, "nlayers out of range"), (2, "conductivity must be > 0"), (4, "thickness must be > 0"),
+                                  (8, "Sensor altitude must be above the top of the model")) if bits & b]
+            raise AssertionError(ValueError("{} bad sounding(s): {}".format(bad, ", ".join(msg))))
 
-    def status(self, pred=None):
-        """int8[B]: 0 = finite predictions, 1 = a non-finite value somewhere (the batch is never aborted; the
-        reference would have carried the NaN/inf of one sounding into that sounding's chain only)."""
-        pred = self.predicted if pred is None else pred
-        return (~torch.isfinite(pred).all(dim=1)).to(torch.int8)
+    def status(self, pred=None, with_outputs=True):
+        """int32[B] status word per sounding (include/geobipy_amd.h GBP_ROW_*: 1 nlayers out of range, 2 bad conductivity,
+        4 bad thickness, 8 bad altitude, 16 non-finite prediction).  A batch is never aborted for one bad row: rows with
+        nlayers > Lmax come back as NaN, the others are untouched."""
+        pred = (self.predicted if pred is None else pred) if with_outputs else None
+        out = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gbp_fdem_validate(self.B, self.Lmax, 2 * self.F if pred is not None else 0,
+                                                     self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
+                                                     self.height.data_ptr(), pred.data_ptr() if pred is not None else None,
+                                                     out.data_ptr(), _stream_ptr(self.device)))
+        return out
 
     # -- launches -----------------------------------------------------------------------------
     def forward(self, out=None):
@@ -98,9 +110,9 @@ class FdemBatch:
         out = self.predicted if out is None else out
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_forward(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
-                                            self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
-                                            out.data_ptr(), _stream_ptr(self.device)))
+            _lib.check(lib.gbp_fdem_forward_ex(self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                               self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
+                                               out.data_ptr(), self.waves, _stream_ptr(self.device)))
         return out
 
     def forward_loglike(self, want_pred=True):
@@ -110,11 +122,11 @@ class FdemBatch:
             ValueError("data, relative_error and additive_error are needed for the likelihood")
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_forward_loglike(
+            _lib.check(lib.gbp_fdem_forward_loglike_ex(
                 self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
                 self.height.data_ptr(), self.data.data_ptr(), self.relative_error.data_ptr(),
                 self.additive_error.data_ptr(), self.predicted.data_ptr() if want_pred else None,
-                self.chi2.data_ptr(), self.logL.data_ptr(), _stream_ptr(self.device)))
+                self.chi2.data_ptr(), self.logL.data_ptr(), self.waves, _stream_ptr(self.device)))
         return self.chi2, self.logL
 
     def loglike(self, pred=None):
@@ -203,7 +215,7 @@ class FdemBatch:
         lib = _lib.load()
         ms = ctypes.c_float()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_time_forward_loglike(
+            _lib.check(lib.gbp_bench_time_forward_loglike(
                 self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
                 self.height.data_ptr(), self.data.data_ptr(), self.relative_error.data_ptr(),
                 self.additive_error.data_ptr(), self.predicted.data_ptr() if want_pred else None,

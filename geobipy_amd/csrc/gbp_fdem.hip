@@ -259,6 +259,13 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     const int nwaves = blockDim.x >> 6;
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform): none of its outputs are written
+    if (L > Lmax) {       // bad row (would overrun the rows of sigma / thk and the LDS layer tables): flag it with NaNs, touch nothing else
+        const double qnan = __builtin_nan("");
+        if (pred != nullptr)
+            for (int i = threadIdx.x; i < 2 * F; i += blockDim.x) pred[(size_t)b * 2 * F + i] = qnan;
+        if (LIKE && threadIdx.x == 0) { chi2[b] = qnan; logL[b] = qnan; }
+        return;
+    }
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
     // every layer conductive enough for the select-free complex sqrt (all but displacement-current dominated models)
@@ -321,6 +328,14 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     const int nwaves = blockDim.x >> 6;
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
+    if (L > Lalloc || L > Lmax) {   // more layers than the launch was sized for: NaN row instead of an LDS / row overrun
+        const double qnan = __builtin_nan("");
+        const size_t n = (size_t)2 * F * Lmax;
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) J[(size_t)b * n + i] = qnan;
+        if (pred != nullptr)
+            for (int i = threadIdx.x; i < 2 * F; i += blockDim.x) pred[(size_t)b * 2 * F + i] = qnan;
+        return;
+    }
     const double* sig = sigma + (size_t)b * Lmax;
     const double* th = thk + (size_t)b * Lmax;
     cplx* sh_D = reinterpret_cast<cplx*>(sh_dyn) + (size_t)wave * Lalloc * GBP_SENS_STRIDE;
@@ -442,6 +457,35 @@ __global__ void k_gauss_loglike(int B, int N, const double* __restrict__ pred, c
     loglike_wave(N, pred + (size_t)b * N, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
 }
 
+// Per-sounding input / output status word (SURVEY 8b "Errors": validate, flag per sounding, never abort the batch).
+__global__ void k_fdem_validate(int B, int Lmax, int N, const int* __restrict__ nlayers, const double* __restrict__ sigma,
+                                const double* __restrict__ thk, const double* __restrict__ height,
+                                const double* __restrict__ pred, int* __restrict__ status)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int st = 0;
+    const int L = nlayers[b];
+    if (L < 1 || L > Lmax) st |= GBP_ROW_BAD_NLAYERS;
+    const int Lc = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+    for (int k = 0; k < Lc; ++k) {
+        const double s = sigma[(size_t)b * Lmax + k];
+        if (!(s > 0.0) || !(s < 1.7976931348623157e308)) st |= GBP_ROW_BAD_SIGMA;
+        if (k < Lc - 1) {
+            const double t = thk[(size_t)b * Lmax + k];
+            if (!(t > 0.0) || !(t < 1.7976931348623157e308)) st |= GBP_ROW_BAD_THICKNESS;
+        }
+    }
+    const double h = height[b];
+    if (!(h >= 0.0) || !(h < 1.7976931348623157e308)) st |= GBP_ROW_BAD_HEIGHT;
+    if (pred != nullptr)
+        for (int i = 0; i < N; ++i) {
+            const double v = pred[(size_t)b * N + i];
+            if (!(v == v) || v > 1.7976931348623157e308 || v < -1.7976931348623157e308) st |= GBP_ROW_NONFINITE_OUTPUT;
+        }
+    status[b] = st;
+}
+
 // Evaluates the device math kernels element-wise (test hook: tests/test_gpu_math.py checks their
 // accuracy on the real hardware, where v_rsq_f64 / v_rcp_f64 seeds differ from the host's).
 __global__ void k_debug_math(int op, int n, const double* __restrict__ x, const double* __restrict__ y,
@@ -478,23 +522,15 @@ size_t dyn_lds_bytes(int nw, int Lmax, int F)
     return (size_t)nw * 2 * Lmax * sizeof(gbp::LayerK) + (size_t)nw * F * sizeof(cplx) + (size_t)Lmax * sizeof(double);
 }
 
-// waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches
-thread_local int g_pinned_waves = 0;   // set by gbp_rj_run for the duration of its launches (gbp_rj_options.forward_waves)
-thread_local int g_user_waves = 0;     // gbp_pin_forward_waves
-thread_local int g_sens_waves = 0;     // waves per workgroup of the Jacobian launches issued by gbp_rj_run
-
-int pick_waves(int B, int F, int Lmax, int max_waves)
+// waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches.  `waves` > 0 is the
+// caller's explicit choice (the *_ex entries); it fixes the summation order of the Hankel sums.
+int pick_waves(int B, int F, int Lmax, int max_waves, int waves)
 {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = std::getenv("GBP_NW");
-        forced = e ? std::atoi(e) : -1;
-    }
     // measured (scripts/sweep_waves.py, 10 frequencies x 8 layers): one wave per sounding is best once every SIMD has a
     // queue of soundings (B >= 49152); below that 4 waves per sounding balance the tail better (+2..6 %), and small
     // batches need 8192 / B waves to fill the chip at all
     const int heuristic = B >= 49152 ? 1 : std::max(4, (8192 + B - 1) / B);
-    int nw = g_pinned_waves > 0 ? g_pinned_waves : (g_user_waves > 0 ? g_user_waves : (forced > 0 ? forced : heuristic));
+    int nw = waves > 0 ? waves : heuristic;
     if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;
     while (nw > 1 && dyn_lds_bytes(nw, Lmax, F) > 60000) --nw;
@@ -646,11 +682,19 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system* sys, int B, int Lmax, const i
                             const double* sigma, const double* thk, const double* height, double* pred,
                             void* stream)
 {
+    return gbp_fdem_forward_ex(sys, B, Lmax, nlayers, sigma, thk, height, pred, 0, stream);
+}
+
+gbp_status gbp_fdem_forward_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                               const double* sigma, const double* thk, const double* height, double* pred,
+                               int waves, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
+    if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
     if (B == 0) return GBP_OK;
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
-    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
+    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr, sys->sigma_direct);
@@ -689,11 +733,20 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax,
                                     const double* obs, const double* rel, const double* add, double* pred,
                                     double* chi2, double* logL, void* stream)
 {
+    return gbp_fdem_forward_loglike_ex(sys, B, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred, chi2, logL, 0, stream);
+}
+
+gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                       const double* sigma, const double* thk, const double* height,
+                                       const double* obs, const double* rel, const double* add, double* pred,
+                                       double* chi2, double* logL, int waves, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
+    if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
     if (B == 0) return GBP_OK;
     if (!obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
-    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64);
+    const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
                        chi2, logL, sys->sigma_direct);
@@ -701,7 +754,19 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax,
     return GBP_OK;
 }
 
-gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+gbp_status gbp_fdem_validate(int B, int Lmax, int N, const int32_t* nlayers, const double* sigma, const double* thk,
+                             const double* height, const double* pred, int32_t* status, void* stream)
+{
+    if (B < 0 || Lmax < 1 || N < 0) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0, Lmax >= 1, N >= 0%s");
+    if (B == 0) return GBP_OK;
+    if (!nlayers || !sigma || !thk || !height || !status) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    hipLaunchKernelGGL(k_fdem_validate, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, Lmax, N, nlayers, sigma,
+                       thk, height, pred, status);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+gbp_status gbp_bench_time_forward_loglike(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
                                          const double* sigma, const double* thk, const double* height,
                                          const double* obs, const double* rel, const double* add, double* pred,
                                          double* chi2, double* logL, void* stream, int reps, float* avg_ms)
@@ -753,6 +818,13 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system* sys, int B, int Lmax, const 
                              const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
                              void* stream)
 {
+    return gbp_fdem_fm_dlogc_ex(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, 0, stream);
+}
+
+gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                                const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                                int waves, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
@@ -761,9 +833,10 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system* sys, int B, int Lmax, const 
     const size_t per_wave = (size_t)max_layers * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK));
     if (per_wave + (size_t)max_layers * 8 > 150000)
         return fail(GBP_ERR_INVALID_ARG, "too many layers for the Jacobian kernel's LDS working set (max ~140)%s");
-    // one frequency per wave at a time, so the result does not depend on nw (no pin needed) and nw should divide nF;
-    // g_sens_waves: the sampler's launches, where only a fraction of the workgroups has work (gbp_rj_run)
-    int nw = g_sens_waves > 0 ? g_sens_waves : pick_waves(B, sys->t.nF, Lmax, sys->t.nF);
+    // one frequency per wave at a time, so the result does not depend on nw and nw should divide nF; `waves` is a
+    // performance hint only (the sampler's launches, where only a fraction of the workgroups has work)
+    if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
+    int nw = pick_waves(B, sys->t.nF, Lmax, sys->t.nF, waves);
     if (nw > sys->t.nF) nw = sys->t.nF;
     while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
     const size_t lds = nw * per_wave + (size_t)max_layers * 8;

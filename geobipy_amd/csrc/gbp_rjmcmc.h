@@ -1231,21 +1231,18 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     if (B == 0) return GBP_OK;
     const int caps[2] = {8 < K ? 8 : K, K};      // Jacobian launches by layer count: <= 8 (the common case, small LDS
     const int nb = K <= 8 ? 1 : 2;               //   footprint, high occupancy) and the rest
-    struct Pin { Pin(int w, int sw) { g_pinned_waves = w; g_sens_waves = sw; } ~Pin() { g_pinned_waves = 0; g_sens_waves = 0; } };
     // Jacobian launches: ~40 % of the chains need one (structure changed / dimension changed), the rest exit at once;
     // size the workgroups for the chains that work, with a wave count that divides nF (one frequency per wave at a time).
     // Measured optimum (6 frequencies): 6 waves up to 4 k chains, 3 at 8 k, 2 at 16 k, 1 from 32 k (36 frequencies: 18 at 1 k
     // chains): ~7 500 working waves for small blocks, growing to ~15 000.
     int sw = 1;
     {
-        static int env = -2;
-        if (env == -2) { const char* e = std::getenv("GBP_RJ_SENS_NW"); env = e ? std::atoi(e) : -1; }
         const int F = sys->t.nF;
-        const double want = env > 0 ? (double)env : 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
+        const double want = 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
         for (int d = 1; d <= F; ++d)                    // the largest divisor of nF not (much) above the target
             if (F % d == 0 && (double)d <= 1.15 * want) sw = d;
     }
-    Pin pin(o->forward_waves, sw);   // forward_waves 0: no pin
+    const int fw = o->forward_waves;   // 0: the forward kernels choose from the batch size
     const int N = o->n_channels;
     auto td_apply = [&](const int32_t* nl, bool with_j, double* pred, double* J, hipStream_t q) -> gbp_status {   // nodal -> windows
         const size_t lds = ((size_t)td->n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
@@ -1262,8 +1259,8 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
     auto fm_dlogc = [&](const int32_t* nl, const double* sigma, double* pred, double* J, hipStream_t q) -> gbp_status {
         for (int i = 0; i < nb; ++i) {
-            gbp_status s2 = gbp_fdem_fm_dlogc(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
-                                              td ? td->J_nodal : J, caps[i], o->exact_jacobian, q);
+            gbp_status s2 = gbp_fdem_fm_dlogc_ex(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
+                                                 td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, q);
             if (s2 != GBP_OK) return s2;
         }
         return td ? td_apply(nl, true, pred, J, q) : GBP_OK;
@@ -1291,10 +1288,10 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
         // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
         //   ... of the proposals that keep their dimension
         if (td == nullptr) {
-            if ((st = gbp_fdem_forward_loglike(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
-                                               c->pred_p, c->misfit_p, c->like_p, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_forward_loglike_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
+                                                  c->pred_p, c->misfit_p, c->like_p, fw, stream)) != GBP_OK) return st;
         } else {
-            if ((st = gbp_fdem_forward(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_forward_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, fw, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr, main_q)) != GBP_OK) return st;
             hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, *o, *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
                                c->misfit_p, c->like_p);
@@ -1317,13 +1314,6 @@ gbp_status gbp_rj_flush_posteriors(const gbp_rj_options* o, const gbp_rj_chains*
     if (st != GBP_OK || c->B == 0 || !c->hitmap) return st;
     hipLaunchKernelGGL(rj::k_rj_flush, dim3(c->B), dim3(64), 0, (hipStream_t)stream, *o, *c);
     GBP_HIP(hipGetLastError());
-    return GBP_OK;
-}
-
-gbp_status gbp_pin_forward_waves(int waves)
-{
-    if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
-    g_user_waves = waves;
     return GBP_OK;
 }
 

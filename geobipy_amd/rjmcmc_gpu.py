@@ -175,11 +175,8 @@ class DeviceChains:
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K), iteration0=z(B, dt=i32))
         self._bind()
         self.iteration = 0
-        _lib.check(_lib.load().gbp_pin_forward_waves(int(forward_waves)))
-        try:
-            self._initialize()
-        finally:
-            _lib.check(_lib.load().gbp_pin_forward_waves(0))
+        self.forward_waves = int(forward_waves)      # also passed explicitly to the forward calls of the initialisation
+        self._initialize()
 
     def _bind(self):
         """(Re)build the gbp_rj_chains struct from the tensors in self.t."""
@@ -252,9 +249,10 @@ class DeviceChains:
 
     # the two evaluations the initialisation needs, through the same entries the sampler uses (overridden for time-domain data)
     def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
-        _lib.check(_lib.load().gbp_fdem_forward_loglike(
+        _lib.check(_lib.load().gbp_fdem_forward_loglike_ex(
             self._h.ptr, k.numel(), self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(), data.data_ptr(),
-            rel.data_ptr(), add.data_ptr(), None if pred is None else pred.data_ptr(), chi2.data_ptr(), logl.data_ptr(), self._stream()))
+            rel.data_ptr(), add.data_ptr(), None if pred is None else pred.data_ptr(), chi2.data_ptr(), logl.data_ptr(),
+            self.forward_waves, self._stream()))
 
     def _eval_jacobian(self, k, sigma, thk, height, J, max_layers):
         _lib.check(_lib.load().gbp_fdem_sensitivity_ex(self._h.ptr, k.numel(), self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),

@@ -164,20 +164,22 @@ class FdemSystem:
             lamda1=f64(lam1))
 
     def handle(self, eps_ppm=0.0, min_altitude=0.0):
-        """Opaque gbp_fdem_system* on the current HIP device (tables uploaded once, then cached).
+        """Opaque gbp_fdem_system* on the CURRENT HIP device (tables uploaded once per device, then cached).
 
         ``eps_ppm > 0`` selects the accuracy-budgeted abscissa window (see gbp_fdem_system_create_windowed):
-        valid for soundings at altitude >= ``min_altitude``; handles are cached per (eps, altitude floor)."""
-        if not eps_ppm > 0.0:
-            if self._handle is None:
-                self._handle = NativeSystem(self.native_args())
-            return self._handle
-        key = (float(eps_ppm), float(np.floor(min_altitude)))      # 1 m altitude bins keep the cache small
-        if not hasattr(self, "_windowed"):
-            self._windowed = {}
-        if key not in self._windowed:
-            self._windowed[key] = NativeSystem(self.native_args(), eps_ppm=key[0], min_altitude=key[1])
-        return self._windowed[key]
+        valid for soundings at altitude >= ``min_altitude``.  Handles are cached per (device, eps, altitude floor): the
+        tables live in the HBM of the device that was current when they were uploaded, so one FdemSystem used on two
+        GPUs of a process gets two handles."""
+        import torch
+        dev = int(torch.cuda.current_device()) if torch.cuda.is_available() else -1
+        if not isinstance(getattr(self, "_handles", None), dict):
+            self._handles = {}
+        windowed = eps_ppm > 0.0
+        key = (dev, float(eps_ppm), float(np.floor(min_altitude))) if windowed else (dev, 0.0, 0.0)   # 1 m altitude bins keep the cache small
+        if key not in self._handles:
+            self._handles[key] = (NativeSystem(self.native_args(), eps_ppm=key[1], min_altitude=key[2]) if windowed
+                                  else NativeSystem(self.native_args()))
+        return self._handles[key]
 
 
 class NativeSystem:

@@ -498,8 +498,8 @@ class TdemDeviceChains(DeviceChains):
         self._td()
         lib, n = _lib.load(), k.numel()
         nodal = torch.empty((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
-        _lib.check(lib.gbp_fdem_forward(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
-                                        nodal.data_ptr(), self._stream()))
+        _lib.check(lib.gbp_fdem_forward_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
+                                           nodal.data_ptr(), self.forward_waves, self._stream()))
         p = torch.matmul(nodal, self._W)
         rg = self.t["rel_group"].long() if self.t["rel_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         ag = self.t["add_group"].long() if self.t["add_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)

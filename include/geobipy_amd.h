@@ -115,6 +115,31 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system *sys, int B, int Lmax, const i
                             const double *sigma, const double *thk, const double *height,
                             double *pred, void *stream);
 
+/* Same with an explicit number of waves per workgroup (1..16; 0 = chosen from the batch size, as gbp_fdem_forward does).
+ * The partial Hankel sums of a frequency are combined in a fixed order PER wave count, so results are bit-reproducible
+ * for a given `waves` and differ in the last digits between wave counts; callers that need results independent of the
+ * batch size (sharded surveys) pass the same `waves` everywhere.  There is no hidden per-thread or environment state. */
+gbp_status gbp_fdem_forward_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                               const double *sigma, const double *thk, const double *height,
+                               double *pred, int waves, void *stream);
+
+/*
+ * Per-sounding status word (SURVEY 8b "Errors"; the reference asserts on the host, FD/fdem1d.py:29,
+ * DP/FdemDataPoint.py:541, and lets NaNs run): status [dev] int32[B] out, OR of the GBP_ROW_* bits.  `pred` [dev]
+ * f64[B, N] may be NULL (inputs only).  The compute entries never abort a batch for one bad row: a row with
+ * nlayers[b] > Lmax (or > max_layers of the Jacobian entries) gets NaN outputs and nothing outside its own rows is
+ * touched; nlayers[b] <= 0 rows are skipped; non-positive sigma / thickness propagate to NaN / inf in that row only.
+ */
+enum {
+    GBP_ROW_BAD_NLAYERS = 1,       /* nlayers[b] < 1 or > Lmax                                   */
+    GBP_ROW_BAD_SIGMA = 2,         /* a used conductivity is not finite and > 0                  */
+    GBP_ROW_BAD_THICKNESS = 4,     /* a used thickness (all but the last layer) is not finite and > 0 */
+    GBP_ROW_BAD_HEIGHT = 8,        /* altitude negative or not finite (FD/fdem1d.py:29)          */
+    GBP_ROW_NONFINITE_OUTPUT = 16  /* a NaN / inf among the sounding's N predicted values        */
+};
+gbp_status gbp_fdem_validate(int B, int Lmax, int N, const int32_t *nlayers, const double *sigma, const double *thk,
+                             const double *height, const double *pred, int32_t *status, void *stream);
+
 /*
  * Gaussian data misfit + log-likelihood for B soundings of N channels each.
  *   pred, obs [dev] f64[B, N];  rel, add [dev] f64[B] (one relative / additive error per sounding,
@@ -139,6 +164,11 @@ gbp_status gbp_fdem_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax,
                                     const double *obs, const double *rel, const double *add,
                                     double *pred, double *chi2, double *logL, void *stream);
 
+gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                       const double *sigma, const double *thk, const double *height,
+                                       const double *obs, const double *rel, const double *add,
+                                       double *pred, double *chi2, double *logL, int waves, void *stream);
+
 /*
  * Batched Jacobian d pred / d ln(sigma_k) (ppm).  Replaces FdemDataPoint.sensitivity -> fdem1dsen ->
  * nbFdem1dsen.   J [dev] f64[B, 2*nF, Lmax] out (columns >= nlayers[b] are set to 0);
@@ -151,7 +181,7 @@ gbp_status gbp_fdem_sensitivity(const gbp_fdem_system *sys, int B, int Lmax, con
 /*
  * Same with two knobs:
  *   max_layers  an upper bound of nlayers[] known to the caller (sizes the kernel's LDS working set;
- *               pass Lmax when unknown).  Soundings with nlayers > max_layers are undefined behaviour.
+ *               pass Lmax when unknown).  A sounding with nlayers > max_layers gets a NaN row (J and pred).
  *   exact       0: reproduce the reference's M1_1 formula bit-for-tolerance (default of
  *               gbp_fdem_sensitivity); 1: the true derivative of the forward recursion -- the reference's
  *               expression at fdem1d_numba.py:269-274 is not.
@@ -170,9 +200,14 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system *sys, int B, int Lmax, const 
                              const double *sigma, const double *thk, const double *height,
                              double *pred, double *J, int max_layers, int exact, void *stream);
 
-/* Timing helper for bench.py: average kernel time (ms) of `reps` launches of the fused kernel,
- * measured with hipEvents recorded on `stream` around the launches. */
-gbp_status gbp_fdem_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+/* `waves` (0..16): waves per workgroup, a performance hint only -- one wave owns a frequency, so neither J nor pred depend on it. */
+gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                const double *sigma, const double *thk, const double *height,
+                                double *pred, double *J, int max_layers, int exact, int waves, void *stream);
+
+/* NOT part of the product interface -- timing helper for bench.py: average kernel time (ms) of `reps` launches of the
+ * fused kernel, measured with hipEvents recorded on `stream` around the launches. */
+gbp_status gbp_bench_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
                                          const double *sigma, const double *thk, const double *height,
                                          const double *obs, const double *rel, const double *add,
                                          double *pred, double *chi2, double *logL, void *stream,
@@ -309,9 +344,6 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, 
                          const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
 gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chains *c, void *stream);
-/* Pin (waves > 0) or release (0) the waves per workgroup of the forward kernels launched from the calling thread;
- * same meaning as gbp_rj_options.forward_waves, for the forward calls made outside gbp_rj_run (chain initialisation). */
-gbp_status gbp_pin_forward_waves(int waves);
 /* Test hook: n uniforms and n standard normals of stream (chain, iteration, stream_id) as the kernels draw them. */
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);

@@ -12,13 +12,13 @@ for name, s in (("resolve(6f)", FdemSystem.read(os.path.join(G, "resolve.stm")))
         b = FdemBatch(s, nl, sig, thk, h, data=np.full((B, 2 * s.nFrequencies), 100.0), relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0))
         out = []
         for nw in (1, 2, 4):
-            _lib.check(_lib.load().gbp_pin_forward_waves(nw))
+            b.waves = nw
             for _ in range(3): b.forward_loglike(want_pred=True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): b.forward_loglike(want_pred=True)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
             out.append(f"nw={nw}: {B*s.nFrequencies/dt/1e6:7.1f}M (s,f)/s")
-        _lib.check(_lib.load().gbp_pin_forward_waves(0))
+        b.waves = 0
         for _ in range(2): b.fm_dlogc(exact=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): b.sensitivity(exact=True, max_layers=max(L, 8) if L <= 8 else L, bucket=False)

@@ -42,9 +42,8 @@ start, Bloc = shard(S, rank, world)
 # the whole survey is drawn with one seed and sliced, so the workload does not depend on the number of ranks
 nl, sigma_true, thk, height = synthetic.draw_models(S, args.layers, seed=synthetic.SEED + 5)
 sl = slice(start, start + Bloc)
-_lib.check(_lib.load().gbp_pin_forward_waves(args.forward_waves))      # the synthetic data must not depend on the shard size either
-clean = FdemBatch(system, nl[sl], sigma_true[sl], thk[sl], height[sl], device=device).forward().cpu().numpy()
-_lib.check(_lib.load().gbp_pin_forward_waves(0))
+clean = FdemBatch(system, nl[sl], sigma_true[sl], thk[sl], height[sl], device=device,
+                  waves=args.forward_waves).forward().cpu().numpy()      # the synthetic data must not depend on the shard size either
 noise = np.random.Generator(np.random.PCG64DXSM(synthetic.SEED + 6)).normal(size=(S, clean.shape[1]))[sl]
 data = clean + noise * np.sqrt((0.05 * clean) ** 2 + 5.0 ** 2)
 options = dict(solve_gradient=True, maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, minimum_thickness=1.0,

@@ -32,11 +32,9 @@ for name, system, height, data, exact in cases:
     ok = all(bool(torch.isfinite(getattr(dc, n)).all()) for n in ("sigma", "rel", "add", "pred", "misfit", "like", "prior", "best_sigma"))
     thk_ = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
     ok &= bool((torch.where(thk_ > 0, thk_, torch.full_like(thk_, 9.0)) > dc.min_width).all()) and k.min() >= 1 and k.max() <= dc.K
-    _lib.check(_lib.load().gbp_pin_forward_waves(dc._o.forward_waves))
     fb = FdemBatch(system, k, dc.sigma.cpu().numpy(), thk_.cpu().numpy(), height, data=data, relative_error=dc.rel[:, 0].cpu().numpy(),
-                   additive_error=dc.add[:, 0].cpu().numpy())
+                   additive_error=dc.add[:, 0].cpu().numpy(), waves=dc._o.forward_waves)
     chi2, logl = fb.forward_loglike()
-    _lib.check(_lib.load().gbp_pin_forward_waves(0))
     ok &= bool(torch.allclose(fb.predicted, dc.pred, rtol=1e-9, atol=1e-7)) and bool(torch.allclose(chi2, dc.misfit, rtol=1e-7))
     kh = dc.k_hist.cpu().numpy().sum(axis=1)
     gave_up = ((dc.limited == 1) & (dc.n_resets == 3)).cpu().numpy()          # restarted five times without a single accepted step

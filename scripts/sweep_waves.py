@@ -15,7 +15,7 @@ for B in (2048, 4096, 8192, 16384, 32768, 65536):
     fb = FdemBatch(system, nl, sg, th, h, data=np.full((B, 20), 100.0), relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0))
     row = []
     for nw in (0, 1, 2, 3, 4, 5, 7, 10):
-        lib.gbp_pin_forward_waves(nw)
+        fb.waves = nw
         for _ in range(3): fb.forward_loglike(want_pred=False)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +25,4 @@ for B in (2048, 4096, 8192, 16384, 32768, 65536):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         row.append(f"nw={nw}: {ms*1e3:7.1f} us {B/ms/1e3:6.2f} M/s")
-    lib.gbp_pin_forward_waves(0)
     print(f"B={B:6d}  " + " | ".join(row), flush=True)

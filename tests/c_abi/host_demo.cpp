@@ -71,9 +71,7 @@ int main(int argc, char** argv)
 
     // initial prediction / misfit / likelihood / Jacobian through the same entries the sampler uses
     double* thk0 = dev<double>((size_t)B * K);
-    CHECK(gbp_pin_forward_waves(4));
-    CHECK(gbp_fdem_forward_loglike(sys, B, K, c.k, c.sigma, thk0, c.height, c.data, c.rel, c.add, c.pred, c.misfit, c.like, nullptr));
-    CHECK(gbp_pin_forward_waves(0));
+    CHECK(gbp_fdem_forward_loglike_ex(sys, B, K, c.k, c.sigma, thk0, c.height, c.data, c.rel, c.add, c.pred, c.misfit, c.like, 4, nullptr));
     CHECK(gbp_fdem_sensitivity_ex(sys, B, K, c.k, c.sigma, thk0, c.height, c.J, 1, 1, nullptr));
     HIP(hipDeviceSynchronize());
     std::vector<double> pred0 = down(c.pred, (size_t)B * N), chi0 = down(c.misfit, B), like0 = down(c.like, B);

@@ -268,6 +268,70 @@ def test_edge_cases():
     assert close(p.cpu().numpy(), ref, PRED_ATOL, PRED_RTOL)
 
 
+def test_bad_rows_are_flagged_and_the_rest_of_the_batch_is_untouched():
+    """SURVEY 8b "Errors": a row with more layers than the launch was sized for (nlayers > Lmax, or > max_layers of the
+    Jacobian entries) comes back as NaN -- no overrun of the LDS layer tables or of its neighbours' rows --, a row with
+    nlayers = 0 is skipped, a non-positive conductivity poisons its own row only; gbp_fdem_validate names the cause."""
+    from geobipy_amd import FdemBatch, _lib, synthetic
+    s = synthetic.syn10_system()
+    B, L, Lmax = 64, 5, 8
+    nl, sig, thk, h = synthetic.draw_models(B, L, seed=21, Lmax=Lmax)
+    good = FdemBatch(s, nl, sig, thk, h, data=np.full((B, 20), 100.0), relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0))
+    p0 = good.forward().clone()
+    c0, l0 = (t.clone() for t in good.forward_loglike())
+    J0 = good.fm_dlogc(exact=True).clone()
+    nl2, sig2, h2 = nl.copy(), sig.copy(), h.copy()
+    nl2[3], nl2[17], nl2[40] = Lmax + 5, 1000000, 0          # too many layers (twice), skipped row
+    sig2[9, 2] = -1.0                                            # bad conductivity
+    h2[11] = -3.0                                                # sensor below the surface
+    bad = FdemBatch(s, nl2, sig2, thk, h2, data=np.full((B, 20), 100.0), relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0))
+    bad.predicted.fill_(-7.0); bad.chi2.fill_(-7.0); bad.logL.fill_(-7.0)
+    c1, l1 = bad.forward_loglike()
+    p1 = bad.predicted
+    ok = np.ones(B, bool); ok[[3, 17, 40, 9, 11]] = False
+    okt = torch.as_tensor(ok, device=p1.device)
+    assert torch.equal(p1[okt], p0[okt]) and torch.equal(c1[okt], c0[okt]) and torch.equal(l1[okt], l0[okt])
+    assert torch.isnan(p1[[3, 17]]).all() and torch.isnan(c1[[3, 17]]).all() and torch.isnan(l1[[3, 17]]).all()
+    assert (p1[40] == -7.0).all() and c1[40] == -7.0                                  # skipped: nothing written
+    st = bad.status().cpu().numpy()
+    assert st[3] == 1 | 16 and st[17] == 1 | 16 and st[40] == 1 and st[9] & 2 and st[11] & 8 and np.all(st[ok] == 0)
+    assert np.all(good.status().cpu().numpy() == 0)
+    good.validate()
+    with pytest.raises(AssertionError):
+        bad.validate()
+    # Jacobian entries: max_layers smaller than a row's layer count
+    J1 = torch.full((B, 20, Lmax), -7.0, dtype=torch.float64, device=p1.device)
+    pj = torch.full((B, 20), -7.0, dtype=torch.float64, device=p1.device)
+    nlj = nl.copy(); nlj[5] = 7                                  # a legal 7-layer row, but the launch is sized for 5
+    nlj_t = torch.as_tensor(nlj, dtype=torch.int32, device=p1.device)
+    _lib.check(_lib.load().gbp_fdem_fm_dlogc(good._h_exact.ptr, B, Lmax, nlj_t.data_ptr(), good.sigma.data_ptr(), good.thk.data_ptr(),
+                                             good.height.data_ptr(), pj.data_ptr(), J1.data_ptr(), 5, 1, None))
+    torch.cuda.synchronize()
+    keep = np.ones(B, bool); keep[5] = False
+    kt = torch.as_tensor(keep, device=p1.device)
+    assert torch.isnan(J1[5]).all() and torch.isnan(pj[5]).all() and torch.equal(J1[kt], J0[kt])
+
+
+def test_explicit_waves_fix_the_summation_order():
+    """gbp_fdem_forward_ex / _loglike_ex: no hidden per-thread state -- the waves per workgroup are an argument; with a fixed
+    value a sounding's numbers do not depend on the batch it is evaluated in, and every choice is within the parity bar."""
+    from geobipy_amd import FdemBatch, synthetic
+    s = synthetic.syn10_system()
+    nl, sig, thk, h = synthetic.draw_models(70000, 8, seed=33)
+    ref = None
+    for w in (1, 2, 4):
+        big = FdemBatch(s, nl, sig, thk, h, waves=w).forward()
+        small = FdemBatch(s, nl[:100], sig[:100], thk[:100], h[:100], waves=w).forward()
+        assert torch.equal(big[:100], small)
+        ref = big if ref is None else ref
+        assert close(big.cpu().numpy(), ref.cpu().numpy(), PRED_ATOL, PRED_RTOL)
+    auto_big = FdemBatch(s, nl, sig, thk, h).forward()            # waves = 0: 1 wave at this size ...
+    auto_small = FdemBatch(s, nl[:100], sig[:100], thk[:100], h[:100]).forward()   # ... many below: same values to rounding only
+    assert close(auto_big[:100].cpu().numpy(), auto_small.cpu().numpy(), PRED_ATOL, PRED_RTOL)
+    with pytest.raises(AssertionError):
+        FdemBatch(s, nl[:4], sig[:4], thk[:4], h[:4], waves=17)
+
+
 @pytest.mark.parametrize("name", ["resolve", "syn10", "mixed"])
 def test_jacobian_fixtures_of_imported_reference(golden_npz, name):
     """FdemDataPoint.sensitivity -> nbFdem1dsen fixtures (reference formula), ragged batch, all tensor ids."""

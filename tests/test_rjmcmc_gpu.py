@@ -146,7 +146,6 @@ def test_rj_entries_refuse_bad_arguments():
     assert lib.gbp_rj_run(None, dc._o, dc._c, 0, 1, 0, None) == -1
     assert status(o=opt(schedule=1, n_markov_chains=10), c=chains(status=None)) == -1
     assert status(c=chains(B=0)) == 0                                   # an empty block is fine
-    assert lib.gbp_pin_forward_waves(17) == -1 and lib.gbp_pin_forward_waves(0) == 0
     assert lib.gbp_rj_flush_posteriors(dc._o, dc._c, None) == 0         # no hit map: nothing to do
 
 
@@ -345,11 +344,9 @@ def test_device_chains_state_is_coherent_after_many_steps():
         if k[b] > 1:
             assert e[b, 0] > dc.min_edge and e[b, k[b] - 2] < dc.max_edge
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
-                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy())
-    from geobipy_amd import _lib
-    _lib.check(_lib.load().gbp_pin_forward_waves(dc._o.forward_waves))   # the summation order the chains ran with
+                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy(),
+                   waves=dc._o.forward_waves)                                # the summation order the chains ran with
     chi2, logl = fb.forward_loglike()
-    _lib.check(_lib.load().gbp_pin_forward_waves(0))
     # proposals that keep their dimension get prediction / chi^2 / logL from the fused forward kernel (bit-equal to this
     # evaluation); the others from the Jacobian pass and the accept kernel (same values, different summation order)
     assert torch.allclose(fb.predicted, dc.pred, rtol=1e-11, atol=1e-9) and torch.allclose(chi2, dc.misfit, rtol=1e-9)
@@ -381,10 +378,9 @@ def test_deep_chains_stay_coherent():
     dc.rel.fill_(0.05); dc.add.fill_(5.0)
     B, Kp, h = dc.B, dc.K, dc._h.ptr
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
-    _lib.check(lib.gbp_pin_forward_waves(dc._o.forward_waves))
-    _lib.check(lib.gbp_fdem_forward_loglike(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
-                                            dc.data.data_ptr(), dc.rel.data_ptr(), dc.add.data_ptr(), dc.pred.data_ptr(),
-                                            dc.misfit.data_ptr(), dc.like.data_ptr(), None))
+    _lib.check(lib.gbp_fdem_forward_loglike_ex(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
+                                               dc.data.data_ptr(), dc.rel.data_ptr(), dc.add.data_ptr(), dc.pred.data_ptr(),
+                                               dc.misfit.data_ptr(), dc.like.data_ptr(), dc._o.forward_waves, None))
     _lib.check(lib.gbp_fdem_sensitivity_ex(h, B, Kp, dc.k.data_ptr(), dc.sigma.data_ptr(), thk.data_ptr(), dc.height.data_ptr(),
                                            dc.J.data_ptr(), Kp, 1, None))
     o = dc.o
@@ -401,9 +397,9 @@ def test_deep_chains_stay_coherent():
     thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64))
     assert torch.all(torch.where(thk > 0, thk, torch.full_like(thk, 9.0)) > dc.min_width)
     fb = FdemBatch(s, k, dc.sigma.cpu().numpy(), thk.cpu().numpy(), dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
-                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy())
+                   relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy(),
+                   waves=dc._o.forward_waves)
     chi2, logl = fb.forward_loglike()
-    _lib.check(lib.gbp_pin_forward_waves(0))
     assert torch.allclose(fb.predicted, dc.pred, rtol=1e-10, atol=1e-8) and torch.allclose(chi2, dc.misfit, rtol=1e-8)
     assert torch.allclose(logl, dc.like, rtol=1e-9) and torch.allclose(full_prior(), dc.prior, rtol=1e-12, atol=0)
 
