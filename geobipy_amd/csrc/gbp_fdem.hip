@@ -467,7 +467,7 @@ __global__ void k_fdem_validate(int B, int Lmax, int N, const int* __restrict__ 
     int st = 0;
     const int L = nlayers[b];
     if (L < 1 || L > Lmax) st |= GBP_ROW_BAD_NLAYERS;
-    const int Lc = L < 0 ? 0 : (L > Lmax ? Lmax : L);
+    const int Lc = (L < 1 || L > Lmax) ? 0 : L;   // a row with a bad layer count has no meaningful layers to check
     for (int k = 0; k < Lc; ++k) {
         const double s = sigma[(size_t)b * Lmax + k];
         if (!(s > 0.0) || !(s < 1.7976931348623157e308)) st |= GBP_ROW_BAD_SIGMA;

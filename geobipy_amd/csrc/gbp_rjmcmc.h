@@ -1240,7 +1240,7 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
         const int F = sys->t.nF;
         const double want = 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
         for (int d = 1; d <= F; ++d)                    // the largest divisor of nF not (much) above the target
-            if (F % d == 0 && (double)d <= 1.15 * want) sw = d;
+            if (F % d == 0 && d <= 16 && (double)d <= 1.15 * want) sw = d;
     }
     const int fw = o->forward_waves;   // 0: the forward kernels choose from the batch size
     const int N = o->n_channels;
