@@ -154,7 +154,7 @@ def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_sc
     hess = op + Ja.T @ (P[:, None] * Ja)
     grad = op @ (np.log(sigma_r) - vp.log_mean) + Ja.T @ (P * (pred[a] - data[a]))
     C = np.linalg.cholesky(hess)
-    z = np.array([v for j in range(32) for v in normal_pair(seed, b, it, 1, j)])[:k]
+    z = np.array([v for j in range((k + 1) // 2) for v in normal_pair(seed, b, it, 1, j)])[:k]      # counter j -> normals 2j, 2j + 1
     log_prop = np.log(sigma_r) - o["alpha"] * np.linalg.solve(hess, grad) + np.linalg.solve(C.T, z)
     return log_prop, C
 
