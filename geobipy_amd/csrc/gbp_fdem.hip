@@ -236,6 +236,58 @@ __device__ __forceinline__ void loglike_wave(int N, const double* p, const doubl
     }
 }
 
+// Forward solve (+ chi^2 / logL) of ONE sounding by the calling workgroup: the body of k_fdem_forward, also called once per
+// iteration by the persistent sampler kernel (gbp_rjmcmc.h).  Every thread of the workgroup must call it (it contains
+// workgroup barriers); `sh_out` holds 2 * GBP_MAX_FREQ doubles, `sh_dyn` dyn_lds_bytes(nwaves, Lmax, F) bytes:
+//   LayerK lay[nwaves][2][Lmax] | cplx part[nwaves][F] | double t2[Lmax]
+template <bool LIKE>
+__device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_out, unsigned char* sh_dyn,
+                                             const Channel* __restrict__ chan, const double* __restrict__ pts, int npts_total,
+                                             int F, int Lmax, int L, const double* __restrict__ sig,
+                                             const double* __restrict__ th, double alt, const double* __restrict__ obs_row,
+                                             double rel_b, double add_b, double* __restrict__ pred_row, double* chi2_b,
+                                             double* logL_b, double sigma_direct)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    // every layer conductive enough for the select-free complex sqrt (all but displacement-current dominated models)
+    const bool direct = wave_min_sigma(sig, L, lane) >= sigma_direct;   // workgroup-uniform
+    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
+    cplx* sh_part_all = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
+    double* sh_t2 = reinterpret_cast<double*>(sh_part_all + (size_t)nwaves * F);
+    for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
+    for (int i = threadIdx.x; i < nwaves * F; i += blockDim.x) sh_part_all[i] = gbp::mk(0.0, 0.0);
+    __syncthreads();
+
+    const int npass = (npts_total + 63) >> 6;
+    const int per = (npass + nwaves - 1) / nwaves;
+    const int p0 = wave * per;
+    const int p1 = min(npass, p0 + per);
+    if (direct)
+        forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane,
+                             sh_part_all + (size_t)wave * F);
+    else
+        forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane,
+                              sh_part_all + (size_t)wave * F);
+    __syncthreads();
+
+    // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum over waves (fixed order: deterministic)
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        double sr = 0.0, si = 0.0;
+        for (int w = 0; w < nwaves; ++w) { sr += sh_part_all[w * F + f].re; si += sh_part_all[w * F + f].im; }
+        const Channel ch = chan[f];
+        sh_out[f] = ch.g_re * sr - ch.g_im * si;
+        sh_out[F + f] = ch.g_re * si + ch.g_im * sr;
+    }
+    __syncthreads();
+
+    const int N = 2 * F;
+    if (pred_row != nullptr)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) pred_row[i] = sh_out[i];
+    if (LIKE && wave == 0) loglike_wave(N, sh_out, obs_row, rel_b, add_b, lane, chi2_b, logL_b);
+}
+
 template <bool LIKE>
 __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict__ chan,
                                                        const double* __restrict__ pts, int npts_total, int F,
@@ -251,12 +303,8 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
-    // dynamic LDS: LayerK lay[nwaves][2][Lmax] | cplx part[nwaves][F] | double t2[Lmax]
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform): none of its outputs are written
     if (L > Lmax) {       // bad row (would overrun the rows of sigma / thk and the LDS layer tables): flag it with NaNs, touch nothing else
@@ -266,86 +314,36 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
         if (LIKE && threadIdx.x == 0) { chi2[b] = qnan; logL[b] = qnan; }
         return;
     }
-    const double* sig = sigma + (size_t)b * Lmax;
-    const double* th = thk + (size_t)b * Lmax;
-    // every layer conductive enough for the select-free complex sqrt (all but displacement-current dominated models)
-    const bool direct = wave_min_sigma(sig, L, lane) >= sigma_direct;   // workgroup-uniform
-    gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
-    cplx* sh_part_all = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
-    double* sh_t2 = reinterpret_cast<double*>(sh_part_all + (size_t)nwaves * F);
-    for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
-    for (int i = threadIdx.x; i < nwaves * F; i += blockDim.x) sh_part_all[i] = gbp::mk(0.0, 0.0);
     const gbp::MathCtx M = math_setup(sh_math);  // ends with __syncthreads()
-
-    const int npass = (npts_total + 63) >> 6;
-    const int per = (npass + nwaves - 1) / nwaves;
-    const int p0 = wave * per;
-    const int p1 = min(npass, p0 + per);
-    if (direct)
-        forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
-                             sh_part_all + (size_t)wave * F);
-    else
-        forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, height[b], p0, p1, lane,
-                              sh_part_all + (size_t)wave * F);
-    __syncthreads();
-
-    // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum over waves (fixed order: deterministic)
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        double sr = 0.0, si = 0.0;
-        for (int w = 0; w < nwaves; ++w) { sr += sh_part_all[w * F + f].re; si += sh_part_all[w * F + f].im; }
-        const Channel ch = chan[f];
-        sh_out[f] = ch.g_re * sr - ch.g_im * si;
-        sh_out[F + f] = ch.g_re * si + ch.g_im * sr;
-    }
-    __syncthreads();
-
-    const int N = 2 * F;
-    if (pred != nullptr)
-        for (int i = threadIdx.x; i < N; i += blockDim.x) pred[(size_t)b * N + i] = sh_out[i];
-    if (LIKE && wave == 0)
-        loglike_wave(N, sh_out, obs + (size_t)b * N, rel[b], add[b], lane, chi2 + b, logL + b);
+    forward_body<LIKE>(M, sh_out, sh_dyn, chan, pts, npts_total, F, Lmax, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
+                       height[b], LIKE ? obs + (size_t)b * 2 * F : nullptr, LIKE ? rel[b] : 0.0, LIKE ? add[b] : 0.0,
+                       pred != nullptr ? pred + (size_t)b * 2 * F : nullptr, LIKE ? chi2 + b : nullptr, LIKE ? logL + b : nullptr,
+                       sigma_direct);
 }
 
-// Jacobian kernel: same decomposition as k_fdem_forward; each lane keeps d rTE / d ln sigma_m for its
-// abscissa in LDS (row m, column lane, row stride 65 slots so that the row sums below are conflict-free),
-// lane m then sums row m over the 64 abscissae.  J[b, f, m] = Re(g * sum), J[b, F + f, m] = Im(g * sum).
+// Jacobian (+ prediction) of ONE sounding by the first `nw_use` waves of the calling workgroup: the body of k_fdem_sens, also
+// called by the persistent sampler kernel.  Each lane keeps d rTE / d ln sigma_m for its abscissa in LDS (row m, column
+// lane, row stride 65 slots so that the row sums below are conflict-free), lane m then sums row m over the 64 abscissae.
+// J[f, m] = Re(g * sum), J[F + f, m] = Im(g * sum).  Every thread of the workgroup must call it (one workgroup barrier).
+//   sh_dyn: cplx D[nw_use][Lalloc][65] | LayerK lay[nw_use][Lalloc] | double t2[Lalloc]
 #define GBP_SENS_STRIDE 65
 template <bool EXACT, int NG>   // NG row groups of 8 layers are summed per evaluation: 1 for models of <= 8 layers, else 8
-__global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ chan, const double* __restrict__ pts,
-                                                    int npts_total, int F, int Lmax, int Lalloc,
-                                                    const int* __restrict__ nlayers,
-                                                    const double* __restrict__ sigma,
-                                                    const double* __restrict__ thk,
-                                                    const double* __restrict__ height, double* __restrict__ J,
-                                                    double* __restrict__ pred)
+__device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* sh_dyn, const Channel* __restrict__ chan,
+                                          const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
+                                          const double* __restrict__ sig, const double* __restrict__ th, double alt,
+                                          double* __restrict__ Jb /* [2F, Lmax] of this sounding */,
+                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use)
 {
-    __shared__ MathLds sh_math;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    // layout: cplx D[nwaves][Lalloc][65] | LayerK lay[nwaves][Lalloc] | double t2[Lalloc]
-    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
-    const int L = nlayers[b];
-    if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
-    if (L > Lalloc || L > Lmax) {   // more layers than the launch was sized for: NaN row instead of an LDS / row overrun
-        const double qnan = __builtin_nan("");
-        const size_t n = (size_t)2 * F * Lmax;
-        for (size_t i = threadIdx.x; i < n; i += blockDim.x) J[(size_t)b * n + i] = qnan;
-        if (pred != nullptr)
-            for (int i = threadIdx.x; i < 2 * F; i += blockDim.x) pred[(size_t)b * 2 * F + i] = qnan;
-        return;
-    }
-    const double* sig = sigma + (size_t)b * Lmax;
-    const double* th = thk + (size_t)b * Lmax;
+    const int nwaves = nw_use;
     cplx* sh_D = reinterpret_cast<cplx*>(sh_dyn) + (size_t)wave * Lalloc * GBP_SENS_STRIDE;
     gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn + (size_t)nwaves * Lalloc * GBP_SENS_STRIDE * sizeof(cplx)) +
                           (size_t)wave * Lalloc;
     double* sh_t2 = reinterpret_cast<double*>(sh_dyn + (size_t)nwaves * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)));
     for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
-    const gbp::MathCtx M = math_setup(sh_math);
-    const double alt = height[b];
-    const int N = 2 * F;
+    __syncthreads();
+    if (wave >= nwaves) return;
 
     for (int f = wave; f < F; f += nwaves) {
         const Channel ch = chan[f];
@@ -386,11 +384,11 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (pred != nullptr && m0 == 0) {      // one wave owns the frequency: fixed summation order for any launch shape
+            if (pred_row != nullptr && m0 == 0) {  // one wave owns the frequency: fixed summation order for any launch shape
                 const double sr = wave_sum(fw_re), si = wave_sum(fw_im);
                 if (lane == 0) {
-                    pred[(size_t)b * N + f] = ch.g_re * sr - ch.g_im * si;
-                    pred[(size_t)b * N + F + f] = ch.g_re * si + ch.g_im * sr;
+                    pred_row[f] = ch.g_re * sr - ch.g_im * si;
+                    pred_row[F + f] = ch.g_re * si + ch.g_im * sr;
                 }
             }
 #pragma unroll
@@ -404,17 +402,45 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                     }
                     const int m = m0 + 8 * g + row;
                     if (m < L && seg == 0) {
-                        J[((size_t)b * N + f) * Lmax + m] = ch.g_re * sr - ch.g_im * si;
-                        J[((size_t)b * N + F + f) * Lmax + m] = ch.g_re * si + ch.g_im * sr;
+                        Jb[(size_t)f * Lmax + m] = ch.g_re * sr - ch.g_im * si;
+                        Jb[(size_t)(F + f) * Lmax + m] = ch.g_re * si + ch.g_im * sr;
                     }
                 }
             }
         }
         for (int m = L + lane; m < Lmax; m += 64) {   // unused columns
-            J[((size_t)b * N + f) * Lmax + m] = 0.0;
-            J[((size_t)b * N + F + f) * Lmax + m] = 0.0;
+            Jb[(size_t)f * Lmax + m] = 0.0;
+            Jb[(size_t)(F + f) * Lmax + m] = 0.0;
         }
     }
+}
+
+template <bool EXACT, int NG>
+__global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ chan, const double* __restrict__ pts,
+                                                    int npts_total, int F, int Lmax, int Lalloc,
+                                                    const int* __restrict__ nlayers,
+                                                    const double* __restrict__ sigma,
+                                                    const double* __restrict__ thk,
+                                                    const double* __restrict__ height, double* __restrict__ J,
+                                                    double* __restrict__ pred)
+{
+    __shared__ MathLds sh_math;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int b = blockIdx.x;
+    const int L = nlayers[b];
+    if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
+    if (L > Lalloc || L > Lmax) {   // more layers than the launch was sized for: NaN row instead of an LDS / row overrun
+        const double qnan = __builtin_nan("");
+        const size_t n = (size_t)2 * F * Lmax;
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) J[(size_t)b * n + i] = qnan;
+        if (pred != nullptr)
+            for (int i = threadIdx.x; i < 2 * F; i += blockDim.x) pred[(size_t)b * 2 * F + i] = qnan;
+        return;
+    }
+    const gbp::MathCtx M = math_setup(sh_math);
+    sens_body<EXACT, NG>(M, sh_dyn, chan, pts, npts_total, F, Lmax, Lalloc, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
+                         height[b], J + (size_t)b * 2 * F * Lmax, pred != nullptr ? pred + (size_t)b * 2 * F : nullptr,
+                         (int)(blockDim.x >> 6));
 }
 
 // chi^2 / logL with an explicit per-channel standard deviation (TdemDataPoint.std is time dependent)

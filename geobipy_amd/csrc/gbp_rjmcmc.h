@@ -10,6 +10,8 @@
 //   k_rj_accept   one wave per chain:  priors, reversible-jump proposal ratio, Metropolis test, state update, posteriors
 #pragma once
 
+#define GBP_RJ_PERSISTENT_CUS 256    /* compute units assumed by gbp_rj_run's choice between its two drivers (MI355X) */
+
 namespace rj {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -35,6 +37,17 @@ __host__ __device__ inline double u53(uint32_t a, uint32_t b)      // [0, 1) wit
 }
 
 constexpr double TWO_PI = 6.283185307179586476925286766559;
+
+// Ordering point between the lanes of ONE wave that exchange data through LDS / global memory (the per-chain stages below are
+// executed by a single wave, inside single-wave workgroups as well as inside the two-wave persistent kernel, so a workgroup
+// barrier would be both unnecessary and -- in the latter -- a deadlock).  A wave's memory operations execute in program order;
+// this only keeps the compiler from moving them across.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct Rng {                                                    // sequential draws of one (chain, iteration, stream)
     uint64_t seed; uint32_t chain, iter, stream, n; double buf; bool have;
@@ -217,11 +230,8 @@ __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& 
 
 // Small blocks of soundings: one wave per chain (4 chains per workgroup).  Lane j holds interface j and layer j, every
 // lane runs the same draws (wave-uniform control flow), neighbour look-ups are cross-lane reads, rows are written coalesced.
-__global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__device__ __forceinline__ void propose_wave_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane)
 {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= c.B) return;
     const int K = o.max_layers;
     const int k = c.k[b];
     const double ej = lane < k - 1 ? c.edges[(size_t)b * K + lane] : INF;
@@ -245,11 +255,16 @@ __global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_r
     if (lane == 0) write_move(o, c, r0, b, action, kr);
 }
 
-// Large blocks: one thread per chain (the wave version would spend 64 lanes on every scalar decision).
-__global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= c.B) return;
+    propose_wave_body(o, c, iter, b, threadIdx.x & 63);
+}
+
+// Large blocks: one thread per chain (the wave version would spend 64 lanes on every scalar decision).
+__device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b)
+{
     const int K = o.max_layers;
     const double* __restrict__ e = c.edges + (size_t)b * K;
     const double* __restrict__ s = c.sigma + (size_t)b * K;
@@ -287,6 +302,13 @@ __global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp
         e_up = e_j; s_up = s_j; e_j = e_dn; s_j = s_dn;
     }
     write_move(o, c, r, b, action, kr);
+}
+
+__global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B) return;
+    propose_thread_body(o, c, iter, b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -346,16 +368,16 @@ __device__ inline void chol_solve(const double* A, int KS, int k, int lane, doub
     if (forward)
         for (int j = 0; j < k; ++j) {
             if (lane == j) g[j] = g[j] / A[j * KS + j];
-            __syncthreads();
+            wave_sync();
             if (lane > j && lane < k) g[lane] -= A[lane * KS + j] * g[j];
-            __syncthreads();
+            wave_sync();
         }
     if (backward)
         for (int j = k - 1; j >= 0; --j) {
             if (lane == j) g[j] = g[j] / A[j * KS + j];
-            __syncthreads();
+            wave_sync();
             if (lane < j) g[lane] -= A[j * KS + lane] * g[j];
-            __syncthreads();
+            wave_sync();
         }
 }
 
@@ -378,12 +400,11 @@ struct Lds {
     static size_t bytes(int K, int N) { return ((size_t)K * (K + 1) + 5 * (size_t)K + 2 * (size_t)N) * sizeof(double); }
 };
 
-__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int min_k)
+__device__ __forceinline__ void newton_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int min_k, int b, int lane,
+                                            unsigned char* sh_dyn)
 {   // Model.stochastic_newton_perturbation (model/Model.py:368-419): precision = J'PJ + Wm'Wm at the remapped model,
     // mean = ln sigma - alpha * precision^-1 g, sample ~ N(mean, precision^-1) = mean + C^-T z with precision = C C'
-    // One wave per chain; chains with at most min_k layers are left to k_rj_newton8.
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    // One wave per chain; chains with at most min_k layers are left to newton8_body.
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
     const int k = c.k_r[b];
@@ -398,7 +419,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     const double lmp = c.log_mean_prior[b];
     const double ls = lane < k ? log(sr[lane]) : 0.0;
     if (lane < k) s.v[lane] = ls - lmp;
-    __syncthreads();
+    wave_sync();
     // row `lane` of J'PJ in column blocks of 8; J[n, j] is a wave-uniform address (scalar loads), J[n, lane] coalesced
     const int li = min(lane, k - 1);
     double gi = 0.0;
@@ -420,20 +441,20 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
         }
     }
     if (lane < k) s.g[lane] = gi + prior_apply(o, s.t2, k, lane, s.v);
-    __syncthreads();
+    wave_sync();
     for (int j = 0; j < k; ++j) {                                // Cholesky, lower, in place
         if (lane == j) {
             double d = s.A[j * KS + j];
             for (int m = 0; m < j; ++m) d -= s.A[j * KS + m] * s.A[j * KS + m];
             s.A[j * KS + j] = sqrt(d);
         }
-        __syncthreads();
+        wave_sync();
         if (lane > j && lane < k) {
             double d = s.A[lane * KS + j];
             for (int m = 0; m < j; ++m) d -= s.A[lane * KS + m] * s.A[j * KS + m];
             s.A[lane * KS + j] = d / s.A[j * KS + j];
         }
-        __syncthreads();
+        wave_sync();
     }
     double* C = c.chol + (size_t)b * K * K;
     if (lane < k)
@@ -445,7 +466,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
         if (2 * lane < K) s.w[2 * lane] = z0;
         if (2 * lane + 1 < K) s.w[2 * lane + 1] = z1;
     }
-    __syncthreads();
+    wave_sync();
     chol_solve(s.A, KS, k, lane, s.w, false, true);
     if (lane < K) {
         const double lp = lane < k ? (ls - o.alpha * s.g[lane]) + s.w[lane] : 0.0;
@@ -454,22 +475,28 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
     }
 }
 
+__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int min_k)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    newton_body(o, c, iter, min_k, blockIdx.x, threadIdx.x, sh_dyn);
+}
+
 // The same for chains with at most 8 layers -- the common case -- packed 8 lanes per chain, 8 chains per wave: row i of the
 // 8 x 8 system lives in the registers of lane i of the chain's group, columns of the Cholesky factor are passed around with
 // cross-lane reads (lane j also keeps column j for the transposed solves), so there is no LDS traffic and no barrier in
 // the factorisation or the substitutions.  Rows >= k are identity rows.
 __device__ inline double group_bcast(double v, int base, int j) { return __shfl(v, base + j, 64); }
 
-__global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+// `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N]
+__device__ __forceinline__ void newton8_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
+                                             unsigned char* sh_dyn, int b_idle = 0)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // P[8][N] | PR[8][N]
-    const int lane = threadIdx.x, slot = lane >> 3, i = lane & 7, base = lane & ~7;
+    const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
     const int K = o.max_layers, N = o.n_channels;
-    const int b = blockIdx.x * 8 + slot;
     int k = b < c.B ? c.k_r[b] : 0;
     const bool live = k >= 1 && k <= 8;              // deeper chains: k_rj_newton.  No early exit: idle groups still take
     if (!live) k = 0;                                //   part in the cross-lane reads
-    const size_t bb = live ? (size_t)b : 0;
+    const size_t bb = live ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used)
     const bool changed = c.action[bb] != NONE;
     const double* J = (changed ? c.J_r : c.J) + bb * N * K;
     const double* pred = (changed ? c.pred_r : c.pred) + bb * N;
@@ -490,7 +517,7 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
     const double v = i < k ? ls - lmp : 0.0;
     const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
-    __syncthreads();
+    wave_sync();
     double arow[8], acol[8];
     double g = 0.0;
 #pragma unroll
@@ -561,6 +588,12 @@ __global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chai
         c.sigma_p[bb * K + i] = i < k ? exp(lp) : 1.0;
         for (int j = i + 8; j < K; j += 8) { c.log_prop[bb * K + j] = 0.0; c.sigma_p[bb * K + j] = 1.0; }
     }
+}
+
+__global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    newton8_body(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
 __device__ inline double log_uniform_prior(double x, double lo, double hi)
@@ -693,10 +726,9 @@ __device__ inline void bookkeeping(const gbp_rj_options& o, const gbp_rj_chains&
     }
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
-{   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to k_rj_accept8
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int min_k, int b,
+                                            int lane, unsigned char* sh_dyn)
+{   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to accept8_body
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
     const int k = c.k_r[b], action = c.action[b];
@@ -737,13 +769,13 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             for (int j = 0; j <= lane; ++j) s.A[lane * KS + j] = C[(size_t)lane * K + j];
             s.v[lane] = lpv[lane] - lmp;
         }
-        __syncthreads();
+        wave_sync();
         if (lane < k) {
             double gi = prior_apply(o, s.t2, k, lane, s.v);
             for (int n = 0; n < N; ++n) gi += Jp[(size_t)n * K + lane] * s.PR[n];
             s.g[lane] = gi;
         }
-        __syncthreads();
+        wave_sync();
         chol_solve(s.A, KS, k, lane, s.g, true, true);           // H g'
         const double lrem = lane < k ? log(c.sigma_r[(size_t)b * K + lane]) : 0.0;
         bool bad = false;
@@ -753,7 +785,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
             s.v[lane] = lrem - mean_r;                           // d1: ln sigma_rem - reverse mean
             s.w[lane] = lpv[lane] - lrem;                        // d2: ln sigma' - ln sigma_rem
         }
-        __syncthreads();
+        wave_sync();
         double q1 = 0.0, q2 = 0.0;                               // |C' d|^2 = d' precision d
         if (lane < k) {
             double a1 = 0.0, a2 = 0.0;
@@ -790,7 +822,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
     const bool accept = !frozen && log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
-    __syncthreads();
+    wave_sync();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
     const Levels lev_c = load_levels(o, c.rel, c.add, (size_t)b);  // (read before the state is overwritten)
@@ -799,7 +831,7 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     if (accept && dwell > 0) {                                   // the model changes: settle the old one first
         hitmap_add<64>(o, c.hitmap + (size_t)b * nh, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, k_prev, lmp, lane, dwell);
         dwell = 0;
-        __syncthreads();
+        wave_sync();
     }
     if (accept) {
         if (lane < K) {
@@ -826,6 +858,12 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
     bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
                     accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
                     accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
+}
+
+__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    accept_body(o, c, iter, accumulate, min_k, blockIdx.x, threadIdx.x, sh_dyn);
 }
 
 // The same for chains whose current and proposed models have at most 8 layers, packed 8 lanes per chain like k_rj_newton8:
@@ -859,17 +897,17 @@ __device__ inline void hitmap_add8(const gbp_rj_options& o, int32_t* hm, const d
     }
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
+// `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: PR[8][N]
+__device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
+                                             unsigned char* sh_dyn, int b_idle = 0)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // PR[8][N]
-    const int lane = threadIdx.x, slot = lane >> 3, i = lane & 7, base = lane & ~7;
+    const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
     const int K = o.max_layers, N = o.n_channels;
-    const int b = blockIdx.x * 8 + slot;
     int k = b < c.B ? c.k_r[b] : 0;
     const int k_prev = b < c.B ? c.k[b] : 0;
     const bool live = k >= 1 && max(k, k_prev) <= 8;         // no early exit: idle groups still take part in cross-lane reads
     if (!live) k = 0;
-    const size_t bb = live ? (size_t)b : 0;
+    const size_t bb = live ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used)
     const int action = live ? c.action[bb] : NONE;
     const bool jump = action == INSERT || action == DELETE;
     const bool frozen = o.schedule == 1 && c.status[bb] != 0;
@@ -918,7 +956,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
         }
     }
     s2 = group_sum8(s2); logdet = group_sum8(logdet); na = group_sum8(na);
-    __syncthreads();
+    wave_sync();
     // reverse-move proposal density (Model.proposal_probabilities :577-659); executed by every group, used by the jumps
     double t2 = 0.0;
     if (i < k - 1 && o.solve_gradient) {
@@ -1021,6 +1059,12 @@ __global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chai
                    accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
 }
 
+__global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    accept8_body(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
+}
+
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
 __global__ __launch_bounds__(64) void k_rj_flush(gbp_rj_options o, gbp_rj_chains c)
 {
@@ -1106,6 +1150,233 @@ __global__ __launch_bounds__(64) void k_td_loglike(gbp_rj_options o, gbp_rj_chai
         chi2[b] = s2;
         logL[b] = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent per-chain sampler: ONE workgroup owns a chain and runs all of its iterations in one launch -- propose ->
+// fm_dlogc at the remapped model -> stochastic-Newton proposal -> fused forward + chi^2 (or fm_dlogc for a dimension change)
+// -> accept / bookkeeping -- with workgroup barriers where the lock-step driver (gbp_rj_run_td below) has kernel boundaries.
+// Chains are independent, so nothing is exchanged between workgroups and there is no lock-step tail: a block of 1 024 chains
+// (BASELINE config 5 split over 8 GPUs) no longer pays ten dependent launches per iteration.  The stages are the SAME device
+// functions the lock-step kernels call, on the same arrays, with the same wave counts, so the chains are bit-identical to
+// gbp_rj_run's (tests/test_rjmcmc_gpu.py::test_persistent_kernel_walks_the_same_chains).
+//   workgroup = `forward_waves` waves (the summation order of the fused forward kernel); the per-chain algebra (8-lane packed
+//   or one-wave variants) runs on wave 0.
+//   dynamic LDS = max over the stages (persistent_lds_bytes), the math tables are staged once per workgroup lifetime.
+// ---------------------------------------------------------------------------------------------------------------
+// The stages are separate (non-inlined) functions so that each gets its own register allocation: inlined into one body the
+// kernel needed 300 VGPRs and > 500 SGPR spills (occupancy 1).  They receive pointers only -- the two parameter blocks and the
+// math tables sit in LDS for the workgroup's lifetime, the polynomial coefficients are re-read from constant memory.
+#ifndef GBP_STAGE_ATTR
+#define GBP_STAGE_ATTR __attribute__((noinline))
+#endif
+struct PersistentCtx {
+    const gbp_rj_options* o;          // LDS copies
+    const gbp_rj_chains* c;
+    MathLds* math;
+    double* sh_out;
+    unsigned char* sh_dyn;
+    const Channel* chan;
+    const double* pts;
+    unsigned char* deep_scratch;      // global working set of this chain's Jacobian pass for models of > 8 layers, or NULL: LDS
+    int npts_total, F, nw_deep, b;
+    double sigma_direct;
+};
+
+// LDS block of one chain in the persistent kernel: the doubles of GBP_RJ_D + data[N], then the int32s of GBP_RJ_I
+__host__ __device__ inline size_t persistent_chain_doubles(int K, int N)
+{
+    return (size_t)9 * K + 4 * (size_t)N + 3 * (size_t)N * K + 11;      // (chol stays in global memory: K^2 doubles, read once per jump)
+}
+__host__ __device__ inline size_t persistent_chain_bytes(int K, int N)
+{
+    return (persistent_chain_doubles(K, N) * sizeof(double) + 4 * sizeof(int32_t) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ gbp::MathCtx math_ctx(MathLds* lds)    // math_setup without the table fill
+{
+    gbp::MathCtx M;
+    M.k = GBP_K;
+    M.e4_v = M.k.e4; M.s2_v = M.k.s2; M.c3_v = M.k.c3;
+    asm volatile("" : "+v"(M.e4_v), "+v"(M.s2_v), "+v"(M.c3_v));
+    M.exp2_64 = lds->exp2_64;
+    M.sincos_64 = lds->sincos_64;
+    return M;
+}
+
+template <bool EXACT>
+__device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_proposal)
+{
+    const gbp_rj_options& o = *x->o;
+    const gbp_rj_chains& c = *x->c;
+    const int b = x->b, K = o.max_layers, N = o.n_channels, L = c.k_r[b];
+    const gbp::MathCtx M = math_ctx(x->math);
+    const double* sig = (at_proposal ? c.sigma_p : c.sigma_r) + (size_t)b * K;
+    double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
+    double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
+    const double* th = c.thk_r + (size_t)b * K;
+    const double alt = c.height[b];
+    if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6));
+    else sens_body<EXACT, 8>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K, L,
+                             sig, th, alt, Jb, pr, x->nw_deep);
+}
+
+__device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
+{
+    const gbp_rj_options& o = *x->o;
+    const gbp_rj_chains& c = *x->c;
+    const int b = x->b, K = o.max_layers, N = o.n_channels;
+    const gbp::MathCtx M = math_ctx(x->math);
+    forward_body<true>(M, x->sh_out, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, c.k_r[b], c.sigma_p + (size_t)b * K,
+                       c.thk_r + (size_t)b * K, c.height[b], c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N,
+                       c.misfit_p + b, c.like_p + b, x->sigma_direct);
+}
+
+__device__ GBP_STAGE_ATTR void stage_propose(const PersistentCtx* x, uint32_t iter, int lane)
+{   // the cooperative variant (lane j holds interface / layer j: one row load instead of a dependent walk); same draws and
+    // the same remapped model as the thread-per-chain kernel the lock-step driver launches
+    if (x->o->max_layers <= 64) propose_wave_body(*x->o, *x->c, iter, x->b, lane);
+    else if (lane == 0) propose_thread_body(*x->o, *x->c, iter, x->b);
+}
+
+__device__ GBP_STAGE_ATTR void stage_newton(const PersistentCtx* x, uint32_t iter, int lane)
+{
+    const gbp_rj_chains& c = *x->c;
+    if (c.k_r[x->b] <= 8) newton8_body(*x->o, c, iter, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
+    else newton_body(*x->o, c, iter, 8, x->b, lane, x->sh_dyn);
+}
+
+__device__ GBP_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t iter, int accumulate, int lane)
+{
+    const gbp_rj_chains& c = *x->c;
+    const int kr = c.k_r[x->b], kp = c.k[x->b];
+    if ((kr > kp ? kr : kp) <= 8) accept8_body(*x->o, c, iter, accumulate, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
+    else accept_body(*x->o, c, iter, accumulate, 8, x->b, lane, x->sh_dyn);
+}
+
+// (launch bound 1024 although 64 ... 256 threads are launched: it caps the kernel AND the stage functions it calls at 128 VGPRs,
+//  the budget the same code has in the lock-step kernels; without it every stage takes ~250 registers: one wave per SIMD)
+// Stage clock of chain 0 (s_memtime ticks of the 100 MHz constant clock, accumulated over the launches since the last reset):
+// propose | fm_dlogc at the remapped model | newton | forward or fm_dlogc at the proposal | accept | iterations.  Read with
+// gbp_rj_debug_stage_ticks; costs one branch per stage in the other workgroups.
+__device__ long long GBP_RJ_TICKS[8];
+
+template <bool EXACT>
+__global__ __launch_bounds__(1024) void k_rj_persistent(gbp_rj_options o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
+                                                       const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
+                                                       uint32_t iter0, int n_iter, int accumulate, int nw_deep,
+                                                       unsigned char* deep_scratch, size_t deep_bytes)
+{
+    __shared__ double sh_out[2 * GBP_MAX_FREQ];
+    __shared__ MathLds sh_math;
+    __shared__ gbp_rj_options sh_o;
+    __shared__ gbp_rj_chains sh_c;
+    __shared__ PersistentCtx sh_x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = o_arg.max_layers, N = o_arg.n_channels;
+    // The chain's rows of every per-chain array -- carried state AND the scratch the stages hand to each other -- live in LDS
+    // for the whole launch: sh_c's pointers are re-based so that `ptr + b * row` lands on the LDS copy (generic pointers:
+    // the stage functions are unchanged and do the same arithmetic).  A dependent global load costs ~1 us, an LDS one ~0.1 us,
+    // and the per-chain algebra is chains of them.  The stage scratch (sh_dyn) follows the chain block.
+    double* ld = reinterpret_cast<double*>(sh_dyn);
+    int32_t* li = reinterpret_cast<int32_t*>(ld + persistent_chain_doubles(K, N));
+    unsigned char* stage_scratch = sh_dyn + persistent_chain_bytes(K, N);
+    if (threadIdx.x == 0) { sh_o = o_arg; sh_c = c_arg; }
+    __syncthreads();
+#define GBP_RJ_D(X)                                                                                                        \
+    X(edges, K, 1) X(sigma, K, 1) X(rel, 1, 1) X(add, 1, 1) X(pred, N, 1) X(J, N * K, 1) X(prior, 1, 1) X(like, 1, 1)      \
+    X(misfit, 1, 1) X(best_posterior, 1, 1) X(best_edges, K, 1) X(best_sigma, K, 1) X(edges_r, K, 1) X(sigma_r, K, 1)       \
+    X(thk_r, K, 1) X(rel_p, 1, 1) X(add_p, 1, 1) X(pred_r, N, 1) X(J_r, N * K, 1) X(log_prop, K, 1)       \
+    X(sigma_p, K, 1) X(pred_p, N, 1) X(misfit_p, 1, 1) X(like_p, 1, 1) X(J_p, N * K, 1) X(log_ratio, 1, 1)
+#define GBP_RJ_I(X) X(k, 1, 1) X(best_k, 1, 1) X(action, 1, 1) X(k_r, 1, 1)
+    {
+        double* p = ld;
+        int32_t* q = li;
+        const size_t bb = (size_t)b;
+#define GBP_IN_D(name, n, carried)                                                                                       \
+    {                                                                                                                    \
+        const size_t cnt = (size_t)(n);                                                                                  \
+        if (carried) for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) p[i] = c_arg.name[bb * cnt + i];             \
+        if (threadIdx.x == 0) sh_c.name = p - bb * cnt;                                                                  \
+        p += cnt;                                                                                                        \
+    }
+        GBP_RJ_D(GBP_IN_D)
+#undef GBP_IN_D
+#define GBP_IN_I(name, n, carried)                                                                                       \
+    {                                                                                                                    \
+        if (carried && threadIdx.x == 0) q[0] = c_arg.name[bb];                                                          \
+        if (threadIdx.x == 0) sh_c.name = q - bb;                                                                        \
+        q += 1;                                                                                                          \
+    }
+        GBP_RJ_I(GBP_IN_I)
+#undef GBP_IN_I
+        // read-only inputs
+        for (size_t i = threadIdx.x; i < (size_t)N; i += blockDim.x) p[i] = c_arg.data[bb * N + i];
+        if (threadIdx.x == 0) sh_c.data = p - bb * N;
+    }
+    if (threadIdx.x == 0) {
+        sh_x.o = &sh_o; sh_x.c = &sh_c; sh_x.math = &sh_math; sh_x.sh_out = sh_out; sh_x.sh_dyn = stage_scratch; sh_x.chan = chan;
+        sh_x.pts = pts; sh_x.deep_scratch = deep_scratch != nullptr ? deep_scratch + (size_t)b * deep_bytes : nullptr;
+        sh_x.npts_total = npts_total; sh_x.F = F; sh_x.nw_deep = nw_deep; sh_x.b = b; sh_x.sigma_direct = sigma_direct;
+    }
+    (void)math_setup(sh_math);                                    // tables -> LDS once per chain; ends with __syncthreads()
+    const int32_t* status = c_arg.status;
+    const int32_t* action_p = sh_c.action;
+    const int schedule = o_arg.schedule;
+    const bool clocked = b == 0 && threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0;   // armed by gbp_rj_debug_stage_ticks(out, 1)
+    long long t0 = clocked ? (long long)wall_clock64() : 0;
+    auto tick = [&](int stage) {
+        if (clocked) { const long long t1 = (long long)wall_clock64(); GBP_RJ_TICKS[stage] += t1 - t0; t0 = t1; }
+    };
+    for (int it = 0; it < n_iter; ++it) {
+        const uint32_t iter = iter0 + (uint32_t)it;
+        if (schedule == 1 && status[b] != 0) break;               // done / failed chains keep their final state (workgroup-uniform)
+        if (wave == 0) stage_propose(&sh_x, iter, lane);
+        __syncthreads();
+        tick(0);
+        const int action = action_p[b];
+        if (action != NONE) {                                     // Model.py:383-384: prediction + Jacobian at the remapped model
+            stage_fm_dlogc<EXACT>(&sh_x, 0);
+            __syncthreads();
+        }
+        tick(1);
+        if (wave == 0) stage_newton(&sh_x, iter, lane);
+        __syncthreads();
+        tick(2);
+        if (action == INSERT || action == DELETE) stage_fm_dlogc<EXACT>(&sh_x, 1);   // Model.py:612: Jacobian + prediction at the proposal
+        else stage_forward(&sh_x);                                // Inference1D.py:572-597: forward + chi^2 + logL of the proposal
+        __syncthreads();
+        tick(3);
+        if (wave == 0) stage_accept(&sh_x, iter, accumulate, lane);
+        __syncthreads();
+        tick(4);
+        if (clocked) GBP_RJ_TICKS[5] += 1;
+    }
+    {   // everything back to the block's arrays (scratch too: the arrays end as the lock-step driver leaves them)
+        const double* p = ld;
+        const int32_t* q = li;
+        const size_t bb = (size_t)b;
+#define GBP_OUT_D(name, n, carried)                                                                                      \
+    {                                                                                                                    \
+        const size_t cnt = (size_t)(n);                                                                                  \
+        for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) c_arg.name[bb * cnt + i] = p[i];                          \
+        p += cnt;                                                                                                        \
+    }
+        GBP_RJ_D(GBP_OUT_D)
+#undef GBP_OUT_D
+#define GBP_OUT_I(name, n, carried)                                                                                      \
+    {                                                                                                                    \
+        if (threadIdx.x == 0) c_arg.name[bb] = q[0];                                                                     \
+        q += 1;                                                                                                          \
+    }
+        GBP_RJ_I(GBP_OUT_I)
+#undef GBP_OUT_I
+    }
+#undef GBP_RJ_D
+#undef GBP_RJ_I
 }
 
 }  // namespace rj
@@ -1207,10 +1478,104 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     return GBP_OK;
 }
 
+// Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind,
+// a pinned wave count.  Returns the workgroup's waves, or 0.
+static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o, int B)
+{
+    if (o->forward_waves < 1 || o->n_rel_groups != 1 || o->n_add_groups != 1) return 0;
+    const int nw = pick_waves(B, sys->t.nF, o->max_layers, (sys->t.npts + 63) / 64, o->forward_waves);   // what the lock-step forward launch uses
+    return nw <= 4 ? nw : 0;
+}
+
+static size_t sens_lds_bytes(int nw, int Lalloc)
+{
+    return (size_t)nw * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)) + (size_t)Lalloc * sizeof(double);
+}
+
+static size_t persistent_lds_bytes(const gbp_fdem_system* sys, const gbp_rj_options* o, int nw)
+{
+    const int K = o->max_layers, N = o->n_channels, F = sys->t.nF;
+    size_t stage = dyn_lds_bytes(nw, K, F);
+    stage = std::max(stage, sens_lds_bytes(nw, K < 8 ? K : 8));
+    stage = std::max(stage, rj::Lds::bytes(K, N));
+    stage = std::max(stage, (size_t)16 * N * sizeof(double));
+    return rj::persistent_chain_bytes(K, N) + stage;
+}
+
+static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
+                                    int n_iterations, int accumulate, void* stream)
+{
+    const int B = c->B, K = o->max_layers, F = sys->t.nF;
+    const int nw = persistent_waves(sys, o, B);
+    if (nw == 0) return fail(GBP_ERR_INVALID_ARG, "the persistent sampler needs frequency-domain data and forward_waves in [1, 4]%s");
+    // LDS per workgroup = the chain's arrays (rj::persistent_chain_bytes) + the largest stage working set.  The Jacobian pass of a
+    // model with more than 8 layers needs 1 KB per layer and wave: kept in LDS it would take the budget of one more resident
+    // chain per CU away from every chain for a rare case, so it works in a per-chain global block instead (stream-ordered
+    // allocation for the duration of the launch).
+    const size_t lds = persistent_lds_bytes(sys, o, nw);
+    if (lds > 64 * 1024) return fail(GBP_ERR_INVALID_ARG, "max_layers x channels too large for the persistent sampler's LDS block%s");
+    const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(nw, K) + 255) & ~(size_t)255) : 0;
+    unsigned char* deep = nullptr;
+    if (deep_bytes > 0) GBP_HIP(hipMallocAsync((void**)&deep, deep_bytes * (size_t)B, (hipStream_t)stream));
+    auto launch = [&](auto kernel) -> gbp_status {
+        if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, *o, *c, sys->d_chan, sys->d_pts, sys->t.npts, F,
+                           sys->sigma_direct, (uint32_t)first_iteration, n_iterations, accumulate, nw, deep, deep_bytes);
+        return GBP_OK;
+    };
+    gbp_status st = o->exact_jacobian ? launch(rj::k_rj_persistent<true>) : launch(rj::k_rj_persistent<false>);
+    const hipError_t le = hipGetLastError();
+    if (deep != nullptr) (void)hipFreeAsync(deep, (hipStream_t)stream);
+    if (st != GBP_OK) return st;
+    if (le != hipSuccess) return fail(GBP_ERR_HIP, "persistent sampler launch: %s", hipGetErrorString(le));
+    return GBP_OK;
+}
+
+gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
+                           int n_iterations, int accumulate, int mode, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK) return st;
+    if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (mode < 0 || mode > 2) return fail(GBP_ERR_INVALID_ARG, "mode must be 0 (auto), 1 (lock-step) or 2 (persistent)%s");
+    if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
+    if (c->B == 0 || n_iterations <= 0) return GBP_OK;
+    if (mode == 0) {
+        // Both drivers walk the same chains; which is faster depends on how many chains share the GPU.  A lock-step iteration
+        // costs ~140 us of dependent launches + ~0.035 us per chain; a persistent workgroup needs ~85 us per iteration of its
+        // chain, with `capacity` of them resident at once (LDS block per workgroup).  Measured crossover (Resolve and the
+        // 10-frequency system, scripts/bench_rj_modes.py): about twice the resident capacity.
+        const int nw = persistent_waves(sys, o, c->B);
+        bool small = false;
+        if (nw > 0 && n_iterations >= 4) {
+            const size_t lds = persistent_lds_bytes(sys, o, nw);
+            const long long per_cu = std::min<long long>(128 * 1024 / (long long)lds, 16 / nw);     // LDS / 128-VGPR wave slots of a CU
+            small = lds <= 64 * 1024 && (long long)c->B <= 2 * GBP_RJ_PERSISTENT_CUS * per_cu;
+        }
+        mode = small ? 2 : 1;
+    }
+    if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, stream);
+    return gbp_rj_run_td(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, stream);
+}
+
+gbp_status gbp_rj_debug_stage_ticks(int64_t* out, int reset)
+{
+    if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
+    long long h[8];
+    GBP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rj::GBP_RJ_TICKS), sizeof(h)));
+    for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
+    if (reset) {                                 // 1: zero the counters and arm the clock; 2: zero and disarm
+        std::memset(h, 0, sizeof(h));
+        h[7] = reset == 1 ? 1 : 0;
+        GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rj::GBP_RJ_TICKS), h, sizeof(h)));
+    }
+    return GBP_OK;
+}
+
 gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
                       int n_iterations, int accumulate, void* stream)
 {
-    return gbp_rj_run_td(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, stream);
+    return gbp_rj_run_mode(sys, o, c, first_iteration, n_iterations, accumulate, 0, stream);
 }
 
 gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,

@@ -260,7 +260,9 @@ class DeviceChains:
                                                        self._stream()))
 
     def _launch(self, n, accumulate):
-        _lib.check(_lib.load().gbp_rj_run(self._h.ptr, self._o, self._c, self.iteration, int(n), int(bool(accumulate)), self._stream()))
+        # run_mode: 0 = the library's choice, 1 = lock-step driver, 2 = persistent per-chain kernel (gbp_rj_run_mode); same chains
+        _lib.check(_lib.load().gbp_rj_run_mode(self._h.ptr, self._o, self._c, self.iteration, int(n), int(bool(accumulate)),
+                                               int(getattr(self, "run_mode", 0)), self._stream()))
 
     # -- sampling ------------------------------------------------------------------------------------------------------
     def run(self, n, accumulate=True):

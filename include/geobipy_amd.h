@@ -327,6 +327,12 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
+/* `mode`: 0 = gbp_rj_run's choice, 1 = lock-step driver (ten stream-ordered launches per iteration over the whole block),
+ * 2 = persistent kernel (one workgroup owns a chain and loops over all n_iterations in ONE launch; frequency-domain data,
+ * forward_waves in [1, 4]).  The two drivers walk bit-identical chains; small blocks (config 5 split over 8 GPUs: 1 024 chains
+ * per GPU) are several times faster in mode 2, large ones in mode 1. */
+gbp_status gbp_rj_run_mode(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
+                           int64_t first_iteration, int n_iterations, int accumulate, int mode, void *stream);
 /*
  * The same for time-domain data (TdemDataPoint): `sys` is the frequency-domain handle of the spline nodes of the system --
  * or of all systems of a multi-moment acquisition merged into one (gbp_hankel_system_create_raw) --, and a constant block
@@ -344,6 +350,11 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, 
                          const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
 gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chains *c, void *stream);
+/* Diagnostics: [host] out[8] = accumulated 100 MHz clock ticks of chain 0 in the persistent kernel's stages (propose, fm_dlogc at
+ * the remapped model, newton, forward / fm_dlogc at the proposal, accept), out[5] = iterations counted; synchronises the device.
+ * reset: 0 read only, 1 zero the counters and arm the clock (off by default: it costs chain 0 a few global updates per iteration),
+ * 2 zero and disarm. */
+gbp_status gbp_rj_debug_stage_ticks(int64_t *out, int reset);
 /* Test hook: n uniforms and n standard normals of stream (chain, iteration, stream_id) as the kernels draw them. */
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);

@@ -578,6 +578,55 @@ def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exact,kw", [(True, dict()), (False, dict()),
+                                      (True, dict(options=dict(maximum_number_of_layers=8, probability_of_birth=0.4))),
+                                      (True, dict(reference_schedule=True, burn_in_min_iterations=60, hitmap=True, n_value_bins=20,
+                                                  options=dict(n_markov_chains=150)))])
+def test_persistent_kernel_walks_the_same_chains(exact, kw):
+    """gbp_rj_run_mode: the persistent per-chain kernel (one workgroup owns a chain and loops over the iterations in ONE launch)
+    and the lock-step driver (ten launches per iteration over the block) are the same device functions on the same arrays
+    with the same wave counts -- the chains, their posteriors and every piece of carried state are bit-identical, also when
+    the run is cut into launches of different lengths, for deep models (> 8 layers: the one-wave variants of the per-chain
+    algebra and the 8-row-group Jacobian pass) and under the reference's burn-in schedule."""
+    B, n_it = 300, 400
+    runs = []
+    for mode, cuts in ((1, (n_it,)), (2, (n_it,)), (2, (1, 7, 150, n_it - 158))):
+        d, s, dc = _chains(B, 31, exact=exact, **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
+        rng = np.random.default_rng(4)
+        data = np.tile(d["data"], (B, 1)) * rng.uniform(0.7, 1.4, (B, 1))
+        dc.data.copy_(torch.as_tensor(data))
+        dc._initialize()
+        if "options" not in kw and not kw:                       # plain options: start a third of the chains from deep models
+            _load_random_state(dc, np.random.default_rng(12), kmax=dc.K)
+            dc.rel.fill_(0.05); dc.add.fill_(5.0)
+            thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
+            dc._eval_loglike(dc.k, dc.sigma, thk, dc.height, dc.data, dc.rel, dc.add, dc.pred, dc.misfit, dc.like)
+            dc._eval_jacobian(dc.k, dc.sigma, thk, dc.height, dc.J, dc.K)
+            dc.prior.copy_(rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
+                           + rg.log_uniform_prior(dc.rel[:, 0], dc._bounds["rel"][0][0], dc._bounds["rel"][1][0])
+                           + rg.log_uniform_prior(dc.add[:, 0], dc._bounds["add"][0][0], dc._bounds["add"][1][0]))
+        dc.run_mode = mode
+        for n in cuts:
+            dc.run(n)
+        torch.cuda.synchronize()
+        runs.append(dc)
+    ref = runs[0]
+    assert int(ref.n_accepted.sum()) > 0.01 * B * n_it and len(torch.unique(ref.k)) >= 3
+    if not kw:
+        assert int((ref.k > 8).sum()) > 5
+    names = ["k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit", "n_accepted", "k_hist", "edge_hist", "rel_hist",
+             "add_hist", "best_posterior", "best_k", "best_edges", "best_sigma", "log_ratio"]
+    if "reference_schedule" in kw:
+        names += ["burned_in_iteration", "status", "hitmap"]
+        names.remove("log_ratio")                                 # scratch of finished chains: the persistent kernel stops touching them
+        assert int((ref.status == 1).sum()) > 0
+    for other in runs[1:]:
+        for n in names:
+            a, b = getattr(ref, n), getattr(other, n)
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-1.25), torch.nan_to_num(b.double(), nan=-1.25)), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exact", [False, True])
 def test_device_chains_sample_like_the_host_chains(exact):
     """The device sampler against the host sampler (rjmcmc.py through BatchedInference -- the code that reproduces
