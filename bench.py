@@ -90,10 +90,82 @@ def cpu_baseline(system, nl, sigma, thk, height, obs, sample, threads):
     return n / dt, dt, (pred, chi2, logl)
 
 
+def rjmcmc_extra(system, height, obs, device, Btot):
+    """BASELINE config 5 numbers for the bench line: 8 192 soundings x 10 000 iterations on this GPU in both Jacobian modes, the
+    1 024-chain block that one GPU gets when config 5 is spread over 8 (lock-step vs persistent driver), and a bounded CPU replay
+    (checker: tests/config5_replay.py = host emulation + C oracle) of a few chains counting exact matches."""
+    import torch
+    from geobipy_amd import DeviceChains
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    opts = dict(maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, initial_relative_error=0.05,
+                minimum_relative_error=0.001, maximum_relative_error=0.5, initial_additive_error=5.0, minimum_additive_error=3.0,
+                maximum_additive_error=20.0, relative_error_proposal_variance=1e-6, additive_error_proposal_variance=1e-6,
+                probability_of_birth=1.0 / 6.0, probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0,
+                probability_of_no_change=0.5)
+    obs_np = obs.cpu().numpy() if torch.is_tensor(obs) else np.asarray(obs)
+    nrj, n_it = min(Btot, 8192), 10000
+    out = {"unit": "chain-iterations/s", "soundings": nrj, "iterations": n_it}
+
+    def timed(dc, n, warm=50):
+        dc.run(warm); torch.cuda.synchronize(device)
+        t0 = time.perf_counter(); dc.run(n); torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    for key, exact in (("reference_jacobian", False), ("exact_jacobian", True)):
+        dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=exact, device=device, **opts)
+        dt = timed(dc, n_it)
+        sm = dc.summaries().cpu().numpy()
+        out[key] = {"value": nrj * n_it / dt, "seconds": dt, "ms_per_lockstep_iteration": 1e3 * dt / n_it,
+                    "acceptance": float(sm[:, 4].mean()), "mean_layers": float(sm[:, 3].mean()),
+                    "median_misfit": float(np.median(dc.misfit.cpu().numpy()))}
+        del dc
+    out["value"] = out["reference_jacobian"]["value"]          # the pinned parity mode is the headline of this object
+    # config 5 over 8 GPUs = 1 024 chains per GPU: the small-block regime
+    small = {}
+    for key, mode in (("lockstep", 1), ("persistent", 2)):
+        dc = DeviceChains(system, height[:1024], obs_np[:1024], seed=1, exact_jacobian=False, device=device, **opts)
+        dc.run_mode = mode
+        small[key] = 1024 * 2000 / timed(dc, 2000, warm=100)
+        del dc
+    out["block_of_1024"] = dict(small, unit="chain-iterations/s", note="one GPU's block when config 5 is spread over 8 GPUs; "
+                                "gbp_rj_run_mode 1 / 2 walk bit-identical chains")
+    # bounded replay on the host cores: 16 chains x 1 500 iterations of the reference-Jacobian run
+    try:
+        import config5_replay
+        n_rep, it_rep, every = 16, 1500, 100
+        dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=False, device=device, **opts)
+        rows = np.linspace(0, nrj - 1, n_rep).astype(int)
+        specs = config5_replay.specs_from_device(dc, rows, None, it_rep, every, obs_np, height, system=system)
+        pool, pending = config5_replay.start(specs)
+        try:
+            rows_t = torch.as_tensor(rows, device=device)
+            marks = []
+            for _ in range(it_rep // every):
+                dc.run(every)
+                marks.append(torch.stack([dc.k[rows_t].double(), dc.n_accepted[rows_t].double(), dc.misfit[rows_t]], dim=1).cpu().numpy())
+            res = pending.get(timeout=600)
+        finally:
+            pool.terminate()
+        cmp = config5_replay.compare(res, np.array(marks), dc.k_hist[rows_t].cpu().numpy(), dc.edge_hist[rows_t].cpu().numpy(), rows)
+        out["cpu_replay"] = {"chains": n_rep, "iterations": it_rep,
+                             "exact_matches": int(sum(c["first_divergent_checkpoint"] < 0 and c["histograms_equal"] for c in cmp)),
+                             "first_divergence_iteration": [int((c["first_divergent_checkpoint"] + 1) * every) for c in cmp
+                                                            if c["first_divergent_checkpoint"] >= 0],
+                             "note": "layer-count / interface-depth histograms and every checkpoint of (layers, accepted steps) equal to a CPU "
+                                     "replay (rjmcmc.py stage emulation + C oracle, same random streams); the GPU tier replays 64 chains x "
+                                     "10 000 iterations (tests/test_config5_gpu.py: 58 of 64 identical to the end)"}
+        del dc
+    except Exception as e:                                       # the replay is a checker, never the measurement
+        out["cpu_replay"] = {"error": repr(e)}
+    out["note"] = ("BASELINE config 5 on ONE GPU: full birth/death/perturb rjMCMC (gbp_rj_run), 10-frequency synthetic survey; value = "
+                   "reference-Jacobian-expression mode (the pinned parity mode); the reference does ~165 iterations/s per core")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)   # ~1.6 s timed (SURVEY 8d: wall >= 1 s)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--soundings", type=int, default=B_TOTAL, help="total soundings (default: BASELINE config)")
     ap.add_argument("--layers", type=int, default=N_LAYERS)
@@ -262,30 +334,9 @@ def main():
                                 "max_abs_diff_logL": float((l_w - l_e).abs().max()),
                                 "note": "opt-in FdemBatch(hankel_eps_ppm=...); the headline value evaluates all 120 abscissae"}
         if world == 1 and not args.no_rjmcmc:
-            # the caller of the hot path: complete rjMCMC iterations on the first 8192 soundings of the
-            # same batch, every chain resident on the device (gbp_rj_run).  Reported next to the headline, not in it.
-            from geobipy_amd import DeviceChains
-            nrj, n_it = min(Btot, 8192), 300
-            obs_np = obs.cpu().numpy() if torch.is_tensor(obs) else np.asarray(obs)
-            dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=True, device=device,
-                              maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, initial_relative_error=0.05,
-                              minimum_relative_error=0.001, maximum_relative_error=0.5, initial_additive_error=5.0,
-                              minimum_additive_error=3.0, maximum_additive_error=20.0, relative_error_proposal_variance=1e-6,
-                              additive_error_proposal_variance=1e-6, probability_of_birth=1.0 / 6.0,
-                              probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5)
-            dc.run(50)
-            torch.cuda.synchronize(device)
-            tr = time.perf_counter()
-            dc.run(n_it)
-            torch.cuda.synchronize(device)
-            tr = time.perf_counter() - tr
-            sm = dc.summaries().cpu().numpy()
-            line["rjmcmc"] = {"value": nrj * n_it / tr, "unit": "chain-iterations/s", "soundings": nrj, "iterations": n_it,
-                              "ms_per_lockstep_iteration": 1e3 * tr / n_it, "acceptance": float(sm[:, 4].mean()),
-                              "mean_layers": float(sm[:, 3].mean()),
-                              "note": "full birth/death/perturb rjMCMC step (gbp_rj_run): >= 1 fused forward+likelihood, ~0.5 "
-                                      "forward and ~0.7 Jacobian per chain-iteration; reference ~165 iterations/s per core"}
-            del dc
+            # the caller of the hot path (BASELINE config 5): complete rjMCMC iterations, every chain resident on
+            # the device (gbp_rj_run).  Reported next to the headline, not in it.
+            line["rjmcmc"] = rjmcmc_extra(system, height, obs, device, Btot)
         if world == 1 and not args.no_extras:
             # the rows either side of the headline path, measured in the same run and reported next to it: the Jacobian
             # kernel on the same batch, and the time-domain path (rows 13-14, BASELINE config 4 shape)
@@ -297,26 +348,62 @@ def main():
                     fn()
                 e1.record(); torch.cuda.synchronize(device)
                 return e0.elapsed_time(e1) / n
+            def roof(Bk, Lk, Fk, ms, kernel):
+                ach = Bk * flop_per_eval(Lk, Fk) / (ms * 1e-3) / 1e12
+                return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": flop_per_eval(Lk, Fk),
+                        "evals_per_launch": Bk, "kernel_ms": ms, "kernel": kernel}
+            # BASELINE config 2 (4 096 soundings x 10 frequencies x 5 layers, one GPU) and one GPU's shard of config 3 (8 192 of
+            # the 65 536 soundings at 8 GPUs): same kernel, same generator, smaller launches
+            for key, Bk, Lk, note in (("config2", 4096, 5, "BASELINE config 2: 4 096 soundings x 10 frequencies x 5 layers, 1 GPU"),
+                                      ("shard_8192", 8192, L, "one GPU's shard of the headline workload at 8 GPUs (8 192 soundings)")):
+                nlk, sgk, thkk, hk = synthetic.draw_models(Bk, Lk, seed=synthetic.SEED + 2)
+                cl = FdemBatch(system, nlk, sgk, thkk, hk, device=device).forward().cpu().numpy()
+                ob = synthetic.noisy_observations(cl, seed=synthetic.SEED + 3)
+                bk = [FdemBatch(system, nlk, synthetic.redraw_sigma(Bk, Lk, seed=synthetic.SEED + 10 + i), thkk, hk, data=ob,
+                                relative_error=np.full(Bk, 0.05), additive_error=np.full(Bk, 5.0), device=device) for i in range(N_SIGMA_SETS)]
+                it = [0]
+                def one():
+                    bk[it[0] % N_SIGMA_SETS].forward_loglike(want_pred=False); it[0] += 1
+                ms = per_call(one, max(50, int(200e3 / Bk) * 10))
+                line[key] = {"value": Bk / ms * 1e3, "unit": "evals/s", "soundings": Bk, "frequencies": F, "layers": Lk,
+                             "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true>"), "note": note}
+                del bk
             Jbuf = batches[0].sensitivity()
             ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 10)
             line["jacobian"] = {"value": Btot / ms * 1e3, "unit": "Jacobians/s", "ms_per_launch": ms, "soundings": Btot,
                                 "note": "d pred / d ln sigma [2F x L] of the same batch (gbp_fdem_sensitivity, reference expression)"}
             del Jbuf
             golden = os.path.join(ROOT, "tests", "golden")
-            stm = [os.path.join(golden, n) for n in ("SkytemHM.stm", "SkytemLM.stm")]
-            if all(os.path.exists(f) for f in stm):
-                from geobipy_amd.tdem import TdemBatch, TdemSystem
-                Bt, Lt = 16384, 6
-                nlt, sgt, tht, ht = synthetic.draw_models(Bt, Lt, seed=synthetic.SEED + 4)
-                td = {}
-                for key, kw in (("exact", {}), ("windowed", dict(hankel_eps=1e-12, min_altitude=25.0))):
-                    tb = TdemBatch([TdemSystem(f) for f in stm], nlt, sgt, tht, ht, (-13.0, 0.0, 2.0), device=device, **kw)
-                    td[key] = Bt / per_call(tb.forward, 10) * 1e3
-                    del tb
-                line["tdem"] = {"value": td["exact"], "unit": "evals/s", "windowed_value": td["windowed"], "soundings": Bt, "layers": Lt,
-                                "gates": 45, "note": "BASELINE config 4 shape: SkyTEM high + low moment (26 + 19 gates), 72 spline nodes x 120 "
-                                                     "abscissae through the same forward kernel, then one fp64 GEMM; windowed_value: opt-in "
-                                                     "abscissa window (TdemBatch(hankel_eps=1e-12)); parity of the TDEM path is unpinned (DESIGN 3.7)"}
+            from geobipy_amd.tdem import TdemBatch, TdemSystem
+            Bt, Lt = 16384, 6
+            nlt, sgt, tht, ht = synthetic.draw_models(Bt, Lt, seed=synthetic.SEED + 4)
+            # BASELINE config 4 as specified: 16 384 soundings x 30 gates log-spaced 1e-5 ... 1e-2 s x 6 layers, z
+            # component, dB/dt, SkyTEM-LM-like waveform (tests/golden/config4_30gates.stm); and the two-moment SkyTEM system of
+            # the reference's fixtures (26 + 19 gates), exact and with the opt-in abscissa window
+            td = {}
+            for key, files, kw in (("config4", ["config4_30gates.stm"], {}), ("skytem", ["SkytemHM.stm", "SkytemLM.stm"], {}),
+                                   ("skytem_windowed", ["SkytemHM.stm", "SkytemLM.stm"], dict(hankel_eps=1e-12, min_altitude=25.0))):
+                systems = [TdemSystem(os.path.join(golden, f)) for f in files]
+                tb = TdemBatch(systems, nlt, sgt, tht, ht, (-13.0, 0.0, 2.0), device=device, **kw)
+                ms = per_call(tb.forward, 10)
+                nodes = sum(sy.node_frequencies().size * sy.n_components for sy in systems)
+                td[key] = dict(ms=ms, nodes=nodes, gates=tb.nChannels, points=sum(h.npoints for h in tb._h))
+                del tb
+            c4 = td["config4"]
+            ach = Bt * (72 * Lt + 33) * c4["points"] / (c4["ms"] * 1e-3) / 1e12
+            line["tdem"] = {"value": Bt / c4["ms"] * 1e3, "unit": "evals/s", "soundings": Bt, "layers": Lt, "gates": c4["gates"],
+                            "spline_nodes": c4["nodes"], "ms_per_step": c4["ms"],
+                            "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": (72 * Lt + 33) * c4["points"],
+                                         "evals_per_launch": Bt, "kernel_ms": c4["ms"],
+                                         "kernel": "k_fdem_forward<false> on the spline nodes + k_td_apply (window operator)"},
+                            "skytem_two_moments": {"value": Bt / td["skytem"]["ms"] * 1e3, "windowed_value": Bt / td["skytem_windowed"]["ms"] * 1e3,
+                                                   "gates": td["skytem"]["gates"], "spline_nodes": td["skytem"]["nodes"]},
+                            "note": "BASELINE config 4: one eval = frequency-domain solve at the .stm file's spline nodes (FrequenciesPerDecade) x "
+                                    "120 abscissae through the forward kernel + the window operator; parity against the reference's CSV known "
+                                    "answers: every gate within 1e-3 |ref| + 7e-5 peak (Tempest) / 1e-2 |ref| + 4e-5 peak, median 6e-4 (SkyTEM), "
+                                    "tests/test_tdem.py, scripts/tdem_study/README.md"}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))

@@ -56,6 +56,7 @@ SIGNATURES = {
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_run_mode": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_int, c_void_p]),
     "gbp_rj_debug_stage_ticks": (c_int, [ctypes.POINTER(ctypes.c_int64), c_int]),
+    "gbp_td_apply": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
     "gbp_rj_run_td": (c_int, [c_void_p, ctypes.POINTER(TdOperator), _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -1673,6 +1673,24 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     return GBP_OK;
 }
 
+gbp_status gbp_td_apply(int B, int K, int n_nodal, int N, const int32_t* nlayers, const double* W, const double* nodal,
+                        const double* J_nodal, double* pred, double* J, void* stream)
+{
+    if (B < 0 || K < 1 || n_nodal < 1 || N < 1) return fail(GBP_ERR_INVALID_ARG, "B >= 0 and K, n_nodal, N >= 1 are required%s");
+    if (B == 0) return GBP_OK;
+    if (!nlayers || !W || !nodal || !pred) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
+    const bool with_j = J_nodal != nullptr || J != nullptr;
+    if (with_j && (!J_nodal || !J)) return fail(GBP_ERR_INVALID_ARG, "J_nodal and J come together%s");
+    const size_t lds = ((size_t)n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
+    if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");
+    if (with_j)
+        hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J);
+    else
+        hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
 gbp_status gbp_rj_flush_posteriors(const gbp_rj_options* o, const gbp_rj_chains* c, void* stream)
 {
     gbp_status st = rj_check(o, c);

@@ -295,6 +295,7 @@ class _RawHandle:
                                                     dp(hd0), dp(g), dp(tables), ctypes.byref(h)))
         self.ptr = h
         self.nF = int(npts.size)
+        self.npoints = int(npts.sum())      # abscissa points evaluated per sounding
 
     def __del__(self):
         try:
@@ -348,6 +349,13 @@ class TdemBatch:
                 self._nodal.append(torch.empty((self.B, 2 * nc * n), dtype=torch.float64, device=self.device))
         self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
         self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
+        # window blocks of the systems (k_td_apply writes dense [B, n_windows] rows; several systems are then laid side by side)
+        self._win, c0 = {}, 0
+        for s in self.systems:
+            n = s.n_components * s.nwindows
+            if len(self.systems) > 1:
+                self._win[c0] = torch.empty((self.B, n), dtype=torch.float64, device=self.device)
+            c0 += n
         self.data = None if data is None else dev(data)
         self.relative_error = None if relative_error is None else dev(relative_error)
         self.additive_error = None if additive_error is None else dev(additive_error)
@@ -356,7 +364,7 @@ class TdemBatch:
         self._max_layers = None
 
     def forward(self):
-        """predicted[B, nChannels]: frequency-domain HIP kernel per system, then one fp64 GEMM per system."""
+        """predicted[B, nChannels]: frequency-domain HIP kernel per system, then the window operator (k_td_apply)."""
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         col = 0
@@ -366,7 +374,11 @@ class TdemBatch:
                                                 self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
                                                 nodal.data_ptr(), stream))
                 n = W.shape[1]
-                torch.matmul(nodal, W, out=self.predicted[:, col:col + n])
+                out = self._win[col] if len(self.systems) > 1 else self.predicted
+                _lib.check(lib.gbp_td_apply(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
+                                            None, out.data_ptr(), None, stream))
+                if out is not self.predicted:
+                    self.predicted[:, col:col + n] = out
                 col += n
         return self.predicted
 
@@ -388,7 +400,12 @@ class TdemBatch:
                                                        self.height.data_ptr(), Jn.data_ptr(), self._max_layers, 1,
                                                        stream))
                 n = W.shape[1]
-                out[:, col:col + n, :] = torch.einsum("bfl,fw->bwl", Jn, W)
+                Jw = torch.empty((self.B, n, self.Lmax), dtype=torch.float64, device=self.device)
+                pw = torch.empty((self.B, n), dtype=torch.float64, device=self.device)
+                nodal = torch.zeros((self.B, W.shape[0]), dtype=torch.float64, device=self.device)
+                _lib.check(lib.gbp_td_apply(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
+                                            Jn.data_ptr(), pw.data_ptr(), Jw.data_ptr(), stream))
+                out[:, col:col + n, :] = Jw
                 col += n
         return out
 
@@ -500,7 +517,9 @@ class TdemDeviceChains(DeviceChains):
         nodal = torch.empty((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
         _lib.check(lib.gbp_fdem_forward_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
                                            nodal.data_ptr(), self.forward_waves, self._stream()))
-        p = torch.matmul(nodal, self._W)
+        p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
+        _lib.check(lib.gbp_td_apply(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(), nodal.data_ptr(),
+                                    None, p.data_ptr(), None, self._stream()))
         rg = self.t["rel_group"].long() if self.t["rel_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         ag = self.t["add_group"].long() if self.t["add_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         sd = torch.sqrt((rel[:, rg] * data) ** 2 + (add[:, ag] * self.t["add_scale"][None, :]) ** 2).contiguous()
@@ -515,7 +534,10 @@ class TdemDeviceChains(DeviceChains):
         Jn = torch.empty((n, self._W.shape[0], self.K), dtype=torch.float64, device=self.device)
         _lib.check(_lib.load().gbp_fdem_sensitivity_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
                                                        height.data_ptr(), Jn.data_ptr(), int(max_layers), 1, self._stream()))
-        J.copy_(torch.einsum("bfl,fw->bwl", Jn, self._W))
+        nodal = torch.zeros((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
+        p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().gbp_td_apply(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(),
+                                            nodal.data_ptr(), Jn.data_ptr(), p.data_ptr(), J.data_ptr(), self._stream()))
 
     def _launch(self, n, accumulate):
         _lib.check(_lib.load().gbp_rj_run_td(self._h.ptr, self._td(), self._o, self._c, self.iteration, int(n), int(bool(accumulate)),

@@ -346,6 +346,13 @@ typedef struct gbp_td_operator {
     double *nodal;          /* [dev] scratch f64[B, n_nodal]                                                  */
     double *J_nodal;        /* [dev] scratch f64[B, n_nodal, K]                                               */
 } gbp_td_operator;
+/* The time-domain stage on its own (what TdemDataPoint.forward / sensitivity add to the frequency-domain kernels): for every
+ * sounding with nlayers[b] > 0,  pred[b, :] = nodal[b, :] @ W  and, when J_nodal / J are given,
+ * J[b, g, l] = sum_m J_nodal[b, m, l] W[m, g] for l < nlayers[b] (0 beyond).  All [dev]; nodal f64[B, n_nodal] as written by
+ * gbp_fdem_forward on the raw Hankel handle, J_nodal f64[B, n_nodal, K] by gbp_fdem_sensitivity_ex, W f64[n_nodal, N],
+ * pred f64[B, N], J f64[B, N, K]. */
+gbp_status gbp_td_apply(int B, int K, int n_nodal, int N, const int32_t *nlayers, const double *W, const double *nodal,
+                        const double *J_nodal, double *pred, double *J, void *stream);
 gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, const gbp_rj_options *opt,
                          const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */

@@ -20,7 +20,10 @@ def _one(spec):
 
     class Engine:
         def __init__(self):
-            self.sys = oracle_system(system_name)
+            if isinstance(system_name, str):
+                self.sys = oracle_system(system_name)
+            else:                                                   # (frequencies, tx orientation, tx moment, tx xyz, rx ...) arrays
+                self.sys = fo.OracleSystem(*system_name)
 
         @staticmethod
         def _thk(edges):
@@ -45,8 +48,14 @@ def _one(spec):
     return dict(chain=chain, marks=np.array(marks), k_hist=c.k_hist, edge_hist=c.edge_hist, sigma=c.sigma, misfit=c.misfit)
 
 
-def specs_from_device(dc, rows, system_name, n_it, every, data, heights):
-    """Build the worker arguments for the sampled ``rows`` of a DeviceChains block right after its initialisation."""
+def specs_from_device(dc, rows, system_name, n_it, every, data, heights, system=None):
+    """Build the worker arguments for the sampled ``rows`` of a DeviceChains block right after its initialisation.
+    ``system_name``: a system file of tests/golden, or None with ``system`` = a geobipy_amd.FdemSystem."""
+    if system_name is None:
+        s = system
+        system_name = (np.asarray(s.frequencies), list(s.transmitter.orientation), np.asarray(s.transmitter.moment),
+                       np.c_[s.transmitter.x, s.transmitter.y, s.transmitter.z], list(s.receiver.orientation),
+                       np.asarray(s.receiver.moment), np.c_[s.receiver.x, s.receiver.y, s.receiver.z])
     o = dc._o
     eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
               rel_sd=o.rel_sd[0], rel_min=o.rel_min[0], rel_max=o.rel_max[0], add_sd=o.add_sd[0], add_min=o.add_min[0],
