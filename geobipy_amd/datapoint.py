@@ -4,8 +4,10 @@ Mirrors (names, argument meaning, error behaviour) the hot-path members of
 ``geobipy/src/classes/data/datapoint/{DataPoint,EmDataPoint,FdemDataPoint}.py``:
 ``forward`` (:524-545), ``sensitivity`` / ``fm_dlogc`` (:530-559), ``std`` (DataPoint.py:268-282),
 ``active`` (EmDataPoint.py:44-56), ``deltaD`` (DataPoint.py:200-214), ``data_misfit`` (:502-525),
-``likelihood`` (:491-500).  Each call is a B = 1 launch of the same kernels ``FdemBatch`` uses; a
-datapoint keeps no CPU implementation of any of them.
+``likelihood`` (:491-500), and the rjMCMC members ``Inference1D.accept_reject`` calls: ``perturb`` (:531-573),
+``probability`` (:454-489), ``set_priors`` / ``set_proposals`` (:575-644).  Each forward / Jacobian / likelihood call is a
+B = 1 launch of the same kernels ``FdemBatch`` uses; a datapoint keeps no CPU implementation of any of them (the CPU test
+tier injects the oracle through the ``engine`` hook).
 """
 from copy import deepcopy
 
@@ -34,6 +36,11 @@ class FdemDataPoint:
         self._relative_error = np.full(self.nSystems, 0.01)
         self._additive_error = np.zeros(self.nSystems)
         self._sensitivity_matrix = None
+        self._rel_prior = self._add_prior = None              # rjmcmc.ErrorPrior once set_priors / set_proposals ran
+        self._prng = None
+        # TEST HOOK: an object with forward(edges, values) / sensitivity(edges, values) replaces the GPU launches (the CPU
+        # tier passes the C oracle); the product never sets it -- without it a missing GPU / library raises
+        self.engine = None
 
     # -- system -------------------------------------------------------------------------------
     @property
@@ -129,7 +136,7 @@ class FdemDataPoint:
         for k, v in self.__dict__.items():
             if k == "_ws":
                 continue                      # device workspace is per object, rebuilt lazily
-            setattr(out, k, v if k == "_system" else deepcopy(v, memo))
+            setattr(out, k, v if k in ("_system", "_prng", "engine") else deepcopy(v, memo))   # shared, like the reference's system / prng
         return out
 
     # -- hot path: every call below is a GPU launch ----------------------------------------------
@@ -190,11 +197,18 @@ class FdemDataPoint:
                          data=self._data[None, :], relative_error=self._relative_error[:1],
                          additive_error=self._additive_error[:1])
 
+    def _engine_model(self, mod):
+        assert np.isinf(mod.mesh.edges[-1]), ValueError("mod.edges must have last entry be infinity for forward modelling.")
+        return np.asarray(mod.mesh.edges[1:-1], dtype=np.float64), np.asarray(mod.values, dtype=np.float64)
+
     def forward(self, mod):
         """Forward model the data from the given model (FdemDataPoint.py:524-545)."""
+        assert isinstance(mod, Model), TypeError("Invalid model class for forward modeling [1D]")
+        if self.engine is not None:
+            self._predictedData[:] = self.engine.forward(*self._engine_model(mod))
+            return
         import torch
         from . import _lib
-        assert isinstance(mod, Model), TypeError("Invalid model class for forward modeling [1D]")
         ws = self._workspace()
         L = self._pack(ws, mod)
         if L is None:                       # deeper than the packed workspace: generic path
@@ -218,7 +232,10 @@ class FdemDataPoint:
     def sensitivity(self, mod, **kwargs):
         """J[2F, L] = d predictedData / d ln(sigma) (FdemDataPoint.py:530-559)."""
         assert isinstance(mod, Model), TypeError("Invalid model class for sensitivity matrix [1D]")
-        self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0]
+        if self.engine is not None:
+            self._sensitivity_matrix = np.asarray(self.engine.sensitivity(*self._engine_model(mod)))
+            return self._sensitivity_matrix
+        self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0][:, : int(mod.mesh.nCells)]
         return self._sensitivity_matrix
 
     def fm_dlogc(self, mod):
@@ -228,6 +245,9 @@ class FdemDataPoint:
         self.sensitivity(mod)
 
     def _loglike(self):
+        if self.engine is not None:
+            from . import rjmcmc
+            return rjmcmc.gauss_loglike(self._predictedData, self._data, self.std)
         import torch
         from . import _lib
         ws = self._workspace()
@@ -265,3 +285,53 @@ class FdemDataPoint:
         """Gaussian likelihood of the predicted data (DataPoint.py:491-500, MvNormalDistribution.py:201-216)."""
         ll = self._loglike()[1]
         return np.float64(ll) if log else np.float64(np.exp(ll))
+
+    # -- rjMCMC members (DataPoint.py:454-489, 531-644): error-level priors, proposals and moves --------------------------
+    def set_priors(self, relative_error_prior=None, additive_error_prior=None, data_prior=None, **kwargs):
+        """DataPoint.set_priors (:575-595): log-uniform priors [minimum, maximum] on the error levels that are solved for
+        (options-file keys solve_relative_error, minimum_relative_error, maximum_relative_error and the additive twins);
+        ``prng`` is remembered for perturb().  The data prior of the reference is the Gaussian likelihood itself
+        (observed data, diagonal covariance std^2) and needs no object here."""
+        from . import rjmcmc
+        self._prng = kwargs.get("prng", self._prng)
+        if relative_error_prior is None and kwargs.get("solve_relative_error", False):
+            relative_error_prior = (kwargs["minimum_relative_error"], kwargs["maximum_relative_error"])
+        if additive_error_prior is None and kwargs.get("solve_additive_error", False):
+            additive_error_prior = (kwargs["minimum_additive_error"], kwargs["maximum_additive_error"])
+        var = lambda p: p.var if p is not None else 0.0
+        if relative_error_prior is not None:
+            lo, hi = (np.atleast_1d(v).astype(np.float64)[0] for v in relative_error_prior)
+            self._rel_prior = rjmcmc.ErrorPrior(lo, hi, var(self._rel_prior))
+        if additive_error_prior is not None:
+            lo, hi = (np.atleast_1d(v).astype(np.float64)[0] for v in additive_error_prior)
+            self._add_prior = rjmcmc.ErrorPrior(lo, hi, var(self._add_prior))
+
+    def set_proposals(self, relative_error_proposal=None, additive_error_proposal=None, **kwargs):
+        """DataPoint.set_proposals (:597-644): log-normal random walks with the options file's proposal variances."""
+        self._prng = kwargs.get("prng", self._prng)
+        if relative_error_proposal is None and kwargs.get("solve_relative_error", False):
+            relative_error_proposal = kwargs["relative_error_proposal_variance"]
+        if additive_error_proposal is None and kwargs.get("solve_additive_error", False):
+            additive_error_proposal = kwargs["additive_error_proposal_variance"]
+        for prior, v in ((self._rel_prior, relative_error_proposal), (self._add_prior, additive_error_proposal)):
+            if v is not None:
+                assert prior is not None, ValueError("set_priors must come before set_proposals")
+                prior.var = float(np.atleast_1d(v)[0])
+
+    def perturb(self):
+        """DataPoint.perturb (:531-573): relative then additive error, each redrawn while outside its prior (the current
+        value is kept at the 10th redraw, StatArray.propose :620-638)."""
+        if self._rel_prior is not None and self._rel_prior.var > 0.0:
+            self._relative_error = np.atleast_1d(self._rel_prior.propose(self._prng, float(self._relative_error[0])))
+        if self._add_prior is not None and self._add_prior.var > 0.0:
+            self._additive_error = np.atleast_1d(self._add_prior.propose(self._prng, float(self._additive_error[0])))
+
+    @property
+    def probability(self):
+        """DataPoint.probability (:454-489): sum of the log priors of the error levels that have one."""
+        p = np.float64(0.0)
+        if self._rel_prior is not None:
+            p += self._rel_prior.log_prior(float(self._relative_error[0]))
+        if self._add_prior is not None:
+            p += self._add_prior.log_prior(float(self._additive_error[0]))
+        return p

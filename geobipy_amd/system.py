@@ -30,7 +30,8 @@ class CircularLoop:
         self.x, self.y, self.z = arr(x), arr(y), arr(z)
         self.moment = arr(moment, 1.0)
         self.pitch, self.roll, self.yaw = arr(pitch), arr(roll), arr(yaw)
-        self.radius = arr(radius, 1.0)
+        self.radius = arr(radius, 0.0)              # the reference default (CircularLoop.py:36-40: zeros)
+        self.elevation = arr(elevation, 0.0)
         self._orientation = np.full(n, 2, dtype=np.int32)
         if orientation is not None:
             self.orientation = orientation

@@ -1,0 +1,130 @@
+"""SURVEY 8b "Python object API kept": the worker loop of the reference's harness (inversion/Inference3D.py:608-620) and the
+body of its Inference1D.accept_reject (inversion/Inference1D.py:537-631) written against geobipy_amd's objects.
+
+  * ``Inference1D(prng=..., world=..., **options)``, ``.initialize(datapoint)``, ``failed = .infer(hdf_file_handle=...)`` -- the
+    three calls of ``_infer_mpi_worker_task`` -- reproduce the reference's own infer() runs (tests/golden/mcmc_reset.npz:
+    iteration counter, decision and restart counters after every update, number of updates, return value);
+  * ``Model.perturb / probability / proposal_probabilities`` and ``FdemDataPoint.perturb / probability / forward /
+    data_misfit / likelihood`` in the reference's call order walk the reference's seeded chain decision by decision
+    (tests/golden/mcmc_detail.npz: 3000 recorded decisions, layer counts and misfits of the reference run).
+CPU tier: the data point's ``engine`` hook carries the C oracle; the GPU tier runs the same sequence on the kernels."""
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_rjmcmc import RESOLVE_OPTIONS, OracleEngine, generator_at
+
+
+def _datapoint(engine=True):
+    from geobipy_amd import FdemDataPoint, FdemSystem
+    d = np.load(os.path.join(GOLDEN, "mcmc_detail.npz"))
+    dp = FdemDataPoint(x=30.0, y=0.0, z=float(d["z"]), elevation=0.0, data=d["data"],
+                       system=FdemSystem.read(os.path.join(GOLDEN, "resolve.stm")), lineNumber=0.0, fiducial=30.0)
+    if engine:
+        dp.engine = OracleEngine("resolve", float(d["z"]))
+    return d, dp
+
+
+def test_worker_task_call_sequence_reproduces_the_reference_infer():
+    from geobipy_amd import Inference1D
+    r = np.load(os.path.join(GOLDEN, "mcmc_reset.npz"))
+    for name in ("free", "short", "stuck1"):
+        window, reset_limit, n_mc, pinned, failed, updates, n_resets = (int(x) for x in r[name + "_meta"])
+        d, datapoint = _datapoint()
+        options = dict(RESOLVE_OPTIONS, n_markov_chains=n_mc, update_plot_every=window, reset_limit=reset_limit,
+                       save_hdf5=False, interactive_plot=True, covariance_scaling=None, parameter_limits=None, seed=1,
+                       data_type="FdemData", system_filename="resolve.stm")          # (the harness passes every key of the file)
+        if pinned:
+            options["parameter_limits"] = r[name + "_limits"]
+        # -- Inference3D._infer_mpi_worker_task, lines 617-620 ------------------------------------------------------------------
+        inference = Inference1D(prng=generator_at(d["rng_state"][0]), world=None, **options)
+        inference.initialize(datapoint)
+        rows = []
+        inference.on_update = lambda s: rows.append((s.iteration, int(s.accepted), s.n_resets, s.n_zero_acceptance, int(s.burned_in)))
+        got = inference.infer(hdf_file_handle=None)
+        # ------------------------------------------------------------------------------------------------------------------------
+        assert got is bool(failed), name
+        assert np.array_equal(np.array(rows), r[name + "_trace"]) and len(rows) == updates and inference.n_resets == n_resets, name
+        assert inference.datapoint is datapoint and inference.datapoint.n_active_channels == 12
+
+
+def _reference_accept_reject(self):
+    """The body of the reference's Inference1D.accept_reject (inversion/Inference1D.py:537-631), statement for statement, on
+    ``self`` = a small holder of (prng, model, datapoint, prior, likelihood, options) built from geobipy_amd objects."""
+    self.prng.random()                                          # the draw inside the debug f-string (:542)
+    test_datapoint = deepcopy(self.datapoint)
+    observation = test_datapoint
+    remapped_model, test_model = self.model.perturb(observation, self.low_variance, self.high_variance, alpha=self.covariance_scaling)
+    test_datapoint.perturb()
+    test_datapoint.forward(test_model)
+    test_data_misfit = test_datapoint.data_misfit()
+    test_prior = test_datapoint.probability
+    if test_prior == -np.inf:
+        self.accepted = False
+        return
+    test_prior += test_model.probability(self.solve_parameter, self.solve_gradient)
+    if test_prior == -np.inf:
+        self.accepted = False
+        return
+    test_likelihood = test_datapoint.likelihood(log=True)
+    proposal, test_proposal = test_model.proposal_probabilities(remapped_model, test_datapoint, alpha=self.covariance_scaling)
+    log_acceptance_ratio = (test_prior - self.prior) + (test_likelihood - self.likelihood) + (proposal - test_proposal)
+    with np.errstate(invalid="ignore", over="ignore"):
+        acceptance_probability = np.inf if log_acceptance_ratio > 11356.0 else np.exp(np.longdouble(log_acceptance_ratio))   # expReal
+        self.accepted = bool(acceptance_probability > self.prng.uniform())
+    if self.accepted:
+        self.data_misfit, self.prior, self.likelihood = test_data_misfit, test_prior, test_likelihood
+        self.model, self.datapoint = test_model, test_datapoint
+
+
+class _Holder:
+    pass
+
+
+def _setup(dp, d):
+    """Inference1D.initialize with the objects' own methods: best half-space, priors, proposals, initial probabilities."""
+    from geobipy_amd import Model, RectilinearMesh1D
+    o = dict(RESOLVE_OPTIONS, solve_relative_error=True, solve_additive_error=True, factor=10.0, gradient_standard_deviation=1.5)
+    prng = generator_at(d["rng_state"][0])
+    dp.relative_error, dp.additive_error = o["initial_relative_error"], o["initial_additive_error"]
+    dp.set_priors(prng=prng, **o)
+    dp.set_proposals(prng=prng, **o)
+    half = d["halfspace"].item()
+    model = Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, np.inf]), values=np.r_[half]).set_priors(prng=prng, value_mean=half, **o)
+    dp.fm_dlogc(model)
+    h = _Holder()
+    h.prng, h.model, h.datapoint = prng, model, dp
+    h.low_variance, h.high_variance, h.covariance_scaling = -np.inf, np.inf, 1.0
+    h.solve_parameter, h.solve_gradient = False, True
+    h.data_misfit = dp.data_misfit()
+    h.prior = model.probability(h.solve_parameter, h.solve_gradient) + dp.probability
+    h.likelihood = dp.likelihood(log=True)
+    return h
+
+
+def _check_chain(h, d, n):
+    acc, ks, mis = [], [], []
+    for _ in range(n):
+        _reference_accept_reject(h)
+        acc.append(h.accepted); ks.append(int(h.model.nCells)); mis.append(h.data_misfit)
+    assert np.array_equal(np.array(acc), d["long_accepted"][:n].astype(bool))
+    assert np.array_equal(np.array(ks), d["long_k"][:n]) and np.allclose(mis, d["long_misfit"][:n], rtol=1e-6)
+    assert sum(acc) > 0.3 * n and max(ks) >= 3
+
+
+def test_reference_accept_reject_body_on_these_objects_walks_the_reference_chain():
+    d, dp = _datapoint()
+    h = _setup(dp, d)
+    assert np.isclose(h.prior, d["cur_prior"][0], rtol=1e-12) and np.isclose(h.likelihood, d["cur_like"][0], rtol=1e-12)
+    _check_chain(h, d, 1000)
+
+
+@pytest.mark.gpu
+def test_reference_accept_reject_body_on_the_gpu_objects():
+    """The same sequence with nothing injected: every forward / Jacobian / likelihood of the objects is a kernel launch."""
+    d, dp = _datapoint(engine=False)
+    assert dp.engine is None
+    _check_chain(_setup(dp, d), d, 300)
