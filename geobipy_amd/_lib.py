@@ -56,6 +56,11 @@ SIGNATURES = {
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_run_mode": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_int, c_void_p]),
     "gbp_rj_debug_stage_ticks": (c_int, [ctypes.POINTER(ctypes.c_int64), c_int]),
+    "gbp_tdem_system_create": (c_int, [ctypes.c_char_p, c_double_p, c_double_p, ctypes.POINTER(c_void_p)]),
+    "gbp_tdem_system_destroy": (None, [c_void_p]),
+    "gbp_tdem_system_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_double_p]),
+    "gbp_tdem_system_tables": (c_int, [c_void_p, c_double_p, c_double_p, c_double_p]),
+    "gbp_tdem_forward": (c_int, [c_void_p, c_int, c_double_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gbp_td_apply": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
     "gbp_rj_run_td": (c_int, [c_void_p, ctypes.POINTER(TdOperator), _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),

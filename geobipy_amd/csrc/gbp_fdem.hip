@@ -884,3 +884,4 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
 }  // extern "C"
 
 #include "gbp_rjmcmc.h"
+#include "gbp_tdem.h"

@@ -1,0 +1,448 @@
+// gbp_tdem.h -- C-level time-domain system (include/geobipy_amd.h, "Time-domain systems"): the counterpart of
+// gatdaem1d.TDAEMSystem(stmfile) / .forwardmodel(Geometry, Earth) as the reference calls it
+// (forwardmodelling/Electromagnetic/TD/tdem1d.py:89-96, system/TdemSystem_GAAEM.py:8-35, system/Loop_pair.py:63-77).
+// Host code only; the device work is gbp_fdem_forward (spline-node spectra on a raw Hankel handle) + k_td_apply (windows).
+// Included at the end of gbp_fdem.hip.  Same pipeline and conventions as geobipy_amd/tdem.py (which the parity tests hold
+// against the reference's CSV known answers): nodes at BaseFrequency * 10^(i / FrequenciesPerDecade), natural cubic spline
+// of Re / Im in log10 f, periodic bipolar waveform by FFT over one period, first-order low-pass sections, area-under-curve
+// or boxcar (+- 1e-7 s) windows, all folded into one matrix W[2 * n_nodes, n_windows] per system.
+#pragma once
+
+#include <map>
+#include <string>
+#include <tuple>
+
+namespace td {
+
+typedef std::complex<double> zc;
+constexpr double PI = 3.14159265358979323846264338327950288;
+constexpr double MU0 = 4.0e-7 * PI;
+
+// ---- FFT of any length (Bluestein on a radix-2 kernel); forward transform, unnormalised ---------------------------------
+inline void fft_pow2(std::vector<zc>& a, bool inverse)
+{
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = 2.0 * PI / (double)len * (inverse ? 1.0 : -1.0);
+        std::vector<zc> w(len / 2);
+        for (size_t k = 0; k < len / 2; ++k) w[k] = zc(std::cos(ang * (double)k), std::sin(ang * (double)k));
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const zc u = a[i + k], v = a[i + k + len / 2] * w[k];
+                a[i + k] = u + v;
+                a[i + k + len / 2] = u - v;
+            }
+    }
+}
+
+inline std::vector<zc> fft_any(const std::vector<zc>& x)
+{
+    const size_t n = x.size();
+    if ((n & (n - 1)) == 0) { std::vector<zc> a = x; fft_pow2(a, false); return a; }
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    std::vector<zc> chirp(n), a(m, zc(0, 0)), b(m, zc(0, 0));
+    for (size_t k = 0; k < n; ++k) {
+        const unsigned long long k2 = ((unsigned long long)k * k) % (2ULL * n);        // k^2 mod 2n keeps the angle small
+        const double ang = -PI * (double)k2 / (double)n;
+        chirp[k] = zc(std::cos(ang), std::sin(ang));
+    }
+    for (size_t k = 0; k < n; ++k) a[k] = x[k] * chirp[k];
+    b[0] = std::conj(chirp[0]);
+    for (size_t k = 1; k < n; ++k) b[k] = b[m - k] = std::conj(chirp[k]);
+    fft_pow2(a, false); fft_pow2(b, false);
+    for (size_t k = 0; k < m; ++k) a[k] *= b[k];
+    fft_pow2(a, true);
+    std::vector<zc> out(n);
+    for (size_t k = 0; k < n; ++k) out[k] = a[k] * chirp[k] / (double)m;
+    return out;
+}
+
+inline double interp1(const std::vector<double>& xp, const std::vector<double>& fp, double x)      // numpy.interp
+{
+    if (x <= xp.front()) return fp.front();
+    if (x >= xp.back()) return fp.back();
+    size_t hi = std::upper_bound(xp.begin(), xp.end(), x) - xp.begin();
+    const size_t lo = hi - 1;
+    return fp[lo] + (fp[hi] - fp[lo]) * (x - xp[lo]) / (xp[hi] - xp[lo]);
+}
+
+// second derivatives of the natural cubic spline through (x, y)
+inline std::vector<double> spline_m(const std::vector<double>& x, const std::vector<double>& y)
+{
+    const int n = (int)x.size();
+    std::vector<double> m(n, 0.0), cp(n, 0.0), dp(n, 0.0);
+    for (int i = 1; i < n - 1; ++i) {
+        const double h0 = x[i] - x[i - 1], h1 = x[i + 1] - x[i];
+        const double a = h0, b = 2.0 * (h0 + h1), c = h1, d = 6.0 * ((y[i + 1] - y[i]) / h1 - (y[i] - y[i - 1]) / h0);
+        const double den = b - a * cp[i - 1];
+        cp[i] = c / den;
+        dp[i] = (d - a * dp[i - 1]) / den;
+    }
+    for (int i = n - 2; i >= 1; --i) m[i] = dp[i] - cp[i] * m[i + 1];
+    return m;
+}
+
+inline double spline_eval(const std::vector<double>& x, const std::vector<double>& y, const std::vector<double>& m, double t)
+{
+    int hi = (int)(std::upper_bound(x.begin(), x.end(), t) - x.begin());
+    hi = std::min(std::max(hi, 1), (int)x.size() - 1);
+    const int lo = hi - 1;
+    const double h = x[hi] - x[lo], A = (x[hi] - t) / h, B = (t - x[lo]) / h;
+    return A * y[lo] + B * y[hi] + ((A * A * A - A) * m[lo] + (B * B * B - B) * m[hi]) * h * h / 6.0;
+}
+
+struct Stm {
+    std::map<std::string, std::string> kv;
+    std::vector<double> wt, wc, w_lo, w_hi;
+    double num(const char* k, double dflt) const
+    {
+        auto it = kv.find(k);
+        return it == kv.end() ? dflt : std::atof(it->second.c_str());
+    }
+    std::string str(const char* k, const char* dflt) const
+    {
+        auto it = kv.find(k);
+        return it == kv.end() ? std::string(dflt) : it->second;
+    }
+};
+
+inline std::string trim(const std::string& s)
+{
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+
+inline bool parse_stm(const char* text, Stm* out)
+{
+    std::string all(text), line;
+    int mode = 0;
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        size_t e = all.find('\n', pos);
+        if (e == std::string::npos) e = all.size();
+        line = all.substr(pos, e - pos);
+        pos = e + 1;
+        const size_t cm = line.find("//");
+        if (cm != std::string::npos) line = line.substr(0, cm);
+        line = trim(line);
+        if (line.empty()) continue;
+        if (line.find("WaveFormCurrent Begin") != std::string::npos) mode = 1;
+        else if (line.find("WindowTimes Begin") != std::string::npos) mode = 2;
+        else if ((line.size() >= 4 && line.compare(line.size() - 4, 4, " End") == 0) || line == "End") mode = 0;
+        else if (mode != 0) {
+            double a = 0, b = 0;
+            if (std::sscanf(line.c_str(), "%lf %lf", &a, &b) != 2) return false;
+            if (mode == 1) { out->wt.push_back(a); out->wc.push_back(b); } else { out->w_lo.push_back(a); out->w_hi.push_back(b); }
+        } else {
+            const size_t eq = line.find('=');
+            if (eq != std::string::npos) out->kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
+        }
+    }
+    return !out->wt.empty() && !out->w_lo.empty() && out->kv.count("BaseFrequency") && out->kv.count("WaveformDigitisingFrequency");
+}
+
+inline std::vector<double> numbers(const std::string& s)
+{
+    std::vector<double> v;
+    const char* p = s.c_str();
+    char* end = nullptr;
+    for (double x = std::strtod(p, &end); p != end; x = std::strtod(p, &end)) { v.push_back(x); p = end; }
+    return v;
+}
+
+}  // namespace td
+
+struct gbp_tdem_system {
+    td::Stm stm;
+    double f0 = 0, fs = 0, moment = 1, loop_radius = 0, scale_x = 0, scale_z = 0;
+    bool dbdt = true, area = false;
+    int n_samples = 0, n_windows = 0, n_components = 0, n_nodes = 0;
+    bool has_x = false, has_z = false;
+    std::vector<double> nodes, centres, W;       // W[2 n_nodes][n_windows] of ONE component (components share it)
+    std::vector<double> w0, w1;                  // Hankel filter weights (J0: 120, J1: 140)
+    std::vector<double> Wb;                      // block matrix for k_td_apply: [2 nc n_nodes][nc n_windows]
+    double* d_Wb = nullptr;
+    std::map<std::tuple<double, double, double>, gbp_fdem_system*> handles;      // raw Hankel handles by receiver offset
+    std::vector<double> h_height;                // staging of the altitudes of the last forward call
+};
+
+namespace td {
+
+inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
+{
+    const Stm& m = s->stm;
+    s->f0 = m.num("BaseFrequency", 0.0);
+    s->fs = m.num("WaveformDigitisingFrequency", 0.0);
+    if (!(s->f0 > 0.0) || !(s->fs > 2.0 * s->f0)) { *msg = "BaseFrequency / WaveformDigitisingFrequency missing or inconsistent"; return GBP_ERR_BAD_SYSTEM; }
+    s->moment = m.num("NumberOfTurns", 1.0) * m.num("PeakCurrent", 1.0) * m.num("LoopArea", 1.0);
+    s->loop_radius = m.num("ModellingLoopRadius", 0.0);
+    s->scale_x = m.num("XOutputScaling", 0.0);
+    s->scale_z = m.num("ZOutputScaling", 0.0);
+    if (m.num("YOutputScaling", 0.0) != 0.0) { *msg = "Y component output is not supported"; return GBP_ERR_BAD_SYSTEM; }
+    s->has_x = s->scale_x != 0.0; s->has_z = s->scale_z != 0.0;
+    s->n_components = (int)s->has_x + (int)s->has_z;
+    if (s->n_components == 0) { *msg = "no output component has a non-zero scaling"; return GBP_ERR_BAD_SYSTEM; }
+    const std::string ot = m.str("OutputType", "dB/dt");
+    s->dbdt = ot.size() >= 2 && (ot[0] == 'd' || ot[0] == 'D') && (ot[1] == 'b' || ot[1] == 'B');
+    const std::string ws = m.str("WindowWeightingScheme", "Boxcar");
+    s->area = ws.size() >= 4 && (ws[0] == 'A' || ws[0] == 'a');
+    const int N = s->n_samples = (int)std::llround(s->fs / s->f0);
+    const int nw = s->n_windows = (int)m.w_lo.size();
+    s->centres.resize(nw);
+    for (int w = 0; w < nw; ++w) {
+        s->centres[w] = 0.5 * (m.w_lo[w] + m.w_hi[w]);
+        if (w > 0 && !(s->centres[w] > s->centres[w - 1])) { *msg = "Receiver window times must monotonically increase"; return GBP_ERR_BAD_SYSTEM; }
+    }
+    // spline nodes: f0 * 10^(i / fpd), one below the base frequency, up to the first at or above Nyquist
+    const double fpd = m.num("FrequenciesPerDecade", 5.0);
+    const int n_up = (int)std::ceil(std::log10(0.5 * s->fs / s->f0) * fpd - 1e-9) + 1;
+    s->nodes.clear();
+    for (int i = -1; i < n_up; ++i) s->nodes.push_back(s->f0 * std::pow(10.0, (double)i / fpd));
+    const int n = s->n_nodes = (int)s->nodes.size();
+    if (2 * n * s->n_components > 2 * GBP_MAX_FREQ) { *msg = "too many spline nodes x components (limit 128)"; return GBP_ERR_BAD_SYSTEM; }
+    // digitised current over one period (a table spanning half a period continues with opposite polarity)
+    const double dt = 1.0 / s->fs, T = 1.0 / s->f0, t0 = m.wt.front();
+    std::vector<zc> cur(N, zc(0, 0));
+    if (std::fabs((m.wt.back() - m.wt.front()) - 0.5 * T) <= 2.0 / s->fs) {
+        const int half = N / 2;
+        for (int i = 0; i < half; ++i) {
+            const double c = interp1(m.wt, m.wc, t0 + (double)i * dt);
+            cur[i] = c; cur[half + i] = -c;
+        }
+    } else {
+        for (int i = 0; i < N; ++i) cur[i] = interp1(m.wt, m.wc, t0 + (double)i * dt);
+    }
+    const std::vector<zc> I = fft_any(cur);
+    const int nh = N / 2 + 1;
+    // g_k = I_k * mu0 * moment * (-i 2 pi f_k for dB/dt) * prod (1 / (1 + i f_k / fc))^order ; g_0 = 0
+    const std::vector<double> fc = numbers(m.str("CutOffFrequency", "")), ord = numbers(m.str("Order", ""));
+    std::vector<zc> g(nh);
+    for (int k = 0; k < nh; ++k) {
+        const double f = (double)k * s->f0;
+        zc fac(MU0 * s->moment, 0.0);
+        if (s->dbdt) fac *= zc(0.0, -2.0 * PI * f);
+        for (size_t q = 0; q < fc.size() && q < ord.size(); ++q) {
+            const zc sec = 1.0 / zc(1.0, f / fc[q]);
+            for (int r = 0; r < (int)ord[q]; ++r) fac *= sec;
+        }
+        g[k] = k == 0 ? zc(0, 0) : I[k] * fac;
+    }
+    // natural cubic spline basis of the nodes at the harmonics (log10 f, clipped to the node range)
+    std::vector<double> x(n);
+    for (int j = 0; j < n; ++j) x[j] = std::log10(s->nodes[j]);
+    std::vector<double> S((size_t)nh * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        std::vector<double> e(n, 0.0);
+        e[j] = 1.0;
+        const std::vector<double> mm = spline_m(x, e);
+        for (int k = 1; k < nh; ++k) {
+            const double f = std::min(std::max((double)k * s->f0, s->nodes.front()), s->nodes.back());
+            S[(size_t)k * n + j] = spline_eval(x, e, mm, std::log10(f));
+        }
+    }
+    // windows: B_w,k = conj(fft(A_w)[k]);  sum_t A_w[t] x_t = (1/N) sum_k c_k Re(X_k B_w,k),  c = 1, 2, ..., 2, (1 if N even)
+    s->W.assign((size_t)2 * n * nw, 0.0);
+    for (int w = 0; w < nw; ++w) {
+        const double a = m.w_lo[w], b = m.w_hi[w];
+        std::vector<zc> A(N, zc(0, 0));
+        if (s->area) {
+            const int Q = 257;
+            for (int q = 0; q < Q; ++q) {
+                const double tq = a + (b - a) * (double)q / (double)(Q - 1);
+                double wq = (b - a) / (double)(Q - 1);
+                if (q == 0 || q == Q - 1) wq *= 0.5;
+                const double p = (tq - t0) / dt;
+                int i0 = (int)std::floor(p);
+                i0 = std::min(std::max(i0, 0), N - 2);
+                const double fr = p - (double)i0;
+                A[i0] += wq * (1.0 - fr) / (b - a);
+                A[i0 + 1] += wq * fr / (b - a);
+            }
+        } else {
+            int cnt = 0;
+            for (int i = 0; i < N; ++i) {
+                const double t = t0 + (double)i * dt;
+                if (t >= a - 1.0e-7 && t <= b + 1.0e-7) ++cnt;
+            }
+            if (cnt == 0) { *msg = "a Boxcar window holds no sample"; return GBP_ERR_BAD_SYSTEM; }
+            for (int i = 0; i < N; ++i) {
+                const double t = t0 + (double)i * dt;
+                if (t >= a - 1.0e-7 && t <= b + 1.0e-7) A[i] = 1.0 / (double)cnt;
+            }
+        }
+        const std::vector<zc> FA = fft_any(A);
+        for (int k = 1; k < nh; ++k) {
+            const double ck = (N % 2 == 0 && k == nh - 1) ? 1.0 : 2.0;
+            const zc gb = g[k] * std::conj(FA[k]) * (ck / (double)N);
+            const double* Sk = &S[(size_t)k * n];
+            for (int j = 0; j < n; ++j) {
+                s->W[(size_t)j * nw + w] += Sk[j] * gb.real();
+                s->W[(size_t)(n + j) * nw + w] -= Sk[j] * gb.imag();
+            }
+        }
+    }
+    // block matrix over the components: nodal layout [Re(comp 0 nodes), Re(comp 1 nodes), Im(comp 0 ...), Im(comp 1 ...)]
+    const int nc = s->n_components;
+    s->Wb.assign((size_t)2 * nc * n * nc * nw, 0.0);
+    const size_t ld = (size_t)nc * nw;
+    for (int c = 0; c < nc; ++c)
+        for (int j = 0; j < n; ++j)
+            for (int w = 0; w < nw; ++w) {
+                s->Wb[((size_t)c * n + j) * ld + (size_t)c * nw + w] = s->W[(size_t)j * nw + w];
+                s->Wb[((size_t)nc * n + (size_t)c * n + j) * ld + (size_t)c * nw + w] = s->W[(size_t)(n + j) * nw + w];
+            }
+    return GBP_OK;
+}
+
+// raw Hankel tables of one receiver offset (geobipy_amd/tdem.py TdemSystem.hankel_tables without the abscissa window)
+inline gbp_status build_handle(gbp_tdem_system* s, double dx, double dy, double dz, gbp_fdem_system** out)
+{
+    const double r = std::hypot(dx, dy), a = s->loop_radius;
+    if (r == 0.0 && !(a > 0.0)) return fail(GBP_ERR_BAD_SYSTEM, "a receiver on the transmitter axis needs a finite ModellingLoopRadius%s");
+    const double rs = r > 0.0 ? r : a;
+    std::vector<int32_t> npts;
+    std::vector<double> wmu, hd0, g, cols[GBP_PT_FIELDS];
+    auto base0 = [](int j) { return std::pow(10.0, -8.3885 + 0.0904226468670 * (double)j); };        // FdemSystem.py:67-83
+    auto base1 = [](int j) { return std::pow(10.0, -7.91001919 + 0.087967143957 * (double)j); };      // :85-101
+    for (int comp = 0; comp < 2; ++comp) {                       // x then z, like the channel layout
+        const bool is_z = comp == 1;
+        if ((is_z && !s->has_z) || (!is_z && !s->has_x)) continue;
+        const bool on_axis = r == 0.0;
+        const bool use_j1 = !is_z || on_axis;
+        const int np = use_j1 ? GBP_NC1 : GBP_NC0;
+        const double div = (on_axis && is_z) ? a : rs;
+        const double sc = is_z ? s->scale_z : s->scale_x;
+        std::vector<double> lam(np), coef(np);
+        for (int j = 0; j < np; ++j) {
+            lam[j] = (use_j1 ? base1(j) : base0(j)) / div;
+            double w = (use_j1 ? s->w1[j] : s->w0[j]) / div;
+            if (!is_z) w *= r > 0.0 ? -dx / r : 0.0;
+            double src;
+            if (on_axis && is_z) src = lam[j] / (2.0 * PI * a);
+            else src = a > 0.0 ? lam[j] * std::cyl_bessel_j(1.0, lam[j] * a) / (2.0 * PI * a) : lam[j] * lam[j] / (4.0 * PI);
+            coef[j] = src * w * sc;
+        }
+        for (int nd = 0; nd < s->n_nodes; ++nd) {
+            npts.push_back(np);
+            wmu.push_back(2.0 * PI * s->nodes[nd] * MU0);
+            hd0.push_back(-dz);
+            g.push_back(1.0); g.push_back(0.0);
+            for (int j = 0; j < np; ++j) {
+                cols[0].push_back(lam[j] * lam[j]); cols[1].push_back(lam[j]); cols[2].push_back(0.0); cols[3].push_back(coef[j]);
+                cols[4].push_back(0.0); cols[5].push_back(lam[j]); cols[6].push_back(0.0);
+            }
+        }
+    }
+    std::vector<double> tables;
+    for (int f = 0; f < GBP_PT_FIELDS; ++f) tables.insert(tables.end(), cols[f].begin(), cols[f].end());
+    return gbp_hankel_system_create_raw((int)npts.size(), npts.data(), wmu.data(), hd0.data(), g.data(), tables.data(), out);
+}
+
+}  // namespace td
+
+extern "C" {
+
+gbp_status gbp_tdem_system_create(const char* stm_text, const double* w0, const double* w1, gbp_tdem_system** out)
+{
+    if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
+    *out = nullptr;
+    if (!stm_text || !w0 || !w1) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    gbp_tdem_system* s = new (std::nothrow) gbp_tdem_system();
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "out of host memory%s");
+    if (!td::parse_stm(stm_text, &s->stm)) { delete s; return fail(GBP_ERR_BAD_SYSTEM, "not a time-domain .stm text (waveform, windows, BaseFrequency, WaveformDigitisingFrequency)%s"); }
+    s->w0.assign(w0, w0 + GBP_NC0);
+    s->w1.assign(w1, w1 + GBP_NC1);
+    const char* msg = "";
+    const gbp_status st = td::build_operator(s, &msg);
+    if (st != GBP_OK) { delete s; return fail(st, "%s", msg); }
+    *out = s;                                   // (host tables only: the operator goes to the device with the first forward call)
+    return GBP_OK;
+}
+
+void gbp_tdem_system_destroy(gbp_tdem_system* s)
+{
+    if (!s) return;
+    for (auto& kv : s->handles) gbp_fdem_system_destroy(kv.second);
+    if (s->d_Wb) (void)hipFree(s->d_Wb);
+    delete s;
+}
+
+gbp_status gbp_tdem_system_info(const gbp_tdem_system* s, int* n_windows, int* n_components, int* n_nodes, double* loop_radius)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (n_windows) *n_windows = s->n_windows;
+    if (n_components) *n_components = s->n_components;
+    if (n_nodes) *n_nodes = s->n_nodes;
+    if (loop_radius) *loop_radius = s->loop_radius;
+    return GBP_OK;
+}
+
+gbp_status gbp_tdem_system_tables(const gbp_tdem_system* s, double* window_centres, double* node_frequencies, double* W)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (window_centres) std::memcpy(window_centres, s->centres.data(), sizeof(double) * s->centres.size());
+    if (node_frequencies) std::memcpy(node_frequencies, s->nodes.data(), sizeof(double) * s->nodes.size());
+    if (W) std::memcpy(W, s->W.data(), sizeof(double) * s->W.size());
+    return GBP_OK;
+}
+
+gbp_status gbp_tdem_forward(gbp_tdem_system* s, int B, const double* geometry, int Lmax, const int32_t* nlayers, const double* sigma,
+                            const double* thk, double* out, void* stream)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
+    if (B == 0) return GBP_OK;
+    if (!geometry || !nlayers || !sigma || !thk || !out) return fail(GBP_ERR_INVALID_ARG, "NULL pointer%s");
+    // Geometry(tx_height, tx_roll, -tx_pitch, -tx_yaw, dx, dy, dz, rx_roll, -rx_pitch, -rx_yaw)  (system/Loop_pair.py:70-77)
+    s->h_height.resize(B);
+    for (int b = 0; b < B; ++b) {
+        const double* gm = geometry + (size_t)b * 10;
+        if (gm[1] != 0.0 || gm[2] != 0.0 || gm[3] != 0.0 || gm[7] != 0.0 || gm[8] != 0.0 || gm[9] != 0.0)
+            return fail(GBP_ERR_INVALID_ARG, "only level flight is supported: roll / pitch / yaw of both loops must be 0%s");
+        if (!(gm[0] >= 0.0) || !std::isfinite(gm[0])) return fail(GBP_ERR_INVALID_ARG, "transmitter height must be finite and >= 0%s");
+        s->h_height[b] = gm[0];
+    }
+    if (s->d_Wb == nullptr) {
+        hipError_t e = hipMalloc((void**)&s->d_Wb, sizeof(double) * s->Wb.size());
+        if (e == hipSuccess) e = hipMemcpy(s->d_Wb, s->Wb.data(), sizeof(double) * s->Wb.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { s->d_Wb = nullptr; return fail(GBP_ERR_HIP, "window operator upload failed: %s", hipGetErrorString(e)); }
+    }
+    const hipStream_t q = (hipStream_t)stream;
+    const int nF = s->n_components * s->n_nodes, n_nodal = 2 * nF, N = s->n_components * s->n_windows;
+    double *d_h = nullptr, *d_nodal = nullptr;
+    GBP_HIP(hipMallocAsync((void**)&d_h, sizeof(double) * (size_t)B, q));
+    GBP_HIP(hipMallocAsync((void**)&d_nodal, sizeof(double) * (size_t)B * n_nodal, q));
+    GBP_HIP(hipMemcpyAsync(d_h, s->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
+    gbp_status st = GBP_OK;
+    for (int b0 = 0; b0 < B && st == GBP_OK;) {                  // runs of soundings that share the receiver offset
+        const double* g0 = geometry + (size_t)b0 * 10;
+        int b1 = b0 + 1;
+        while (b1 < B && geometry[(size_t)b1 * 10 + 4] == g0[4] && geometry[(size_t)b1 * 10 + 5] == g0[5] && geometry[(size_t)b1 * 10 + 6] == g0[6]) ++b1;
+        const auto key = std::make_tuple(g0[4], g0[5], g0[6]);
+        auto it = s->handles.find(key);
+        if (it == s->handles.end()) {
+            gbp_fdem_system* h = nullptr;
+            st = td::build_handle(s, g0[4], g0[5], g0[6], &h);
+            if (st != GBP_OK) break;
+            it = s->handles.emplace(key, h).first;
+        }
+        const int n = b1 - b0;
+        st = gbp_fdem_forward_ex(it->second, n, Lmax, nlayers + b0, sigma + (size_t)b0 * Lmax, thk + (size_t)b0 * Lmax, d_h + b0,
+                                 d_nodal + (size_t)b0 * n_nodal, 0, stream);
+        if (st == GBP_OK)
+            st = gbp_td_apply(n, Lmax, n_nodal, N, nlayers + b0, s->d_Wb, d_nodal + (size_t)b0 * n_nodal, nullptr, out + (size_t)b0 * N, nullptr, stream);
+        b0 = b1;
+    }
+    (void)hipFreeAsync(d_h, q);
+    (void)hipFreeAsync(d_nodal, q);
+    return st;
+}
+
+}  // extern "C"

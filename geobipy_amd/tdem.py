@@ -284,6 +284,56 @@ class TdemSystem:
         return bx, bz
 
 
+class NativeTdemSystem:
+    """The C-level time-domain system (``gbp_tdem_system_create`` on the text of a ``.stm`` file): GA-AEM's
+    ``TDAEMSystem(stmfile)`` / ``forwardmodel(Geometry, Earth)`` boundary without Python in the path
+    (include/geobipy_amd.h "Time-domain systems").  ``forward(geometry[B, 10], nlayers, sigma, thk)`` -> windows on the device."""
+
+    def __init__(self, system_filename):
+        lib = _lib.load()
+        self._lib = lib
+        h = ctypes.c_void_p()
+        text = open(system_filename, "rb").read()
+        w0, w1 = np.ascontiguousarray(W0_J0_120), np.ascontiguousarray(W1_J1_140)
+        _lib.check(lib.gbp_tdem_system_create(text, w0.ctypes.data_as(_lib.c_double_p), w1.ctypes.data_as(_lib.c_double_p), ctypes.byref(h)))
+        self.ptr = h
+        nw, nc, nn, a = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+        _lib.check(lib.gbp_tdem_system_info(h, ctypes.byref(nw), ctypes.byref(nc), ctypes.byref(nn), ctypes.byref(a)))
+        self.nwindows, self.n_components, self.n_nodes, self._loop_radius = nw.value, nc.value, nn.value, a.value
+
+    def loopRadius(self):
+        return self._loop_radius
+
+    def tables(self):
+        """(window centres, spline-node frequencies, W[2 n_nodes, n_windows]) as the library built them."""
+        c, f, W = np.empty(self.nwindows), np.empty(self.n_nodes), np.empty((2 * self.n_nodes, self.nwindows))
+        dp = lambda x: x.ctypes.data_as(_lib.c_double_p)
+        _lib.check(self._lib.gbp_tdem_system_tables(self.ptr, dp(c), dp(f), dp(W)))
+        return c, f, W
+
+    def forward(self, geometry, nlayers, sigma, thk, device=None):
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        geometry = np.ascontiguousarray(geometry, dtype=np.float64)
+        B = geometry.shape[0]
+        assert geometry.shape == (B, 10), ValueError("geometry must have shape [B, 10] (Loop_pair.py:70-77)")
+        sg = torch.as_tensor(np.asarray(sigma), dtype=torch.float64).to(device).contiguous()
+        th = torch.as_tensor(np.asarray(thk), dtype=torch.float64).to(device).contiguous()
+        nl = torch.as_tensor(np.broadcast_to(np.asarray(nlayers), (B,)).copy(), dtype=torch.int32).to(device)
+        out = torch.empty((B, self.n_components * self.nwindows), dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            _lib.check(self._lib.gbp_tdem_forward(self.ptr, B, geometry.ctypes.data_as(_lib.c_double_p), sg.shape[1], nl.data_ptr(),
+                                                  sg.data_ptr(), th.data_ptr(), out.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._lib.gbp_tdem_system_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class _RawHandle:
     def __init__(self, npts, wmu, hd0, g, tables):
         lib = _lib.load()

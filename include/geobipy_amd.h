@@ -357,6 +357,29 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, 
                          const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
 gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chains *c, void *stream);
+/* ------------------------------------------------------------------------------------------------
+ * Time-domain systems at the C level (SURVEY 8b "TDEM boundary"): what the reference gets from GA-AEM's
+ *   gatdaem1d.TDAEMSystem(stmfile)                     system/TdemSystem_GAAEM.py:8-35
+ *   .forwardmodel(Geometry, Earth) -> SX / SZ          forwardmodelling/Electromagnetic/TD/tdem1d.py:89-96
+ *   Geometry(tx_height, tx_roll, -tx_pitch, -tx_yaw, txrx_dx, txrx_dy, txrx_dz, rx_roll, -rx_pitch, -rx_yaw)   system/Loop_pair.py:70-77
+ * gbp_tdem_system_create parses the TEXT of a .stm file ([host], NUL-terminated) and folds waveform, spline, low-pass
+ * filters and windows into one matrix (geobipy_amd/csrc/gbp_tdem.h); w0[120] / w1[140]: the J0 / J1 Hankel filter weights
+ * (the same [host] arrays gbp_fdem_system_create takes).  gbp_tdem_forward: geometry [host] f64[B, 10] as above -- level
+ * flight only (non-zero attitude angles are refused), runs of soundings with the same receiver offset share one launch (a
+ * survey flown with nominal geometry is one run); nlayers / sigma / thk [dev] as in gbp_fdem_forward; out [dev]
+ * f64[B, n_components * n_windows], components x then z, in the reference's sign convention for predicted_secondary_field
+ * (TdemDataPoint.py:1013-1015).  Stream-ordered; the handle must not be used from two threads at once.
+ */
+typedef struct gbp_tdem_system gbp_tdem_system;
+gbp_status gbp_tdem_system_create(const char *stm_text, const double *w0, const double *w1, gbp_tdem_system **out);
+void gbp_tdem_system_destroy(gbp_tdem_system *sys);
+gbp_status gbp_tdem_system_info(const gbp_tdem_system *sys, int *n_windows, int *n_components, int *n_nodes, double *loop_radius);
+/* [host] out: window centres [n_windows] (= gatdaem1d windows.centre), spline-node frequencies [n_nodes], the per-component
+ * operator W [2 * n_nodes, n_windows]; any may be NULL */
+gbp_status gbp_tdem_system_tables(const gbp_tdem_system *sys, double *window_centres, double *node_frequencies, double *W);
+gbp_status gbp_tdem_forward(gbp_tdem_system *sys, int B, const double *geometry, int Lmax, const int32_t *nlayers,
+                            const double *sigma, const double *thk, double *out, void *stream);
+
 /* Diagnostics: [host] out[8] = accumulated 100 MHz clock ticks of chain 0 in the persistent kernel's stages (propose, fm_dlogc at
  * the remapped model, newton, forward / fm_dlogc at the proposal, accept), out[5] = iterations counted; synchronises the device.
  * reset: 0 read only, 1 zero the counters and arm the clock (off by default: it costs chain 0 a few global updates per iteration),

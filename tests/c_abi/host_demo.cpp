@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/geobipy_amd.h"
@@ -100,12 +101,44 @@ int main(int argc, char** argv)
     std::vector<int64_t> acc = down(c.n_accepted, B);
     std::vector<double> sg = down(c.sigma, (size_t)B * K), mis = down(c.misfit, B);
 
+    // time-domain boundary (optional 3rd argument: a .stm file): gbp_tdem_system_create on its TEXT, then B soundings of a
+    // 3-layer earth through gbp_tdem_forward(handle, B, geometry[B, 10], ...) -- the GA-AEM call of TD/tdem1d.py:89-96
+    std::vector<double> td_out;
+    if (argc > 3) {
+        FILE* sf = std::fopen(argv[3], "rb");
+        if (!sf) return 1;
+        std::string text;
+        char buf[4096];
+        for (size_t n; (n = std::fread(buf, 1, sizeof(buf), sf)) > 0;) text.append(buf, n);
+        std::fclose(sf);
+        gbp_tdem_system* ts = nullptr;
+        CHECK(gbp_tdem_system_create(text.c_str(), w0.data(), w1.data(), &ts));
+        int nw = 0, nc = 0, nn = 0;
+        double radius = 0.0;
+        CHECK(gbp_tdem_system_info(ts, &nw, &nc, &nn, &radius));
+        std::vector<double> geom((size_t)B * 10, 0.0), tsig((size_t)B * 3), tthk((size_t)B * 3, 0.0);
+        std::vector<int32_t> tnl(B, 3);
+        for (int b = 0; b < B; ++b) {
+            geom[(size_t)b * 10] = height[b]; geom[(size_t)b * 10 + 4] = -13.0; geom[(size_t)b * 10 + 6] = 2.0;
+            tsig[(size_t)b * 3] = 0.01; tsig[(size_t)b * 3 + 1] = 0.1; tsig[(size_t)b * 3 + 2] = sigma0[b];
+            tthk[(size_t)b * 3] = 20.0 + b; tthk[(size_t)b * 3 + 1] = 40.0;
+        }
+        int32_t* d_nl = up(tnl);
+        double *d_sg = up(tsig), *d_th = up(tthk), *d_o = dev<double>((size_t)B * nc * nw);
+        CHECK(gbp_tdem_forward(ts, B, geom.data(), 3, d_nl, d_sg, d_th, d_o, nullptr));
+        HIP(hipDeviceSynchronize());
+        td_out = down(d_o, (size_t)B * nc * nw);
+        gbp_tdem_system_destroy(ts);
+        std::printf("time domain: %d windows x %d component(s), %d spline nodes, loop radius %.3f m\n", nw, nc, nn, radius);
+    }
+
     FILE* g = std::fopen(argv[2], "wb");
     if (!g) return 1;
     std::fwrite(pred0.data(), 8, pred0.size(), g); std::fwrite(chi0.data(), 8, B, g); std::fwrite(like0.data(), 8, B, g);
     std::vector<double> kd(k.begin(), k.end()), ad(acc.begin(), acc.end()), khd(kh.begin(), kh.end());
     std::fwrite(kd.data(), 8, kd.size(), g); std::fwrite(ad.data(), 8, ad.size(), g); std::fwrite(khd.data(), 8, khd.size(), g);
     std::fwrite(sg.data(), 8, sg.size(), g); std::fwrite(mis.data(), 8, B, g);
+    if (!td_out.empty()) std::fwrite(td_out.data(), 8, td_out.size(), g);
     std::fclose(g);
     gbp_fdem_system_destroy(sys);
     std::printf("%s: %d chains x %d iterations through the C ABI\n", gbp_version(), B, n_it);

@@ -56,9 +56,10 @@ def test_cpp_host_runs_the_sampler_through_the_c_abi(tmp_path):
                            a["lamda0"].ravel(), a["w1"], a["lamda1"].ravel(), height, data.ravel(), sigma0, np.array(opt, dtype=np.float64)])
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     blob.astype(np.float64).tofile(fin)
-    out = subprocess.run([exe, fin, fout], capture_output=True, text=True)
+    stm = os.path.join(GOLDEN, "SkytemLM.stm")
+    out = subprocess.run([exe, fin, fout, stm], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "chains x 300 iterations through the C ABI" in out.stdout
+    assert "chains x 300 iterations through the C ABI" in out.stdout and "time domain: 19 windows x 1 component(s), 22 spline nodes" in out.stdout
     r = np.fromfile(fout)
     N = 2 * s.nFrequencies
     off = 0
@@ -72,4 +73,11 @@ def test_cpp_host_runs_the_sampler_through_the_c_abi(tmp_path):
     assert np.array_equal(nxt(B), dc.k.cpu().numpy()) and np.array_equal(nxt(B), dc.n_accepted.cpu().numpy())
     assert np.array_equal(nxt(B * (K + 1)).reshape(B, K + 1), dc.k_hist.cpu().numpy())
     assert np.array_equal(nxt(B * K).reshape(B, K), dc.sigma.cpu().numpy()) and np.array_equal(nxt(B), dc.misfit.cpu().numpy())
+    # the time-domain entries from the same host: equal to the Python host's TdemBatch on the same soundings
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    tsig = np.stack([np.full(B, 0.01), np.full(B, 0.1), sigma0], axis=1)
+    tthk = np.stack([20.0 + np.arange(B), np.full(B, 40.0), np.zeros(B)], axis=1)
+    py = TdemBatch(TdemSystem(stm), np.full(B, 3), tsig, tthk, height, (-13.0, 0.0, 2.0)).forward().cpu().numpy()
+    td = nxt(B * 19).reshape(B, 19)
+    assert np.abs(td - py).max() <= 1e-10 * np.abs(py).max()
     assert off == r.size and dc.n_accepted.sum() > 1000

@@ -90,6 +90,61 @@ def test_system_file_and_time_operator_on_host():
     assert abs(bx / tp[0, 15] - 1) < 1e-9 and abs(bz / tp[0, 16] - 1) < 1e-9      # PX, PZ columns
 
 
+def test_c_level_system_builds_the_same_operator_as_the_python_host():
+    """gbp_tdem_system_create on the TEXT of the .stm files (no GPU needed: host tables): window centres, spline nodes and the
+    folded time-domain operator W equal geobipy_amd.tdem.TdemSystem's (numpy FFT / scipy spline) to 1e-10 of its largest entry."""
+    from geobipy_amd.tdem import NativeTdemSystem, TdemSystem
+    for name in ("SkytemHM.stm", "SkytemLM.stm", "tempest.stm", "config4_30gates.stm", "ideal_stepoff.stm"):
+        py, c = TdemSystem(os.path.join(GOLDEN, name)), NativeTdemSystem(os.path.join(GOLDEN, name))
+        centres, nodes, W = c.tables()
+        assert (c.nwindows, c.n_components, c.n_nodes) == (py.nwindows, py.n_components, py.node_frequencies().size)
+        assert c.loopRadius() == py.loopRadius() and np.allclose(centres, py.off_time, rtol=1e-14) and np.allclose(nodes, py.node_frequencies(), rtol=1e-13)
+        Wp = py.time_operator()
+        assert np.abs(W - Wp).max() <= 1e-10 * np.abs(Wp).max(), (name, np.abs(W - Wp).max() / np.abs(Wp).max())
+    from geobipy_amd import _lib
+    import ctypes
+    h = ctypes.c_void_p()
+    w = np.zeros(140)
+    assert _lib.load().gbp_tdem_system_create(b"not a system file", w.ctypes.data_as(_lib.c_double_p), w.ctypes.data_as(_lib.c_double_p),
+                                              ctypes.byref(h)) == -3
+
+
+@pytest.mark.gpu
+def test_c_level_forward_equals_the_python_host_path_and_the_reference_csv():
+    """gbp_tdem_forward(handle, B, geometry[B, 10], ...): same windows as TdemBatch (the Python host over the same kernels),
+    inside the CSV bars; soundings with different receiver offsets in one call; attitude angles are refused."""
+    torch = pytest.importorskip("torch")
+    from geobipy_amd import _lib
+    from geobipy_amd.tdem import NativeTdemSystem, TdemBatch, TdemSystem
+    model = "glacial"
+    sig = np.tile(WEDGE_CONDUCTIVITY[model], (79, 1))
+    thk = np.stack([ZW, ZD - ZW, np.zeros(79)], axis=1)
+    sk, tp = load("skytem", model), load("tempest", model)
+    for name, off, alt, ref, fam in (("SkytemLM.stm", SKYTEM_OFFSET, 30.0, sk[:, 41:60], "skytem"), ("tempest.stm", TEMPEST_OFFSET, 120.0, tp[:, 17:47], "tempest")):
+        c = NativeTdemSystem(os.path.join(GOLDEN, name))
+        geom = np.zeros((79, 10))
+        geom[:, 0], geom[:, 4:7] = alt, off
+        out = c.forward(geom, np.full(79, 3), sig, thk).cpu().numpy()
+        py = TdemBatch(TdemSystem(os.path.join(GOLDEN, name)), np.full(79, 3), sig, thk, np.full(79, alt), off).forward().cpu().numpy()
+        assert np.abs(out - py).max() <= 1e-10 * np.abs(py).max()
+        n = c.nwindows
+        for i in range(79):
+            for j in range(c.n_components):
+                assert within_bar(out[i, j * n:(j + 1) * n], ref[i, j * n:(j + 1) * n], fam), (name, i, j)
+    # two receiver offsets in one call = two runs; each equals its own batch
+    c = NativeTdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))
+    geom = np.zeros((40, 10))
+    geom[:, 0] = np.linspace(25.0, 45.0, 40)
+    geom[:20, 4:7], geom[20:, 4:7] = SKYTEM_OFFSET, (-17.0, 0.0, 2.5)
+    out = c.forward(geom, np.full(40, 3), sig[:40], thk[:40]).cpu().numpy()
+    for sl, off in ((slice(0, 20), SKYTEM_OFFSET), (slice(20, 40), (-17.0, 0.0, 2.5))):
+        py = TdemBatch(TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm")), np.full(20, 3), sig[sl], thk[sl], geom[sl, 0], off).forward().cpu().numpy()
+        assert np.abs(out[sl] - py).max() <= 1e-10 * np.abs(py).max()
+    geom[3, 2] = 1.5                                             # pitch
+    with pytest.raises(_lib.NativeLibraryError):
+        c.forward(geom, np.full(40, 3), sig[:40], thk[:40])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", sorted(WEDGE_CONDUCTIVITY))
 def test_gpu_tdem_vs_oracle_and_reference_csv(model):
