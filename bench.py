@@ -52,9 +52,11 @@ def bytes_per_eval(L, F, with_pred):
 def measured_traffic(Btot, L, world):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in
     separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note) -- only for the profiled shape."""
-    path = os.path.join(ROOT, "profiles", "r1", f"summary_bench_{Btot}x{N_FREQ}x{L}.json")
-    if world != 1 or not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_bench_{Btot}x{N_FREQ}x{L}.json")))
+    if world != 1 or not found:
         return None
+    path = found[-1]                                   # the latest round's PMC passes
     d = json.load(open(path))["derived"]
     return d["hbm_fetch_bytes_x2_gfx950_correction"] + d["hbm_write_bytes_raw"]
 

@@ -1,7 +1,8 @@
-"""profiles/r1/summary_bench_65536x10x8.json from the rocprofv3 CSVs of profiles/run_profile.sh <tag> (gpurun_out/prof/<tag>)."""
+"""profiles/<round>/summary_bench_65536x10x8.json (python profiles/summarise_bench.py <tag> [round]) from the rocprofv3 CSVs of profiles/run_profile.sh <tag> (gpurun_out/prof/<tag>)."""
 import csv, json, os, sys, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+rnd = sys.argv[2] if len(sys.argv) > 2 else tag
 src = os.path.join(R, "gpurun_out", "prof", tag)
 KERNEL = "k_fdem_forward<true>"
 B, L, F = 65536, 8, 10
@@ -47,5 +48,5 @@ out = {
         "effective_clock_GHz_profiled": cycles / (sum(dur) / len(dur)),
     },
 }
-json.dump(out, open(os.path.join(R, "profiles", "r1", "summary_bench_65536x10x8.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "profiles", rnd, "summary_bench_65536x10x8.json"), "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("kernel_trace", "dispatch", "derived")}, indent=1))

@@ -66,5 +66,5 @@ out["us_per_iteration_all_kernels"] = round(sum(v["us_per_iteration"] for v in o
 out["note_overlap"] = ("at this block size the Jacobian pass of the dimension-changing proposals runs on a side stream next to the fused "
                        "forward kernel: their durations overlap (each is longer than it would be alone), so the sum over kernels exceeds the "
                        "wall time per iteration printed by the benchmark (1.47 ms in the traced run)")
-json.dump(out, open(os.path.join(R, "profiles", "r1", "summary_rjmcmc_65536.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "profiles", (sys.argv[1] if len(sys.argv) > 1 else "r2"), "summary_rjmcmc_65536.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
