@@ -71,6 +71,8 @@ SIGNATURES = {
     "gbp_fdem_system_create": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_create_windowed": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.c_double, ctypes.c_double,
                                                                                          ctypes.POINTER(c_void_p)]),
+    "gbp_fdem_system_create_binned": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.c_double, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "gbp_fdem_system_bin_points": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int)]),
     "gbp_fdem_system_npoints": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "gbp_hankel_system_create_raw": (c_int, [c_int, c_int32_p] + [c_double_p] * 4 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_destroy": (None, [c_void_p]),

@@ -39,7 +39,7 @@ class FdemBatch:
     """
 
     def __init__(self, system, nlayers, sigma, thk, height, data=None, relative_error=None, additive_error=None,
-                 device=None, hankel_eps_ppm=0.0, waves=0):
+                 device=None, hankel_eps_ppm=None, waves=0):
         if not torch.cuda.is_available():
             raise _lib.NativeLibraryError("FdemBatch needs a HIP device (torch.cuda.is_available() is False); "
                                           "there is no CPU fallback")
@@ -53,7 +53,12 @@ class FdemBatch:
         with torch.cuda.device(self.device):
             self._h_exact = system.handle()
         self._h = self._h_exact
-        self.hankel_eps_ppm = float(hankel_eps_ppm)
+        # Abscissa window: by default a sounding is evaluated with the filter abscissae whose terms can add up
+        # to more than 1e-10 ppm at its own altitude (|rTE| <= 1 bounds every term) -- about half of the 120, every output
+        # within 1e-10 ppm of the full sums, i.e. far below their own rounding error (1e-8 ppm) and the parity bar (1e-7 ppm),
+        # and independent of the batch the sounding is in.  hankel_eps_ppm=0: all 120 / 140 abscissae.
+        from .system import DEFAULT_HANKEL_EPS_PPM
+        self.hankel_eps_ppm = DEFAULT_HANKEL_EPS_PPM if hankel_eps_ppm is None else float(hankel_eps_ppm)
         self.F = system.nFrequencies
         self.sigma = _dev_f64(sigma, self.device)
         assert self.sigma.dim() == 2, ValueError("sigma must have shape [B, Lmax]")
@@ -67,9 +72,10 @@ class FdemBatch:
         assert self.nlayers.numel() == self.B
         self.height = _dev_f64(height, self.device, (self.B,))
         if self.hankel_eps_ppm > 0.0 and self.B > 0:
-            # opt-in accuracy-budgeted abscissa window: the altitude floor of THIS batch (one sync, at construction)
+            # the 1 m altitude bins this batch touches (one sync, at construction); the window itself is per sounding
+            lo_hi = torch.stack([self.height.min(), self.height.max()]).cpu().numpy()
             with torch.cuda.device(self.device):
-                self._h = system.handle(self.hankel_eps_ppm, float(self.height.min().item()))
+                self._h = system.handle_binned(self.hankel_eps_ppm, float(lo_hi[0]), float(lo_hi[1]))
         self.data = None if data is None else _dev_f64(data, self.device)
         if self.data is not None:
             assert tuple(self.data.shape) == (self.B, 2 * self.F), ValueError("data must have shape [B, 2F]")

@@ -43,10 +43,24 @@ gbp_status fail(gbp_status code, const char* fmt, const char* detail = "")
 
 }  // namespace
 
+// Per-altitude-bin abscissa windows of one system (gbp_fdem_system_create_binned): bin i holds the tables windowed for soundings
+// at altitude >= bin0 + i metres; the kernel picks a sounding's bin from its own altitude, so the terms that are evaluated for
+// a sounding depend on that sounding only (never on the batch it is evaluated in).
+struct BinDesc {
+    int chan_off;        // first Channel of the bin in d_bin_chan
+    int npts_total;      // points of the bin's flattened list (stride of its SoA)
+    long long pts_off;   // first double of the bin's SoA in d_bin_pts
+};
+
 struct gbp_fdem_system {
     gbp::SystemTables t;      // host copy (channels, H0, point tables)
     Channel* d_chan = nullptr;
     double* d_pts = nullptr;  // SoA, GBP_PT_FIELDS arrays of [npts] (gbp_fdem_point.h)
+    int bin0 = 0, n_bins = 0;
+    BinDesc* d_bins = nullptr;
+    Channel* d_bin_chan = nullptr;
+    double* d_bin_pts = nullptr;
+    std::vector<int> bin_npts;
     // Soundings whose layers all have sigma >= sigma_direct take the kernels' csqrt_upper2<DIRECT> branch: for every
     // frequency f and abscissa with a = lambda^2 - omega^2 mu0 eps0 < 0,  -a <= wmu_f sigma / 4, i.e. b^2 >= 16 a^2.
     // (= 4 omega_max eps0, 2.9e-5 S/m at 130 kHz; 0 for tables without a displacement-current term)
@@ -299,12 +313,23 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
                                                        const double* __restrict__ rel,
                                                        const double* __restrict__ add, double* __restrict__ pred,
                                                        double* __restrict__ chi2, double* __restrict__ logL,
-                                                       double sigma_direct)
+                                                       double sigma_direct, const BinDesc* __restrict__ bins, int bin0, int n_bins,
+                                                       const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
+    if (bins != nullptr) {                                  // this sounding's abscissa window: the bin of its own altitude
+        const double alt = height[b];
+        if (alt >= (double)bin0) {                          // (below the first bin, NaN: all abscissae)
+            const int bi = min((int)(alt - (double)bin0), n_bins - 1);
+            const BinDesc d = bins[bi];
+            chan = bin_chan + d.chan_off;
+            pts = bin_pts + d.pts_off;
+            npts_total = d.npts_total;
+        }
+    }
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform): none of its outputs are written
     if (L > Lmax) {       // bad row (would overrun the rows of sigma / thk and the LDS layer tables): flag it with NaNs, touch nothing else
@@ -634,6 +659,57 @@ gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t* tid, const dou
     return GBP_OK;
 }
 
+gbp_status gbp_fdem_system_create_binned(int nF, const int32_t* tid, const double* frequencies, const double* tx_z,
+                                         const double* rx_z, const double* tx_moment, const double* scale,
+                                         const double* rx_off, const double* separation, const double* w0,
+                                         const double* lamda0, const double* w1, const double* lamda1, double eps_ppm,
+                                         int first_altitude_m, int n_bins, gbp_fdem_system** out)
+{
+    if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
+    *out = nullptr;
+    if (!(eps_ppm > 0.0) || first_altitude_m < 0 || n_bins < 1 || n_bins > 1024)
+        return fail(GBP_ERR_INVALID_ARG, "eps_ppm > 0, first_altitude_m >= 0 and 1 <= n_bins <= 1024 are required%s");
+    gbp_fdem_system* s = nullptr;
+    gbp_status st = gbp_fdem_system_create(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0, lamda0, w1, lamda1, &s);
+    if (st != GBP_OK) return st;
+    std::vector<BinDesc> desc(n_bins);
+    std::vector<Channel> chans;
+    std::vector<double> pts;
+    s->bin_npts.resize(n_bins);
+    for (int i = 0; i < n_bins; ++i) {
+        gbp::SystemTables t = s->t;                      // the exact tables, then windowed for altitude >= first + i metres
+        gbp::window_system_tables(&t, eps_ppm, (double)(first_altitude_m + i));
+        desc[i].chan_off = (int)chans.size();
+        desc[i].npts_total = t.npts;
+        desc[i].pts_off = (long long)pts.size();
+        s->bin_npts[i] = t.npts;
+        chans.insert(chans.end(), t.chan.begin(), t.chan.end());
+        pts.insert(pts.end(), t.soa.begin(), t.soa.end());
+    }
+    s->bin0 = first_altitude_m;
+    s->n_bins = n_bins;
+    hipError_t e = hipMalloc((void**)&s->d_bins, sizeof(BinDesc) * desc.size());
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_chan, sizeof(Channel) * chans.size());
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_pts, sizeof(double) * pts.size());
+    if (e == hipSuccess) e = hipMemcpy(s->d_bins, desc.data(), sizeof(BinDesc) * desc.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_bin_chan, chans.data(), sizeof(Channel) * chans.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_bin_pts, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gbp_fdem_system_destroy(s);
+        return fail(GBP_ERR_HIP, "bin table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return GBP_OK;
+}
+
+gbp_status gbp_fdem_system_bin_points(const gbp_fdem_system* sys, int altitude_m, int* npts)
+{
+    if (!sys || !npts) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    if (sys->n_bins == 0 || altitude_m < sys->bin0) { *npts = sys->t.npts; return GBP_OK; }
+    *npts = sys->bin_npts[std::min(altitude_m - sys->bin0, sys->n_bins - 1)];
+    return GBP_OK;
+}
+
 gbp_status gbp_hankel_system_create_raw(int nF, const int32_t* npts, const double* wmu, const double* hd0,
                                         const double* g, const double* tables, gbp_fdem_system** out)
 {
@@ -680,6 +756,9 @@ void gbp_fdem_system_destroy(gbp_fdem_system* sys)
     if (!sys) return;
     if (sys->d_chan) (void)hipFree(sys->d_chan);
     if (sys->d_pts) (void)hipFree(sys->d_pts);
+    if (sys->d_bins) (void)hipFree(sys->d_bins);
+    if (sys->d_bin_chan) (void)hipFree(sys->d_bin_chan);
+    if (sys->d_bin_pts) (void)hipFree(sys->d_bin_pts);
     delete sys;
 }
 
@@ -723,7 +802,7 @@ gbp_status gbp_fdem_forward_ex(const gbp_fdem_system* sys, int B, int Lmax, cons
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
-                       nullptr, pred, nullptr, nullptr, sys->sigma_direct);
+                       nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -775,7 +854,7 @@ gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lm
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
-                       chi2, logL, sys->sigma_direct);
+                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

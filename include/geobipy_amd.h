@@ -94,6 +94,22 @@ gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t *tid, const dou
                                            const double *w0, const double *lamda0, const double *w1,
                                            const double *lamda1, double eps_ppm, double min_altitude,
                                            gbp_fdem_system **out);
+/*
+ * The same window chosen PER SOUNDING: n_bins table sets, set i windowed for altitudes >= first_altitude_m + i metres; the
+ * forward kernels look up a sounding's set from its own altitude (below first_altitude_m: all abscissae; above the last bin:
+ * the last set, whose bound still holds).  What is evaluated for a sounding therefore depends on that sounding alone --
+ * results do not change with the batch a sounding is evaluated in -- and every output stays within eps_ppm of the full
+ * 120 / 140-point sums (geobipy_amd's default 1e-10 ppm: two orders below the rounding error of those sums themselves, three
+ * below the parity bar).  This is the handle geobipy_amd.FdemBatch uses by default.  The Jacobian entries ignore the bins (all abscissae).
+ */
+gbp_status gbp_fdem_system_create_binned(int nF, const int32_t *tid, const double *frequencies,
+                                         const double *tx_z, const double *rx_z, const double *tx_moment,
+                                         const double *scale, const double *rx_off, const double *separation,
+                                         const double *w0, const double *lamda0, const double *w1,
+                                         const double *lamda1, double eps_ppm, int first_altitude_m, int n_bins,
+                                         gbp_fdem_system **out);
+/* abscissa points a sounding at (integer) altitude_m is evaluated with */
+gbp_status gbp_fdem_system_bin_points(const gbp_fdem_system *sys, int altitude_m, int *npts);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);
 gbp_status gbp_fdem_system_npoints(const gbp_fdem_system *sys, int *npts);  /* abscissa points evaluated per sounding */
 gbp_status gbp_fdem_system_nfreq(const gbp_fdem_system *sys, int *nF);

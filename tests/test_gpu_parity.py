@@ -431,21 +431,37 @@ def test_datapoint_sensitivity_and_fm_dlogc():
 
 
 def test_abscissa_window_mode():
-    """Opt-in accuracy-budgeted abscissa window: same results to within the budget, fewer abscissa points."""
+    """FdemBatch's default: a sounding is evaluated with the filter abscissae whose terms can exceed 1e-10 ppm in total at its
+    OWN altitude (1 m bins, |rTE| <= 1) -- same results as the full 120-point sums (hankel_eps_ppm=0) to within the budget,
+    about half the abscissa points, and bit-identical whatever batch the sounding is evaluated in."""
     from geobipy_amd import FdemBatch, synthetic
     s = synthetic.syn10_system()
     B, L = 8192, 8
     nl, sig, thk, h = synthetic.draw_models(B, L, seed=21)
-    exact = FdemBatch(s, nl, sig, thk, h)
+    h[:5] = [0.3, 3.0, 12.0, 300.0, 2000.0]                     # below / above the usual survey altitudes, beyond the bin range
+    exact = FdemBatch(s, nl, sig, thk, h, hankel_eps_ppm=0.0)
     p0 = exact.forward().clone()
-    for eps in [1e-12, 1e-10]:
+    assert exact._h.npoints == 1200 and exact._h.bins is None
+    for eps in [None, 1e-12]:
         win = FdemBatch(s, nl, sig, thk, h, hankel_eps_ppm=eps)
-        assert win._h.npoints < 0.75 * exact._h.npoints and win._h.npoints >= 64 * 10
+        budget = 1e-10 if eps is None else eps
+        assert win._h.bins is not None and win._h.bin_points(30.0) < 0.75 * 1200 and win._h.bin_points(30.0) >= 64 * 10
+        assert win._h.bin_points(45.0) <= win._h.bin_points(25.0) <= win._h.bin_points(1.0) <= 1200
         p1 = win.forward()
-        assert float((p1 - p0).abs().max()) <= eps + 1e-13 * float(p0.abs().max())
+        assert float((p1 - p0).abs().max()) <= budget + 1e-13 * float(p0.abs().max())
+    # a sounding's numbers do not depend on its batch (the bins are absolute): any sub-batch, any order, other neighbours
+    full = FdemBatch(s, nl, sig, thk, h, waves=2).forward()
+    idx = np.random.default_rng(3).permutation(B)[:500]
+    sub = FdemBatch(s, nl[idx], sig[idx], thk[idx], h[idx], waves=2).forward()
+    assert torch.equal(sub, full[torch.as_tensor(idx, device=full.device)])
+    c0, l0 = FdemBatch(s, nl, sig, thk, h, data=np.full((B, 20), 80.0), relative_error=np.full(B, 0.05), additive_error=np.full(B, 5.0),
+                       hankel_eps_ppm=0.0).forward_loglike()
+    c1, l1 = FdemBatch(s, nl, sig, thk, h, data=np.full((B, 20), 80.0), relative_error=np.full(B, 0.05),
+                       additive_error=np.full(B, 5.0)).forward_loglike()
+    assert torch.allclose(c0, c1, rtol=1e-11, atol=1e-8) and torch.allclose(l0, l1, rtol=1e-11, atol=1e-8)
     # the Jacobian always uses the full tables
-    assert torch.equal(FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64], hankel_eps_ppm=1e-12).sensitivity(),
-                       FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64]).sensitivity())
+    assert torch.equal(FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64]).sensitivity(),
+                       FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64], hankel_eps_ppm=0.0).sensitivity())
 
 
 def test_find_best_halfspace_matches_brute_force():

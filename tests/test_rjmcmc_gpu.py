@@ -345,7 +345,7 @@ def test_device_chains_state_is_coherent_after_many_steps():
             assert e[b, 0] > dc.min_edge and e[b, k[b] - 2] < dc.max_edge
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
                    relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy(),
-                   waves=dc._o.forward_waves)                                # the summation order the chains ran with
+                   waves=dc._o.forward_waves, hankel_eps_ppm=0.0)            # the summation order and the abscissae the chains ran with
     chi2, logl = fb.forward_loglike()
     # proposals that keep their dimension get prediction / chi^2 / logL from the fused forward kernel (bit-equal to this
     # evaluation); the others from the Jacobian pass and the accept kernel (same values, different summation order)
