@@ -26,8 +26,9 @@ def parse(argv=None):
     p.add_argument("--data_filename", default=None, help="override data_filename in parameter file")
     p.add_argument("--exact-jacobian", action="store_true", help="true derivative in the proposals (DESIGN.md 3.4)")
     p.add_argument("--no-hitmap", action="store_true", help="skip the conductivity-depth hit map")
-    p.add_argument("--hankel-eps", type=float, default=0.0,
-                   help="opt-in accuracy budget of the Hankel-filter abscissa window (ppm for frequency-domain data, relative for time-domain data)")
+    p.add_argument("--hankel-eps", type=float, default=None,
+                   help="accuracy budget of the Hankel-filter abscissa window: ppm for frequency-domain data (default 1e-10, 0 = all "
+                        "abscissae), relative for time-domain data (default off)")
     a = p.parse_args(argv)
     if a.seed is not None:
         a.seed = int(a.seed)

@@ -56,7 +56,9 @@ class FdemBatch:
         # Abscissa window: by default a sounding is evaluated with the filter abscissae whose terms can add up
         # to more than 1e-10 ppm at its own altitude (|rTE| <= 1 bounds every term) -- about half of the 120, every output
         # within 1e-10 ppm of the full sums, i.e. far below their own rounding error (1e-8 ppm) and the parity bar (1e-7 ppm),
-        # and independent of the batch the sounding is in.  hankel_eps_ppm=0: all 120 / 140 abscissae.
+        # and independent of the batch the sounding is in.  The Jacobian uses the same window: rTE is analytic and bounded by
+        # 1 for conductivities in the right half plane, so |d rTE / d ln sigma_k| <= 2/pi (Cauchy estimate on the strip
+        # |Im ln sigma| < pi/2) and the dropped terms are bounded by the same sum.  hankel_eps_ppm=0: all 120 / 140 abscissae.
         from .system import DEFAULT_HANKEL_EPS_PPM
         self.hankel_eps_ppm = DEFAULT_HANKEL_EPS_PPM if hankel_eps_ppm is None else float(hankel_eps_ppm)
         self.F = system.nFrequencies
@@ -151,7 +153,7 @@ class FdemBatch:
         J = torch.empty((self.B, 2 * self.F, self.Lmax), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gbp_fdem_fm_dlogc(
-                self._h_exact.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
+                self._h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(), self.sigma.data_ptr(), self.thk.data_ptr(),
                 self.height.data_ptr(), self.predicted.data_ptr(), J.data_ptr(), self.Lmax, 1 if exact else 0,
                 _stream_ptr(self.device)))
         return J
@@ -191,7 +193,7 @@ class FdemBatch:
     def _launch_sens(self, nlayers, sigma, thk, height, out, max_layers, exact):
         lib = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h_exact.ptr, nlayers.numel(), self.Lmax, nlayers.data_ptr(),
+            _lib.check(lib.gbp_fdem_sensitivity_ex(self._h.ptr, nlayers.numel(), self.Lmax, nlayers.data_ptr(),
                                                    sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
                                                    out.data_ptr(), int(max_layers), 1 if exact else 0,
                                                    _stream_ptr(self.device)))

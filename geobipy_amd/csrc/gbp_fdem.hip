@@ -447,13 +447,23 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                                     const double* __restrict__ sigma,
                                                     const double* __restrict__ thk,
                                                     const double* __restrict__ height, double* __restrict__ J,
-                                                    double* __restrict__ pred)
+                                                    double* __restrict__ pred, const BinDesc* __restrict__ bins, int bin0, int n_bins,
+                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
 {
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
+    if (bins != nullptr) {                                  // this sounding's abscissa window (see k_fdem_forward)
+        const double alt = height[b];
+        if (alt >= (double)bin0) {
+            const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
+            chan = bin_chan + d.chan_off;
+            pts = bin_pts + d.pts_off;
+            npts_total = d.npts_total;
+        }
+    }
     if (L > Lalloc || L > Lmax) {   // more layers than the launch was sized for: NaN row instead of an LDS / row overrun
         const double qnan = __builtin_nan("");
         const size_t n = (size_t)2 * F * Lmax;
@@ -948,7 +958,8 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
     auto launch = [&](auto kernel) -> gbp_status {
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
-                           Lmax, max_layers, nlayers, sigma, thk, height, J, pred);
+                           Lmax, max_layers, nlayers, sigma, thk, height, J, pred, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
+                           sys->d_bin_pts);
         return GBP_OK;
     };
     // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs

@@ -1265,7 +1265,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(1024) void k_rj_persistent(gbp_rj_options o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
                                                        const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                        uint32_t iter0, int n_iter, int accumulate, int nw_deep,
-                                                       unsigned char* deep_scratch, size_t deep_bytes)
+                                                       unsigned char* deep_scratch, size_t deep_bytes, const BinDesc* __restrict__ bins,
+                                                       int bin0, int n_bins, const Channel* __restrict__ bin_chan,
+                                                       const double* __restrict__ bin_pts)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
@@ -1316,6 +1318,15 @@ __global__ __launch_bounds__(1024) void k_rj_persistent(gbp_rj_options o_arg, gb
         // read-only inputs
         for (size_t i = threadIdx.x; i < (size_t)N; i += blockDim.x) p[i] = c_arg.data[bb * N + i];
         if (threadIdx.x == 0) sh_c.data = p - bb * N;
+    }
+    if (bins != nullptr) {                                        // the chain's abscissa window: the bin of its sounding's altitude
+        const double alt = c_arg.height[b];
+        if (alt >= (double)bin0) {
+            const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
+            chan = bin_chan + d.chan_off;
+            pts = bin_pts + d.pts_off;
+            npts_total = d.npts_total;
+        }
     }
     if (threadIdx.x == 0) {
         sh_x.o = &sh_o; sh_x.c = &sh_c; sh_x.math = &sh_math; sh_x.sh_out = sh_out; sh_x.sh_dyn = stage_scratch; sh_x.chan = chan;
@@ -1520,7 +1531,8 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
     auto launch = [&](auto kernel) -> gbp_status {
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, *o, *c, sys->d_chan, sys->d_pts, sys->t.npts, F,
-                           sys->sigma_direct, (uint32_t)first_iteration, n_iterations, accumulate, nw, deep, deep_bytes);
+                           sys->sigma_direct, (uint32_t)first_iteration, n_iterations, accumulate, nw, deep, deep_bytes, sys->d_bins,
+                           sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
         return GBP_OK;
     };
     gbp_status st = o->exact_jacobian ? launch(rj::k_rj_persistent<true>) : launch(rj::k_rj_persistent<false>);

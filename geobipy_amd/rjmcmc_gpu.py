@@ -75,15 +75,15 @@ class DeviceChains:
     :641-688) evaluated on the device: a chain burns in at the first iteration > ``burn_in_min_iterations`` whose misfit
     is below the number of active channels (its posteriors and best model restart there), is done ``n_markov_chains``
     iterations later and has failed if it has not burned in after ``n_markov_chains`` iterations; see ``infer``.
-    ``hankel_eps_ppm`` > 0: evaluate only the filter abscissae whose total contribution can exceed that many ppm at the
-    altitude floor ``min_altitude`` (default: the lowest sounding of this block; pass the survey's floor for results that
-    do not depend on the sharding) -- 1e-12 keeps 673 of 1200 points of the 10-frequency system and changes predictions and
-    Jacobians by < 2e-12 ppm.
+    ``hankel_eps_ppm``: every chain evaluates only the filter abscissae whose terms can add up to more than that many ppm
+    at its own sounding's altitude (1 m altitude bins, so the result does not depend on the sharding; default 1e-10 keeps
+    about 600 of the 1200 points of the 10-frequency system; predictions and true-derivative Jacobians move by less than
+    that bound); 0 evaluates all 120 / 140 abscissae.  ``min_altitude`` is accepted and ignored.
     hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_value_bins, n_depth_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
-                 first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=0.0,
+                 first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
                  min_altitude=None, add_scale=None, rel_group=None, add_group=None, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
@@ -94,10 +94,10 @@ class DeviceChains:
         f64 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64).to(self.device).contiguous()
         data, heights = f64(data), f64(heights)
         with torch.cuda.device(self.device):
-            if hankel_eps_ppm > 0.0:          # opt-in abscissa window (FdemBatch(hankel_eps_ppm=...))
-                floor = float(heights.min()) if min_altitude is None else float(min_altitude)
-                assert floor <= float(heights.min()), ValueError("min_altitude must not exceed the lowest sounding")
-                self._h = system.handle(float(hankel_eps_ppm), floor)
+            from .system import DEFAULT_HANKEL_EPS_PPM
+            self.hankel_eps_ppm = DEFAULT_HANKEL_EPS_PPM if hankel_eps_ppm is None else float(hankel_eps_ppm)
+            if self.hankel_eps_ppm > 0.0 and heights.numel() > 0 and hasattr(system, "handle_binned"):   # per-chain abscissa window, as FdemBatch
+                self._h = system.handle_binned(self.hankel_eps_ppm, float(heights.min()), float(heights.max()))
             else:
                 self._h = system.handle()
         self.B, self.N = data.shape

@@ -100,7 +100,9 @@ gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t *tid, const dou
  * the last set, whose bound still holds).  What is evaluated for a sounding therefore depends on that sounding alone --
  * results do not change with the batch a sounding is evaluated in -- and every output stays within eps_ppm of the full
  * 120 / 140-point sums (geobipy_amd's default 1e-10 ppm: two orders below the rounding error of those sums themselves, three
- * below the parity bar).  This is the handle geobipy_amd.FdemBatch uses by default.  The Jacobian entries ignore the bins (all abscissae).
+ * below the parity bar).  This is the handle geobipy_amd.FdemBatch and DeviceChains use by default.  The Jacobian kernels and
+ * the sampler (gbp_rj_run*) use the same per-sounding sets: rTE is analytic in each layer's conductivity and bounded by 1 on the
+ * right half plane, hence |d rTE / d ln sigma_k| <= 2/pi, and the terms dropped from a true-derivative entry obey the same bound.
  */
 gbp_status gbp_fdem_system_create_binned(int nF, const int32_t *tid, const double *frequencies,
                                          const double *tx_z, const double *rx_z, const double *tx_moment,

@@ -63,8 +63,13 @@ for k in sorted(dur, key=lambda k: -sum(dur[k])):
         d["hbm_write_MB_per_iteration"] = sum(wr[k]["WRITE_SIZE"]) * 1024 / N_IT / 1e6
     out["kernels"][k] = {a: (round(b, 3) if isinstance(b, float) else b) for a, b in d.items()}
 out["us_per_iteration_all_kernels"] = round(sum(v["us_per_iteration"] for v in out["kernels"].values()), 1)
+import re
+try:
+    wall = re.search(r"([0-9.]+ ms) per lockstep iteration", open(os.path.join(src, "kt.log")).read()).group(1)
+except Exception:
+    wall = "see kt.log"
 out["note_overlap"] = ("at this block size the Jacobian pass of the dimension-changing proposals runs on a side stream next to the fused "
                        "forward kernel: their durations overlap (each is longer than it would be alone), so the sum over kernels exceeds the "
-                       "wall time per iteration printed by the benchmark (1.47 ms in the traced run)")
+                       "wall time per iteration printed by the benchmark (%s in the traced run)" % wall)
 json.dump(out, open(os.path.join(R, "profiles", (sys.argv[1] if len(sys.argv) > 1 else "r2"), "summary_rjmcmc_65536.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

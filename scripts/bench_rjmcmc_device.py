@@ -21,7 +21,7 @@ for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192,6553
     heights = rng.uniform(25.0, 40.0, B)
     t0 = time.perf_counter()
     dc = DeviceChains(s, heights, data, seed=1, exact_jacobian=True, forward_waves=int(os.environ.get('RJ_WAVES', 2)),
-                      hankel_eps_ppm=float(os.environ.get('RJ_EPS', 0.0)), min_altitude=25.0, **o)
+                      hankel_eps_ppm=(float(os.environ['RJ_EPS']) if 'RJ_EPS' in os.environ else None), **o)
     torch.cuda.synchronize(); t_init = time.perf_counter() - t0
     dc.run(20); torch.cuda.synchronize()
     t0 = time.perf_counter(); dc.run(n_it); torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -47,8 +47,9 @@ int main(int argc, char** argv)
     for (int i = 0; i < nF; ++i) tid[i] = (int32_t)tid_d[i];
 
     gbp_fdem_system* sys = nullptr;
-    CHECK(gbp_fdem_system_create(nF, tid.data(), freq.data(), tx_z.data(), rx_z.data(), tx_m.data(), scale.data(), rx_off.data(), sep.data(),
-                                 w0.data(), lam0.data(), w1.data(), lam1.data(), &sys));
+    // per-sounding abscissa windows, 1 m altitude bins from 20 m up: the handle geobipy_amd's Python host side uses by default
+    CHECK(gbp_fdem_system_create_binned(nF, tid.data(), freq.data(), tx_z.data(), rx_z.data(), tx_m.data(), scale.data(), rx_off.data(),
+                                        sep.data(), w0.data(), lam0.data(), w1.data(), lam1.data(), 1.0e-10, 20, 64, &sys));
     // chain state: half-space models
     std::vector<int32_t> k1(B, 1);
     std::vector<double> sig((size_t)B * K, 1.0), edges((size_t)B * K, INFINITY), rel(B, opt[0]), add(B, opt[1]), lmp(B);

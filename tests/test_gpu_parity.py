@@ -304,7 +304,7 @@ def test_bad_rows_are_flagged_and_the_rest_of_the_batch_is_untouched():
     pj = torch.full((B, 20), -7.0, dtype=torch.float64, device=p1.device)
     nlj = nl.copy(); nlj[5] = 7                                  # a legal 7-layer row, but the launch is sized for 5
     nlj_t = torch.as_tensor(nlj, dtype=torch.int32, device=p1.device)
-    _lib.check(_lib.load().gbp_fdem_fm_dlogc(good._h_exact.ptr, B, Lmax, nlj_t.data_ptr(), good.sigma.data_ptr(), good.thk.data_ptr(),
+    _lib.check(_lib.load().gbp_fdem_fm_dlogc(good._h.ptr, B, Lmax, nlj_t.data_ptr(), good.sigma.data_ptr(), good.thk.data_ptr(),
                                              good.height.data_ptr(), pj.data_ptr(), J1.data_ptr(), 5, 1, None))
     torch.cuda.synchronize()
     keep = np.ones(B, bool); keep[5] = False
@@ -459,9 +459,14 @@ def test_abscissa_window_mode():
     c1, l1 = FdemBatch(s, nl, sig, thk, h, data=np.full((B, 20), 80.0), relative_error=np.full(B, 0.05),
                        additive_error=np.full(B, 5.0)).forward_loglike()
     assert torch.allclose(c0, c1, rtol=1e-11, atol=1e-8) and torch.allclose(l0, l1, rtol=1e-11, atol=1e-8)
-    # the Jacobian always uses the full tables
-    assert torch.equal(FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64]).sensitivity(),
-                       FdemBatch(s, nl[:64], sig[:64], thk[:64], h[:64], hankel_eps_ppm=0.0).sensitivity())
+    # the Jacobian uses the same window: |d rTE / d ln sigma| <= 2/pi bounds the dropped terms of the true derivative by the
+    # same sum; the reference's expression (not a derivative) is measured
+    for exact_j, bar in ((True, 1e-10), (False, 1e-8)):
+        jw = FdemBatch(s, nl[:512], sig[:512], thk[:512], h[:512]).sensitivity(exact=exact_j)
+        ja = FdemBatch(s, nl[:512], sig[:512], thk[:512], h[:512], hankel_eps_ppm=0.0).sensitivity(exact=exact_j)
+        dj = float((jw - ja).abs().max())
+        print("abscissa window, Jacobian (exact=%s): max |dJ| = %.3g ppm per ln(sigma)" % (exact_j, dj))
+        assert dj <= bar + 2e-15 * float(ja.abs().max())          # + a few ulp of the largest entries (different summation order)
 
 
 def test_find_best_halfspace_matches_brute_force():

@@ -345,7 +345,7 @@ def test_device_chains_state_is_coherent_after_many_steps():
             assert e[b, 0] > dc.min_edge and e[b, k[b] - 2] < dc.max_edge
     fb = FdemBatch(s, k, sig, thk, dc.height.cpu().numpy(), data=dc.data.cpu().numpy(),
                    relative_error=dc.rel[:, 0].cpu().numpy(), additive_error=dc.add[:, 0].cpu().numpy(),
-                   waves=dc._o.forward_waves, hankel_eps_ppm=0.0)            # the summation order and the abscissae the chains ran with
+                   waves=dc._o.forward_waves)            # the summation order and the abscissa windows the chains ran with
     chi2, logl = fb.forward_loglike()
     # proposals that keep their dimension get prediction / chi^2 / logL from the fused forward kernel (bit-equal to this
     # evaluation); the others from the Jacobian pass and the accept kernel (same values, different summation order)
@@ -460,11 +460,11 @@ def test_posterior_accumulators_match_a_host_replay():
 
 @pytest.mark.gpu
 def test_abscissa_window_does_not_change_the_chains():
-    """Opt-in hankel_eps_ppm = 1e-12: predictions and Jacobians move by < 2e-12 ppm, so 300 iterations take the same
-    decisions and end in the same models to 1e-8."""
-    _, _, a = _chains(64, 31, exact=True, n_it=300)
-    _, _, w = _chains(64, 31, exact=True, n_it=300, hankel_eps_ppm=1e-12)
-    assert w._h.npoints < a._h.npoints
+    """The default per-chain abscissa window (1e-10 ppm): predictions and Jacobians move by < 1e-10 ppm against the full
+    120-point sums (hankel_eps_ppm=0), so 300 iterations take the same decisions and end in the same models to 1e-8."""
+    _, _, a = _chains(64, 31, exact=True, n_it=300, hankel_eps_ppm=0.0)
+    _, _, w = _chains(64, 31, exact=True, n_it=300)
+    assert w._h.bins is not None and a._h.bins is None
     assert torch.equal(a.k, w.k) and torch.equal(a.n_accepted, w.n_accepted) and torch.equal(a.k_hist, w.k_hist)
     assert torch.allclose(a.sigma, w.sigma, rtol=1e-8) and torch.allclose(a.misfit, w.misfit, rtol=1e-8)
 
