@@ -357,8 +357,9 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                                           const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
                                           const double* __restrict__ sig, const double* __restrict__ th, double alt,
                                           double* __restrict__ Jb /* [2F, Lmax] of this sounding */,
-                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use)
-{
+                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to)
+{   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
+    // sampler, whose consumers never read a column >= L, passes L rounded up to 8 and leaves the rest of the row alone)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = nw_use;
@@ -433,7 +434,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                 }
             }
         }
-        for (int m = L + lane; m < Lmax; m += 64) {   // unused columns
+        for (int m = L + lane; m < zero_to; m += 64) {   // unused columns
             Jb[(size_t)f * Lmax + m] = 0.0;
             Jb[(size_t)(F + f) * Lmax + m] = 0.0;
         }
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                                     const double* __restrict__ thk,
                                                     const double* __restrict__ height, double* __restrict__ J,
                                                     double* __restrict__ pred, const BinDesc* __restrict__ bins, int bin0, int n_bins,
-                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
+                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts,
+                                                    int compact_rows)
 {
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     const gbp::MathCtx M = math_setup(sh_math);
     sens_body<EXACT, NG>(M, sh_dyn, chan, pts, npts_total, F, Lmax, Lalloc, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
                          height[b], J + (size_t)b * 2 * F * Lmax, pred != nullptr ? pred + (size_t)b * 2 * F : nullptr,
-                         (int)(blockDim.x >> 6));
+                         (int)(blockDim.x >> 6), compact_rows ? min(Lmax, (L + 7) & ~7) : Lmax);
 }
 
 // chi^2 / logL with an explicit per-channel standard deviation (TdemDataPoint.std is time dependent)
@@ -612,6 +614,10 @@ gbp_status check_batch(const gbp_fdem_system* sys, int B, int Lmax, const void* 
 }
 
 }  // namespace
+
+static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                                  const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                                  int waves, int compact_rows, void* stream);
 
 extern "C" {
 
@@ -940,6 +946,16 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
                                 const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
                                 int waves, void* stream)
 {
+    return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, stream);
+}
+
+}  // extern "C"
+
+// compact_rows != 0 (the sampler's launches): only the columns up to the layer count rounded up to 8 are written
+static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                                  const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                                  int waves, int compact_rows, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
@@ -959,7 +975,7 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
                            Lmax, max_layers, nlayers, sigma, thk, height, J, pred, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                           sys->d_bin_pts);
+                           sys->d_bin_pts, compact_rows);
         return GBP_OK;
     };
     // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs
@@ -970,8 +986,6 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
-
-}  // extern "C"
 
 #include "gbp_rjmcmc.h"
 #include "gbp_tdem.h"

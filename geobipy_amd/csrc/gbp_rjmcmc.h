@@ -263,11 +263,14 @@ __global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_r
 }
 
 // Large blocks: one thread per chain (the wave version would spend 64 lanes on every scalar decision).
-__device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b)
+// e, s: the chain's current rows; er, sr, tr: where the remapped rows go (er / sr may be e / s themselves: entry j is written
+// after entry j + 1 has been read, and choose_move is done with e before the first write).  PAIRS: rows in global memory are
+// written two entries (16 bytes) at a time when they are 16-byte aligned (K even).
+template <bool PAIRS>
+__device__ __forceinline__ void propose_rows(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b, const double* e,
+                                             const double* s, double* er, double* sr, double* tr)
 {
     const int K = o.max_layers;
-    const double* __restrict__ e = c.edges + (size_t)b * K;
-    const double* __restrict__ s = c.sigma + (size_t)b * K;
     const int k = c.k[b];
     Rng r(o.seed, chain_key(o, c, b), iter, 0);
     int action, idx;
@@ -275,14 +278,9 @@ __device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, con
     choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return e[j]; },
                 [&](double depth) { int pos = 0; while (pos < k - 1 && e[pos] < depth) ++pos; return pos; }, action, idx, val);
     const int kr = k + (action == INSERT) - (action == DELETE);
-    double* __restrict__ er = c.edges_r + (size_t)b * K;
-    double* __restrict__ sr = c.sigma_r + (size_t)b * K;
-    double* __restrict__ tr = c.thk_r + (size_t)b * K;
     double above = 0.0;
     double e_j = 0 < k - 1 ? e[0] : INF, s_j = 0 < k ? s[0] : 1.0, e_up = e_j, s_up = s_j;   // rolling window over the rows
-    // rows are written two entries (16 bytes) at a time when they are 16-byte aligned (K even): a thread's stores are 8 K
-    // bytes apart from its neighbour's, so every store instruction touches 64 cache lines -- half as many instructions
-    const bool pairs = (K & 1) == 0;
+    const bool pairs = PAIRS && (K & 1) == 0;
     double ev0 = 0.0, sv0 = 0.0, tv0 = 0.0;
     for (int j = 0; j < K; ++j) {
         const double e_dn = j + 1 < k - 1 ? e[j + 1] : INF, s_dn = j + 1 < k ? s[j + 1] : 1.0;
@@ -304,11 +302,82 @@ __device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, con
     write_move(o, c, r, b, action, kr);
 }
 
+__device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b)
+{
+    const int K = o.max_layers;
+    propose_rows<true>(o, c, iter, b, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, c.edges_r + (size_t)b * K,
+                       c.sigma_r + (size_t)b * K, c.thk_r + (size_t)b * K);
+}
+
 __global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;
     propose_thread_body(o, c, iter, b);
+}
+
+// The same, with the rows of the workgroup's 64 chains staged through LDS: a thread's row is 8 K bytes from its neighbour's,
+// so in the kernel above every load of the serial loop over the row is a separate trip to memory (the loop is latency bound)
+// and every store instruction writes 64 partial cache lines (2.7 x write amplification measured, profiles/r2).  Here the 64
+// rows, contiguous in memory, come in and go out as whole cache lines and the serial loop runs on LDS (row stride K | 1
+// doubles: the 64 lanes of a column access fall on distinct bank pairs).  Same draws, same values.
+#define GBP_RJ_PROPOSE_ROWS 64
+#define GBP_RJ_PROPOSE_THREADS 256
+__global__ __launch_bounds__(GBP_RJ_PROPOSE_THREADS) void k_rj_propose_staged(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int K = o.max_layers, KS = K | 1, t = threadIdx.x;
+    const int b0 = blockIdx.x * GBP_RJ_PROPOSE_ROWS, nb = min(GBP_RJ_PROPOSE_ROWS, c.B - b0);
+    double* se = reinterpret_cast<double*>(sh_dyn);
+    double* ss = se + GBP_RJ_PROPOSE_ROWS * KS;
+    double* st = ss + GBP_RJ_PROPOSE_ROWS * KS;
+    const size_t g0 = (size_t)b0 * K;                              // (b0 is a multiple of 64: 16-byte aligned for any K)
+    const int n_el = nb * K, n_pair = (n_el + 1) >> 1;
+    // copy in: all four waves, 16 bytes per lane and array, four loads in flight per lane before the first LDS write
+    for (int p0 = t; p0 < n_pair; p0 += 4 * GBP_RJ_PROPOSE_THREADS) {
+        double2 ve[4], vs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * GBP_RJ_PROPOSE_THREADS;
+            if (p < n_pair) {
+                if (2 * p + 1 < n_el) {
+                    ve[u] = *reinterpret_cast<const double2*>(c.edges + g0 + 2 * p);
+                    vs[u] = *reinterpret_cast<const double2*>(c.sigma + g0 + 2 * p);
+                } else {
+                    ve[u] = make_double2(c.edges[g0 + 2 * p], 0.0);
+                    vs[u] = make_double2(c.sigma[g0 + 2 * p], 0.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * GBP_RJ_PROPOSE_THREADS;
+            if (p < n_pair) {
+                const int i0 = 2 * p, r0 = i0 / K, c0 = i0 - r0 * K;
+                se[r0 * KS + c0] = ve[u].x; ss[r0 * KS + c0] = vs[u].x;
+                if (i0 + 1 < n_el) {
+                    const int r1 = c0 + 1 < K ? r0 : r0 + 1, c1 = c0 + 1 < K ? c0 + 1 : 0;
+                    se[r1 * KS + c1] = ve[u].y; ss[r1 * KS + c1] = vs[u].y;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t < nb) propose_rows<false>(o, c, iter, b0 + t, se + t * KS, ss + t * KS, se + t * KS, ss + t * KS, st + t * KS);
+    __syncthreads();
+    for (int p = t; p < n_pair; p += GBP_RJ_PROPOSE_THREADS) {
+        const int i0 = 2 * p, r0 = i0 / K, c0 = i0 - r0 * K;
+        const int r1 = c0 + 1 < K ? r0 : r0 + 1, c1 = c0 + 1 < K ? c0 + 1 : 0;
+        if (i0 + 1 < n_el) {
+            *reinterpret_cast<double2*>(c.edges_r + g0 + i0) = make_double2(se[r0 * KS + c0], se[r1 * KS + c1]);
+            *reinterpret_cast<double2*>(c.sigma_r + g0 + i0) = make_double2(ss[r0 * KS + c0], ss[r1 * KS + c1]);
+            *reinterpret_cast<double2*>(c.thk_r + g0 + i0) = make_double2(st[r0 * KS + c0], st[r1 * KS + c1]);
+        } else {
+            c.edges_r[g0 + i0] = se[r0 * KS + c0];
+            c.sigma_r[g0 + i0] = ss[r0 * KS + c0];
+            c.thk_r[g0 + i0] = st[r0 * KS + c0];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -840,9 +909,11 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
         }
         for (int n = lane; n < N; n += 64) c.pred[(size_t)b * N + n] = c.pred_p[(size_t)b * N + n];
         if (action != NONE) {
+            // (the columns the Jacobian pass wrote: layer count rounded up to 8)
             const double* Js = (action == PERTURB ? c.J_r : c.J_p) + (size_t)b * N * K;
             double* Jd = c.J + (size_t)b * N * K;
-            for (int i = lane; i < N * K; i += 64) Jd[i] = Js[i];
+            const int kc = min(K, (k + 7) & ~7);
+            for (int i = lane; i < N * kc; i += 64) { const int n = i / kc, j = i - n * kc; Jd[(size_t)n * K + j] = Js[(size_t)n * K + j]; }
         }
         if (lane == 0) {
             c.k[b] = k;
@@ -1036,8 +1107,8 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
         }
         for (int n = i; n < N; n += 8) c.pred[bb * N + n] = c.pred_p[bb * N + n];
         if (action != NONE) {
-            // (columns 0..7 only: both models have at most 8 layers, and the columns beyond are zero in c.J already --
-            //  the one-wave kernel, which hands such chains over, copies whole rows)
+            // (columns 0..7 only: both models have at most 8 layers, the Jacobian pass wrote these 8 columns, and nothing reads
+            //  a column at or beyond the layer count)
             const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
             double* Jd = c.J + bb * N * K;
             if (i < K)
@@ -1216,9 +1287,9 @@ __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_pro
     double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
     const double* th = c.thk_r + (size_t)b * K;
     const double alt = c.height[b];
-    if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6));
+    if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6), min(K, 8));
     else sens_body<EXACT, 8>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K, L,
-                             sig, th, alt, Jb, pr, x->nw_deep);
+                             sig, th, alt, Jb, pr, x->nw_deep, min(K, (L + 7) & ~7));
 }
 
 __device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
@@ -1450,14 +1521,24 @@ gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    // one thread per chain is the faster variant at every block size measured (256 ... 65536 chains); the cooperative
-    // one-wave-per-chain kernel is kept as an independent implementation of the same draws (test hook: GBP_RJ_PROPOSE=wave)
+    // one thread per chain (rows staged through LDS) is the faster variant at every block size measured (256 ... 65536 chains);
+    // the unstaged kernel and the cooperative one-wave-per-chain kernel are kept as independent implementations of the same
+    // draws (test hooks: GBP_RJ_PROPOSE=thread / wave)
     const char* force = std::getenv("GBP_RJ_PROPOSE");
     if (force && force[0] == 'w')
         hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
-    else
+    else if (force && force[0] == 't')
         hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
                            (uint32_t)iteration);
+    else {
+        const size_t lds = (size_t)3 * GBP_RJ_PROPOSE_ROWS * (o->max_layers | 1) * sizeof(double);
+        if (lds > 64 * 1024)          // rows too long to stage 64 of them (max_layers > 42): the unstaged kernel
+            hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
+                               (uint32_t)iteration);
+        else
+            hipLaunchKernelGGL(rj::k_rj_propose_staged, dim3((c->B + GBP_RJ_PROPOSE_ROWS - 1) / GBP_RJ_PROPOSE_ROWS),
+                               dim3(GBP_RJ_PROPOSE_THREADS), lds, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+    }
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1636,8 +1717,9 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
     auto fm_dlogc = [&](const int32_t* nl, const double* sigma, double* pred, double* J, hipStream_t q) -> gbp_status {
         for (int i = 0; i < nb; ++i) {
-            gbp_status s2 = gbp_fdem_fm_dlogc_ex(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
-                                                 td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, q);
+            // (compact rows: the consumers read columns < layer count only, so the columns beyond it rounded up to 8 are not touched)
+            gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
+                                            td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, q);
             if (s2 != GBP_OK) return s2;
         }
         return td ? td_apply(nl, true, pred, J, q) : GBP_OK;

@@ -136,7 +136,11 @@ class DeviceChains:
         ro.alpha = float(o["covariance_scaling"])
         # error levels: one of each for frequency-domain data; time-domain data have one relative level per system x
         # component and one additive level per system (options given as lists, as in the reference's skytem / tempest files)
-        vec = lambda key, n: np.broadcast_to(np.atleast_1d(np.asarray(o[key], dtype=np.float64)), (n,)).copy()
+        def vec(key, n):
+            if o.get(key) is None:
+                raise KeyError("option '{}' is required (error-level bounds and proposal variances are read even when the "
+                               "level is not solved for: the prior of the fixed level uses them)".format(key))
+            return np.broadcast_to(np.atleast_1d(np.asarray(o[key], dtype=np.float64)), (n,)).copy()
         self.n_rel_groups = Gr = 1 if rel_group is None else int(np.max(rel_group)) + 1
         self.n_add_groups = Ga = 1 if add_group is None else int(np.max(add_group)) + 1
         ro.n_rel_groups, ro.n_add_groups = Gr, Ga

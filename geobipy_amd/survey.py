@@ -182,7 +182,13 @@ class TdemData:
                      y=("n", "y", "northing"), z=("alt", "altitude", "laser", "bheight", "height"))
         idx = {r: find(names) for r, names in roles.items()}
         elev = next((j for j, h in enumerate(low) if h in ("dtm", "dem_elev", "dem_np", "topo", "elev", "elevation")), None)
-        dcols = [j for j, h in enumerate(low) if "_time_" in h and h[0] == "s"]
+        # data columns: the reference's rule (TdemData.py:622-631): a header containing off_time / x_time / y_time / z_time is a
+        # window of the secondary field, unless it also contains 'err' (an error column, not read here)
+        is_win = lambda h: any(t in h for t in ("off_time", "x_time", "y_time", "z_time"))
+        dcols = [j for j, h in enumerate(low) if is_win(h) and "err" not in h]
+        if not dcols:
+            raise ValueError("{}: no data columns (headers containing off_time, x_time, y_time or z_time); found {}".format(
+                data_filename, header))
         table = np.atleast_2d(np.loadtxt(data_filename, delimiter=",", skiprows=1))
         off = [table[:, low.index(k)] for k in ("txrx_dx", "txrx_dy", "txrx_dz")]
         assert all(np.all(v == v[0]) for v in off), NotImplementedError("the transmitter-receiver offset must be the same for every sounding")
@@ -297,6 +303,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         raise NotImplementedError("the device sampler handles FdemData and TdemData; {} is not supported".format(o["data_type"]))
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
+    if o.get("ignore_likelihood"):
+        # the reference then samples the prior alone (Inference1D.py:394, 519, 551, 596: no stochastic Newton step, no data term)
+        raise NotImplementedError("ignore_likelihood (prior-only sampling) is not supported by the device sampler")
     # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
     # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- the height stays fixed there too
     if data is not None:

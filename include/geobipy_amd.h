@@ -86,7 +86,7 @@ gbp_status gbp_hankel_system_create_raw(int nF, const int32_t *npts, const doubl
  * Same system with an accuracy-budgeted abscissa window (opt-in): abscissae whose contribution to ANY output
  * is provably (|rTE| <= 1) below eps_ppm in total, for every sounding at altitude >= min_altitude, are left
  * out of the tables (typically half of the 120 at eps_ppm = 1e-12).  eps_ppm <= 0 = all abscissae, i.e.
- * gbp_fdem_system_create.  Not for gbp_fdem_sensitivity (the bound does not cover the Jacobian).
+ * gbp_fdem_system_create.  The Jacobian kernels use the same window (see gbp_fdem_system_create_binned for the bound).
  */
 gbp_status gbp_fdem_system_create_windowed(int nF, const int32_t *tid, const double *frequencies,
                                            const double *tx_z, const double *rx_z, const double *tx_moment,

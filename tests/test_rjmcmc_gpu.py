@@ -199,10 +199,11 @@ def test_propose_kernel_matches_the_emulation():
             assert np.array_equal(nl_a[:, b], want_a) and np.array_equal(nl_c[:, b], want_c)
             seen.add(a)
     assert seen == {0, 1, 2, 3} and kept > 20          # all four moves, and the give-up path of the error proposal
-    # the one-thread-per-chain variant used for large blocks writes the same bits
+    # the three implementations of the draws write the same bits: one wave per chain, one thread per chain, and the default
+    # (one thread per chain, rows staged through LDS)
     names = ("action", "k_r", "nl_a", "nl_c", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p")
     out = {}
-    for variant in ("wave", "thread"):
+    for variant in ("wave", "thread", "default"):
         os.environ["GBP_RJ_PROPOSE"] = variant
         try:
             for n in names:
@@ -212,7 +213,7 @@ def test_propose_kernel_matches_the_emulation():
         finally:
             del os.environ["GBP_RJ_PROPOSE"]
     for n in names:
-        assert torch.equal(out["wave"][n], out["thread"][n]), n
+        assert torch.equal(out["wave"][n], out["thread"][n]) and torch.equal(out["default"][n], out["thread"][n]), n
     assert np.array_equal(out["wave"]["action"].cpu().numpy(), act)
 
 
