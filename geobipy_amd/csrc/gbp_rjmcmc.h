@@ -14,6 +14,37 @@
 
 namespace rj {
 
+// The caller's options plus the logarithms of the option constants the stages need at every iteration (prior bounds of the
+// error levels, depth range, prior normalisations): computed once per launch on the host (extend(), std::log) instead of ~20
+// library calls per chain and iteration.
+struct RjOpt : gbp_rj_options {
+    double log_min_edge, log_max_edge, log_layers_m1, log_value_precision, log_gradient_precision;
+    double log_rel_min[4], log_rel_max[4], log_add_min[4], log_add_max[4];
+    double nlog_rel_span[4], nlog_add_span[4];               // -log(log(max) - log(min)): the log-uniform prior density
+};
+
+inline RjOpt extend(const gbp_rj_options& o)
+{
+    static thread_local gbp_rj_options last;                  // (every launch of a run passes the same options)
+    static thread_local RjOpt cached;
+    static thread_local bool have = false;
+    if (have && std::memcmp(&last, &o, sizeof(o)) == 0) return cached;
+    RjOpt x;
+    static_cast<gbp_rj_options&>(x) = o;
+    x.log_min_edge = std::log(o.min_edge); x.log_max_edge = std::log(o.max_edge);
+    x.log_layers_m1 = std::log((double)o.max_layers - 1.0);
+    x.log_value_precision = std::log(o.value_precision); x.log_gradient_precision = std::log(o.gradient_precision);
+    for (int g = 0; g < 4; ++g) {
+        x.log_rel_min[g] = std::log(o.rel_min[g]); x.log_rel_max[g] = std::log(o.rel_max[g]);
+        x.log_add_min[g] = std::log(o.add_min[g]); x.log_add_max[g] = std::log(o.add_max[g]);
+        x.nlog_rel_span[g] = -std::log(x.log_rel_max[g] - x.log_rel_min[g]);
+        x.nlog_add_span[g] = -std::log(x.log_add_max[g] - x.log_add_min[g]);
+    }
+    std::memcpy(&last, &o, sizeof(o)); cached = x; have = true;
+    return x;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11), counter = (chain, iteration, stream, draw), key = seed
 // ---------------------------------------------------------------------------------------------------------------
@@ -49,35 +80,52 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The transcendental functions and the generator are CALLED, not inlined: inlined at their ~60 call sites they made the
+// proposal stage 13 000 instructions (27 000 in the persistent kernel's copy) and the accept stage 11 000 -- ~400 KB of code
+// per iteration of the persistent kernel against a 64 KB instruction cache, for stages that run as one wave per SIMD and
+// cannot hide a fetch miss.  Same library routines, same bits.
+#define GBP_RJ_CALL __attribute__((noinline))
+__device__ GBP_RJ_CALL double rj_log(double x) { return log(x); }
+__device__ GBP_RJ_CALL double rj_exp(double x) { return exp(x); }
+__device__ GBP_RJ_CALL U4 philox_call(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t n)
+{
+    return philox(seed, chain, iter, stream, n);
+}
+__device__ GBP_RJ_CALL double box_muller_cos(double u1, double u2) { return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2); }
+__device__ GBP_RJ_CALL void box_muller_pair(double u1, double u2, double* z0, double* z1)
+{
+    const double rad = sqrt(-2.0 * log(1.0 - u1)), ang = TWO_PI * u2;
+    *z0 = rad * cos(ang); *z1 = rad * sin(ang);
+}
+
 struct Rng {                                                    // sequential draws of one (chain, iteration, stream)
     uint64_t seed; uint32_t chain, iter, stream, n; double buf; bool have;
     __device__ Rng(uint64_t s, uint32_t c, uint32_t i, uint32_t st) : seed(s), chain(c), iter(i), stream(st), n(0), buf(0.0), have(false) {}
     __device__ double uniform()
     {
         if (have) { have = false; return buf; }
-        const U4 r = philox(seed, chain, iter, stream, n++);
+        const U4 r = philox_call(seed, chain, iter, stream, n++);
         buf = u53(r.z, r.w); have = true;
         return u53(r.x, r.y);
     }
     __device__ double normal()
     {
         const double u1 = uniform(), u2 = uniform();
-        return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2);
+        return box_muller_cos(u1, u2);
     }
 };
 
 __device__ inline void normal_pair(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t j, double& z0, double& z1)
 {
-    const U4 r = philox(seed, chain, iter, stream, j);
-    const double rad = sqrt(-2.0 * log(1.0 - u53(r.x, r.y))), ang = TWO_PI * u53(r.z, r.w);
-    z0 = rad * cos(ang); z1 = rad * sin(ang);
+    const U4 r = philox_call(seed, chain, iter, stream, j);
+    box_muller_pair(u53(r.x, r.y), u53(r.z, r.w), &z0, &z1);
 }
 
 enum { NONE = 0, INSERT = 1, DELETE = 2, PERTURB = 3 };
 
 // Key of chain b's random streams: its global index in the survey, so that the chains do not depend on how the survey is
-// sharded or on the rows of a block being re-packed (chain_id), see gbp_rj_options.first_chain.
-__device__ inline uint32_t chain_key(const gbp_rj_options& o, const gbp_rj_chains& c, int b)
+// sharded or on the rows of a block being re-packed (chain_id), see RjOpt.first_chain.
+__device__ inline uint32_t chain_key(const RjOpt& o, const gbp_rj_chains& c, int b)
 {
     return (uint32_t)((c.chain_id != nullptr && b < c.B) ? (uint64_t)c.chain_id[b] : o.first_chain + (uint64_t)b);
 }
@@ -90,7 +138,7 @@ constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 // additive level per system, DataPoint.py:268-282 / TdemDataPoint.py:361-365; FDEM with one system: one of each).
 struct Levels { double rel[4], add[4]; };
 
-__device__ inline Levels load_levels(const gbp_rj_options& o, const double* rel, const double* add, size_t b)
+__device__ inline Levels load_levels(const RjOpt& o, const double* rel, const double* add, size_t b)
 {
     Levels e;
 #pragma unroll
@@ -115,7 +163,7 @@ __device__ inline double variance_at(const gbp_rj_chains& c, const Levels& e, do
 // Joint proposal of the G levels of one kind (StatArray.propose with a multivariate log-normal proposal of diagonal
 // covariance, statistics/StatArray.py:578-638): all are redrawn while any is outside its prior; the current values are
 // kept at the 10th redraw.
-__device__ inline void propose_levels(Rng& r, const double* cur, int G, const double* sd, const double* lo, const double* hi, double* out)
+__device__ inline void propose_levels(Rng& r, const double* cur, int G, const double* sd, const double* llo, const double* lhi, double* out)
 {
     double x[4];
     bool ok;
@@ -124,8 +172,8 @@ __device__ inline void propose_levels(Rng& r, const double* cur, int G, const do
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (g < G) {
-                x[g] = log(cur[g]) + sd[g] * r.normal();
-                ok = ok && x[g] >= log(lo[g]) && x[g] <= log(hi[g]);
+                x[g] = rj_log(cur[g]) + sd[g] * r.normal();
+                ok = ok && x[g] >= llo[g] && x[g] <= lhi[g];
             }
     };
     draw();
@@ -139,7 +187,7 @@ __device__ inline void propose_levels(Rng& r, const double* cur, int G, const do
         }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) out[g] = g < G ? exp(x[g]) : cur[g];
+    for (int g = 0; g < 4; ++g) out[g] = g < G ? rj_exp(x[g]) : cur[g];
 }
 
 __device__ inline int bucket_of(int k) { return k <= 8 ? 0 : 1; }
@@ -147,11 +195,11 @@ __device__ inline int bucket_of(int k) { return k <= 8 ? 0 : 1; }
 // The structural move of one chain (RectilinearMesh1D.perturb :1018-1118).  edge(j): interface j of the current model;
 // below(depth): number of interfaces shallower than depth.
 template <class EdgeAt, class CountBelow>
-__device__ inline void choose_move(const gbp_rj_options& o, Rng& r, int k, bool idle, EdgeAt edge, CountBelow below, int& action,
+__device__ inline void choose_move(const RjOpt& o, Rng& r, int k, bool idle, EdgeAt edge, CountBelow below, int& action,
                                    int& idx, double& val)
 {
     const int K = o.max_layers;
-    const double lo = log(o.min_edge), hi = log(o.max_edge), mw = o.min_width;
+    const double lo = o.log_min_edge, hi = o.log_max_edge, mw = o.min_width;
     action = NONE; idx = 0; val = 0.0;
     bool done = idle;
     for (int round = 0; round < 8 && !done; ++round) {          // redraw the event when the tries run out
@@ -159,7 +207,7 @@ __device__ inline void choose_move(const gbp_rj_options& o, Rng& r, int k, bool 
         const double u = r.uniform() * (pb + pd + pp + o.p_none);
         if (u < pb) {                                           // birth (:1061-1081); the reference's 10th try always fails
             for (int t = 0; t < 9; ++t) {
-                const double depth = exp(lo + r.uniform() * (hi - lo));
+                const double depth = rj_exp(lo + r.uniform() * (hi - lo));
                 const int pos = below(depth);
                 const double prev = pos > 0 ? edge(pos - 1) : 0.0, next = pos < k - 1 ? edge(pos) : INF;
                 if (depth - prev > mw && next - depth > mw) { action = INSERT; idx = pos + 1; val = depth; done = true; break; }
@@ -204,7 +252,7 @@ __device__ inline void remap_entry(int action, int idx, double val, int kr, int 
     }
 }
 
-__device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr)
+__device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr)
 {   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-2: by bucket), error proposals
     const int bk = bucket_of(kr);
     const bool jump = action == INSERT || action == DELETE;
@@ -219,8 +267,8 @@ __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& 
     // error levels (DataPoint.perturb: relative then additive)
     const Levels cur = load_levels(o, c.rel, c.add, (size_t)b);
     Levels out = cur;
-    if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.rel_min, o.rel_max, out.rel);
-    if (o.solve_additive_error) propose_levels(r, cur.add, o.n_add_groups, o.add_sd, o.add_min, o.add_max, out.add);
+    if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.log_rel_min, o.log_rel_max, out.rel);
+    if (o.solve_additive_error) propose_levels(r, cur.add, o.n_add_groups, o.add_sd, o.log_add_min, o.log_add_max, out.add);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g < o.n_rel_groups) c.rel_p[(size_t)b * o.n_rel_groups + g] = out.rel[g];
@@ -230,7 +278,7 @@ __device__ inline void write_move(const gbp_rj_options& o, const gbp_rj_chains& 
 
 // Small blocks of soundings: one wave per chain (4 chains per workgroup).  Lane j holds interface j and layer j, every
 // lane runs the same draws (wave-uniform control flow), neighbour look-ups are cross-lane reads, rows are written coalesced.
-__device__ __forceinline__ void propose_wave_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane)
+__device__ __forceinline__ void propose_wave_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane)
 {
     const int K = o.max_layers;
     const int k = c.k[b];
@@ -255,7 +303,7 @@ __device__ __forceinline__ void propose_wave_body(const gbp_rj_options& o, const
     if (lane == 0) write_move(o, c, r0, b, action, kr);
 }
 
-__global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(256) void k_rj_propose_wave(RjOpt o, gbp_rj_chains c, uint32_t iter)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= c.B) return;
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(256) void k_rj_propose_wave(gbp_rj_options o, gbp_r
 // after entry j + 1 has been read, and choose_move is done with e before the first write).  PAIRS: rows in global memory are
 // written two entries (16 bytes) at a time when they are 16-byte aligned (K even).
 template <bool PAIRS>
-__device__ __forceinline__ void propose_rows(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b, const double* e,
+__device__ __forceinline__ void propose_rows(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b, const double* e,
                                              const double* s, double* er, double* sr, double* tr)
 {
     const int K = o.max_layers;
@@ -302,14 +350,14 @@ __device__ __forceinline__ void propose_rows(const gbp_rj_options& o, const gbp_
     write_move(o, c, r, b, action, kr);
 }
 
-__device__ __forceinline__ void propose_thread_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int b)
+__device__ __forceinline__ void propose_thread_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b)
 {
     const int K = o.max_layers;
     propose_rows<true>(o, c, iter, b, c.edges + (size_t)b * K, c.sigma + (size_t)b * K, c.edges_r + (size_t)b * K,
                        c.sigma_r + (size_t)b * K, c.thk_r + (size_t)b * K);
 }
 
-__global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(128) void k_rj_propose_thread(RjOpt o, gbp_rj_chains c, uint32_t iter)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;
@@ -323,7 +371,7 @@ __global__ __launch_bounds__(128) void k_rj_propose_thread(gbp_rj_options o, gbp
 // doubles: the 64 lanes of a column access fall on distinct bank pairs).  Same draws, same values.
 #define GBP_RJ_PROPOSE_ROWS 64
 #define GBP_RJ_PROPOSE_THREADS 256
-__global__ __launch_bounds__(GBP_RJ_PROPOSE_THREADS) void k_rj_propose_staged(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(GBP_RJ_PROPOSE_THREADS) void k_rj_propose_staged(RjOpt o, gbp_rj_chains c, uint32_t iter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int K = o.max_layers, KS = K | 1, t = threadIdx.x;
@@ -391,7 +439,7 @@ __device__ inline double width_x(const double* e, int k, int j)
     return (e[k - 2] - (k > 2 ? e[k - 3] : 0.0)) + e[k - 2];
 }
 
-__device__ inline void prior_t2(const gbp_rj_options& o, const double* e, int k, int lane, double* t2)
+__device__ inline void prior_t2(const RjOpt& o, const double* e, int k, int lane, double* t2)
 {
     if (lane < k - 1) {
         const double c2c = 0.5 * (width_x(e, k, lane) + width_x(e, k, lane + 1)) * (double)(k - 1);
@@ -400,7 +448,7 @@ __device__ inline void prior_t2(const gbp_rj_options& o, const double* e, int k,
 }
 
 // (Wm'Wm v)_i for the tridiagonal prior operator (Model.prior_derivative, model/Model.py:421-430)
-__device__ inline double prior_apply(const gbp_rj_options& o, const double* t2, int k, int i, const double* v)
+__device__ inline double prior_apply(const RjOpt& o, const double* t2, int k, int i, const double* v)
 {
     if (k == 1) return (o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0)) * v[0];
     const double up = i > 0 ? t2[i - 1] : 0.0, dn = i < k - 1 ? t2[i] : 0.0;
@@ -410,7 +458,7 @@ __device__ inline double prior_apply(const gbp_rj_options& o, const double* t2, 
     return y;
 }
 
-__device__ inline double prior_entry(const gbp_rj_options& o, const double* t2, int k, int i, int j)   // j <= i
+__device__ inline double prior_entry(const RjOpt& o, const double* t2, int k, int i, int j)   // j <= i
 {
     if (k == 1) return o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
     if (i == j) return o.value_precision + (i > 0 ? t2[i - 1] : 0.0) + (i < k - 1 ? t2[i] : 0.0);
@@ -469,7 +517,7 @@ struct Lds {
     static size_t bytes(int K, int N) { return ((size_t)K * (K + 1) + 5 * (size_t)K + 2 * (size_t)N) * sizeof(double); }
 };
 
-__device__ __forceinline__ void newton_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int min_k, int b, int lane,
+__device__ __forceinline__ void newton_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int min_k, int b, int lane,
                                             unsigned char* sh_dyn)
 {   // Model.stochastic_newton_perturbation (model/Model.py:368-419): precision = J'PJ + Wm'Wm at the remapped model,
     // mean = ln sigma - alpha * precision^-1 g, sample ~ N(mean, precision^-1) = mean + C^-T z with precision = C C'
@@ -486,7 +534,7 @@ __device__ __forceinline__ void newton_body(const gbp_rj_options& o, const gbp_r
     data_weights(c, c.data + (size_t)b * N, pred, load_levels(o, c.rel, c.add, (size_t)b), N, lane, 64, s.P, s.PR);
     prior_t2(o, e, k, lane, s.t2);
     const double lmp = c.log_mean_prior[b];
-    const double ls = lane < k ? log(sr[lane]) : 0.0;
+    const double ls = lane < k ? rj_log(sr[lane]) : 0.0;
     if (lane < k) s.v[lane] = ls - lmp;
     wave_sync();
     // row `lane` of J'PJ in column blocks of 8; J[n, j] is a wave-uniform address (scalar loads), J[n, lane] coalesced
@@ -540,11 +588,11 @@ __device__ __forceinline__ void newton_body(const gbp_rj_options& o, const gbp_r
     if (lane < K) {
         const double lp = lane < k ? (ls - o.alpha * s.g[lane]) + s.w[lane] : 0.0;
         c.log_prop[(size_t)b * K + lane] = lp;
-        c.sigma_p[(size_t)b * K + lane] = lane < k ? exp(lp) : 1.0;
+        c.sigma_p[(size_t)b * K + lane] = lane < k ? rj_exp(lp) : 1.0;
     }
 }
 
-__global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int min_k)
+__global__ __launch_bounds__(64) void k_rj_newton(RjOpt o, gbp_rj_chains c, uint32_t iter, int min_k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     newton_body(o, c, iter, min_k, blockIdx.x, threadIdx.x, sh_dyn);
@@ -557,7 +605,7 @@ __global__ __launch_bounds__(64) void k_rj_newton(gbp_rj_options o, gbp_rj_chain
 __device__ inline double group_bcast(double v, int base, int j) { return __shfl(v, base + j, 64); }
 
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N]
-__device__ __forceinline__ void newton8_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
+__device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle = 0)
 {
     const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
@@ -582,7 +630,7 @@ __device__ __forceinline__ void newton8_body(const gbp_rj_options& o, const gbp_
     const double t2_sh = __shfl(t2, max(lane - 1, 0), 64);
     const double t2_up = i > 0 ? t2_sh : 0.0;
     const double lmp = c.log_mean_prior[bb];
-    const double ls = i < k ? log(c.sigma_r[bb * K + i]) : 0.0;
+    const double ls = i < k ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
     const double v = i < k ? ls - lmp : 0.0;
     const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
@@ -654,60 +702,58 @@ __device__ __forceinline__ void newton8_body(const gbp_rj_options& o, const gbp_
     if (live && i < K) {                             // (max_layers may be smaller than the group)
         const double lp = i < k ? (ls - o.alpha * step) + w : 0.0;
         c.log_prop[bb * K + i] = lp;
-        c.sigma_p[bb * K + i] = i < k ? exp(lp) : 1.0;
+        c.sigma_p[bb * K + i] = i < k ? rj_exp(lp) : 1.0;
         for (int j = i + 8; j < K; j += 8) { c.log_prop[bb * K + j] = 0.0; c.sigma_p[bb * K + j] = 1.0; }
     }
 }
 
-__global__ __launch_bounds__(64) void k_rj_newton8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     newton8_body(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
-__device__ inline double log_uniform_prior(double x, double lo, double hi)
+__device__ inline double log_uniform_prior(double x, double llo, double lhi, double nlog_span)
 {
-    const double lx = log(x), llo = log(lo), lhi = log(hi);
-    return (lx >= llo && lx <= lhi) ? -log(lhi - llo) : -INF;
+    const double lx = rj_log(x);
+    return (lx >= llo && lx <= lhi) ? nlog_span : -INF;
 }
 
-__device__ inline double levels_log_prior(const double* x, int G, const double* lo, const double* hi)
+__device__ inline double levels_log_prior(const double* x, int G, const double* llo, const double* lhi, const double* nlog_span)
 {
     double p = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        if (g < G) p += log_uniform_prior(x[g], lo[g], hi[g]);
+        if (g < G) p += log_uniform_prior(x[g], llo[g], lhi[g], nlog_span[g]);
     return p;
 }
 
 // Error-level posteriors (DataPoint.set_posteriors :651-694): n_error_bins cells uniform in log10 between the prior bounds.
-__device__ inline void error_hist_add(const gbp_rj_options& o, const gbp_rj_chains& c, size_t b, const Levels& e)
+__device__ inline void error_hist_add(const RjOpt& o, const gbp_rj_chains& c, size_t b, const Levels& e)
 {
     if (c.rel_hist == nullptr) return;
     const double inv_ln10 = 0.43429448190325182765, nb = (double)o.n_error_bins;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g < o.n_rel_groups) {
-            const double r0 = log(o.rel_min[g]) * inv_ln10, r1 = log(o.rel_max[g]) * inv_ln10;
-            const int ir = min(max((int)floor((log(e.rel[g]) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
+            const double r0 = o.log_rel_min[g] * inv_ln10, r1 = o.log_rel_max[g] * inv_ln10;
+            const int ir = min(max((int)floor((rj_log(e.rel[g]) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
             c.rel_hist[(b * o.n_rel_groups + g) * o.n_error_bins + ir] += 1;
         }
         if (g < o.n_add_groups) {
-            const double a0 = log(o.add_min[g]) * inv_ln10, a1 = log(o.add_max[g]) * inv_ln10;
-            const int ia = min(max((int)floor((log(e.add[g]) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
+            const double a0 = o.log_add_min[g] * inv_ln10, a1 = o.log_add_max[g] * inv_ln10;
+            const int ia = min(max((int)floor((rj_log(e.add[g]) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
             c.add_hist[(b * o.n_add_groups + g) * o.n_error_bins + ia] += 1;
         }
     }
 }
 
-// sum over the groups of the log-uniform priors of one kind of level
-__device__ inline double levels_log_prior(const double* x, int G, const double* lo, const double* hi);
 
 // Conductivity-depth hit map (Model.update_parameter_posterior :819-847): `weight` counts of model (ec, sc, kc) added to one
 // chain's map hm[n_value_bins][n_depth_bins]; W lanes share the depth cells.  The samplers call it when a chain's model
 // changes (with the number of iterations the old model was the current one) instead of once per iteration.
 template <int W>
-__device__ inline void hitmap_add(const gbp_rj_options& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
+__device__ inline void hitmap_add(const RjOpt& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
                                   int i, int weight)
 {
     const double inv_ln10 = 0.43429448190325182765, Wd = o.value_half_width;
@@ -715,7 +761,7 @@ __device__ inline void hitmap_add(const gbp_rj_options& o, int32_t* hm, const do
         const double zc = ((double)cell + 0.5) * o.depth_bin_width;
         int layer = 0;
         while (layer < kc - 1 && ec[layer] <= zc) ++layer;
-        const double v = (log(sc[layer]) - lmp) * inv_ln10;
+        const double v = (rj_log(sc[layer]) - lmp) * inv_ln10;
         const int bin = min(max((int)floor((v + Wd) / (2.0 * Wd) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
         hm[(size_t)bin * o.n_depth_bins + cell] += weight;       // depth fastest: a layer's cells are one contiguous run
     }
@@ -732,7 +778,7 @@ __device__ inline double group_sum8(double v)
 // (the proposal buffers when accepted, the untouched state otherwise), never read back from what other lanes just wrote;
 // all lanes of a chain sit in one wave, so program order is the only ordering needed between them.
 template <int W>
-__device__ inline void bookkeeping(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
+__device__ inline void bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
                                    int kc, const double* ec, const double* sc, double post, double best_prev, double misfit_now,
                                    const Levels& lev, double lmp, int dwell)
 {
@@ -795,7 +841,7 @@ __device__ inline void bookkeeping(const gbp_rj_options& o, const gbp_rj_chains&
     }
 }
 
-__device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int min_k, int b,
+__device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int min_k, int b,
                                             int lane, unsigned char* sh_dyn)
 {   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to accept8_body
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
@@ -807,27 +853,27 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
     const double* tr = c.thk_r + (size_t)b * K;
     const double lmp = c.log_mean_prior[b];
     // priors of the proposal (Model.probability :533-575: uniform on k, normal on the gradient of ln sigma)
-    double prior_p = -log((double)K - 1.0);
+    double prior_p = -o.log_layers_m1;
     if (o.solve_value) {                                         // log-normal prior on the values (solve_parameter)
         double d2 = 0.0;
         if (lane < k) { const double d = lpv[lane] - lmp; d2 = d * d; }
         d2 = wave_sum(d2);
-        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * log(o.value_precision) - 0.5 * o.value_precision * d2;
+        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * o.log_value_precision - 0.5 * o.value_precision * d2;
     }
     if (o.solve_gradient) {
         double g2 = 0.0;
-        if (lane < k - 1) { const double g = (lpv[lane + 1] - lpv[lane]) / log(tr[lane]); g2 = g * g; }
+        if (lane < k - 1) { const double g = (lpv[lane + 1] - lpv[lane]) / rj_log(tr[lane]); g2 = g * g; }
         g2 = wave_sum(g2);
         const double n = (double)max(1, k - 1);
-        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
+        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * o.log_gradient_precision - 0.5 * o.gradient_precision * g2;
     }
     if (o.value_max > 0.0) {                                     // parameter_limits (Model.probability :555-558)
         const double sp = lane < k ? c.sigma_p[(size_t)b * K + lane] : o.value_min;
         if (__any(!(sp >= o.value_min && sp <= o.value_max))) prior_p = -INF;
     }
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, (size_t)b);
-    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.rel_min, o.rel_max);
-    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.add_min, o.add_max);
+    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
+    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
     double dq = 0.0;
     if (action == INSERT || action == DELETE) {                  // Model.proposal_probabilities (model/Model.py:577-659)
         const double* Jp = c.J_p + (size_t)b * N * K;
@@ -846,7 +892,7 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
         }
         wave_sync();
         chol_solve(s.A, KS, k, lane, s.g, true, true);           // H g'
-        const double lrem = lane < k ? log(c.sigma_r[(size_t)b * K + lane]) : 0.0;
+        const double lrem = lane < k ? rj_log(c.sigma_r[(size_t)b * K + lane]) : 0.0;
         bool bad = false;
         if (lane < k) {
             const double mean_r = lpv[lane] + o.alpha * s.g[lane];
@@ -875,7 +921,7 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
             if (ov > 0.0) {
                 const double var = variance_at(c, lev_p, ov, i);
                 const double r = (pp[i] - ov) * (1.0 / sqrt(var));
-                s2 += r * r; logdet += log(var); na += 1.0;
+                s2 += r * r; logdet += rj_log(var); na += 1.0;
             }
         }
         s2 = wave_sum(s2); logdet = wave_sum(logdet); na = wave_sum(na);
@@ -888,9 +934,9 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
     const int k_prev = c.k[b];                                   // (the carried state, read before it is overwritten)
     const double prior_c = c.prior[b], like_c = c.like[b], misfit_c = c.misfit[b], best_prev = c.best_posterior[b];
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
-    const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
+    const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
-    const bool accept = !frozen && log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
+    const bool accept = !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
     wave_sync();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
@@ -931,7 +977,7 @@ __device__ __forceinline__ void accept_body(const gbp_rj_options& o, const gbp_r
                     accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
+__global__ __launch_bounds__(64) void k_rj_accept(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     accept_body(o, c, iter, accumulate, min_k, blockIdx.x, threadIdx.x, sh_dyn);
@@ -943,14 +989,14 @@ __global__ __launch_bounds__(64) void k_rj_accept(gbp_rj_options o, gbp_rj_chain
 // hitmap_add for the packed kernel (kc <= 8, 8 lanes per chain): the interface depths and the value bin of every layer
 // are gathered into registers once (cross-lane reads issued by the whole wave), so a depth cell costs a few compares
 // instead of a logarithm and a search through global memory.  Called by all 8 lanes of a group; `on`: the group really adds.
-__device__ inline void hitmap_add8(const gbp_rj_options& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
+__device__ inline void hitmap_add8(const RjOpt& o, int32_t* hm, const double* ec, const double* sc, int kc, double lmp,
                                    int i, int base, int weight, bool on)
 {
     const double inv_ln10 = 0.43429448190325182765, Wd = o.value_half_width;
     double my_edge = INF;
     int my_bin = 0;
     if (on && i < kc) {
-        const double v = (log(sc[i]) - lmp) * inv_ln10;
+        const double v = (rj_log(sc[i]) - lmp) * inv_ln10;
         my_bin = min(max((int)floor((v + Wd) / (2.0 * Wd) * (double)o.n_value_bins), 0), o.n_value_bins - 1);
         if (i < kc - 1) my_edge = ec[i];
     }
@@ -969,7 +1015,7 @@ __device__ inline void hitmap_add8(const gbp_rj_options& o, int32_t* hm, const d
 }
 
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: PR[8][N]
-__device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
+__device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle = 0)
 {
     const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
@@ -987,18 +1033,18 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
     const double lpv = i < k ? c.log_prop[bb * K + i] : 0.0;
     const double lpv_dn = __shfl(lpv, min(lane + 1, 63), 64);
     // priors of the proposal
-    double prior_p = -log((double)K - 1.0);
+    double prior_p = -o.log_layers_m1;
     if (o.solve_value) {
         const double d = i < k ? lpv - lmp : 0.0;
         const double d2 = group_sum8(d * d);
-        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * log(o.value_precision) - 0.5 * o.value_precision * d2;
+        prior_p += -0.5 * (double)k * LOG_2PI + 0.5 * (double)k * o.log_value_precision - 0.5 * o.value_precision * d2;
     }
     if (o.solve_gradient) {
         double g = 0.0;
-        if (i < k - 1) g = (lpv_dn - lpv) / log(c.thk_r[bb * K + i]);
+        if (i < k - 1) g = (lpv_dn - lpv) / rj_log(c.thk_r[bb * K + i]);
         const double g2 = group_sum8(g * g);
         const double n = (double)max(1, k - 1);
-        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * log(o.gradient_precision) - 0.5 * o.gradient_precision * g2;
+        prior_p += -0.5 * n * LOG_2PI + 0.5 * n * o.log_gradient_precision - 0.5 * o.gradient_precision * g2;
     }
     if (o.value_max > 0.0) {                         // parameter_limits (Model.probability :555-558)
         const double sp = i < k ? c.sigma_p[bb * K + i] : o.value_min;
@@ -1006,8 +1052,8 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
         if ((out >> base) & 0xFFull) prior_p = -INF;
     }
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, bb);
-    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.rel_min, o.rel_max);
-    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.add_min, o.add_max);
+    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
+    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
     // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian
     double* PR = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * N;
     double s2 = 0.0, logdet = 0.0, na = 0.0;
@@ -1020,7 +1066,7 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
             if (ov > 0.0) {
                 const double var = variance_at(c, lev_p, ov, n);
                 const double r = (pp[n] - ov) * (1.0 / sqrt(var));
-                s2 += r * r; logdet += log(var); na += 1.0;
+                s2 += r * r; logdet += rj_log(var); na += 1.0;
                 pr = (1.0 / var) * (pp[n] - ov);
             }
             PR[n] = pr;
@@ -1028,7 +1074,10 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
     }
     s2 = group_sum8(s2); logdet = group_sum8(logdet); na = group_sum8(na);
     wave_sync();
-    // reverse-move proposal density (Model.proposal_probabilities :577-659); executed by every group, used by the jumps
+    // reverse-move proposal density (Model.proposal_probabilities :577-659); executed by every group of a wave that holds a
+    // dimension-changing proposal (wave-uniform branch: the cross-lane reads inside are issued by all 64 lanes), used by the jumps
+    double dq = 0.0;
+    if (__ballot(jump) != 0ull) {
     double t2 = 0.0;
     if (i < k - 1 && o.solve_gradient) {
         const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
@@ -1071,7 +1120,7 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
     }
     const double mean_r = lpv + o.alpha * grad;
     const bool bad = row && !(fabs(mean_r) < 11356.0);
-    const double lrem = row ? log(c.sigma_r[bb * K + i]) : 0.0;
+    const double lrem = row ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
     const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
     double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
 #pragma unroll
@@ -1081,14 +1130,15 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
     }
     const double q1 = group_sum8(row ? a1 * a1 : 0.0), q2 = group_sum8(row ? a2 * a2 : 0.0);
     const unsigned long long badmask = __ballot(bad);
-    double dq = jump ? -0.5 * q1 + 0.5 * q2 : 0.0;
+    dq = jump ? -0.5 * q1 + 0.5 * q2 : 0.0;
     if ((badmask >> base) & 0xFFull) dq = __builtin_nan("");
+    }
     const double misfit_p = jump ? s2 : c.misfit_p[bb];
     const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : c.like_p[bb];
     const double prior_c = c.prior[bb], like_c = c.like[bb], best_prev = c.best_posterior[bb];
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
-    const U4 rr = philox(o.seed, chain_key(o, c, b), iter, 2, 0);
-    const bool accept = live && !frozen && log(u53(rr.x, rr.y)) < log_ratio;
+    const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
+    const bool accept = live && !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
     const double misfit_c = c.misfit[bb];
@@ -1130,14 +1180,14 @@ __device__ __forceinline__ void accept8_body(const gbp_rj_options& o, const gbp_
                    accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept8(gbp_rj_options o, gbp_rj_chains c, uint32_t iter, int accumulate)
+__global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     accept8_body(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
-__global__ __launch_bounds__(64) void k_rj_flush(gbp_rj_options o, gbp_rj_chains c)
+__global__ __launch_bounds__(64) void k_rj_flush(RjOpt o, gbp_rj_chains c)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int dwell = c.hit_dwell[b];
@@ -1198,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
 }
 
 // chi^2 / logL with the per-channel additive scale, for the soundings with nl > 0 (one wave per sounding)
-__global__ __launch_bounds__(64) void k_td_loglike(gbp_rj_options o, gbp_rj_chains c, const int* __restrict__ nl,
+__global__ __launch_bounds__(64) void k_td_loglike(RjOpt o, gbp_rj_chains c, const int* __restrict__ nl,
                                                    const double* __restrict__ pred, const double* __restrict__ rel,
                                                    const double* __restrict__ add, double* __restrict__ chi2,
                                                    double* __restrict__ logL)
@@ -1213,7 +1263,7 @@ __global__ __launch_bounds__(64) void k_td_loglike(gbp_rj_options o, gbp_rj_chai
         if (ov > 0.0) {
             const double var = variance_at(c, e, ov, i);
             const double r = (pred[(size_t)b * N + i] - ov) * (1.0 / sqrt(var));
-            s2 += r * r; logdet += log(var); na += 1.0;
+            s2 += r * r; logdet += rj_log(var); na += 1.0;
         }
     }
     s2 = wave_sum(s2); logdet = wave_sum(logdet); na = wave_sum(na);
@@ -1242,7 +1292,7 @@ __global__ __launch_bounds__(64) void k_td_loglike(gbp_rj_options o, gbp_rj_chai
 #define GBP_STAGE_ATTR __attribute__((noinline))
 #endif
 struct PersistentCtx {
-    const gbp_rj_options* o;          // LDS copies
+    const RjOpt* o;          // LDS copies
     const gbp_rj_chains* c;
     MathLds* math;
     double* sh_out;
@@ -1278,7 +1328,7 @@ __device__ __forceinline__ gbp::MathCtx math_ctx(MathLds* lds)    // math_setup 
 template <bool EXACT>
 __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_proposal)
 {
-    const gbp_rj_options& o = *x->o;
+    const RjOpt& o = *x->o;
     const gbp_rj_chains& c = *x->c;
     const int b = x->b, K = o.max_layers, N = o.n_channels, L = c.k_r[b];
     const gbp::MathCtx M = math_ctx(x->math);
@@ -1294,7 +1344,7 @@ __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_pro
 
 __device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
 {
-    const gbp_rj_options& o = *x->o;
+    const RjOpt& o = *x->o;
     const gbp_rj_chains& c = *x->c;
     const int b = x->b, K = o.max_layers, N = o.n_channels;
     const gbp::MathCtx M = math_ctx(x->math);
@@ -1333,7 +1383,7 @@ __device__ GBP_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t ite
 __device__ long long GBP_RJ_TICKS[8];
 
 template <bool EXACT>
-__global__ __launch_bounds__(1024) void k_rj_persistent(gbp_rj_options o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
+__global__ __launch_bounds__(1024) void k_rj_persistent(RjOpt o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
                                                        const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                        uint32_t iter0, int n_iter, int accumulate, int nw_deep,
                                                        unsigned char* deep_scratch, size_t deep_bytes, const BinDesc* __restrict__ bins,
@@ -1342,7 +1392,7 @@ __global__ __launch_bounds__(1024) void k_rj_persistent(gbp_rj_options o_arg, gb
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
-    __shared__ gbp_rj_options sh_o;
+    __shared__ RjOpt sh_o;
     __shared__ gbp_rj_chains sh_c;
     __shared__ PersistentCtx sh_x;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -1526,18 +1576,18 @@ gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64
     // draws (test hooks: GBP_RJ_PROPOSE=thread / wave)
     const char* force = std::getenv("GBP_RJ_PROPOSE");
     if (force && force[0] == 'w')
-        hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+        hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration);
     else if (force && force[0] == 't')
-        hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
+        hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rj::extend(*o), *c,
                            (uint32_t)iteration);
     else {
         const size_t lds = (size_t)3 * GBP_RJ_PROPOSE_ROWS * (o->max_layers | 1) * sizeof(double);
         if (lds > 64 * 1024)          // rows too long to stage 64 of them (max_layers > 42): the unstaged kernel
-            hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *o, *c,
+            hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rj::extend(*o), *c,
                                (uint32_t)iteration);
         else
             hipLaunchKernelGGL(rj::k_rj_propose_staged, dim3((c->B + GBP_RJ_PROPOSE_ROWS - 1) / GBP_RJ_PROPOSE_ROWS),
-                               dim3(GBP_RJ_PROPOSE_THREADS), lds, (hipStream_t)stream, *o, *c, (uint32_t)iteration);
+                               dim3(GBP_RJ_PROPOSE_THREADS), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration);
     }
     GBP_HIP(hipGetLastError());
     return GBP_OK;
@@ -1549,9 +1599,9 @@ gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     if (st != GBP_OK || c->B == 0) return st;
     // chains with <= 8 layers: packed kernel (8 per wave); the others: one wave each
     hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                       *o, *c, (uint32_t)iteration);
+                       rj::extend(*o), *c, (uint32_t)iteration);
     if (o->max_layers > 8)
-        hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+        hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
                            *c, (uint32_t)iteration, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
@@ -1562,9 +1612,9 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
     hipLaunchKernelGGL(rj::k_rj_accept8, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                       *o, *c, (uint32_t)iteration, accumulate);
+                       rj::extend(*o), *c, (uint32_t)iteration, accumulate);
     if (o->max_layers > 8)
-        hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, *o,
+        hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
                            *c, (uint32_t)iteration, accumulate, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
@@ -1611,7 +1661,7 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
     if (deep_bytes > 0) GBP_HIP(hipMallocAsync((void**)&deep, deep_bytes * (size_t)B, (hipStream_t)stream));
     auto launch = [&](auto kernel) -> gbp_status {
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, *o, *c, sys->d_chan, sys->d_pts, sys->t.npts, F,
+        hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, rj::extend(*o), *c, sys->d_chan, sys->d_pts, sys->t.npts, F,
                            sys->sigma_direct, (uint32_t)first_iteration, n_iterations, accumulate, nw, deep, deep_bytes, sys->d_bins,
                            sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
         return GBP_OK;
@@ -1752,7 +1802,7 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
         } else {
             if ((st = gbp_fdem_forward_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, fw, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr, main_q)) != GBP_OK) return st;
-            hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, *o, *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
+            hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, rj::extend(*o), *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
                                c->misfit_p, c->like_p);
             GBP_HIP(hipGetLastError());
         }
@@ -1789,7 +1839,7 @@ gbp_status gbp_rj_flush_posteriors(const gbp_rj_options* o, const gbp_rj_chains*
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0 || !c->hitmap) return st;
-    hipLaunchKernelGGL(rj::k_rj_flush, dim3(c->B), dim3(64), 0, (hipStream_t)stream, *o, *c);
+    hipLaunchKernelGGL(rj::k_rj_flush, dim3(c->B), dim3(64), 0, (hipStream_t)stream, rj::extend(*o), *c);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
