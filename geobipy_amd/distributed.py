@@ -71,3 +71,71 @@ class SummaryGather:
                 s, n = int(self.starts[r]), int(self.sizes[r])
                 self.out[s:s + n].copy_(self.recv[r * self.pad: r * self.pad + n])
         return self.out
+
+
+class ChunkQueue:
+    """Dynamic scheduling of chunks of soundings over the ranks of a job.
+
+    The reference's master hands the next data point to whichever worker reports back (Inference3D.py:518-635), because
+    soundings take different numbers of iterations to burn in and a static split leaves ranks idle.  Here there is no master
+    rank and there are no messages: every rank draws the index of its next chunk from ONE atomic counter in the job's
+    key-value store (``TCPStore.add``, the store ``init_process_group`` already created), until the chunks run out.  A chunk
+    is a contiguous block of soundings, large enough to fill a GPU (the unit of work of the device sampler is a block of
+    chains, not one sounding).  Iterating yields (start, size); without an initialised process group it runs through all chunks.
+    """
+
+    def __init__(self, n_items, chunk, key="gbp_chunk_queue", store=None):
+        assert chunk >= 1
+        self.n_items, self.chunk = int(n_items), int(chunk)
+        self.n_chunks = (self.n_items + self.chunk - 1) // self.chunk
+        self.key = key
+        self._local = 0
+        self.store = store
+        if store is None and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self.store = distributed_c10d._get_default_store()
+
+    def take(self):
+        """Index of the next chunk, or None when all are taken."""
+        if self.store is None:
+            c, self._local = self._local, self._local + 1
+        else:
+            c = int(self.store.add(self.key, 1)) - 1
+        return c if c < self.n_chunks else None
+
+    def __iter__(self):
+        while True:
+            c = self.take()
+            if c is None:
+                return
+            s = c * self.chunk
+            yield s, min(self.chunk, self.n_items - s)
+
+
+def gather_rows(rows, values, N, group=None):
+    """[N, C] on rank 0 (None elsewhere) from every rank's (rows[m] int64, values[m, C] float64): the exchange at the end of a
+    dynamically scheduled job, where a rank's rows are not a contiguous block.  Two collectives: the row counts, then one
+    ``all_gather_into_tensor`` of blocks padded to the largest count, the row index travelling as an extra column."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev, C = values.device, values.shape[1]
+    if world == 1:
+        out = torch.empty((N, C), dtype=torch.float64, device=dev)
+        out[rows] = values
+        return out
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([rows.numel()], dtype=torch.int64, device=dev), group=group)
+    pad = int(counts.max())
+    send = torch.zeros((max(pad, 1), C + 1), dtype=torch.float64, device=dev)
+    send[:rows.numel(), 0] = rows.to(torch.float64)
+    send[:rows.numel(), 1:] = values
+    recv = torch.empty((world * max(pad, 1), C + 1), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    if rank != 0:
+        return None
+    out = torch.empty((N, C), dtype=torch.float64, device=dev)
+    for r in range(world):
+        n = int(counts[r])
+        block = recv[r * max(pad, 1): r * max(pad, 1) + n]
+        out[block[:, 0].to(torch.int64)] = block[:, 1:]
+    return out

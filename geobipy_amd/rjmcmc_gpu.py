@@ -79,12 +79,14 @@ class DeviceChains:
     at its own sounding's altitude (1 m altitude bins, so the result does not depend on the sharding; default 1e-10 keeps
     about 600 of the 1200 points of the 10-frequency system; predictions and true-derivative Jacobians move by less than
     that bound); 0 evaluates all 120 / 140 abscissae.  ``min_altitude`` is accepted and ignored.
+    ``chain_id`` (int64[B], optional): the key of every chain's random streams (default ``first_chain + row``) -- pass the
+    soundings' global indices when a block holds a non-contiguous selection of a survey.
     hitmap=True also accumulates the conductivity-depth hit map, int32[B, n_value_bins, n_depth_bins] (440 KB per
     sounding with the default grids: 29 GB for 65536 soundings -- sized for 288 GB of HBM)."""
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
-                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, **options):
+                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -167,7 +169,8 @@ class DeviceChains:
         i32v = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev).contiguous()
         self.t = t = dict(
             rel_group=i32v(rel_group), add_group=i32v(add_group),
-            add_scale=None if add_scale is None else f64(add_scale), chain_id=None, data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B, Gr), add=z(B, Ga),
+            add_scale=None if add_scale is None else f64(add_scale),
+            chain_id=None if chain_id is None else torch.as_tensor(np.asarray(chain_id), dtype=torch.int64).to(dev).contiguous(), data=data, height=heights, log_mean_prior=z(B), k=z(B, dt=i32), edges=z(B, K), sigma=z(B, K), rel=z(B, Gr), add=z(B, Ga),
             pred=z(B, N), J=z(B, N, K), prior=z(B), like=z(B), misfit=z(B), action=z(B, dt=i32), k_r=z(B, dt=i32),
             nl_a=z(3, B, dt=i32), nl_c=z(3, B, dt=i32), nl_b=z(B, dt=i32), edges_r=z(B, K), sigma_r=z(B, K), thk_r=z(B, K), rel_p=z(B, Gr), add_p=z(B, Ga),
             pred_r=z(B, N), J_r=z(B, N, K), chol=z(B, K, K), log_prop=z(B, K), sigma_p=z(B, K), pred_p=z(B, N), misfit_p=z(B),

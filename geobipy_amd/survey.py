@@ -150,17 +150,24 @@ class FdemData:
 class TdemData:
     """A set of time-domain soundings (classes/data/dataset/TdemData.py): location, altitude, transmitter-receiver offset and
     the window data of every system, columns ``S<system><component>_time_<t>`` of the reference's CSV files in file order
-    (system 0 component X then Z windows, system 1 ...), which is TdemBatch's channel layout.  The device sampler shares one
-    transmitter-receiver offset over a block, so the offsets of the file must be constant; attitude angles must be zero."""
+    (system 0 component X then Z windows, system 1 ...), which is TdemBatch's channel layout.  ``offset``: one (dx, dy, dz) for
+    the set or one per sounding [nPoints, 3] (columns txrx_dx / dy / dz); the Hankel tables depend on it, so ``infer`` runs the
+    soundings of every distinct offset as a block of their own.  ``primary_field`` [nPoints, components]: the PX / PY / PZ
+    columns of Tempest files (TempestData.py), kept for the caller, NaN when absent.  Attitude angles must be zero."""
 
-    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset):
+    MAX_OFFSET_GROUPS = 64
+
+    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset, primary_field=None):
         from .tdem import TdemSystem
         systems = [system] if isinstance(system, (str, TdemSystem)) else list(system)
         self.system = [s if isinstance(s, TdemSystem) else TdemSystem(s) for s in systems]
         f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         self.lineNumber, self.fiducial = f64(lineNumber), f64(fiducial)
         self.x, self.y, self.z, self.elevation = f64(x), f64(y), f64(z), f64(elevation)
-        self.data, self.offset = f64(data), tuple(float(v) for v in offset)
+        self.data = f64(data)
+        off = np.asarray(offset, dtype=np.float64)
+        self.offsets = np.array(np.broadcast_to(off, (self.x.size, 3)), dtype=np.float64)      # per sounding (own, writable copy)
+        self.primary_field = None if primary_field is None else f64(primary_field)
         n = sum(s.n_components * s.nwindows for s in self.system)
         assert self.data.shape == (self.nPoints, n), ValueError("data must have shape (nPoints, {})".format(n))
 
@@ -171,6 +178,19 @@ class TdemData:
     @property
     def nChannels(self):
         return self.data.shape[1]
+
+    @property
+    def offset(self):
+        """The one transmitter-receiver offset of the set (raises when the soundings do not share one)."""
+        assert np.all(self.offsets == self.offsets[0]), ValueError("the soundings have different transmitter-receiver offsets; use .offsets")
+        return tuple(float(v) for v in self.offsets[0])
+
+    def offset_groups(self, rows=None):
+        """[(offset triple, row indices)] of the distinct offsets among ``rows`` (default: all), in order of first appearance."""
+        rows = np.arange(self.nPoints) if rows is None else np.asarray(rows)
+        uniq, first, inverse = np.unique(self.offsets[rows], axis=0, return_index=True, return_inverse=True)
+        order = np.argsort(first)
+        return [(tuple(float(v) for v in uniq[g]), rows[np.nonzero(inverse.ravel() == g)[0]]) for g in order]
 
     @classmethod
     def read_csv(cls, data_filename, system_filename):
@@ -190,18 +210,25 @@ class TdemData:
             raise ValueError("{}: no data columns (headers containing off_time, x_time, y_time or z_time); found {}".format(
                 data_filename, header))
         table = np.atleast_2d(np.loadtxt(data_filename, delimiter=",", skiprows=1))
-        off = [table[:, low.index(k)] for k in ("txrx_dx", "txrx_dy", "txrx_dz")]
-        assert all(np.all(v == v[0]) for v in off), NotImplementedError("the transmitter-receiver offset must be the same for every sounding")
+        off = np.stack([table[:, low.index(k)] for k in ("txrx_dx", "txrx_dy", "txrx_dz")], axis=1)
+        pcols = sorted(j for j, h in enumerate(low) if h in ("px", "py", "pz"))            # TdemData.py:632, primary_channels.sort()
         for k in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"):
             if k in low:
                 assert not np.any(table[:, low.index(k)]), NotImplementedError("attitude angles are not supported (level flight)")
         c = lambda r: table[:, idx[r]]
         return cls(system_filename, c("line"), c("fid"), c("x"), c("y"), c("z"),
-                   table[:, elev] if elev is not None else np.zeros(table.shape[0]), table[:, dcols], [v[0] for v in off])
+                   table[:, elev] if elev is not None else np.zeros(table.shape[0]), table[:, dcols], off,
+                   primary_field=table[:, pcols] if pcols else None)
 
     def subset(self, rows):
-        return TdemData(self.system, self.lineNumber[rows], self.fiducial[rows], self.x[rows], self.y[rows], self.z[rows],
-                        self.elevation[rows], self.data[rows], self.offset)
+        return type(self)(self.system, self.lineNumber[rows], self.fiducial[rows], self.x[rows], self.y[rows], self.z[rows],
+                          self.elevation[rows], self.data[rows], self.offsets[rows],
+                          primary_field=None if self.primary_field is None else self.primary_field[rows])
+
+
+class TempestData(TdemData):
+    """Fixed-wing Tempest soundings (classes/data/dataset/TempestData.py): the same file layout with X and Z components, the
+    per-sounding transmitter-receiver offsets and the primary-field columns PX / PZ."""
 
 
 class SurveyResult(dict):
@@ -281,11 +308,17 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
 
 
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
-          exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, **overrides):
+          exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
+          chunk=None, **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
+    ``schedule``: "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
+    of ``chunk`` soundings (default: a 16th of a rank's static share, at least 256) from a shared counter until none are left
+    (``distributed.ChunkQueue``; the reference's master / worker loop, Inference3D.py:518-635, without a master), which evens
+    out the different numbers of iterations soundings need.  Chains are keyed by the sounding's row in the data file, so the
+    results do not depend on the schedule.
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
     expression.  ``hankel_eps``: accuracy-budgeted window of the Hankel filter abscissae.  Frequency domain: ppm, per
@@ -337,31 +370,84 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         common.update(min_altitude=float(np.min(ds.z)), hankel_eps=float(hankel_eps))
     elif not time_domain and hankel_eps is not None:
         common.update(hankel_eps_ppm=float(hankel_eps))
-    if time_domain:
-        from .tdem import TdemDeviceChains
-        dc = TdemDeviceChains(ds.system, ds.z[sl], ds.data[sl], ds.offset, **common)
-    else:
-        dc = DeviceChains(ds.system, ds.z[sl], ds.data[sl], exact_jacobian=exact_jacobian, **common)
-    dc.infer(check_every=check_every)
-    K, nz, ne, t = dc.K, dc.n_depth_bins, dc.n_error_bins, dc.t
     f64 = lambda x: x.to(torch.float64)
     col = lambda x: f64(x)[:, None]
-    named = [("status", col(t["status"])), ("burned_in_iteration", col(t["burned_in_iteration"])), ("n_accepted", col(t["n_accepted"])),
-             ("misfit", col(t["misfit"])), ("relative_error", t["rel"]), ("additive_error", t["add"]), ("n_layers", col(t["k"])),
-             ("best_n_layers", col(t["best_k"])), ("best_posterior", col(t["best_posterior"])), ("best_edges", t["best_edges"]),
-             ("best_conductivity", t["best_sigma"]), ("layer_count_posterior", f64(t["k_hist"])),
-             ("interface_posterior", f64(t["edge_hist"])), ("relative_error_posterior", f64(t["rel_hist"]).flatten(1)),
-             ("additive_error_posterior", f64(t["add_hist"]).flatten(1))]
-    if hitmap:
-        mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
-        named += [("mean_log10_conductivity", mean)] + [("log10_conductivity_" + q, p) for q, p in zip(("p05", "p50", "p95"), pct)]
-    local = torch.cat([v for _, v in named], dim=1).contiguous()
-    if world > 1:                                   # the one exchange of the job: per-sounding result rows to rank 0
-        from .distributed import SummaryGather
-        g = SummaryGather(ds.nPoints, local.shape[1], local.device)
-        gathered = g.finish(g.launch(*[local[:, i] for i in range(local.shape[1])]))
+
+    def run_block(idx, offset=None):
+        """Chains of the soundings ``idx`` (rows of ds, ascending) to completion -> (sampler, [(name, [len(idx), w])])."""
+        kw = dict(common)
+        if idx.size != n or idx[0] != start:        # a selection of the shard: key every chain by its own row of the data file
+            kw.pop("first_chain")
+            kw["chain_id"] = int(rows[0]) + idx
+        if time_domain:
+            from .tdem import TdemDeviceChains
+            dc = TdemDeviceChains(ds.system, ds.z[idx], ds.data[idx], offset, **kw)
+        else:
+            dc = DeviceChains(ds.system, ds.z[idx], ds.data[idx], exact_jacobian=exact_jacobian, **kw)
+        dc.infer(check_every=check_every)
+        t = dc.t
+        named = [("status", col(t["status"])), ("burned_in_iteration", col(t["burned_in_iteration"])), ("n_accepted", col(t["n_accepted"])),
+                 ("misfit", col(t["misfit"])), ("relative_error", t["rel"]), ("additive_error", t["add"]), ("n_layers", col(t["k"])),
+                 ("best_n_layers", col(t["best_k"])), ("best_posterior", col(t["best_posterior"])), ("best_edges", t["best_edges"]),
+                 ("best_conductivity", t["best_sigma"]), ("layer_count_posterior", f64(t["k_hist"])),
+                 ("interface_posterior", f64(t["edge_hist"])), ("relative_error_posterior", f64(t["rel_hist"]).flatten(1)),
+                 ("additive_error_posterior", f64(t["add_hist"]).flatten(1))]
+        if hitmap:
+            mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
+            named += [("mean_log10_conductivity", mean)] + [("log10_conductivity_" + q, p) for q, p in zip(("p05", "p50", "p95"), pct)]
+        return dc, named
+
+    state = dict(iterations=0, dc=None, named=None)
+
+    def process(first, count):
+        """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
+        span = np.arange(first, first + count)
+        if time_domain:
+            # the Hankel tables depend on the transmitter-receiver offset: one block of chains per distinct offset
+            blocks = ds.offset_groups(span) if count > 0 else [(tuple(ds.offsets[0]) if ds.nPoints else (0.0, 0.0, 0.0), span)]
+            if len(blocks) > TdemData.MAX_OFFSET_GROUPS:
+                raise NotImplementedError("{} distinct transmitter-receiver offsets in {} soundings: the device sampler builds one set "
+                                          "of Hankel tables per offset -- bin the offsets (e.g. to 0.1 m) first".format(len(blocks), count))
+        else:
+            blocks = [(None, span)]
+        out = None
+        for off, idx in blocks:
+            dc, named = run_block(idx, off)
+            part = torch.cat([v for _, v in named], dim=1).contiguous()
+            state.update(iterations=max(state["iterations"], dc.iteration), dc=dc, named=named)
+            if len(blocks) == 1:
+                return part
+            if out is None:
+                out = torch.empty((count, part.shape[1]), dtype=torch.float64, device=part.device)
+            out[torch.as_tensor(idx - first, device=part.device)] = part
+        return out
+
+    assert schedule in ("static", "dynamic"), ValueError("schedule must be 'static' or 'dynamic'")
+    if schedule == "static":
+        local = process(start, n)
+        if world > 1:                               # the one exchange of the job: per-sounding result rows to rank 0
+            from .distributed import SummaryGather
+            g = SummaryGather(ds.nPoints, local.shape[1], local.device)
+            gathered = g.finish(g.launch(*[local[:, i] for i in range(local.shape[1])]))
+        else:
+            gathered = local
     else:
-        gathered = local
+        from .distributed import ChunkQueue, gather_rows
+        n = -1                                      # (every block is a selection: chains keyed by chain_id)
+        size = int(chunk) if chunk else max(256, -(-ds.nPoints // (16 * world)))
+        done_rows, done_vals = [], []
+        for first, count in ChunkQueue(ds.nPoints, size):
+            done_vals.append(process(first, count))
+            done_rows.append(torch.arange(first, first + count, dtype=torch.int64, device=done_vals[-1].device))
+        if not done_vals:                           # this rank got no chunk: an empty block fixes the row width and the device
+            done_vals.append(process(0, 0))
+            done_rows.append(torch.zeros(0, dtype=torch.int64, device=done_vals[-1].device))
+        gathered = gather_rows(torch.cat(done_rows), torch.cat(done_vals), ds.nPoints)
+    iterations_run, dc, named = state["iterations"], state["dc"], state["named"]
+    if world > 1:                                   # an unfinished chain's count is the longest run of any rank
+        it = torch.tensor([iterations_run], dtype=torch.int64, device=dc.device)
+        dist.all_reduce(it, op=dist.ReduceOp.MAX)
+        iterations_run = int(it)
     if rank != 0:
         return None
     r = gathered.cpu().numpy()
@@ -379,9 +465,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         res[name] = block[:, 0] if w == 1 else block
     for name, G in (("relative_error_posterior", dc.n_rel_groups), ("additive_error_posterior", dc.n_add_groups)):
         if G > 1:                                   # [S, groups, cells]; ne cells, uniform in log10 between the prior bounds
-            res[name] = res[name].reshape(-1, G, ne)
+            res[name] = res[name].reshape(-1, G, dc.n_error_bins)
     n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
-    ran = np.where(res["status"] == 1, res["burned_in_iteration"] + n_mc + 1, np.where(res["status"] == 2, n_mc, dc.iteration))
+    ran = np.where(res["status"] == 1, res["burned_in_iteration"] + n_mc + 1, np.where(res["status"] == 2, n_mc, iterations_run))
     res["iterations"] = ran.astype(np.int64)
     res["acceptance"] = res.pop("n_accepted") / np.maximum(1, ran)
     for k_ in ("status", "burned_in_iteration", "n_layers", "best_n_layers"):

@@ -24,7 +24,7 @@ Conventions recovered from the reference's fixtures: moment = NumberOfTurns * Pe
 an order-n ``LowPassFilter`` is n cascaded first-order sections; a waveform table that covers half a period
 is continued with opposite polarity; "dB/dt" output is the receiver voltage convention -dB/dt; the
 reference negates GA-AEM's z components (TdemDataPoint.py:1013-1015), which makes Z positive-up.
-Limitations: level flight (pitch = roll = yaw = 0) and one Tx-Rx offset per batch.
+Limitations: level flight (pitch = roll = yaw = 0); soundings are evaluated in groups of equal Tx-Rx offset.
 """
 import ctypes
 
@@ -360,7 +360,9 @@ class TdemBatch:
     """B TDEM soundings on one GPU, all systems of a (multi-moment) acquisition in one object.
 
     ``systems``: list of TdemSystem (e.g. SkyTEM high and low moment); ``offset`` = (dx, dy, dz) of the
-    receiver relative to the transmitter (Loop_pair, system/Loop_pair.py:63-77), shared by the batch.
+    receiver relative to the transmitter (Loop_pair, system/Loop_pair.py:63-77): one triple shared by the batch, or one per
+    sounding ([B, 3]).  The Hankel tables depend on the offset, so soundings are evaluated in groups of equal offset (one
+    set of tables and one launch sequence per distinct offset; results come back in the caller's row order).
     Channel layout of ``predicted``: system 0 components x then z, each over its windows, then system 1 ...
     (the reference's ``predicted_secondary_field`` layout).
     """
@@ -374,7 +376,32 @@ class TdemBatch:
             raise _lib.NativeLibraryError("TdemBatch needs a HIP device; there is no CPU fallback")
         self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.offset = tuple(float(v) for v in offset)
+        self._groups = None
+        off = np.asarray(offset, dtype=np.float64)
+        if off.ndim == 2:
+            uniq, inverse = np.unique(off, axis=0, return_inverse=True)
+            if uniq.shape[0] > 1:          # one child batch per distinct offset
+                sub = lambda a, m: None if a is None else np.asarray(a)[m]
+                bc = lambda a, n: np.broadcast_to(np.asarray(a), (n,) + np.shape(a)[1:]) if np.ndim(a) >= 1 else np.full(n, a)
+                n_all = off.shape[0]
+                nl_all, h_all = bc(nlayers, n_all), bc(height, n_all)
+                floor = float(np.min(h_all)) if min_altitude is None else float(min_altitude)
+                self._groups = []
+                for g in range(uniq.shape[0]):
+                    m = np.nonzero(inverse.ravel() == g)[0]
+                    child = TdemBatch(self.systems, nl_all[m], np.asarray(sigma)[m], np.asarray(thk)[m], h_all[m], tuple(uniq[g]),
+                                      data=sub(data, m), relative_error=sub(relative_error, m), additive_error=sub(additive_error, m),
+                                      device=self.device, hankel_eps=hankel_eps, min_altitude=floor)
+                    self._groups.append((torch.as_tensor(m, device=self.device), child))
+                self.offset = off
+                self.B, self.Lmax = np.asarray(sigma).shape
+                self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
+                self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
+                self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
+                self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
+                return
+            off = uniq[0]
+        self.offset = tuple(float(v) for v in off)
         dev = lambda a, dt=torch.float64: torch.as_tensor(np.array(a), dtype=dt).to(self.device).contiguous()
         self.sigma, self.thk = dev(sigma), dev(thk)
         self.B, self.Lmax = self.sigma.shape
@@ -415,6 +442,10 @@ class TdemBatch:
 
     def forward(self):
         """predicted[B, nChannels]: frequency-domain HIP kernel per system, then the window operator (k_td_apply)."""
+        if self._groups is not None:
+            for rows, child in self._groups:
+                self.predicted[rows] = child.forward()
+            return self.predicted
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         col = 0
@@ -435,7 +466,12 @@ class TdemBatch:
     def sensitivity(self):
         """J[B, nChannels, Lmax] = d predicted / d ln(sigma) (the reference obtains it from gatdaem1d's
         derivative call, TD/tdem1d.py:98-154): exact frequency-domain Jacobian of the nodal values (Jacobian
-        kernel on the raw handle) pushed through the same linear time-domain operator, one GEMM per system."""
+        kernel on the raw handle) pushed through the same linear time-domain operator (k_td_apply)."""
+        if self._groups is not None:
+            out = torch.empty((self.B, self.nChannels, self.Lmax), dtype=torch.float64, device=self.device)
+            for rows, child in self._groups:
+                out[rows] = child.sensitivity()
+            return out
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         out = torch.empty((self.B, self.nChannels, self.Lmax), dtype=torch.float64, device=self.device)
@@ -465,6 +501,11 @@ class TdemBatch:
         holds one level per (system, component) in the reference's order ``(i * n_components) + j``; ``additive_error[B,
         n_systems]`` one per system.  A ``relative_error`` with one column per SYSTEM is accepted for single-component
         systems only (where the two layouts coincide)."""
+        if self._groups is not None:
+            out = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
+            for rows, child in self._groups:
+                out[rows] = child.std()
+            return out
         n_groups = sum(s.n_components for s in self.systems)
         assert self.relative_error.shape[1] == n_groups, ValueError(
             "relative_error needs one level per (system, component): {} columns, got {}".format(n_groups, self.relative_error.shape[1]))
@@ -483,6 +524,11 @@ class TdemBatch:
 
     def forward_loglike(self):
         """forward + chi^2 + log-likelihood (DataPoint.data_misfit / likelihood with the TDEM error model)."""
+        if self._groups is not None:
+            for rows, child in self._groups:
+                c2, ll = child.forward_loglike()
+                self.chi2[rows], self.logL[rows], self.predicted[rows] = c2, ll, child.predicted
+            return self.chi2, self.logL
         self.forward()
         sd = self.std()
         lib = _lib.load()

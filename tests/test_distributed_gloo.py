@@ -61,3 +61,61 @@ def test_shards_cover_the_batch_exactly():
             assert sizes.sum() == N and np.all(np.diff(starts) == sizes[:-1])
             assert sizes.max() - sizes.min() <= 1
             assert [shard(N, r, w) for r in range(w)] == [(int(a), int(b)) for a, b in zip(starts, sizes)]
+
+
+def _queue_worker(rank, world, port, N, chunk, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from geobipy_amd.distributed import ChunkQueue, gather_rows
+        q = ChunkQueue(N, chunk)
+        rows, vals, mine = [], [], []
+        for s, m in q:
+            mine.append((s, m))
+            idx = torch.arange(s, s + m, dtype=torch.int64)
+            rows.append(idx)
+            vals.append(torch.stack([idx.double() * 3.0 - 1.0, torch.full((m,), float(rank), dtype=torch.float64)], dim=1))
+            time.sleep(0.002 * (1 + 3 * rank))          # a slow rank: the others take what it leaves
+        r = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.int64)
+        v = torch.cat(vals) if vals else torch.zeros((0, 2), dtype=torch.float64)
+        out = gather_rows(r, v, N)
+        counts = [None] * world
+        dist.all_gather_object(counts, len(mine))
+        if rank == 0:
+            ref = torch.arange(N, dtype=torch.float64) * 3.0 - 1.0
+            ok = bool(torch.equal(out[:, 0], ref)) and sum(counts) == q.n_chunks
+            owners = out[:, 1].reshape(-1)
+            ret.put((ok, counts, sorted(set(owners.tolist()))))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,chunk", [(2, 1000, 64), (3, 130, 16)])
+def test_dynamic_chunk_queue_gloo(world, N, chunk):
+    """Every chunk is taken exactly once (atomic counter in the job's store), whichever rank gets to it; rank 0 assembles
+    the rows wherever they were computed.  The slow rank ends up with fewer chunks."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_queue_worker, args=(r, world, port, N, chunk, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ok, counts, owners = ret.get(timeout=5)
+    assert ok is True and sum(counts) == (N + chunk - 1) // chunk
+    assert counts[0] >= counts[-1]                     # the fastest rank did not do less than the slowest
+    print("chunks per rank:", counts, "owners seen:", owners)
+
+
+def test_chunk_queue_without_a_process_group():
+    from geobipy_amd.distributed import ChunkQueue, gather_rows
+    assert list(ChunkQueue(10, 4)) == [(0, 4), (4, 4), (8, 2)] and list(ChunkQueue(0, 4)) == []
+    rows = torch.tensor([2, 0, 1])
+    out = gather_rows(rows, torch.tensor([[2.0], [0.0], [1.0]], dtype=torch.float64), 3)
+    assert out[:, 0].tolist() == [0.0, 1.0, 2.0]

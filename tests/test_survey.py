@@ -79,6 +79,90 @@ def test_read_time_domain_csv_and_options():
     assert sub.nPoints == 2 and np.array_equal(sub.data, raw[3:5, 15:60]) and sub.offset == ds.offset
 
 
+def test_read_tempest_csv_with_per_sounding_geometry(tmp_path):
+    """The reference's Tempest file layout (TempestData.py:644-690): X and Z windows, primary-field columns, one
+    transmitter-receiver offset per sounding.  Column rule of TdemData.read_csv (TdemData.py:622-632)."""
+    src = os.path.join(GOLDEN, "tempest_glacial_clean.csv")
+    stm = os.path.join(GOLDEN, "tempest.stm")
+    ds = survey.TempestData.read_csv(src, stm)
+    raw = np.loadtxt(src, delimiter=",", skiprows=1)
+    assert ds.nPoints == 79 and ds.nChannels == 30 and ds.offset == (-107.0, 0.0, -45.0) and np.all(ds.z == 120.0)
+    assert np.array_equal(ds.data, raw[:, 17:47]) and np.array_equal(ds.primary_field, raw[:, 15:17])
+    assert np.allclose(ds.primary_field[0], [34.27253218749016, 17.55503396713325])
+    # the primary field the file carries is the free-space field of the system's dipole pair
+    bx, bz = ds.system[0].primary_field(*ds.offset)
+    assert np.allclose([bx, bz], ds.primary_field[0], rtol=1e-9)
+    # a file whose soundings do not share one offset
+    with open(src) as f:
+        lines = f.read().splitlines()
+    head = lines[0].split(",")
+    jx, jz = head.index("txrx_dx"), head.index("txrx_dz")
+    rows = [l.split(",") for l in lines[1:]]
+    for i, r in enumerate(rows):
+        if i % 3 == 1:
+            r[jx], r[jz] = "-108.5", "-44.0"
+        if i % 3 == 2:
+            r[jz] = "-46.25"
+    out = tmp_path / "tempest_mixed.csv"
+    out.write_text("\n".join([lines[0]] + [",".join(r) for r in rows]) + "\n")
+    mixed = survey.TempestData.read_csv(str(out), stm)
+    with pytest.raises(AssertionError):
+        mixed.offset
+    groups = mixed.offset_groups()
+    assert [g[0] for g in groups] == [(-107.0, 0.0, -45.0), (-108.5, 0.0, -44.0), (-107.0, 0.0, -46.25)]
+    assert [g[1].tolist() for g in groups] == [list(range(0, 79, 3)), list(range(1, 79, 3)), list(range(2, 79, 3))]
+    sub = mixed.subset(np.array([1, 2, 4]))
+    assert isinstance(sub, survey.TempestData) and sub.offsets.tolist() == [[-108.5, 0.0, -44.0], [-107.0, 0.0, -46.25], [-108.5, 0.0, -44.0]]
+    assert [g[1].tolist() for g in sub.offset_groups(np.array([1, 2]))] == [[1], [2]]
+    # error columns and unknown layouts
+    bad = tmp_path / "bad.csv"
+    bad.write_text(lines[0].replace("S0X_time_", "S0X_gate_").replace("S0Z_time_", "S0Z_gate_") + "\n" + lines[1] + "\n")
+    with pytest.raises(ValueError, match="no data columns"):
+        survey.TempestData.read_csv(str(bad), stm)
+
+
+@pytest.mark.gpu
+def test_time_domain_soundings_with_different_offsets():
+    """Soundings are evaluated, and inverted, in groups of equal transmitter-receiver offset: a batch with per-sounding
+    offsets returns what per-offset batches return, and in a survey the chains of a sounding do not depend on the other
+    soundings' geometry (streams keyed by the row of the data file)."""
+    import torch
+    from geobipy_amd import synthetic
+    from geobipy_amd.tdem import TdemBatch, TdemSystem
+    systems = [TdemSystem(os.path.join(GOLDEN, "tempest.stm"))]
+    B = 90
+    nl, sig, thk, _ = synthetic.draw_models(B, 5, seed=4)
+    h = np.full(B, 120.0) + np.arange(B) % 7
+    offs = np.array([(-107.0, 0.0, -45.0), (-108.5, 0.0, -44.0), (-107.0, 0.0, -46.25)])
+    off = offs[np.arange(B) % 3]
+    data = np.full((B, 30), 1.0)
+    mixed = TdemBatch(systems, nl, sig, thk, h, off, data=data, relative_error=np.full((B, 2), 0.03), additive_error=np.full((B, 1), 0.01))
+    pm = mixed.forward().clone()
+    cm, lm = (t.clone() for t in mixed.forward_loglike())
+    Jm = mixed.sensitivity()
+    for g in range(3):
+        m = np.nonzero(np.arange(B) % 3 == g)[0]
+        one = TdemBatch(systems, nl[m], sig[m], thk[m], h[m], tuple(offs[g]), data=data[m], relative_error=np.full((m.size, 2), 0.03),
+                        additive_error=np.full((m.size, 1), 0.01))
+        mt = torch.as_tensor(m, device=pm.device)
+        assert torch.equal(one.forward(), pm[mt]) and torch.equal(one.sensitivity(), Jm[mt])
+        c1, l1 = one.forward_loglike()
+        assert torch.equal(c1, cm[mt]) and torch.equal(l1, lm[mt])
+    assert float((pm[0] - pm[1]).abs().max()) > 0          # (the geometry matters)
+    # survey: SkyTEM soundings, every other one with the receiver 0.5 m higher
+    o = survey.read_options(os.path.join(GOLDEN, "skytem_options_small"))
+    ds = survey.TdemData.read_csv(o["data_filename"], o["system_filename"])
+    keep = np.arange(24)
+    ds = ds.subset(keep)
+    same = survey.infer(os.path.join(GOLDEN, "skytem_options_small"), data=ds, burn_in_min_iterations=300, check_every=300, n_markov_chains=600)
+    ds2 = ds.subset(np.arange(24))
+    ds2.offsets[1::2, 2] += 0.5
+    mix = survey.infer(os.path.join(GOLDEN, "skytem_options_small"), data=ds2, burn_in_min_iterations=300, check_every=300, n_markov_chains=600)
+    for k in ("status", "burned_in_iteration", "misfit", "best_conductivity", "interface_posterior", "layer_count_posterior"):
+        assert np.array_equal(mix[k][0::2], same[k][0::2]), k
+    assert not np.array_equal(mix["misfit"][1::2], same["misfit"][1::2])
+
+
 @pytest.mark.gpu
 def test_invert_a_time_domain_survey():
     """The reference's SkyTEM example shape: two moments, per-system error levels from the options file; clean wedge data
@@ -101,6 +185,17 @@ def test_invert_a_time_domain_survey():
     win = survey.infer(os.path.join(GOLDEN, "skytem_options_small"), data=ds, burn_in_min_iterations=1000, check_every=500, hankel_eps=1e-12)
     wd = win["status"] == 1
     assert wd.sum() >= 45 and np.median(win["misfit"][wd]) < 70.0 and abs(win["n_layers"].mean() - res["n_layers"].mean()) < 0.5
+
+
+@pytest.mark.gpu
+def test_dynamic_schedule_gives_the_static_result():
+    """schedule="dynamic": the soundings are inverted chunk by chunk (here by the one rank there is); chains are keyed by the
+    row of the data file, so every number equals the static run's."""
+    static = survey.infer(OPTIONS, exact_jacobian=True)
+    dyn = survey.infer(OPTIONS, exact_jacobian=True, schedule="dynamic", chunk=5)
+    assert set(static) == set(dyn)
+    for k in static:
+        assert np.array_equal(np.asarray(static[k]), np.asarray(dyn[k]), equal_nan=True), k
 
 
 @pytest.mark.gpu
