@@ -108,12 +108,37 @@ __device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
     return M;
 }
 
+#ifndef GBP_WAVE_SUM_BPERMUTE
+// Sum over the 64 lanes, returned to every lane as a wave-uniform value.  DPP tree (quad swaps, half-row and row mirrors, row
+// broadcasts: VALU moves, no LDS crossbar round trips), total read from lane 63 with v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // (masked-off rows add +0.0)
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = dpp_add<0xB1, 0xf>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);      // row_mirror: every lane of a row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 -> rows 2 and 3: lane 63 holds the total
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+#else
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+#endif
 
 // Smallest conductivity of the sounding (wave-uniform, returned in SGPRs; each wave of the workgroup evaluates it).
 __device__ __forceinline__ double wave_min_sigma(const double* __restrict__ sig, int L, int lane)

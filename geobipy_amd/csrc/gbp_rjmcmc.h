@@ -602,7 +602,43 @@ __global__ __launch_bounds__(64) void k_rj_newton(RjOpt o, gbp_rj_chains c, uint
 // 8 x 8 system lives in the registers of lane i of the chain's group, columns of the Cholesky factor are passed around with
 // cross-lane reads (lane j also keeps column j for the transposed solves), so there is no LDS traffic and no barrier in
 // the factorisation or the substitutions.  Rows >= k are identity rows.
-__device__ inline double group_bcast(double v, int base, int j) { return __shfl(v, base + j, 64); }
+// Cross-lane reads within a chain's group of 8 lanes as DPP moves (VALU, a few cycles) instead of ds_bpermute (a trip through
+// the LDS crossbar, ~150 cycles): the factorisation and the substitutions below are chains of ~60 DEPENDENT cross-lane reads,
+// executed by one wave per SIMD in the small-block regime, so their latency is what an iteration costs.  Issued by all 64 lanes.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int J>   // the value lane J (0..7) of the caller's 8-lane group holds
+__device__ __forceinline__ double group_bcast_c(double v)
+{
+    constexpr int q = J & 3;
+    const double a = dpp_mov64<q | (q << 2) | (q << 4) | (q << 6)>(v);   // quad_perm [q,q,q,q]: every quad, its own lane q
+    const double b = dpp_mov64<0x141>(a);                                // row_half_mirror: the other quad's lane q
+    return (((int)threadIdx.x >> 2) & 1) == (J >> 2) ? a : b;
+}
+__device__ __forceinline__ double group_bcast(double v, int base, int j)   // j: a constant after unrolling
+{
+    (void)base;
+    switch (j) {
+        case 0: return group_bcast_c<0>(v);
+        case 1: return group_bcast_c<1>(v);
+        case 2: return group_bcast_c<2>(v);
+        case 3: return group_bcast_c<3>(v);
+        case 4: return group_bcast_c<4>(v);
+        case 5: return group_bcast_c<5>(v);
+        case 6: return group_bcast_c<6>(v);
+        default: return group_bcast_c<7>(v);
+    }
+}
+// the neighbour lanes' values (row_shr:1 / row_shl:1 -- within rows of 16 lanes; callers use them inside a group of 8 only:
+// lane 0 of a group ignores `up`, lane 7 ignores `dn`)
+__device__ __forceinline__ double lane_up(double v) { return dpp_mov64<0x111>(v); }
+__device__ __forceinline__ double lane_dn(double v) { return dpp_mov64<0x101>(v); }
 
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N]
 __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
@@ -627,12 +663,12 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
         t2 = o.gradient_precision / (c2c * c2c);
     }
     // (cross-lane reads are issued by all lanes -- a lane that sits out of the instruction cannot be read from)
-    const double t2_sh = __shfl(t2, max(lane - 1, 0), 64);
+    const double t2_sh = lane_up(t2);
     const double t2_up = i > 0 ? t2_sh : 0.0;
     const double lmp = c.log_mean_prior[bb];
     const double ls = i < k ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
     const double v = i < k ? ls - lmp : 0.0;
-    const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
+    const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
     wave_sync();
     double arow[8], acol[8];
@@ -769,7 +805,8 @@ __device__ inline void hitmap_add(const RjOpt& o, int32_t* hm, const double* ec,
 
 __device__ inline double group_sum8(double v)
 {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    // (the pairs of the xor butterfly: lane ^ 1, lane ^ 2, then the other quad -- whose four lanes hold one value)
+    v += dpp_mov64<0xB1>(v); v += dpp_mov64<0x4E>(v); v += dpp_mov64<0x141>(v);
     return v;
 }
 
@@ -1031,7 +1068,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const double* e = c.edges_r + bb * K;
     const double lmp = c.log_mean_prior[bb];
     const double lpv = i < k ? c.log_prop[bb * K + i] : 0.0;
-    const double lpv_dn = __shfl(lpv, min(lane + 1, 63), 64);
+    const double lpv_dn = lane_dn(lpv);
     // priors of the proposal
     double prior_p = -o.log_layers_m1;
     if (o.solve_value) {
@@ -1083,10 +1120,10 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
         const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
         t2 = o.gradient_precision / (c2c * c2c);
     }
-    const double t2_sh = __shfl(t2, max(lane - 1, 0), 64);
+    const double t2_sh = lane_up(t2);
     const double t2_up = i > 0 ? t2_sh : 0.0;
     const double v = i < k ? lpv - lmp : 0.0;
-    const double v_sh_up = __shfl(v, max(lane - 1, 0), 64), v_sh_dn = __shfl(v, min(lane + 1, 63), 64);
+    const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
     double arow[8], acol[8];
     const bool row = jump && i < k;
