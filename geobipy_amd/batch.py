@@ -45,8 +45,8 @@ class FdemBatch:
                                           "there is no CPU fallback")
         _lib.load()
         self.system = system
-        # waves per workgroup of the forward kernels: 0 = chosen from the batch size; 1..16 fixes the summation order of the
-        # Hankel sums, i.e. makes the values independent of how the soundings are batched (gbp_fdem_forward_ex)
+        # waves per workgroup of the forward kernels: 0 = chosen from the batch size; 1..16 = fixed.  A performance hint: the
+        # values do not depend on it, nor on how the soundings are batched (gbp_fdem_forward_ex)
         self.waves = int(waves)
         assert 0 <= self.waves <= 16, ValueError("waves must be in [0, 16]")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

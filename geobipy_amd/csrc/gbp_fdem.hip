@@ -167,22 +167,24 @@ __device__ __forceinline__ void setup_layers(gbp::LayerK* lay, double wmu, const
 // Forward solve over a contiguous range of 64-point passes of the sounding's FLATTENED (frequency, abscissa)
 // point list (P points: 120 per zz frequency, 140 per xz/zx, 260 per xx).  Flattening matters because 120 is
 // not a multiple of 64: per-frequency passes would idle 8 of 128 lanes, the flat list idles < 64 of P.
-// A pass may straddle two frequencies ("cur" below the boundary lane, "next" above it): each lane picks its
-// frequency's layer constants (two LDS slots) and altitude term, and accumulates into acc_c / acc_n; when a
-// frequency completes (or the range ends) the wave reduces and stores the partial sum in sh_part[f].
+// A pass may straddle two frequencies ("cur" below the boundary lane, "next" above it; never three: a frequency has at
+// least 64 points): each lane picks its frequency's layer constants (two LDS slots) and altitude term.
+// Summation order: every pass reduces its lanes' terms -- per frequency -- to ONE partial sum, sh_part[p][0] for the
+// frequency its first point belongs to and sh_part[p][1] for the one that starts inside it; forward_body adds a frequency's
+// partials in pass order.  The result therefore does not depend on which wave ran which pass: any number of waves per
+// sounding gives the same bits.
 template <bool DIRECT>   // csqrt_upper2<DIRECT> is valid for every layer and abscissa of this sounding (gbp_fdem_system::sigma_direct)
 __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Channel* __restrict__ chan,
                                                const double* __restrict__ pts, int P, int F, int L,
                                                const double* __restrict__ sig, const double* sh_t2,
                                                gbp::LayerK* sh_lay /* [2][Lmax] */, int Lmax, double alt, int p0,
-                                               int p1, int lane, cplx* sh_part /* [F] of this wave */)
+                                               int p1, int lane, cplx* sh_part /* [npass][2] of the sounding */)
 {
     if (p0 >= p1) return;
     int cur = 0;
     while (cur + 1 < F && chan[cur].off + chan[cur].npts <= 64 * p0) ++cur;
     int slot = 0;
     bool cur_ready = false;
-    double acc_cr = 0.0, acc_ci = 0.0, acc_nr = 0.0, acc_ni = 0.0;
     for (int p = p0; p < p1; ++p) {
         const Channel cc = chan[cur];
         if (!cur_ready) {
@@ -217,32 +219,18 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
         gbp::rte_num_den<DIRECT>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
         const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
         if (has_next) {
-            acc_cr += in_next ? 0.0 : t.re;
-            acc_ci += in_next ? 0.0 : t.im;
-            acc_nr += in_next ? t.re : 0.0;
-            acc_ni += in_next ? t.im : 0.0;
+            const double sr = wave_sum(in_next ? 0.0 : t.re), si = wave_sum(in_next ? 0.0 : t.im);
+            const double nr = wave_sum(in_next ? t.re : 0.0), ni = wave_sum(in_next ? t.im : 0.0);
+            if (lane == 0) { sh_part[2 * p] = gbp::mk(sr, si); sh_part[2 * p + 1] = gbp::mk(nr, ni); }
         } else {
-            acc_cr += t.re;
-            acc_ci += t.im;
+            const double sr = wave_sum(t.re), si = wave_sum(t.im);
+            if (lane == 0) sh_part[2 * p] = gbp::mk(sr, si);
         }
-
-        const bool done = base + 64 >= end_cur;   // frequency `cur` has no points beyond this pass
-        const bool last = p == p1 - 1;
-        if (done || last) {
-            const double sr = wave_sum(acc_cr), si = wave_sum(acc_ci);
-            if (lane == 0) sh_part[cur] = gbp::mk(sr, si);
-            if (last && has_next) {
-                const double nr = wave_sum(acc_nr), ni = wave_sum(acc_ni);
-                if (lane == 0) sh_part[cur + 1] = gbp::mk(nr, ni);
-            }
-            if (done) {
-                ++cur;
-                acc_cr = acc_nr; acc_ci = acc_ni;
-                acc_nr = 0.0; acc_ni = 0.0;
-                cur_ready = has_next;
-                slot ^= 1;
-                if (cur >= F) break;
-            }
+        if (base + 64 >= end_cur) {   // frequency `cur` has no points beyond this pass
+            ++cur;
+            cur_ready = has_next;
+            slot ^= 1;
+            if (cur >= F) break;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -277,45 +265,49 @@ __device__ __forceinline__ void loglike_wave(int N, const double* p, const doubl
 
 // Forward solve (+ chi^2 / logL) of ONE sounding by the calling workgroup: the body of k_fdem_forward, also called once per
 // iteration by the persistent sampler kernel (gbp_rjmcmc.h).  Every thread of the workgroup must call it (it contains
-// workgroup barriers); `sh_out` holds 2 * GBP_MAX_FREQ doubles, `sh_dyn` dyn_lds_bytes(nwaves, Lmax, F) bytes:
-//   LayerK lay[nwaves][2][Lmax] | cplx part[nwaves][F] | double t2[Lmax]
+// workgroup barriers); `sh_out` holds 2 * GBP_MAX_FREQ doubles, `sh_dyn` dyn_lds_bytes(nwaves, Lmax, passes) bytes:
+//   LayerK lay[nwaves][2][Lmax] | cplx part[passes][2] | double t2[Lmax]
+// The passes are shared by the first `nw_use` waves of the workgroup (the others only take part in the barriers); the result
+// does not depend on nw_use (see forward_passes).
 template <bool LIKE>
 __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_out, unsigned char* sh_dyn,
                                              const Channel* __restrict__ chan, const double* __restrict__ pts, int npts_total,
                                              int F, int Lmax, int L, const double* __restrict__ sig,
                                              const double* __restrict__ th, double alt, const double* __restrict__ obs_row,
                                              double rel_b, double add_b, double* __restrict__ pred_row, double* chi2_b,
-                                             double* logL_b, double sigma_direct)
+                                             double* logL_b, double sigma_direct, int nw_use)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
+    const int nwaves = nw_use;
+    const int npass = (npts_total + 63) >> 6;
     // every layer conductive enough for the select-free complex sqrt (all but displacement-current dominated models)
     const bool direct = wave_min_sigma(sig, L, lane) >= sigma_direct;   // workgroup-uniform
     gbp::LayerK* sh_lay = reinterpret_cast<gbp::LayerK*>(sh_dyn) + (size_t)wave * 2 * Lmax;
-    cplx* sh_part_all = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
-    double* sh_t2 = reinterpret_cast<double*>(sh_part_all + (size_t)nwaves * F);
+    cplx* sh_part = reinterpret_cast<cplx*>(sh_dyn + (size_t)nwaves * 2 * Lmax * sizeof(gbp::LayerK));
+    double* sh_t2 = reinterpret_cast<double*>(sh_part + (size_t)2 * npass);
     for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
-    for (int i = threadIdx.x; i < nwaves * F; i += blockDim.x) sh_part_all[i] = gbp::mk(0.0, 0.0);
     __syncthreads();
 
-    const int npass = (npts_total + 63) >> 6;
-    const int per = (npass + nwaves - 1) / nwaves;
-    const int p0 = wave * per;
-    const int p1 = min(npass, p0 + per);
-    if (direct)
-        forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane,
-                             sh_part_all + (size_t)wave * F);
-    else
-        forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane,
-                              sh_part_all + (size_t)wave * F);
+    if (wave < nwaves) {
+        const int per = (npass + nwaves - 1) / nwaves;
+        const int p0 = wave * per;
+        const int p1 = min(npass, p0 + per);
+        if (direct)
+            forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part);
+        else
+            forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part);
+    }
     __syncthreads();
 
-    // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum over waves (fixed order: deterministic)
+    // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum of the frequency's per-pass partials in pass order
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
-        double sr = 0.0, si = 0.0;
-        for (int w = 0; w < nwaves; ++w) { sr += sh_part_all[w * F + f].re; si += sh_part_all[w * F + f].im; }
         const Channel ch = chan[f];
+        double sr = 0.0, si = 0.0;
+        for (int p = ch.off >> 6; 64 * p < ch.off + ch.npts; ++p) {
+            const cplx v = sh_part[2 * p + (64 * p >= ch.off ? 0 : 1)];   // the pass's own frequency, or the one starting inside it
+            sr += v.re; si += v.im;
+        }
         sh_out[f] = ch.g_re * sr - ch.g_im * si;
         sh_out[F + f] = ch.g_re * si + ch.g_im * sr;
     }
@@ -368,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     forward_body<LIKE>(M, sh_out, sh_dyn, chan, pts, npts_total, F, Lmax, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
                        height[b], LIKE ? obs + (size_t)b * 2 * F : nullptr, LIKE ? rel[b] : 0.0, LIKE ? add[b] : 0.0,
                        pred != nullptr ? pred + (size_t)b * 2 * F : nullptr, LIKE ? chi2 + b : nullptr, LIKE ? logL + b : nullptr,
-                       sigma_direct);
+                       sigma_direct, (int)(blockDim.x >> 6));
 }
 
 // Jacobian (+ prediction) of ONE sounding by the first `nw_use` waves of the calling workgroup: the body of k_fdem_sens, also
@@ -605,13 +597,13 @@ namespace {
 
 typedef std::complex<double> zc;
 
-size_t dyn_lds_bytes(int nw, int Lmax, int F)
+size_t dyn_lds_bytes(int nw, int Lmax, int passes)
 {
-    return (size_t)nw * 2 * Lmax * sizeof(gbp::LayerK) + (size_t)nw * F * sizeof(cplx) + (size_t)Lmax * sizeof(double);
+    return (size_t)nw * 2 * Lmax * sizeof(gbp::LayerK) + (size_t)2 * passes * sizeof(cplx) + (size_t)Lmax * sizeof(double);
 }
 
 // waves per workgroup: enough workgroups x waves to fill 256 CUs x 8 waves even for small batches.  `waves` > 0 is the
-// caller's explicit choice (the *_ex entries); it fixes the summation order of the Hankel sums.
+// caller's explicit choice (the *_ex entries).  Results do not depend on it (forward_passes).
 int pick_waves(int B, int F, int Lmax, int max_waves, int waves)
 {
     // measured (scripts/sweep_waves.py, 10 frequencies x 8 layers): one wave per sounding is best once every SIMD has a
@@ -621,7 +613,7 @@ int pick_waves(int B, int F, int Lmax, int max_waves, int waves)
     int nw = waves > 0 ? waves : heuristic;
     if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;
-    while (nw > 1 && dyn_lds_bytes(nw, Lmax, F) > 60000) --nw;
+    while (nw > 1 && dyn_lds_bytes(nw, Lmax, max_waves) > 60000) --nw;
     if (nw < 1) nw = 1;
     return nw;
 }
@@ -841,7 +833,7 @@ gbp_status gbp_fdem_forward_ex(const gbp_fdem_system* sys, int B, int Lmax, cons
     if (B == 0) return GBP_OK;
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
-    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
+    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
     GBP_HIP(hipGetLastError());
@@ -893,7 +885,7 @@ gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lm
     if (B == 0) return GBP_OK;
     if (!obs || !rel || !add || !chi2 || !logL) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
-    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, sys->t.nF), (hipStream_t)stream, sys->d_chan,
+    hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
                        chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
     GBP_HIP(hipGetLastError());

@@ -1316,10 +1316,10 @@ __global__ __launch_bounds__(64) void k_td_loglike(RjOpt o, gbp_rj_chains c, con
 // -> accept / bookkeeping -- with workgroup barriers where the lock-step driver (gbp_rj_run_td below) has kernel boundaries.
 // Chains are independent, so nothing is exchanged between workgroups and there is no lock-step tail: a block of 1 024 chains
 // (BASELINE config 5 split over 8 GPUs) no longer pays ten dependent launches per iteration.  The stages are the SAME device
-// functions the lock-step kernels call, on the same arrays, with the same wave counts, so the chains are bit-identical to
-// gbp_rj_run's (tests/test_rjmcmc_gpu.py::test_persistent_kernel_walks_the_same_chains).
-//   workgroup = `forward_waves` waves (the summation order of the fused forward kernel); the per-chain algebra (8-lane packed
-//   or one-wave variants) runs on wave 0.
+// functions the lock-step kernels call, on the same arrays (their results do not depend on the number of waves), so the chains
+// are bit-identical to gbp_rj_run's (tests/test_rjmcmc_gpu.py::test_persistent_kernel_walks_the_same_chains).
+//   workgroup = persistent_waves() waves for the physics stages; the per-chain algebra (8-lane packed or one-wave variants)
+//   runs on wave 0.
 //   dynamic LDS = max over the stages (persistent_lds_bytes), the math tables are staged once per workgroup lifetime.
 // ---------------------------------------------------------------------------------------------------------------
 // The stages are separate (non-inlined) functions so that each gets its own register allocation: inlined into one body the
@@ -1387,7 +1387,7 @@ __device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
     const gbp::MathCtx M = math_ctx(x->math);
     forward_body<true>(M, x->sh_out, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, c.k_r[b], c.sigma_p + (size_t)b * K,
                        c.thk_r + (size_t)b * K, c.height[b], c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N,
-                       c.misfit_p + b, c.like_p + b, x->sigma_direct);
+                       c.misfit_p + b, c.like_p + b, x->sigma_direct, (int)(blockDim.x >> 6));
 }
 
 __device__ GBP_STAGE_ATTR void stage_propose(const PersistentCtx* x, uint32_t iter, int lane)
@@ -1657,15 +1657,6 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     return GBP_OK;
 }
 
-// Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind,
-// a pinned wave count.  Returns the workgroup's waves, or 0.
-static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o, int B)
-{
-    if (o->forward_waves < 1 || o->n_rel_groups != 1 || o->n_add_groups != 1) return 0;
-    const int nw = pick_waves(B, sys->t.nF, o->max_layers, (sys->t.npts + 63) / 64, o->forward_waves);   // what the lock-step forward launch uses
-    return nw <= 4 ? nw : 0;
-}
-
 static size_t sens_lds_bytes(int nw, int Lalloc)
 {
     return (size_t)nw * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)) + (size_t)Lalloc * sizeof(double);
@@ -1673,12 +1664,40 @@ static size_t sens_lds_bytes(int nw, int Lalloc)
 
 static size_t persistent_lds_bytes(const gbp_fdem_system* sys, const gbp_rj_options* o, int nw)
 {
-    const int K = o->max_layers, N = o->n_channels, F = sys->t.nF;
-    size_t stage = dyn_lds_bytes(nw, K, F);
+    const int K = o->max_layers, N = o->n_channels;
+    size_t stage = dyn_lds_bytes(nw, K, (sys->t.npts + 63) / 64);
     stage = std::max(stage, sens_lds_bytes(nw, K < 8 ? K : 8));
     stage = std::max(stage, rj::Lds::bytes(K, N));
     stage = std::max(stage, (size_t)16 * N * sizeof(double));
     return rj::persistent_chain_bytes(K, N) + stage;
+}
+
+// Chains resident at once on the GPU with `nw` waves per workgroup: LDS block per workgroup / 128-VGPR wave slots of a CU.
+static long long persistent_capacity(const gbp_fdem_system* sys, const gbp_rj_options* o, int nw)
+{
+    const size_t lds = persistent_lds_bytes(sys, o, nw);
+    if (lds > 64 * 1024) return 0;
+    return (long long)GBP_RJ_PERSISTENT_CUS * std::min<long long>(128 * 1024 / (long long)lds, 16 / nw);
+}
+
+// Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind.
+// Returns the workgroup's waves, or 0.  The physics stages share a sounding's passes / frequencies among the waves and their
+// results do not depend on how many there are (forward_passes, sens_body), so the count is a pure performance choice: the
+// most waves (up to 4: the per-chain stages run on one) with which the whole block is still resident at once, else the count
+// with the largest capacity.  `forward_waves` > 0 pins it (tests).
+static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o, int B)
+{
+    if (o->n_rel_groups != 1 || o->n_add_groups != 1) return 0;
+    const int top = std::min(4, std::min(sys->t.nF, (sys->t.npts + 63) / 64));
+    if (o->forward_waves > 0) return std::min(o->forward_waves, 4);
+    int best = 0;
+    long long best_cap = 0;
+    for (int nw = top; nw >= 1; --nw) {
+        const long long cap = persistent_capacity(sys, o, nw);
+        if (cap >= B) return nw;
+        if (cap > best_cap) { best_cap = cap; best = nw; }
+    }
+    return best;
 }
 
 static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
@@ -1686,7 +1705,7 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
 {
     const int B = c->B, K = o->max_layers, F = sys->t.nF;
     const int nw = persistent_waves(sys, o, B);
-    if (nw == 0) return fail(GBP_ERR_INVALID_ARG, "the persistent sampler needs frequency-domain data and forward_waves in [1, 4]%s");
+    if (nw == 0) return fail(GBP_ERR_INVALID_ARG, "the persistent sampler needs frequency-domain data with one error level of each kind%s");
     // LDS per workgroup = the chain's arrays (rj::persistent_chain_bytes) + the largest stage working set.  The Jacobian pass of a
     // model with more than 8 layers needs 1 KB per layer and wave: kept in LDS it would take the budget of one more resident
     // chain per CU away from every chain for a rare case, so it works in a per-chain global block instead (stream-ordered
@@ -1727,11 +1746,7 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // 10-frequency system, scripts/bench_rj_modes.py): about twice the resident capacity.
         const int nw = persistent_waves(sys, o, c->B);
         bool small = false;
-        if (nw > 0 && n_iterations >= 4) {
-            const size_t lds = persistent_lds_bytes(sys, o, nw);
-            const long long per_cu = std::min<long long>(128 * 1024 / (long long)lds, 16 / nw);     // LDS / 128-VGPR wave slots of a CU
-            small = lds <= 64 * 1024 && (long long)c->B <= 2 * GBP_RJ_PERSISTENT_CUS * per_cu;
-        }
+        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= 2 * persistent_capacity(sys, o, nw);
         mode = small ? 2 : 1;
     }
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, stream);

@@ -66,11 +66,10 @@ class DeviceChains:
     (documentation_source/source/supplementary/options_files/resolve_options).
 
     ``first_chain``: global index of the block's first sounding -- the random streams are keyed by the global chain
-    index, so a survey produces the same chains on 1 GPU or sharded over 8 -- bit for bit as long as ``forward_waves`` pins
-    the forward kernels' waves per workgroup (the default, 2, is the best single choice from 8k to 64k chains per GPU --
-    4 is 3 % faster at 2k chains, 1 is 1 % faster at 64k; with 0
-    they adapt it to the block size, which changes the summation order of the Hankel sums in the last bits, and long
-    chains of differently sized blocks drift apart).
+    index, so a survey produces the same chains on 1 GPU or sharded over 8, bit for bit.  ``forward_waves``: the forward
+    kernels' waves per workgroup, a performance hint only (the Hankel sums are reduced per 64-point pass and added in pass
+    order, whatever wave ran the pass); the default, 2, is the best single choice from 1k to 64k chains per GPU, 0 lets the
+    library choose from the block size.
     ``reference_schedule``: per-sounding burn-in / stop rule of the reference (Inference1D.update :713-737, infer
     :641-688) evaluated on the device: a chain burns in at the first iteration > ``burn_in_min_iterations`` whose misfit
     is below the number of active channels (its posteriors and best model restart there), is done ``n_markov_chains``

@@ -268,9 +268,10 @@ typedef struct gbp_rj_options {
                                        n_markov_chains iterations later, and has failed when it has not burned in after
                                        n_markov_chains iterations; done / failed chains keep their final state          */
     int32_t burn_in_min_iterations, n_markov_chains;
-    int32_t forward_waves;       /* 0: the forward kernels pick their waves per workgroup from the batch size (fastest);
-                                    > 0: fixed, which fixes the summation order of the Hankel sums and so makes the
-                                    chains bit-identical for any sharding of the survey                 */
+    int32_t forward_waves;       /* waves per sounding of the forward launches (and per chain of the persistent kernel):
+                                    0 = chosen from the block size, > 0 = fixed.  A performance hint only: the Hankel sums
+                                    are reduced per 64-point pass and added in pass order, so the chains are bit-identical
+                                    for any value, block size and sharding of the survey                 */
     double min_edge, max_edge, min_width; /* min_edge already raised to min_width (RectilinearMesh1D.py:358-360) */
     double p_birth, p_death, p_perturb, p_none;
     double value_precision;      /* 1 / ln(1 + factor)^2                                              */

@@ -20,7 +20,7 @@ for B in [int(v) for v in (sys.argv[3].split(',') if len(sys.argv) > 3 else '256
     data = synthetic.noisy_observations(clean)
     out = []
     for mode in (1, 2):
-        for fw in ((2,) if mode == 1 else (1, 2, 4)):
+        for fw in ((0, 2, 4) if mode == 1 else (0, 2, 3, 4)):
             dc = DeviceChains(system, h, data, seed=3, exact_jacobian=exact, forward_waves=fw, **o)
             dc.run_mode = mode
             n_warm, n_it = 200, (2000 if B <= 8192 else 300)

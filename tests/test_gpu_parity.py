@@ -312,22 +312,25 @@ def test_bad_rows_are_flagged_and_the_rest_of_the_batch_is_untouched():
     assert torch.isnan(J1[5]).all() and torch.isnan(pj[5]).all() and torch.equal(J1[kt], J0[kt])
 
 
-def test_explicit_waves_fix_the_summation_order():
-    """gbp_fdem_forward_ex / _loglike_ex: no hidden per-thread state -- the waves per workgroup are an argument; with a fixed
-    value a sounding's numbers do not depend on the batch it is evaluated in, and every choice is within the parity bar."""
+def test_results_do_not_depend_on_the_waves_per_sounding():
+    """gbp_fdem_forward_ex / _loglike_ex: the waves per workgroup are an explicit argument (no hidden per-thread state) and a
+    performance hint only -- every 64-point pass reduces to one partial sum per frequency and a frequency's partials are added
+    in pass order, so 1, 2, 3, 4, 8 or 16 waves, a large batch (one wave per sounding chosen automatically) or a small one (many
+    waves) return the same bits.  Default abscissa windows and all abscissae (passes that straddle two frequencies)."""
     from geobipy_amd import FdemBatch, synthetic
     s = synthetic.syn10_system()
     nl, sig, thk, h = synthetic.draw_models(70000, 8, seed=33)
-    ref = None
-    for w in (1, 2, 4):
-        big = FdemBatch(s, nl, sig, thk, h, waves=w).forward()
-        small = FdemBatch(s, nl[:100], sig[:100], thk[:100], h[:100], waves=w).forward()
-        assert torch.equal(big[:100], small)
-        ref = big if ref is None else ref
-        assert close(big.cpu().numpy(), ref.cpu().numpy(), PRED_ATOL, PRED_RTOL)
-    auto_big = FdemBatch(s, nl, sig, thk, h).forward()            # waves = 0: 1 wave at this size ...
-    auto_small = FdemBatch(s, nl[:100], sig[:100], thk[:100], h[:100]).forward()   # ... many below: same values to rounding only
-    assert close(auto_big[:100].cpu().numpy(), auto_small.cpu().numpy(), PRED_ATOL, PRED_RTOL)
+    data, rel, add = np.full((70000, 20), 80.0), np.full(70000, 0.05), np.full(70000, 5.0)
+    for eps in (None, 0.0):
+        ref = FdemBatch(s, nl, sig, thk, h, data=data, relative_error=rel, additive_error=add, hankel_eps_ppm=eps)     # waves = 0: 1 wave at this size
+        rc, rl = (t.clone() for t in ref.forward_loglike())
+        for w in (1, 2, 3, 4, 8, 16, 0):
+            n = 70000 if w in (1, 4) else 3000
+            fb = FdemBatch(s, nl[:n], sig[:n], thk[:n], h[:n], data=data[:n], relative_error=rel[:n], additive_error=add[:n], waves=w,
+                           hankel_eps_ppm=eps)
+            c2, ll = fb.forward_loglike()
+            assert torch.equal(fb.predicted, ref.predicted[:n]) and torch.equal(c2, rc[:n]) and torch.equal(ll, rl[:n]), (eps, w)
+            assert torch.equal(fb.forward(), ref.predicted[:n])
     with pytest.raises(AssertionError):
         FdemBatch(s, nl[:4], sig[:4], thk[:4], h[:4], waves=17)
 
