@@ -74,6 +74,9 @@ SIGNATURES = {
     "gbp_fdem_system_create_binned": (c_int, [c_int, c_int32_p] + [c_double_p] * 11 + [ctypes.c_double, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_bin_points": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int)]),
     "gbp_fdem_system_npoints": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "gbp_hankel_system_add_bins": (c_int, [c_void_p, ctypes.c_double, c_int, c_int, c_int]),
+    "gbp_hankel_system_clear_bins": (c_int, [c_void_p]),
+    "gbp_tdem_system_set_hankel_eps": (c_int, [c_void_p, ctypes.c_double]),
     "gbp_hankel_system_create_raw": (c_int, [c_int, c_int32_p] + [c_double_p] * 4 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_destroy": (None, [c_void_p]),
     "gbp_fdem_system_nfreq": (c_int, [c_void_p, ctypes.POINTER(c_int)]),

@@ -705,13 +705,39 @@ gbp_status gbp_fdem_system_create_binned(int nF, const int32_t* tid, const doubl
     gbp_fdem_system* s = nullptr;
     gbp_status st = gbp_fdem_system_create(nF, tid, frequencies, tx_z, rx_z, tx_moment, scale, rx_off, separation, w0, lamda0, w1, lamda1, &s);
     if (st != GBP_OK) return st;
+    st = gbp_hankel_system_add_bins(s, eps_ppm, 0, first_altitude_m, n_bins);
+    if (st != GBP_OK) {
+        gbp_fdem_system_destroy(s);
+        return st;
+    }
+    *out = s;
+    return GBP_OK;
+}
+
+gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system* s)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (s->d_bins) { (void)hipFree(s->d_bins); s->d_bins = nullptr; }
+    if (s->d_bin_chan) { (void)hipFree(s->d_bin_chan); s->d_bin_chan = nullptr; }
+    if (s->d_bin_pts) { (void)hipFree(s->d_bin_pts); s->d_bin_pts = nullptr; }
+    s->n_bins = 0;
+    s->bin_npts.clear();
+    return GBP_OK;
+}
+
+gbp_status gbp_hankel_system_add_bins(gbp_fdem_system* s, double eps, int relative, int first_altitude_m, int n_bins)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (!(eps > 0.0) || first_altitude_m < 0 || n_bins < 1 || n_bins > 1024)
+        return fail(GBP_ERR_INVALID_ARG, "eps > 0, first_altitude_m >= 0 and 1 <= n_bins <= 1024 are required%s");
+    (void)gbp_hankel_system_clear_bins(s);                                      // (replaces an earlier set)
     std::vector<BinDesc> desc(n_bins);
     std::vector<Channel> chans;
     std::vector<double> pts;
     s->bin_npts.resize(n_bins);
     for (int i = 0; i < n_bins; ++i) {
         gbp::SystemTables t = s->t;                      // the exact tables, then windowed for altitude >= first + i metres
-        gbp::window_system_tables(&t, eps_ppm, (double)(first_altitude_m + i));
+        gbp::window_system_tables(&t, eps, (double)(first_altitude_m + i), relative != 0);
         desc[i].chan_off = (int)chans.size();
         desc[i].npts_total = t.npts;
         desc[i].pts_off = (long long)pts.size();
@@ -728,10 +754,9 @@ gbp_status gbp_fdem_system_create_binned(int nF, const int32_t* tid, const doubl
     if (e == hipSuccess) e = hipMemcpy(s->d_bin_chan, chans.data(), sizeof(Channel) * chans.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(s->d_bin_pts, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        gbp_fdem_system_destroy(s);
+        s->n_bins = 0;
         return fail(GBP_ERR_HIP, "bin table upload failed: %s", hipGetErrorString(e));
     }
-    *out = s;
     return GBP_OK;
 }
 

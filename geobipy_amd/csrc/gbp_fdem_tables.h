@@ -143,7 +143,10 @@ inline int build_system_tables(int nF, const int32_t* tid, const double* frequen
 // by more than eps_ppm.  At eps = 1e-12 ppm (1e-5 of the parity tolerance, 5000x below the reference's own
 // arithmetic noise) roughly half of the 120 abscissae go.  At least 64 points per frequency are kept so that
 // a 64-lane pass never spans more than two frequencies.  eps_ppm <= 0 leaves the tables untouched.
-inline void window_system_tables(SystemTables* s, double eps_ppm, double min_altitude)
+// relative = true: eps is a fraction of |g_f sum_j coef_j exp(ue_j hD)|, the value the sum takes for rTE = 1 (the image-source
+// field: the inductive limit, the largest a frequency's output gets) at min_altitude -- for tables whose outputs are not ppm
+// (the time-domain nodal spectra, gbp_hankel_system_create_raw).
+inline void window_system_tables(SystemTables* s, double eps_ppm, double min_altitude, bool relative = false)
 {
     if (!(eps_ppm > 0.0)) return;
     const int P = s->npts;
@@ -160,11 +163,22 @@ inline void window_system_tables(SystemTables* s, double eps_ppm, double min_alt
             const double cabs = std::hypot(s->soa[3 * (size_t)P + q], s->soa[4 * (size_t)P + q]);
             T[j] = gabs * cabs * std::exp(s->soa[5 * (size_t)P + q] * std::min(hD, 0.0));
         }
+        double budget = 0.5 * eps_ppm;
+        if (relative) {
+            double sr = 0.0, si = 0.0, tsum = 0.0;
+            for (int j = 0; j < ch.npts; ++j) {
+                const int q = ch.off + j;
+                const double d = std::exp(s->soa[5 * (size_t)P + q] * std::min(hD, 0.0));
+                sr += s->soa[3 * (size_t)P + q] * d; si += s->soa[4 * (size_t)P + q] * d; tsum += T[j];
+            }
+            const double scale = gabs * std::hypot(sr, si);
+            budget *= scale > 0.0 ? scale : tsum;
+        }
         int lo = 0, hi = ch.npts;
         double acc = 0.0;
-        while (lo < hi && acc + T[lo] <= 0.5 * eps_ppm) acc += T[lo++];
+        while (lo < hi && acc + T[lo] <= budget) acc += T[lo++];
         acc = 0.0;
-        while (hi > lo && acc + T[hi - 1] <= 0.5 * eps_ppm) acc += T[--hi];
+        while (hi > lo && acc + T[hi - 1] <= budget) acc += T[--hi];
         while (hi - lo < 64 && (lo > 0 || hi < ch.npts)) {   // keep >= 64 points: re-admit the larger neighbour
             if (lo > 0 && (hi >= ch.npts || T[lo - 1] >= T[hi])) --lo; else ++hi;
         }

@@ -171,6 +171,7 @@ struct gbp_tdem_system {
     double* d_Wb = nullptr;
     std::map<std::tuple<double, double, double>, gbp_fdem_system*> handles;      // raw Hankel handles by receiver offset
     std::vector<double> h_height;                // staging of the altitudes of the last forward call
+    double hankel_eps = 1.0e-12;                 // per-sounding abscissa windows (gbp_tdem_system_set_hankel_eps); 0: all abscissae
 };
 
 namespace td {
@@ -374,6 +375,16 @@ void gbp_tdem_system_destroy(gbp_tdem_system* s)
     delete s;
 }
 
+gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system* s, double eps)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (!(eps >= 0.0)) return fail(GBP_ERR_INVALID_ARG, "eps must be >= 0%s");
+    if (eps != s->hankel_eps)                 // the cached tables were windowed for the old budget
+        for (auto& kv : s->handles) gbp_hankel_system_clear_bins(kv.second);
+    s->hankel_eps = eps;
+    return GBP_OK;
+}
+
 gbp_status gbp_tdem_system_info(const gbp_tdem_system* s, int* n_windows, int* n_components, int* n_nodes, double* loop_radius)
 {
     if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
@@ -434,6 +445,17 @@ gbp_status gbp_tdem_forward(gbp_tdem_system* s, int B, const double* geometry, i
             it = s->handles.emplace(key, h).first;
         }
         const int n = b1 - b0;
+        if (s->hankel_eps > 0.0) {        // per-sounding abscissa windows: 1 m altitude bins covering this run (kept, and widened, across calls)
+            double lo = s->h_height[b0], hi = lo;
+            for (int b = b0; b < b1; ++b) { lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]); }
+            gbp_fdem_system* h = it->second;
+            int first = (int)std::floor(lo), last = std::min((int)std::floor(hi), first + 1023);
+            if (h->n_bins == 0 || first < h->bin0 || last >= h->bin0 + h->n_bins) {
+                if (h->n_bins > 0) { first = std::min(first, h->bin0); last = std::min(std::max(last, h->bin0 + h->n_bins - 1), first + 1023); }
+                st = gbp_hankel_system_add_bins(h, s->hankel_eps, 1, first, last - first + 1);
+                if (st != GBP_OK) break;
+            }
+        }
         st = gbp_fdem_forward_ex(it->second, n, Lmax, nlayers + b0, sigma + (size_t)b0 * Lmax, thk + (size_t)b0 * Lmax, d_h + b0,
                                  d_nodal + (size_t)b0 * n_nodal, 0, stream);
         if (st == GBP_OK)

@@ -322,9 +322,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
     expression.  ``hankel_eps``: accuracy-budgeted window of the Hankel filter abscissae.  Frequency domain: ppm, per
-    sounding, default 1e-10 (``DeviceChains(hankel_eps_ppm=...)``; 0 = all abscissae).  Time domain: opt-in (default off),
-    relative to the inductive-limit value (``TdemDeviceChains(hankel_eps=...)``), with the lowest sounding of the WHOLE
-    selection as the altitude floor, so that every rank builds the same tables."""
+    sounding, default 1e-10 (``DeviceChains(hankel_eps_ppm=...)``; 0 = all abscissae).  Time domain: relative to the
+    inductive-limit value of every nodal sum, per sounding, default 1e-12 (``TdemDeviceChains(hankel_eps=...)``; 0 = all)."""
     import torch
     import torch.distributed as dist
     from .distributed import shard
@@ -366,8 +365,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
     common = dict(seed=int(seed) % (1 << 64), device=device, hitmap=hitmap, first_chain=int(rows[0]) + start, reference_schedule=True,
                   burn_in_min_iterations=burn_in_min_iterations, **{k: o[k] for k in keys if o.get(k) is not None})
-    if time_domain and hankel_eps is not None and hankel_eps > 0.0:
-        common.update(min_altitude=float(np.min(ds.z)), hankel_eps=float(hankel_eps))
+    if time_domain and hankel_eps is not None:
+        common.update(hankel_eps=float(hankel_eps))
     elif not time_domain and hankel_eps is not None:
         common.update(hankel_eps_ppm=float(hankel_eps))
     f64 = lambda x: x.to(torch.float64)

@@ -212,14 +212,9 @@ class TdemSystem:
         return W
 
     # -- Hankel tables of the frequency-domain stage ------------------------------------------------------
-    def hankel_tables(self, dx, dy, dz, eps=0.0, min_altitude=0.0):
-        """Raw point tables for gbp_hankel_system_create_raw, one "frequency" per (component, node).
-
-        ``eps`` > 0 (opt-in): leave out the filter abscissae at both ends whose terms cannot add up to more than ``eps`` times
-        the inductive-limit value of the sum (|rTE| <= 1; the image-source field, the largest the nodal values get) for any
-        sounding at altitude >= ``min_altitude``: e^{-lam (2 alt + dz)} kills the large abscissae, lam^2 the small ones.
-        At eps = 1e-12 and the 30 m of a SkyTEM survey about half of the 120 abscissae remain -- one 64-lane pass of the
-        kernels instead of two (at least 64 are kept).
+    def hankel_tables(self, dx, dy, dz):
+        """Raw point tables for gbp_hankel_system_create_raw, one "frequency" per (component, node), all 120 / 140 filter
+        abscissae (the per-sounding abscissa windows are cut from them by gbp_hankel_system_add_bins).
 
         Vertical field of a horizontal loop of radius a carrying the current of a unit-moment dipole, at
         horizontal distance r and total height (z_tx + z_rx) = 2*altitude + dz:
@@ -246,23 +241,6 @@ class TdemSystem:
             else:
                 src = lam * j1(lam * a) / (2.0 * np.pi * a) if a > 0.0 else lam * lam / (4.0 * np.pi)
             coef = src * w * self.scaling[comp]
-            if eps > 0.0:
-                damp = np.exp(-lam * max(2.0 * float(min_altitude) + dz, 0.0))
-                T = np.abs(coef) * damp
-                scale = abs(np.sum(coef * damp))
-                budget = 0.5 * eps * (scale if scale > 0.0 else T.sum())
-                lo, hi, acc = 0, lam.size, 0.0
-                while lo < hi and acc + T[lo] <= budget:
-                    acc += T[lo]; lo += 1
-                acc = 0.0
-                while hi > lo and acc + T[hi - 1] <= budget:
-                    acc += T[hi - 1]; hi -= 1
-                while hi - lo < 64 and (lo > 0 or hi < lam.size):      # the kernels want >= 64 points: re-admit the larger neighbour
-                    if lo > 0 and (hi >= lam.size or T[lo - 1] >= T[hi]):
-                        lo -= 1
-                    else:
-                        hi += 1
-                lam, coef = lam[lo:hi], coef[lo:hi]
             for f in fn:
                 npts.append(lam.size)
                 wmu.append(2.0 * np.pi * f * MU0)
@@ -334,8 +312,21 @@ class NativeTdemSystem:
             pass
 
 
+DEFAULT_TDEM_HANKEL_EPS = 1.0e-12      # relative to the inductive-limit value of every nodal sum (gbp_hankel_system_add_bins)
+
+
+def _altitude_bins(heights):
+    """(first altitude in metres, number of 1 m bins) covering the given altitudes (at most 1024 bins)."""
+    h = np.asarray(heights, dtype=np.float64)
+    lo = max(0, int(np.floor(np.nanmin(h)))) if h.size else 0
+    hi = max(lo, int(np.floor(np.nanmax(h)))) if h.size else lo
+    return lo, min(hi - lo + 1, 1024)
+
+
 class _RawHandle:
-    def __init__(self, npts, wmu, hd0, g, tables):
+    def __init__(self, npts, wmu, hd0, g, tables, eps=0.0, bins=None):
+        """``eps`` > 0 and ``bins`` = (first altitude, count): per-sounding abscissa windows in 1 m altitude bins, each nodal
+        sum within ``eps`` times its inductive-limit value of the full sum (gbp_hankel_system_add_bins, relative budget)."""
         lib = _lib.load()
         self._lib = lib
         h = ctypes.c_void_p()
@@ -345,7 +336,17 @@ class _RawHandle:
                                                     dp(hd0), dp(g), dp(tables), ctypes.byref(h)))
         self.ptr = h
         self.nF = int(npts.size)
-        self.npoints = int(npts.sum())      # abscissa points evaluated per sounding
+        self.npoints = int(npts.sum())      # abscissa points of the full tables
+        self.bins = None
+        if eps > 0.0 and bins is not None:
+            _lib.check(lib.gbp_hankel_system_add_bins(h, float(eps), 1, int(bins[0]), int(bins[1])))
+            self.bins = (int(bins[0]), int(bins[1]))
+
+    def bin_points(self, altitude):
+        """Abscissa points a sounding at this altitude is evaluated with."""
+        n = ctypes.c_int(0)
+        _lib.check(self._lib.gbp_fdem_system_bin_points(self.ptr, int(np.floor(altitude)), ctypes.byref(n)))
+        return n.value
 
     def __del__(self):
         try:
@@ -368,10 +369,12 @@ class TdemBatch:
     """
 
     def __init__(self, systems, nlayers, sigma, thk, height, offset, data=None, relative_error=None,
-                 additive_error=None, device=None, hankel_eps=0.0, min_altitude=None):
-        """``hankel_eps`` > 0: accuracy-budgeted abscissa window (TdemSystem.hankel_tables) for soundings at altitude >=
-        ``min_altitude`` (default: the lowest of this batch; pass the survey's floor for results that do not depend on how
-        the soundings are batched)."""
+                 additive_error=None, device=None, hankel_eps=None, min_altitude=None):
+        """``hankel_eps``: accuracy budget of the abscissa window every sounding is evaluated with -- the filter abscissae whose
+        terms can add up to more than that fraction of a nodal sum's inductive-limit value at the sounding's OWN altitude (1 m
+        bins, |rTE| <= 1; the same bound as FdemBatch's), so a sounding's numbers do not depend on its batch.
+        Default 1e-12 (about half of the 120 / 140 abscissae at survey altitudes); 0: all abscissae.  ``min_altitude`` is
+        accepted for compatibility and ignored."""
         if not torch.cuda.is_available():
             raise _lib.NativeLibraryError("TdemBatch needs a HIP device; there is no CPU fallback")
         self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
@@ -385,13 +388,12 @@ class TdemBatch:
                 bc = lambda a, n: np.broadcast_to(np.asarray(a), (n,) + np.shape(a)[1:]) if np.ndim(a) >= 1 else np.full(n, a)
                 n_all = off.shape[0]
                 nl_all, h_all = bc(nlayers, n_all), bc(height, n_all)
-                floor = float(np.min(h_all)) if min_altitude is None else float(min_altitude)
                 self._groups = []
                 for g in range(uniq.shape[0]):
                     m = np.nonzero(inverse.ravel() == g)[0]
                     child = TdemBatch(self.systems, nl_all[m], np.asarray(sigma)[m], np.asarray(thk)[m], h_all[m], tuple(uniq[g]),
                                       data=sub(data, m), relative_error=sub(relative_error, m), additive_error=sub(additive_error, m),
-                                      device=self.device, hankel_eps=hankel_eps, min_altitude=floor)
+                                      device=self.device, hankel_eps=hankel_eps)
                     self._groups.append((torch.as_tensor(m, device=self.device), child))
                 self.offset = off
                 self.B, self.Lmax = np.asarray(sigma).shape
@@ -408,11 +410,11 @@ class TdemBatch:
         self.nlayers = dev(np.broadcast_to(np.asarray(nlayers), (self.B,)), torch.int32)
         self.height = dev(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,)))
         self._h, self._W, self._nodal = [], [], []
-        floor = float(np.min(height)) if min_altitude is None else float(min_altitude)
-        assert not hankel_eps > 0.0 or floor <= float(np.min(height)), ValueError("min_altitude must not exceed the lowest sounding")
+        self.hankel_eps = DEFAULT_TDEM_HANKEL_EPS if hankel_eps is None else float(hankel_eps)
+        bins = _altitude_bins(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,))) if self.B > 0 else None
         with torch.cuda.device(self.device):
             for s in self.systems:
-                h = _RawHandle(*s.hankel_tables(*self.offset, eps=float(hankel_eps), min_altitude=floor))
+                h = _RawHandle(*s.hankel_tables(*self.offset), eps=self.hankel_eps, bins=bins)
                 self._h.append(h)
                 n = s.node_frequencies().size
                 W = s.time_operator()
@@ -581,17 +583,18 @@ class TdemDeviceChains(DeviceChains):
         class _Handle:                    # what DeviceChains asks of an acquisition system
             def handle(self_inner):
                 if getattr(outer, "_raw", None) is None:
-                    parts = [s.hankel_tables(*outer._offset, eps=outer._hankel_eps, min_altitude=outer._floor) for s in systems]
+                    parts = [s.hankel_tables(*outer._offset) for s in systems]
                     cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p[j] for p in parts], axis=ax))
-                    outer._raw = _RawHandle(cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1))
+                    outer._raw = _RawHandle(cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1), eps=outer._hankel_eps,
+                                            bins=_altitude_bins(heights))
                 return outer._raw
         kw.pop("exact_jacobian", None)
         kw.pop("hankel_eps_ppm", None)
-        # opt-in abscissa window (TdemSystem.hankel_tables): hankel_eps relative to the inductive-limit value, valid above min_altitude
-        self._hankel_eps = float(kw.pop("hankel_eps", 0.0) or 0.0)
-        floor = kw.pop("min_altitude", None)
-        self._floor = float(np.min(heights)) if floor is None else float(floor)
-        assert not self._hankel_eps > 0.0 or self._floor <= float(np.min(heights)), ValueError("min_altitude must not exceed the lowest sounding")
+        # per-chain abscissa window (1 m altitude bins): hankel_eps relative to the inductive-limit value of every nodal sum;
+        # default 1e-12, 0 = all abscissae (min_altitude: accepted and ignored)
+        eps = kw.pop("hankel_eps", None)
+        self._hankel_eps = DEFAULT_TDEM_HANKEL_EPS if eps is None else float(eps)
+        kw.pop("min_altitude", None)
         super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=np.asarray(add_scale),
                          rel_group=np.asarray(rel_group, dtype=np.int32), add_group=np.asarray(add_group, dtype=np.int32), **kw)
 

@@ -110,6 +110,15 @@ gbp_status gbp_fdem_system_create_binned(int nF, const int32_t *tid, const doubl
                                          const double *w0, const double *lamda0, const double *w1,
                                          const double *lamda1, double eps_ppm, int first_altitude_m, int n_bins,
                                          gbp_fdem_system **out);
+/*
+ * Per-sounding windows for ANY handle (gbp_fdem_system_create, gbp_hankel_system_create_raw): builds the n_bins table sets
+ * from the handle's own tables, replacing an earlier set.  relative = 0: eps in the units of the output (ppm for gbp_fdem
+ * systems; gbp_fdem_system_create_binned = create + this).  relative = 1: eps as a fraction of the value a frequency's sum takes
+ * for rTE = 1 at the bin's altitude (the image-source field, the largest the output gets) -- for raw tables whose outputs are not
+ * ppm: the time-domain nodal spectra (geobipy_amd.TdemBatch and gbp_tdem_forward use 1e-12).  _clear_bins: back to all abscissae.
+ */
+gbp_status gbp_hankel_system_add_bins(gbp_fdem_system *sys, double eps, int relative, int first_altitude_m, int n_bins);
+gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system *sys);
 /* abscissa points a sounding at (integer) altitude_m is evaluated with */
 gbp_status gbp_fdem_system_bin_points(const gbp_fdem_system *sys, int altitude_m, int *npts);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);
@@ -393,6 +402,9 @@ typedef struct gbp_tdem_system gbp_tdem_system;
 gbp_status gbp_tdem_system_create(const char *stm_text, const double *w0, const double *w1, gbp_tdem_system **out);
 void gbp_tdem_system_destroy(gbp_tdem_system *sys);
 gbp_status gbp_tdem_system_info(const gbp_tdem_system *sys, int *n_windows, int *n_components, int *n_nodes, double *loop_radius);
+/* accuracy budget of the per-sounding abscissa windows of gbp_tdem_forward, relative to the inductive-limit value of every nodal
+ * sum (default 1e-12: about half of the 120 / 140 abscissae at survey altitudes, far below anything the windows resolve); 0 = all */
+gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system *sys, double eps);
 /* [host] out: window centres [n_windows] (= gatdaem1d windows.centre), spline-node frequencies [n_nodes], the per-component
  * operator W [2 * n_nodes, n_windows]; any may be NULL */
 gbp_status gbp_tdem_system_tables(const gbp_tdem_system *sys, double *window_centres, double *node_frequencies, double *W);

@@ -11,8 +11,8 @@ G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "t
 B, L = 16384, 6
 nl, sig, thk, h = synthetic.draw_models(B, L, seed=4)
 systems = [TdemSystem(os.path.join(G, "SkytemHM.stm")), TdemSystem(os.path.join(G, "SkytemLM.stm"))]
-eps = float(os.environ.get('TD_EPS', 0.0))       # opt-in abscissa window (TdemBatch(hankel_eps=...)); heights are 25 - 45 m
-b = TdemBatch(systems, nl, sig, thk, h, (-13.0, 0.0, 2.0), hankel_eps=eps, min_altitude=25.0)
+eps = float(os.environ['TD_EPS']) if 'TD_EPS' in os.environ else None      # None: default per-sounding abscissa windows (1e-12); 0: all abscissae
+b = TdemBatch(systems, nl, sig, thk, h, (-13.0, 0.0, 2.0), hankel_eps=eps)
 b.forward(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 20

@@ -22,7 +22,7 @@ ap.add_argument("--iterations", type=int, default=10000)
 ap.add_argument("--layers", type=int, default=4, help="layers of the synthetic true models")
 ap.add_argument("--seed", type=int, default=2026)
 ap.add_argument("--forward-waves", type=int, default=2, help="pinned waves per workgroup of the forward kernels (0 = adaptive)")
-ap.add_argument("--hankel-eps-ppm", type=float, default=0.0, help="opt-in abscissa window (0 = all 120 / 140 abscissae)")
+ap.add_argument("--hankel-eps-ppm", type=float, default=None, help="abscissa window budget (default 1e-10 ppm; 0 = all 120 / 140 abscissae)")
 ap.add_argument("--reference-jacobian", action="store_true", help="use the reference's Jacobian expression in the proposals")
 args = ap.parse_args()
 rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
@@ -53,7 +53,7 @@ options = dict(solve_gradient=True, maximum_number_of_layers=30, minimum_depth=1
                probability_of_perturb=1.0 / 6.0, probability_of_no_change=0.5)
 dc = DeviceChains(system, height[sl], data, seed=args.seed, exact_jacobian=not args.reference_jacobian, first_chain=start,
                   forward_waves=args.forward_waves, device=device, hankel_eps_ppm=args.hankel_eps_ppm,
-                  min_altitude=float(height.min()), **options)
+                  **options)
 m0 = dc.misfit.clone()
 K = dc.K
 gather = SummaryGather(S, 6 + K + 1, device)

@@ -9,7 +9,7 @@ from geobipy_amd.tdem import TdemDeviceChains
 from test_tdem_sampler import _survey, OFFSET
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n_mc = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
-eps = float(os.environ.get("TD_EPS", 0.0))
+eps = float(os.environ["TD_EPS"]) if "TD_EPS" in os.environ else None
 s, h, data, scale, opts, _ = _survey(B, seed=3)
 opts = dict(opts, n_markov_chains=n_mc)
 dc = TdemDeviceChains(s, h, data, OFFSET, seed=2, reference_schedule=True, hitmap=True, n_value_bins=60, hankel_eps=eps, **opts)

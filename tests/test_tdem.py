@@ -179,9 +179,10 @@ def test_gpu_tdem_vs_oracle_and_reference_csv(model):
 
 @pytest.mark.gpu
 def test_gpu_tdem_abscissa_window():
-    """Opt-in window of the Hankel filter (TdemSystem.hankel_tables(eps=...)): 64 of the 120 / 140 abscissae at the survey
-    altitudes, window values and their Jacobian within the budget of the exact sum -- SkyTEM (two moments, 30 m) and
-    TEMPEST (120 m, x and z components), soundings at and above the altitude floor."""
+    """Default path: every sounding is evaluated with the filter abscissae that can matter at ITS altitude (1 m bins, relative
+    budget 1e-12 of the inductive-limit value; gbp_hankel_system_add_bins): 64 of the 120 / 140 abscissae at the survey
+    altitudes, window values and their Jacobian within the budget of the full sums (hankel_eps=0), and a sounding's numbers
+    independent of the batch it is in -- SkyTEM (two moments, 30 m) and TEMPEST (120 m, x and z components)."""
     torch = pytest.importorskip("torch")
     from geobipy_amd import synthetic
     from geobipy_amd.tdem import TdemBatch, TdemSystem
@@ -192,27 +193,21 @@ def test_gpu_tdem_abscissa_window():
         systems = [TdemSystem(os.path.join(GOLDEN, n)) for n in names]
         h = floor + rng.uniform(0.0, 20.0, B)
         h[0] = floor
-        exact = TdemBatch(systems, nl, sig, thk, h, off)
-        win = TdemBatch(systems, nl, sig, thk, h, off, hankel_eps=1e-12, min_altitude=floor)
-        n_exact, n_win = lib_points(exact), lib_points(win)
-        assert n_win < 0.6 * n_exact
+        exact = TdemBatch(systems, nl, sig, thk, h, off, hankel_eps=0.0)
+        win = TdemBatch(systems, nl, sig, thk, h, off)
+        assert all(hh.bins is None for hh in exact._h) and all(hh.bins is not None for hh in win._h)
+        n_exact, n_win = sum(hh.npoints for hh in exact._h), sum(hh.bin_points(floor) for hh in win._h)
+        assert n_win < 0.6 * n_exact and sum(hh.bin_points(floor + 19.5) for hh in win._h) <= n_win
         pe, pw = exact.forward().clone(), win.forward().clone()
         top = pe.abs().max(dim=1, keepdim=True).values
         assert float(((pe - pw).abs() / top).max()) < 1e-11
         Je, Jw = exact.sensitivity().clone(), win.sensitivity().clone()
         assert float((Je - Jw).abs().max() / Je.abs().max()) < 1e-9
-    with pytest.raises(AssertionError):
-        TdemBatch(systems, nl, sig, thk, h, off, hankel_eps=1e-12, min_altitude=floor + 50.0)
+        idx = rng.permutation(B)[:40]
+        sub = TdemBatch(systems, nl[idx], sig[idx], thk[idx], h[idx], off)
+        assert torch.equal(sub.forward(), pw[torch.as_tensor(idx, device=pw.device)])
 
 
-def lib_points(batch):
-    import ctypes
-    from geobipy_amd import _lib
-    n, tot = ctypes.c_int(0), 0
-    for h in batch._h:
-        _lib.check(_lib.load().gbp_fdem_system_npoints(h.ptr, ctypes.byref(n)))
-        tot += n.value
-    return tot
 
 
 @pytest.mark.gpu
