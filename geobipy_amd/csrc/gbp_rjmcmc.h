@@ -1548,6 +1548,55 @@ __global__ __launch_bounds__(1024) void k_rj_persistent(RjOpt o_arg, gbp_rj_chai
 #undef GBP_RJ_I
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lock-step driver, fused physics launches (frequency-domain data): ONE launch per stage instead of one per kind of evaluation
+// and layer-count bucket.  Stage 0 = prediction + Jacobian at the remapped model of the chains whose structure changed; stage 1 =
+// the evaluation at the proposal -- prediction + Jacobian for the chains that change dimension, fused forward + chi^2 + logL for
+// all others.  A workgroup owns a chain and branches on its move (workgroup-uniform), calling the bodies of k_fdem_sens /
+// k_fdem_forward: same values (they do not depend on the wave count), 7 launches per iteration instead of 10, and the two kinds
+// of evaluation of stage 1 fill the GPU together instead of one after the other with a tail each.  Models of more than 8 layers
+// keep their Jacobian working set in a per-chain global block (as in the persistent kernel), so the LDS block is the small one.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(1024) void k_rj_physics(RjOpt o, gbp_rj_chains c, const Channel* __restrict__ chan,
+                                                    const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
+                                                    int stage, unsigned char* deep_scratch, size_t deep_bytes,
+                                                    const BinDesc* __restrict__ bins, int bin0, int n_bins,
+                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
+{
+    __shared__ double sh_out[2 * GBP_MAX_FREQ];
+    __shared__ MathLds sh_math;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int b = blockIdx.x;
+    const int action = c.action[b];
+    if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
+    const int K = o.max_layers, N = o.n_channels, L = c.k_r[b];
+    const double alt = c.height[b];
+    if (bins != nullptr && alt >= (double)bin0) {                 // the chain's abscissa window: the bin of its sounding's altitude
+        const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
+        chan = bin_chan + d.chan_off;
+        pts = bin_pts + d.pts_off;
+        npts_total = d.npts_total;
+    }
+    const gbp::MathCtx M = math_setup(sh_math);                   // ends with __syncthreads()
+    const bool jump = action == INSERT || action == DELETE;
+    const int nw = (int)(blockDim.x >> 6);
+    if (stage == 0 || jump) {
+        const bool at_proposal = stage == 1;
+        const double* sig = (at_proposal ? c.sigma_p : c.sigma_r) + (size_t)b * K;
+        double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
+        double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
+        const double* th = c.thk_r + (size_t)b * K;
+        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8));
+        else sens_body<EXACT, 8>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
+                                 min(K, (L + 7) & ~7));
+    } else {
+        forward_body<true>(M, sh_out, sh_dyn, chan, pts, npts_total, F, K, L, c.sigma_p + (size_t)b * K, c.thk_r + (size_t)b * K, alt,
+                           c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N, c.misfit_p + b, c.like_p + b,
+                           sigma_direct, nw);
+    }
+}
+
 }  // namespace rj
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1657,6 +1706,9 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     return GBP_OK;
 }
 
+static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
+                                  int64_t first_iteration, int n_iterations, int accumulate, bool fused, void* stream);
+
 static size_t sens_lds_bytes(int nw, int Lalloc)
 {
     return (size_t)nw * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)) + (size_t)Lalloc * sizeof(double);
@@ -1736,7 +1788,8 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK) return st;
     if (!sys) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
-    if (mode < 0 || mode > 2) return fail(GBP_ERR_INVALID_ARG, "mode must be 0 (auto), 1 (lock-step) or 2 (persistent)%s");
+    if (mode < 0 || mode > 3)
+        return fail(GBP_ERR_INVALID_ARG, "mode must be 0 (auto), 1 (lock-step), 2 (persistent) or 3 (lock-step, one launch per evaluation kind)%s");
     if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
     if (c->B == 0 || n_iterations <= 0) return GBP_OK;
     if (mode == 0) {
@@ -1750,7 +1803,7 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         mode = small ? 2 : 1;
     }
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, stream);
-    return gbp_rj_run_td(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, stream);
+    return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, stream);
 }
 
 gbp_status gbp_rj_debug_stage_ticks(int64_t* out, int reset)
@@ -1775,6 +1828,14 @@ gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const
 
 gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
                          int64_t first_iteration, int n_iterations, int accumulate, void* stream)
+{
+    return rj_run_lockstep(sys, td, o, c, first_iteration, n_iterations, accumulate, td == nullptr, stream);
+}
+
+}  // extern "C"
+
+static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
+                                  int64_t first_iteration, int n_iterations, int accumulate, bool fused, void* stream)
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK) return st;
@@ -1832,6 +1893,41 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     // chains and for time-domain blocks of any size (more kernels per branch), but the two cross-stream waits cost more than
     // the overlap gains below ~32 k chains x 6 frequencies (-3 % at 8 192, -9 % at 1 024): only large launches fork.
     const hipStream_t main_q = (hipStream_t)stream;
+    // Fused physics launches pay below the size from which the two evaluations at the proposals overlap on two streams anyway
+    // (scripts/bench_rj_modes.py, mode 1 vs 3: +17 % at 1 024 chains, +4 % at 8 192, -8 % at 65 536, where the forward chains
+    // would run at the Jacobian pass's occupancy).
+    if (fused && td == nullptr && (long long)B * sys->t.nF < 196608) {
+        // one physics launch per stage (k_rj_physics): 7 launches per iteration
+        const int nw = std::max(1, std::min(sw, 4));
+        const size_t lds = std::max(dyn_lds_bytes(nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(nw, K < 8 ? K : 8));
+        const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(nw, K) + 255) & ~(size_t)255) : 0;
+        unsigned char* deep = nullptr;
+        if (deep_bytes > 0) GBP_HIP(hipMallocAsync((void**)&deep, deep_bytes * (size_t)B, main_q));
+        const rj::RjOpt ox = rj::extend(*o);
+        auto physics = [&](int stage) {
+            if (o->exact_jacobian)
+                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(B), dim3(64 * nw), lds, main_q, ox, *c, sys->d_chan, sys->d_pts, sys->t.npts,
+                                   sys->t.nF, sys->sigma_direct, stage, deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
+                                   sys->d_bin_pts);
+            else
+                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(B), dim3(64 * nw), lds, main_q, ox, *c, sys->d_chan, sys->d_pts, sys->t.npts,
+                                   sys->t.nF, sys->sigma_direct, stage, deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
+                                   sys->d_bin_pts);
+        };
+        for (int it = 0; it < n_iterations && st == GBP_OK; ++it) {
+            const int64_t iter = first_iteration + it;
+            if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) break;
+            physics(0);                                   // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
+            if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) break;
+            physics(1);                                   // Inference1D.py:572-597 / Model.py:612: every proposal's evaluation
+            st = gbp_rj_accept(o, c, iter, accumulate, stream);
+        }
+        const hipError_t le = hipGetLastError();
+        if (deep != nullptr) (void)hipFreeAsync(deep, main_q);
+        if (st != GBP_OK) return st;
+        if (le != hipSuccess) return fail(GBP_ERR_HIP, "sampler launch: %s", hipGetErrorString(le));
+        return GBP_OK;
+    }
     const bool fork = td != nullptr || (long long)B * sys->t.nF >= 196608;
     SideStream* ss = fork ? side_stream() : nullptr;
     if (fork && ss == nullptr) return fail(GBP_ERR_HIP, "side stream: %s", hipGetErrorString(hipGetLastError()));
@@ -1868,6 +1964,8 @@ gbp_status gbp_rj_run_td(const gbp_fdem_system* sys, const gbp_td_operator* td, 
     }
     return GBP_OK;
 }
+
+extern "C" {
 
 gbp_status gbp_td_apply(int B, int K, int n_nodal, int N, const int32_t* nlayers, const double* W, const double* nodal,
                         const double* J_nodal, double* pred, double* J, void* stream)

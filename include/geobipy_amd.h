@@ -355,10 +355,12 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
-/* `mode`: 0 = gbp_rj_run's choice, 1 = lock-step driver (ten stream-ordered launches per iteration over the whole block),
- * 2 = persistent kernel (one workgroup owns a chain and loops over all n_iterations in ONE launch; frequency-domain data,
- * forward_waves in [1, 4]).  The two drivers walk bit-identical chains; small blocks (config 5 split over 8 GPUs: 1 024 chains
- * per GPU) are several times faster in mode 2, large ones in mode 1. */
+/* `mode`: 0 = gbp_rj_run's choice, 1 = lock-step driver (seven stream-ordered launches per iteration over the whole block:
+ * propose, the evaluations at the remapped models, Newton (2), the evaluations at the proposals, accept (2)),
+ * 2 = persistent kernel (one workgroup owns a chain and loops over all n_iterations in ONE launch; frequency-domain data),
+ * 3 = lock-step with one launch per kind of evaluation and layer-count bucket (ten per iteration; what time-domain blocks use).
+ * All drivers walk bit-identical chains; small blocks (config 5 split over 8 GPUs: 1 024 chains per GPU) are about twice as
+ * fast in mode 2, large ones in mode 1. */
 gbp_status gbp_rj_run_mode(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                            int64_t first_iteration, int n_iterations, int accumulate, int mode, void *stream);
 /*

@@ -585,13 +585,14 @@ def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
                                                   options=dict(n_markov_chains=150)))])
 def test_persistent_kernel_walks_the_same_chains(exact, kw):
     """gbp_rj_run_mode: the persistent per-chain kernel (one workgroup owns a chain and loops over the iterations in ONE launch)
-    and the lock-step driver (ten launches per iteration over the block) are the same device functions on the same arrays
-    with the same wave counts -- the chains, their posteriors and every piece of carried state are bit-identical, also when
+    and the two lock-step drivers (mode 1: seven launches per iteration, one fused physics launch per stage; mode 3: ten, one
+    per kind of evaluation and layer-count bucket) are the same device functions on the same arrays, and their results do not
+    depend on the wave counts -- the chains, their posteriors and every piece of carried state are bit-identical, also when
     the run is cut into launches of different lengths, for deep models (> 8 layers: the one-wave variants of the per-chain
     algebra and the 8-row-group Jacobian pass) and under the reference's burn-in schedule."""
     B, n_it = 300, 400
     runs = []
-    for mode, cuts in ((1, (n_it,)), (2, (n_it,)), (2, (1, 7, 150, n_it - 158))):
+    for mode, cuts in ((1, (n_it,)), (3, (n_it,)), (2, (n_it,)), (2, (1, 7, 150, n_it - 158))):
         d, s, dc = _chains(B, 31, exact=exact, **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
         rng = np.random.default_rng(4)
         data = np.tile(d["data"], (B, 1)) * rng.uniform(0.7, 1.4, (B, 1))
