@@ -638,7 +638,7 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
 
 extern "C" {
 
-const char* gbp_version(void) { return "geobipy_amd 0.1 (gfx950)"; }
+const char* gbp_version(void) { return "geobipy_amd 0.2 (gfx950)"; }
 const char* gbp_last_error(void) { return g_err; }
 
 gbp_status gbp_device_count(int* count)
