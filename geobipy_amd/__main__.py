@@ -29,6 +29,9 @@ def parse(argv=None):
     p.add_argument("--hankel-eps", type=float, default=None,
                    help="accuracy budget of the Hankel-filter abscissa window: ppm for frequency-domain data (default 1e-10, 0 = all "
                         "abscissae), relative for time-domain data (default off)")
+    p.add_argument("--no-containers", action="store_true",
+                   help="skip the reference-layout results containers (<line>.h5, or <line>.h5.npz without h5py); the per-line "
+                        "summary files <line>.npz are always written")
     p.add_argument("--schedule", choices=("static", "dynamic"), default="static",
                    help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
                         "(the reference's master / worker scheduling)")
@@ -60,7 +63,8 @@ def main(argv=None):
         shutil.copy(a.options_file, a.output_directory)            # kept with the results, like the reference does
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
-                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, data_directory=a.data_directory,
+                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=None if a.no_containers else a.output_directory,
+                       data_directory=a.data_directory,
                        data_filename=a.data_filename)
     if rank == 0:
         paths = res.save_lines(a.output_directory)

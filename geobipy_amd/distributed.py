@@ -139,3 +139,42 @@ def gather_rows(rows, values, N, group=None):
         block = recv[r * max(pad, 1): r * max(pad, 1) + n]
         out[block[:, 0].to(torch.int64)] = block[:, 1:]
     return out
+
+
+def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
+    """Generator for rank 0: (rows int64[m] numpy, [block[m, W_i] numpy ...]) chunk by chunk, over every rank's rows -- the
+    bounded-memory exchange for per-sounding payloads too large to gather at once (config 5's conductivity-depth hit maps are
+    440 KB per sounding: SURVEY 8e).  ``rows``: this rank's global row indices (int64 tensor); ``blocks``: tensors [len(rows),
+    W_i] on one device, any dtypes.  Point-to-point: rank r sends its chunks in order, rank 0 receives into one reusable buffer
+    per block; other ranks get an empty generator (iterate it all the same -- that is what sends)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = blocks[0].device
+    m = int(rows.numel())
+    own = lambda x: (x.clone() if x.device.type == "cpu" else x.cpu()).numpy()        # (a receive buffer is reused: hand out copies)
+    to_host = lambda r, bs, a, b: (own(r[a:b]), [own(x[a:b]) for x in bs])
+    if world == 1:
+        for a in range(0, m, chunk_rows):
+            yield to_host(rows, blocks, a, min(m, a + chunk_rows))
+        return
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([m], dtype=torch.int64, device=dev), group=group)
+    counts = counts.cpu().tolist()
+    if rank == 0:
+        for a in range(0, m, chunk_rows):
+            yield to_host(rows, blocks, a, min(m, a + chunk_rows))
+        rbuf = torch.empty(chunk_rows, dtype=torch.int64, device=dev)
+        bufs = [torch.empty((chunk_rows,) + tuple(b.shape[1:]), dtype=b.dtype, device=dev) for b in blocks]
+        for r in range(1, world):
+            for a in range(0, counts[r], chunk_rows):
+                n = min(chunk_rows, counts[r] - a)
+                dist.recv(rbuf[:n], src=r, group=group)
+                for buf in bufs:
+                    dist.recv(buf[:n], src=r, group=group)
+                yield to_host(rbuf, bufs, 0, n)
+    else:
+        for a in range(0, m, chunk_rows):
+            b = min(m, a + chunk_rows)
+            dist.send(rows[a:b].contiguous(), dst=0, group=group)
+            for x in blocks:
+                dist.send(x[a:b].contiguous(), dst=0, group=group)

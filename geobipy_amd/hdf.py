@@ -322,3 +322,90 @@ def write_inference1d(parent, inf, index=None):
     m["values/data"][i, :] = vals
     m["values/posterior/values/data"][i, :, :] = p.values
     m["values/posterior/mesh/y/relative_to/data"][i] = g_["value_to"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-line containers from the device sampler (survey.infer(results_directory=...)): the same tree, one row per sounding,
+# filled from the chains' device-resident posteriors instead of a host Inference1D
+# ---------------------------------------------------------------------------------------------------------------
+class LineSpec:
+    """What ``create_inference1d`` reads of an initialised Inference1D, built from a DeviceChains block instead: the
+    acquisition system, the options, and the posterior grids (the device accumulators bin on the reference's grids:
+    RectilinearMesh1D.set_posteriors :1438-1455, Model.set_posteriors)."""
+
+    def __init__(self, system, n_channels, options, n_value_bins=250):
+        from types import SimpleNamespace
+        from .inference import OPTION_DEFAULTS
+        o = dict(OPTION_DEFAULTS)
+        o.update({k: v for k, v in dict(options).items() if v is not None})
+        self.options = o
+        self.datapoint = SimpleNamespace(nChannels=int(n_channels), system=[system], nSystems=1)
+        min_width = float(o["minimum_thickness"])
+        half = 4.0 * np.log(1.0 + float(o["factor"]))
+        self.posteriors = SimpleNamespace(depth_edges=np.arange(0.0, 1.1 * float(o["maximum_depth"]), 0.5 * min_width),
+                                          value_edges=np.linspace(-half, half, int(n_value_bins) + 1) / np.log(10.0), relative_to=np.nan)
+        self.interactive_plot = False
+        self.reciprocate_parameter = bool(o.get("reciprocate_parameters", True))
+        self.n_markov_chains = int(o["n_markov_chains"])
+
+
+# per-sounding fields of a finished block, as survey.infer ships them to the writing rank: (name, columns, kind)
+def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True):
+    f64 = [("x", 1), ("y", 1), ("z", 1), ("elevation", 1), ("line_number", 1), ("fiducial", 1), ("data", N), ("predicted", N),
+           ("relative_error", 1), ("additive_error", 1), ("log_mean_prior", 1), ("best_edges", K), ("best_sigma", K)]
+    i32 = [("status", 1), ("burned_in_iteration", 1), ("iterations", 1), ("best_k", 1), ("k_hist", K + 1), ("edge_hist", n_depth),
+           ("rel_hist", n_err), ("add_hist", n_err)] + ([("hitmap", n_value * n_depth)] if hitmap else [])
+    return f64, i32
+
+
+def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True):
+    """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
+    LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  Not written: the
+    per-iteration traces ``acceptance_rate`` / ``phids`` (the device sampler keeps no per-iteration history), ``best_iteration``,
+    the wall-clock fields."""
+    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap)
+    col, F, I = 0, {}, {}
+    for name, w in ff:
+        F[name] = f64[:, col:col + w]
+        col += w
+    col = 0
+    for name, w in fi:
+        I[name] = i32[:, col:col + w]
+        col += w
+    o = options
+    rel_to = np.log10(0.5 * (o["maximum_relative_error"] - o["minimum_relative_error"]))
+    add_to = np.log10(0.5 * (o["maximum_additive_error"] - o["minimum_additive_error"]))
+    idx = np.asarray(index)
+    parent["iteration"][idx] = I["iterations"][:, 0]
+    parent["burned_in_iteration"][idx] = np.maximum(I["burned_in_iteration"][:, 0], 0)
+    parent["burned_in"][idx] = I["status"][:, 0] == 1
+    parent["multiplier"][idx] = 1.0
+    parent["halfspace/data"][idx] = np.exp(F["log_mean_prior"][:, 0])
+    d = parent["data"]
+    for key in ("x", "y", "z", "elevation", "line_number"):
+        d[key + "/data"][idx] = F[key][:, 0]
+    d["data/data"][idx, :] = F["data"]
+    d["predicted_data/data"][idx, :] = F["predicted"]
+    d["std/data"][idx, :] = np.sqrt((F["relative_error"] * F["data"]) ** 2.0 + F["additive_error"] ** 2.0)
+    d["relative_error/data"][idx] = F["relative_error"][:, 0]
+    d["additive_error/data"][idx] = F["additive_error"][:, 0]
+    d["relative_error/posterior/values/data"][idx, :] = I["rel_hist"]
+    d["additive_error/posterior/values/data"][idx, :] = I["add_hist"]
+    d["relative_error/posterior/mesh/y/relative_to/data"][idx] = rel_to
+    d["additive_error/posterior/mesh/y/relative_to/data"][idx] = add_to
+    m = parent["model"]
+    k = I["best_k"][:, 0]
+    m["mesh/nCells/data"][idx] = k
+    m["mesh/nCells/posterior/values/data"][idx, :] = I["k_hist"]
+    rows = np.full((idx.size, K + 1), np.nan)
+    vals = np.full((idx.size, K), np.nan)
+    for j in range(idx.size):
+        kj = int(k[j])
+        rows[j, :kj + 1] = np.r_[0.0, F["best_edges"][j, :kj - 1], np.inf]
+        vals[j, :kj] = F["best_sigma"][j, :kj]
+    m["mesh/y/edges/data"][idx, :] = rows
+    m["mesh/y/edges/posterior/values/data"][idx, :] = I["edge_hist"]
+    m["values/data"][idx, :] = vals
+    if hitmap:
+        m["values/posterior/values/data"][idx, :, :] = I["hitmap"].reshape(idx.size, n_value, n_depth)
+    m["values/posterior/mesh/y/relative_to/data"][idx] = F["log_mean_prior"][:, 0] / np.log(10.0)

@@ -289,6 +289,41 @@ def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     return mean, pct
 
 
+def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
+    """Rank 0 receives every rank's rows chunk by chunk and fills one container per flight line (geobipy_amd.hdf)."""
+    import torch
+    from . import hdf
+    from .distributed import stream_rows_to_root
+    K, N, nd, nv = dc.K, dc.N, dc.n_depth_bins, dc.n_value_bins
+    wf = sum(w for _, w in hdf.device_row_fields(N, K, nd, nv, hitmap=hitmap)[0])
+    wi = sum(w for _, w in hdf.device_row_fields(N, K, nd, nv, hitmap=hitmap)[1])
+    dev = dc.device
+    cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt, device=dev)
+    rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, wf, torch.float64), cat(2, wi, torch.int32)
+    assert f_t.shape[1] == wf and i_t.shape[1] == wi
+    lines = {}
+    for rows_np, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
+        for ln in np.unique(f[:, 4]):
+            if ln not in lines:
+                fid = np.sort(ds.fiducial[ds.lineNumber == ln])
+                path = os.path.join(directory, "{}.h5".format(ln))
+                root = hdf.open_results(path)
+                hdf.create_inference1d(root, hdf.LineSpec(ds.system, N, o, n_value_bins=nv), add_axis=fid)
+                lines[ln] = (root, fid, path)
+            root, fid, _ = lines[ln]
+            m = f[:, 4] == ln
+            hdf.write_device_rows(root, np.searchsorted(fid, f[m, 5]), f[m], i[m], N, K, nd, nv, o, hitmap=hitmap)
+    paths = []
+    for ln, (root, fid, path) in lines.items():
+        if isinstance(root, hdf.NpzGroup):
+            root.save(path)                        # numpy appends .npz: <line>.h5.npz (+ <line>.h5.attrs.json)
+            paths.append(path + ".npz")
+        else:
+            root.close()
+            paths.append(path)
+    return paths
+
+
 def select_soundings(ds, index=None, fiducial=None, line_number=None):
     """Row indices chosen by the reference's --index / --fiducial / --line switches (Inference3D.infer_serial :458-500:
     one data point by position, or by fiducial on a line); all rows when none is given."""
@@ -309,7 +344,7 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
 
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
           exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
-          chunk=None, **overrides):
+          chunk=None, results_directory=None, **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
@@ -319,6 +354,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     (``distributed.ChunkQueue``; the reference's master / worker loop, Inference3D.py:518-635, without a master), which evens
     out the different numbers of iterations soundings need.  Chains are keyed by the sounding's row in the data file, so the
     results do not depend on the schedule.
+    ``results_directory``: also write the reference's per-line results containers there (``<line number>.h5``: the layout of
+    Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf``; ``<line number>.h5.npz`` with the same dataset paths when
+    h5py is not installed) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
+    map), best model and its predicted data.  The rows travel to rank 0 in bounded chunks (``distributed.stream_rows_to_root``).
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
     expression.  ``hankel_eps``: accuracy-budgeted window of the Hankel filter abscissae.  Frequency domain: ppm, per
@@ -397,6 +436,32 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         return dc, named
 
     state = dict(iterations=0, dc=None, named=None)
+    if results_directory is not None and time_domain:
+        raise NotImplementedError("results containers are written for frequency-domain surveys (FdemData)")
+    shipped = []                                   # per block: (rows, float64 block, int32 block) of hdf.device_row_fields
+
+    def payload(dc, idx):
+        """The rows of hdf.device_row_fields for a finished block (device tensors)."""
+        from .batch import FdemBatch
+        from .rjmcmc_gpu import layer_widths
+        t, dev = dc.t, dc.device
+        n_mc = int(o["n_markov_chains"])
+        none = t["best_k"] < 1                      # (a chain that never recorded a best model: its current one)
+        bk = torch.where(none, t["k"], t["best_k"])
+        be = torch.where(none[:, None], t["edges"], t["best_edges"])
+        bs = torch.where(none[:, None], t["sigma"], t["best_sigma"])
+        pred = FdemBatch(ds.system, bk, bs, layer_widths(be, bk.to(torch.int64)), t["height"], device=dev).forward()
+        host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
+        f64_block = torch.cat([host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
+                               t["rel"][:, :1], t["add"][:, :1], t["log_mean_prior"][:, None], be, bs], dim=1).contiguous()
+        st, bi = t["status"].to(torch.int32), t["burned_in_iteration"].to(torch.int32)
+        ran = torch.where(st == 1, bi + n_mc + 1, torch.where(st == 2, torch.full_like(bi, n_mc), torch.full_like(bi, dc.iteration)))
+        cols = [st[:, None], bi[:, None], ran[:, None], bk.to(torch.int32)[:, None], t["k_hist"], t["edge_hist"], t["rel_hist"].flatten(1),
+                t["add_hist"].flatten(1)]
+        if hitmap:
+            cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
+        return (torch.as_tensor(np.asarray(idx), dtype=torch.int64, device=dev), f64_block,
+                torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous())
 
     def process(first, count):
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
@@ -412,6 +477,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         out = None
         for off, idx in blocks:
             dc, named = run_block(idx, off)
+            if results_directory is not None:
+                shipped.append(payload(dc, idx))
             part = torch.cat([v for _, v in named], dim=1).contiguous()
             state.update(iterations=max(state["iterations"], dc.iteration), dc=dc, named=named)
             if len(blocks) == 1:
@@ -447,6 +514,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         it = torch.tensor([iterations_run], dtype=torch.int64, device=dc.device)
         dist.all_reduce(it, op=dist.ReduceOp.MAX)
         iterations_run = int(it)
+    if results_directory is not None:
+        _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
     if rank != 0:
         return None
     r = gathered.cpu().numpy()

@@ -119,3 +119,43 @@ def test_chunk_queue_without_a_process_group():
     rows = torch.tensor([2, 0, 1])
     out = gather_rows(rows, torch.tensor([[2.0], [0.0], [1.0]], dtype=torch.float64), 3)
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0]
+
+
+def _stream_worker(rank, world, port, N, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geobipy_amd.distributed import shard, stream_rows_to_root
+        start, n = shard(N)
+        rows = torch.arange(start, start + n, dtype=torch.int64)
+        f = torch.stack([rows.double() * 0.5, rows.double() + 1000.0], dim=1)
+        i = (rows[:, None] * 3 + torch.arange(5)[None, :]).to(torch.int32)
+        got_rows, got_f, got_i, sizes = [], [], [], []
+        for r, (bf, bi) in stream_rows_to_root(rows, [f, i], chunk_rows=7):
+            got_rows.append(r); got_f.append(bf); got_i.append(bi); sizes.append(len(r))
+        if rank == 0:
+            r = np.concatenate(got_rows); order = np.argsort(r)
+            ok = (np.array_equal(r[order], np.arange(N)) and np.array_equal(np.concatenate(got_f)[order][:, 1], np.arange(N) + 1000.0)
+                  and np.array_equal(np.concatenate(got_i)[order][:, 4], np.arange(N) * 3 + 4) and max(sizes) <= 7
+                  and np.concatenate(got_i).dtype == np.int32)
+            ret.put(bool(ok))
+        else:
+            assert not got_rows
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N", [(2, 50), (3, 20)])
+def test_stream_rows_to_root_gloo(world, N):
+    """Bounded-memory exchange of per-sounding payloads: rank 0 sees every rank's rows in chunks of at most chunk_rows."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, N, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True

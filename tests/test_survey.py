@@ -188,6 +188,54 @@ def test_invert_a_time_domain_survey():
 
 
 @pytest.mark.gpu
+def test_survey_writes_the_reference_results_containers(tmp_path):
+    """survey.infer(results_directory=...): one container per flight line in the reference's HDF5 layout (hdf_schema.json;
+    .h5.npz with the same dataset paths here, h5py is not installed), every sounding's row filled from the device sampler's
+    posteriors -- consistent with the summaries the same call returns, whichever schedule delivered the rows."""
+    import json
+    from geobipy_amd import hdf
+    out = tmp_path / "res"
+    out.mkdir()
+    res = survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out))
+    ds = survey.FdemData.read_csv(survey.read_options(OPTIONS)["data_filename"], survey.read_options(OPTIONS)["system_filename"])
+    lines = np.unique(ds.lineNumber)
+    schema = json.load(open(os.path.join(GOLDEN, "hdf_schema.json")))["tree"]
+    for ln in lines:
+        z = np.load(out / "{}.h5.npz".format(ln))
+        attrs = json.load(open(out / "{}.h5.attrs.json".format(ln)))
+        assert sorted(z.files) == sorted(p for p, v in schema.items() if v["kind"] == "dataset")
+        assert attrs["/model/values"]["repr"] == "StatArray" and attrs["/data"]["repr"] == "FdemData"
+        m = ds.lineNumber == ln
+        order = np.argsort(ds.fiducial[m])
+        rows = np.nonzero(m)[0][order]
+        n = rows.size
+        assert np.array_equal(z["/data/fiducial/data"], ds.fiducial[rows]) and np.array_equal(z["/data/data/data"], ds.data[rows])
+        assert np.array_equal(z["/model/mesh/nCells/posterior/values/data"], res["layer_count_posterior"][rows])
+        assert np.array_equal(z["/model/mesh/y/edges/posterior/values/data"], res["interface_posterior"][rows])
+        assert np.array_equal(z["/model/mesh/nCells/data"], res["best_n_layers"][rows])
+        assert np.array_equal(z["/burned_in"], res["status"][rows] == 1) and np.array_equal(z["/iteration"], res["iterations"][rows])
+        for j, r in enumerate(rows):
+            k = int(res["best_n_layers"][r])
+            assert np.array_equal(z["/model/values/data"][j, :k], res["best_conductivity"][r, :k]) and np.all(np.isnan(z["/model/values/data"][j, k:]))
+        hm = z["/model/values/posterior/values/data"]
+        assert hm.shape == (n, 250, z["/model/values/posterior/mesh/z/edges/data"].size - 1) and hm.dtype == np.int32
+        # every accumulated iteration puts one count in every depth cell of the hit map, and one in the layer-count histogram
+        assert np.array_equal(hm.sum(axis=1)[:, 0], z["/model/mesh/nCells/posterior/values/data"].sum(axis=1))
+        # predicted data of the best model: close to the data where the chain converged
+        done = z["/burned_in"]
+        chi2 = (((z["/data/predicted_data/data"] - z["/data/data/data"]) / z["/data/std/data"]) ** 2).sum(axis=1)
+        assert np.all(np.isfinite(chi2)) and np.median(chi2[done]) < 40.0
+    # the dynamic schedule delivers the same files
+    out2 = tmp_path / "res2"
+    out2.mkdir()
+    survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out2), schedule="dynamic", chunk=7)
+    for ln in lines:
+        a, b = np.load(out / "{}.h5.npz".format(ln)), np.load(out2 / "{}.h5.npz".format(ln))
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.gpu
 def test_dynamic_schedule_gives_the_static_result():
     """schedule="dynamic": the soundings are inverted chunk by chunk (here by the one rank there is); chains are keyed by the
     row of the data file, so every number equals the static run's."""
