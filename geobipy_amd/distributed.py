@@ -160,6 +160,11 @@ def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
     counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([m], dtype=torch.int64, device=dev), group=group)
     counts = counts.cpu().tolist()
+    if dist.get_backend(group) == "gloo" and dev.type != "cpu":      # gloo's point-to-point wants host memory: stage the chunks
+        dev = torch.device("cpu")
+        stage = lambda x: x.cpu()
+    else:
+        stage = lambda x: x.contiguous()
     if rank == 0:
         for a in range(0, m, chunk_rows):
             yield to_host(rows, blocks, a, min(m, a + chunk_rows))
@@ -175,6 +180,6 @@ def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
     else:
         for a in range(0, m, chunk_rows):
             b = min(m, a + chunk_rows)
-            dist.send(rows[a:b].contiguous(), dst=0, group=group)
+            dist.send(stage(rows[a:b]), dst=0, group=group)
             for x in blocks:
-                dist.send(x[a:b].contiguous(), dst=0, group=group)
+                dist.send(stage(x[a:b]), dst=0, group=group)

@@ -236,6 +236,36 @@ def test_survey_writes_the_reference_results_containers(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_write_the_files_one_rank_writes(tmp_path):
+    """The N > 1 path of the survey driver end to end -- two processes (gloo, sharing this GPU) launched as the command line is
+    launched on a node, dynamic chunk queue, summaries gathered, posterior rows streamed to rank 0 -- against the
+    single-process run: every file the same, array for array."""
+    import socket
+    import subprocess
+    import sys
+    from geobipy_amd.__main__ import main
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    assert main([OPTIONS, str(one), "--exact-jacobian"]) == 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GBP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "geobipy_amd", OPTIONS, str(two), "--exact-jacobian", "--schedule", "dynamic",
+                        "--chunk", "9"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    names = sorted(n for n in os.listdir(one) if n.endswith(".npz"))
+    assert names == sorted(n for n in os.listdir(two) if n.endswith(".npz")) and any(n.endswith(".h5.npz") for n in names)
+    for n in names:
+        a, b = np.load(one / n), np.load(two / n)
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (n, k)
+
+
+@pytest.mark.gpu
 def test_dynamic_schedule_gives_the_static_result():
     """schedule="dynamic": the soundings are inverted chunk by chunk (here by the one rank there is); chains are keyed by the
     row of the data file, so every number equals the static run's."""
