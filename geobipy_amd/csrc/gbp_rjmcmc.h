@@ -1724,12 +1724,14 @@ static size_t persistent_lds_bytes(const gbp_fdem_system* sys, const gbp_rj_opti
     return rj::persistent_chain_bytes(K, N) + stage;
 }
 
-// Chains resident at once on the GPU with `nw` waves per workgroup: LDS block per workgroup / 128-VGPR wave slots of a CU.
+// Chains resident at once on the GPU with `nw` waves per workgroup: a CU's 160 KB of LDS over the workgroup's block (dynamic
+// + ~4.75 KB of static: math tables, output row, the two parameter blocks) / its 16 wave slots at 128 VGPRs.  Checked against
+// measurements (scripts/bench_rj_modes.py): Resolve, 30 layers: 6 / 4 / 3 workgroups per CU with 1 / 2 / 3 waves.
 static long long persistent_capacity(const gbp_fdem_system* sys, const gbp_rj_options* o, int nw)
 {
     const size_t lds = persistent_lds_bytes(sys, o, nw);
     if (lds > 64 * 1024) return 0;
-    return (long long)GBP_RJ_PERSISTENT_CUS * std::min<long long>(128 * 1024 / (long long)lds, 16 / nw);
+    return (long long)GBP_RJ_PERSISTENT_CUS * std::min<long long>(160 * 1024 / (long long)(lds + 4864), 16 / nw);
 }
 
 // Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind.
@@ -1793,13 +1795,14 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
     if (o->n_channels != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_channels must be 2 * nF of the system%s");
     if (c->B == 0 || n_iterations <= 0) return GBP_OK;
     if (mode == 0) {
-        // Both drivers walk the same chains; which is faster depends on how many chains share the GPU.  A lock-step iteration
-        // costs ~140 us of dependent launches + ~0.035 us per chain; a persistent workgroup needs ~85 us per iteration of its
-        // chain, with `capacity` of them resident at once (LDS block per workgroup).  Measured crossover (Resolve and the
-        // 10-frequency system, scripts/bench_rj_modes.py): about twice the resident capacity.
+        // All drivers walk the same chains; which is faster depends on how many chains share the GPU.  A persistent workgroup
+        // needs ~57 us per iteration of its chain whatever the block; the lock-step driver ~95 us of dependent launches +
+        // ~0.02 us per chain.  Measured (Resolve and the 10-frequency system, scripts/bench_rj_modes.py): the persistent kernel
+        // wins while the whole block is resident at once (1 536 Resolve chains with one wave each: 20.2 vs 14.0 M
+        // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
         const int nw = persistent_waves(sys, o, c->B);
         bool small = false;
-        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= 2 * persistent_capacity(sys, o, nw);
+        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
         mode = small ? 2 : 1;
     }
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, stream);
