@@ -1738,12 +1738,12 @@ static long long persistent_capacity(const gbp_fdem_system* sys, const gbp_rj_op
 // Returns the workgroup's waves, or 0.  The physics stages share a sounding's passes / frequencies among the waves and their
 // results do not depend on how many there are (forward_passes, sens_body), so the count is a pure performance choice: the
 // most waves (up to 4: the per-chain stages run on one) with which the whole block is still resident at once, else the count
-// with the largest capacity.  `forward_waves` > 0 pins it (tests).
-static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o, int B)
+// with the largest capacity.  With `pinned` (an explicit gbp_rj_run_mode(.., 2, ..)) `forward_waves` > 0 fixes it.
+static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o, int B, bool pinned)
 {
     if (o->n_rel_groups != 1 || o->n_add_groups != 1) return 0;
     const int top = std::min(4, std::min(sys->t.nF, (sys->t.npts + 63) / 64));
-    if (o->forward_waves > 0) return std::min(o->forward_waves, 4);
+    if (pinned && o->forward_waves > 0) return std::min(o->forward_waves, 4);
     int best = 0;
     long long best_cap = 0;
     for (int nw = top; nw >= 1; --nw) {
@@ -1755,10 +1755,10 @@ static int persistent_waves(const gbp_fdem_system* sys, const gbp_rj_options* o,
 }
 
 static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
-                                    int n_iterations, int accumulate, void* stream)
+                                    int n_iterations, int accumulate, bool pinned, void* stream)
 {
     const int B = c->B, K = o->max_layers, F = sys->t.nF;
-    const int nw = persistent_waves(sys, o, B);
+    const int nw = persistent_waves(sys, o, B, pinned);
     if (nw == 0) return fail(GBP_ERR_INVALID_ARG, "the persistent sampler needs frequency-domain data with one error level of each kind%s");
     // LDS per workgroup = the chain's arrays (rj::persistent_chain_bytes) + the largest stage working set.  The Jacobian pass of a
     // model with more than 8 layers needs 1 KB per layer and wave: kept in LDS it would take the budget of one more resident
@@ -1800,12 +1800,13 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // ~0.02 us per chain.  Measured (Resolve and the 10-frequency system, scripts/bench_rj_modes.py): the persistent kernel
         // wins while the whole block is resident at once (1 536 Resolve chains with one wave each: 20.2 vs 14.0 M
         // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
-        const int nw = persistent_waves(sys, o, c->B);
+        const int nw = persistent_waves(sys, o, c->B, false);
         bool small = false;
         if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
-        mode = small ? 2 : 1;
+        if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
+        mode = 1;
     }
-    if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, stream);
+    if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, true, stream);
     return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, stream);
 }
 

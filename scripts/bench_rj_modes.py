@@ -20,7 +20,7 @@ for B in [int(v) for v in (sys.argv[3].split(',') if len(sys.argv) > 3 else '256
     data = synthetic.noisy_observations(clean)
     out = []
     for mode in (3, 1, 2, 0):
-        for fw in ((2,) if mode != 2 else (0, 2)) if mode != 0 else (0,):
+        for fw in ((2,) if mode != 2 else (0, 2)):
             dc = DeviceChains(system, h, data, seed=3, exact_jacobian=exact, forward_waves=fw, **o)
             dc.run_mode = mode
             n_warm, n_it = 200, (2000 if B <= 8192 else 300)
