@@ -76,6 +76,8 @@ SIGNATURES = {
     "gbp_fdem_system_npoints": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "gbp_hankel_system_add_bins": (c_int, [c_void_p, ctypes.c_double, c_int, c_int, c_int]),
     "gbp_hankel_system_clear_bins": (c_int, [c_void_p]),
+    "gbp_hankel_system_add_set": (c_int, [c_void_p, c_double_p, c_double_p]),
+    "gbp_hankel_system_set_rows": (c_int, [c_void_p, c_void_p]),
     "gbp_tdem_system_set_hankel_eps": (c_int, [c_void_p, ctypes.c_double]),
     "gbp_hankel_system_create_raw": (c_int, [c_int, c_int32_p] + [c_double_p] * 4 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_destroy": (None, [c_void_p]),

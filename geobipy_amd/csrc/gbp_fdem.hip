@@ -57,6 +57,11 @@ struct gbp_fdem_system {
     Channel* d_chan = nullptr;
     double* d_pts = nullptr;  // SoA, GBP_PT_FIELDS arrays of [npts] (gbp_fdem_point.h)
     int bin0 = 0, n_bins = 0;
+    // Further table sets of the same layout (gbp_hankel_system_add_set: e.g. the tables of other transmitter-receiver offsets);
+    // row b of a launch uses set d_row_set[b] (gbp_hankel_system_set_rows; NULL: set 0).  Descriptor layout in d_bins: the n_bins
+    // altitude windows of set 0, then per further set its full tables followed by its n_bins windows.
+    std::vector<gbp::SystemTables> extra_sets;
+    const int32_t* d_row_set = nullptr;
     BinDesc* d_bins = nullptr;
     Channel* d_bin_chan = nullptr;
     double* d_bin_pts = nullptr;
@@ -106,6 +111,15 @@ __device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
     M.exp2_64 = lds.exp2_64;
     M.sincos_64 = lds.sincos_64;
     return M;
+}
+
+// Descriptor of (table set, altitude) in gbp_fdem_system::d_bins, or -1 for "the handle's own tables" (set 0 below the first bin).
+__device__ __forceinline__ int table_slot(double alt, int set, int bin0, int n_bins)
+{
+    const bool binned = n_bins > 0 && alt >= (double)bin0;
+    const int bi = binned ? min((int)(alt - (double)bin0), n_bins - 1) : 0;
+    if (set == 0) return binned ? bi : -1;
+    return n_bins + (set - 1) * (n_bins + 1) + (binned ? 1 + bi : 0);
 }
 
 #ifndef GBP_WAVE_SUM_BPERMUTE
@@ -331,17 +345,17 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
                                                        const double* __restrict__ add, double* __restrict__ pred,
                                                        double* __restrict__ chi2, double* __restrict__ logL,
                                                        double sigma_direct, const BinDesc* __restrict__ bins, int bin0, int n_bins,
-                                                       const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
+                                                       const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts,
+                                                       const int* __restrict__ row_set)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
-    if (bins != nullptr) {                                  // this sounding's abscissa window: the bin of its own altitude
-        const double alt = height[b];
-        if (alt >= (double)bin0) {                          // (below the first bin, NaN: all abscissae)
-            const int bi = min((int)(alt - (double)bin0), n_bins - 1);
-            const BinDesc d = bins[bi];
+    if (bins != nullptr) {                                  // this sounding's table set and abscissa window (the bin of its own altitude)
+        const int slot = table_slot(height[b], row_set != nullptr ? row_set[b] : 0, bin0, n_bins);
+        if (slot >= 0) {                                    // (set 0 below the first bin, NaN: the handle's own tables, all abscissae)
+            const BinDesc d = bins[slot];
             chan = bin_chan + d.chan_off;
             pts = bin_pts + d.pts_off;
             npts_total = d.npts_total;
@@ -467,17 +481,17 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                                     const double* __restrict__ height, double* __restrict__ J,
                                                     double* __restrict__ pred, const BinDesc* __restrict__ bins, int bin0, int n_bins,
                                                     const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts,
-                                                    int compact_rows)
+                                                    int compact_rows, const int* __restrict__ row_set)
 {
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int b = blockIdx.x;
     const int L = nlayers[b];
     if (L <= 0) return;   // sounding skipped by the caller (workgroup-uniform)
-    if (bins != nullptr) {                                  // this sounding's abscissa window (see k_fdem_forward)
-        const double alt = height[b];
-        if (alt >= (double)bin0) {
-            const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
+    if (bins != nullptr) {                                  // this sounding's table set and abscissa window (see k_fdem_forward)
+        const int slot = table_slot(height[b], row_set != nullptr ? row_set[b] : 0, bin0, n_bins);
+        if (slot >= 0) {
+            const BinDesc d = bins[slot];
             chan = bin_chan + d.chan_off;
             pts = bin_pts + d.pts_off;
             npts_total = d.npts_total;
@@ -728,22 +742,32 @@ gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system* s)
 gbp_status gbp_hankel_system_add_bins(gbp_fdem_system* s, double eps, int relative, int first_altitude_m, int n_bins)
 {
     if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
-    if (!(eps > 0.0) || first_altitude_m < 0 || n_bins < 1 || n_bins > 1024)
+    const bool sets_only = n_bins == 0 && eps == 0.0 && !s->extra_sets.empty();     // descriptors of the further sets' full tables
+    if (!sets_only && (!(eps > 0.0) || first_altitude_m < 0 || n_bins < 1 || n_bins > 1024))
         return fail(GBP_ERR_INVALID_ARG, "eps > 0, first_altitude_m >= 0 and 1 <= n_bins <= 1024 are required%s");
     (void)gbp_hankel_system_clear_bins(s);                                      // (replaces an earlier set)
-    std::vector<BinDesc> desc(n_bins);
+    std::vector<BinDesc> desc;
     std::vector<Channel> chans;
     std::vector<double> pts;
-    s->bin_npts.resize(n_bins);
-    for (int i = 0; i < n_bins; ++i) {
-        gbp::SystemTables t = s->t;                      // the exact tables, then windowed for altitude >= first + i metres
-        gbp::window_system_tables(&t, eps, (double)(first_altitude_m + i), relative != 0);
-        desc[i].chan_off = (int)chans.size();
-        desc[i].npts_total = t.npts;
-        desc[i].pts_off = (long long)pts.size();
-        s->bin_npts[i] = t.npts;
+    auto push = [&](const gbp::SystemTables& t) {
+        BinDesc d;
+        d.chan_off = (int)chans.size();
+        d.npts_total = t.npts;
+        d.pts_off = (long long)pts.size();
+        desc.push_back(d);
         chans.insert(chans.end(), t.chan.begin(), t.chan.end());
         pts.insert(pts.end(), t.soa.begin(), t.soa.end());
+    };
+    s->bin_npts.resize(n_bins);
+    for (int k = 0; k <= (int)s->extra_sets.size(); ++k) {
+        const gbp::SystemTables& full = k == 0 ? s->t : s->extra_sets[k - 1];
+        if (k > 0) push(full);                           // a further set's own tables (soundings below the first bin)
+        for (int i = 0; i < n_bins; ++i) {
+            gbp::SystemTables t = full;                  // the exact tables, then windowed for altitude >= first + i metres
+            gbp::window_system_tables(&t, eps, (double)(first_altitude_m + i), relative != 0);
+            if (k == 0) s->bin_npts[i] = t.npts;
+            push(t);
+        }
     }
     s->bin0 = first_altitude_m;
     s->n_bins = n_bins;
@@ -757,6 +781,26 @@ gbp_status gbp_hankel_system_add_bins(gbp_fdem_system* s, double eps, int relati
         s->n_bins = 0;
         return fail(GBP_ERR_HIP, "bin table upload failed: %s", hipGetErrorString(e));
     }
+    return GBP_OK;
+}
+
+gbp_status gbp_hankel_system_add_set(gbp_fdem_system* s, const double* hd0, const double* tables)
+{
+    if (!s || !hd0 || !tables) return fail(GBP_ERR_INVALID_ARG, "NULL argument%s");
+    gbp::SystemTables t = s->t;                          // same frequencies, weights and point counts: other altitude terms and points
+    for (int f = 0; f < t.nF; ++f) t.chan[f].hd0 = hd0[f];
+    t.soa.assign(tables, tables + (size_t)GBP_PT_FIELDS * t.npts);
+    s->extra_sets.push_back(std::move(t));
+    (void)gbp_hankel_system_clear_bins(s);               // descriptors are rebuilt by the next gbp_hankel_system_add_bins
+    return GBP_OK;
+}
+
+gbp_status gbp_hankel_system_set_rows(gbp_fdem_system* s, const int32_t* d_set_of_row)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (d_set_of_row != nullptr && !s->extra_sets.empty() && s->d_bins == nullptr)
+        return fail(GBP_ERR_INVALID_ARG, "table sets need their descriptors: call gbp_hankel_system_add_bins after the last add_set%s");
+    s->d_row_set = d_set_of_row;
     return GBP_OK;
 }
 
@@ -860,7 +904,8 @@ gbp_status gbp_fdem_forward_ex(const gbp_fdem_system* sys, int B, int Lmax, cons
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
-                       nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
+                       nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts,
+                       sys->d_row_set);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -912,7 +957,7 @@ gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lm
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
-                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts);
+                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts, sys->d_row_set);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1017,7 +1062,7 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
                            Lmax, max_layers, nlayers, sigma, thk, height, J, pred, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                           sys->d_bin_pts, compact_rows);
+                           sys->d_bin_pts, compact_rows, sys->d_row_set);
         return GBP_OK;
     };
     // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs

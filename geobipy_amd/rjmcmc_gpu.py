@@ -191,6 +191,11 @@ class DeviceChains:
         for name in _lib.RJ_CHAIN_FIELDS:
             setattr(rc, name, None if self.t[name] is None else self.t[name].data_ptr())
         self._c = rc
+        self._set_row_map(None)
+
+    def _set_row_map(self, index):
+        """Hook for samplers whose system handle holds per-row state (time-domain chains with per-sounding geometry): the
+        launches that follow evaluate the block's rows ``index`` (int64 tensor), or -- None -- the block's rows in order."""
 
     def __getattr__(self, name):              # chain state by the names of gbp_rj_chains
         t = self.__dict__.get("t")
@@ -223,8 +228,10 @@ class DeviceChains:
             chi2 = torch.empty(n, dtype=torch.float64, device=self.device)
             logl = torch.empty_like(chi2)
             hh, dd, rr, aa, thk = rep(t["height"]), rep(t["data"]), rep(t["rel"]), rep(t["add"]), torch.zeros_like(sig)
+            self._set_row_map(torch.arange(s0, s0 + nb, device=self.device).repeat_interleave(100))
             self._eval_loglike(k1, sig, thk, hh, dd, rr, aa, None, chi2, logl)
             best[s0:s0 + nb] = torch.argmin(chi2.view(nb, 100), dim=1)
+        self._set_row_map(None)
         t["k"].fill_(1)
         t["sigma"].fill_(1.0)
         t["sigma"][:, 0] = grid[best]

@@ -151,11 +151,11 @@ class TdemData:
     """A set of time-domain soundings (classes/data/dataset/TdemData.py): location, altitude, transmitter-receiver offset and
     the window data of every system, columns ``S<system><component>_time_<t>`` of the reference's CSV files in file order
     (system 0 component X then Z windows, system 1 ...), which is TdemBatch's channel layout.  ``offset``: one (dx, dy, dz) for
-    the set or one per sounding [nPoints, 3] (columns txrx_dx / dy / dz); the Hankel tables depend on it, so ``infer`` runs the
-    soundings of every distinct offset as a block of their own.  ``primary_field`` [nPoints, components]: the PX / PY / PZ
+    the set or one per sounding [nPoints, 3] (columns txrx_dx / dy / dz); the Hankel tables depend on it, so ``infer`` builds one
+    table set per distinct offset and every chain runs with its own.  ``primary_field`` [nPoints, components]: the PX / PY / PZ
     columns of Tempest files (TempestData.py), kept for the caller, NaN when absent.  Attitude angles must be zero."""
 
-    MAX_OFFSET_GROUPS = 64
+    MAX_OFFSET_SETS = 4096
 
     def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset, primary_field=None):
         from .tdem import TdemSystem
@@ -467,11 +467,13 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
         span = np.arange(first, first + count)
         if time_domain:
-            # the Hankel tables depend on the transmitter-receiver offset: one block of chains per distinct offset
-            blocks = ds.offset_groups(span) if count > 0 else [(tuple(ds.offsets[0]) if ds.nPoints else (0.0, 0.0, 0.0), span)]
-            if len(blocks) > TdemData.MAX_OFFSET_GROUPS:
-                raise NotImplementedError("{} distinct transmitter-receiver offsets in {} soundings: the device sampler builds one set "
-                                          "of Hankel tables per offset -- bin the offsets (e.g. to 0.1 m) first".format(len(blocks), count))
+            # the Hankel tables depend on the transmitter-receiver offset: the block's handle holds one table set per distinct
+            # offset and every chain runs with its own (TdemDeviceChains(offset=[n, 3])) -- one block whatever the geometry
+            n_off = len(ds.offset_groups(span)) if count > 0 else 1
+            if n_off > TdemData.MAX_OFFSET_SETS:
+                raise NotImplementedError("{} distinct transmitter-receiver offsets in {} soundings: the device sampler holds one set of "
+                                          "Hankel tables (~2 MB) per offset -- bin the offsets (e.g. to 0.1 m) first".format(n_off, count))
+            blocks = [(ds.offsets[span] if count > 0 else (0.0, 0.0, 0.0), span)]
         else:
             blocks = [(None, span)]
         out = None

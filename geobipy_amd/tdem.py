@@ -324,9 +324,11 @@ def _altitude_bins(heights):
 
 
 class _RawHandle:
-    def __init__(self, npts, wmu, hd0, g, tables, eps=0.0, bins=None):
+    def __init__(self, npts, wmu, hd0, g, tables, eps=0.0, bins=None, more_sets=()):
         """``eps`` > 0 and ``bins`` = (first altitude, count): per-sounding abscissa windows in 1 m altitude bins, each nodal
-        sum within ``eps`` times its inductive-limit value of the full sum (gbp_hankel_system_add_bins, relative budget)."""
+        sum within ``eps`` times its inductive-limit value of the full sum (gbp_hankel_system_add_bins, relative budget).
+        ``more_sets``: [(hd0, tables), ...] further table sets of the same layout (other transmitter-receiver offsets,
+        gbp_hankel_system_add_set); ``set_rows`` then says which set every row of a launch uses."""
         lib = _lib.load()
         self._lib = lib
         h = ctypes.c_void_p()
@@ -338,9 +340,22 @@ class _RawHandle:
         self.nF = int(npts.size)
         self.npoints = int(npts.sum())      # abscissa points of the full tables
         self.bins = None
+        self.n_sets = 1 + len(more_sets)
+        self._rows = None
+        for hd0_k, tables_k in more_sets:
+            hd0_k, tables_k = np.ascontiguousarray(hd0_k, dtype=np.float64), np.ascontiguousarray(tables_k, dtype=np.float64)
+            assert tables_k.shape == tables.shape and hd0_k.shape == hd0.shape, ValueError("table sets must share one layout")
+            _lib.check(lib.gbp_hankel_system_add_set(h, dp(hd0_k), dp(tables_k)))
         if eps > 0.0 and bins is not None:
             _lib.check(lib.gbp_hankel_system_add_bins(h, float(eps), 1, int(bins[0]), int(bins[1])))
             self.bins = (int(bins[0]), int(bins[1]))
+        elif more_sets:
+            _lib.check(lib.gbp_hankel_system_add_bins(h, 0.0, 1, 0, 0))      # descriptors of the sets' full tables only
+
+    def set_rows(self, set_of_row):
+        """Row b of the launches that follow uses table set ``set_of_row[b]`` (int32 device tensor, kept alive here; None: set 0)."""
+        self._rows = None if set_of_row is None else set_of_row.to(torch.int32).contiguous()
+        _lib.check(self._lib.gbp_hankel_system_set_rows(self.ptr, None if self._rows is None else self._rows.data_ptr()))
 
     def bin_points(self, altitude):
         """Abscissa points a sounding at this altitude is evaluated with."""
@@ -379,11 +394,17 @@ class TdemBatch:
             raise _lib.NativeLibraryError("TdemBatch needs a HIP device; there is no CPU fallback")
         self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._groups = None
+        self._groups, self._sets = None, None
         off = np.asarray(offset, dtype=np.float64)
         if off.ndim == 2:
             uniq, inverse = np.unique(off, axis=0, return_inverse=True)
-            if uniq.shape[0] > 1:          # one child batch per distinct offset
+            tabs = [[s_.hankel_tables(*uniq[g]) for g in range(uniq.shape[0])] for s_ in self.systems] if uniq.shape[0] > 1 else None
+            same_layout = tabs is not None and all(np.array_equal(t[0], ts[0][0]) for ts in tabs for t in ts)
+            if same_layout:                # one table set per distinct offset, all soundings in one launch
+                self._sets = (tabs, torch.as_tensor(inverse.ravel().astype(np.int32), device=self.device))
+                self.offsets = off
+                off = uniq[0]
+            elif uniq.shape[0] > 1:        # (an on-axis receiver among them: other filters, other layout) one child batch per offset
                 sub = lambda a, m: None if a is None else np.asarray(a)[m]
                 bc = lambda a, n: np.broadcast_to(np.asarray(a), (n,) + np.shape(a)[1:]) if np.ndim(a) >= 1 else np.full(n, a)
                 n_all = off.shape[0]
@@ -413,8 +434,13 @@ class TdemBatch:
         self.hankel_eps = DEFAULT_TDEM_HANKEL_EPS if hankel_eps is None else float(hankel_eps)
         bins = _altitude_bins(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,))) if self.B > 0 else None
         with torch.cuda.device(self.device):
-            for s in self.systems:
-                h = _RawHandle(*s.hankel_tables(*self.offset), eps=self.hankel_eps, bins=bins)
+            for i_sys, s in enumerate(self.systems):
+                if self._sets is None:
+                    h = _RawHandle(*s.hankel_tables(*self.offset), eps=self.hankel_eps, bins=bins)
+                else:
+                    ts = self._sets[0][i_sys]
+                    h = _RawHandle(*ts[0], eps=self.hankel_eps, bins=bins, more_sets=[(t[2], t[4]) for t in ts[1:]])
+                    h.set_rows(self._sets[1])
                 self._h.append(h)
                 n = s.node_frequencies().size
                 W = s.time_operator()
@@ -544,7 +570,9 @@ class TdemBatch:
 
 class TdemDeviceChains(DeviceChains):
     """Device-resident rjMCMC (rjmcmc_gpu.DeviceChains) for time-domain soundings: one system or the systems of a
-    multi-moment acquisition (e.g. SkyTEM high + low moment), sharing one transmitter-receiver geometry.
+    multi-moment acquisition (e.g. SkyTEM high + low moment).  ``offset``: the transmitter-receiver offset (dx, dy, dz) of the
+    block, or one per sounding [B, 3] -- the handle then holds one set of Hankel tables per distinct offset and every chain is
+    evaluated with its own (gbp_hankel_system_add_set / _set_rows): soundings of different geometry advance in the same launches.
 
     The systems' spline nodes are merged into ONE frequency-domain handle (all (system, component, node) triples are
     "frequencies" of the sampler's forward / Jacobian launches) and ``gbp_rj_run_td`` turns the nodal spectra -- and their
@@ -558,7 +586,13 @@ class TdemDeviceChains(DeviceChains):
     def __init__(self, systems, heights, data, offset, **kw):
         systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         assert all(isinstance(s, TdemSystem) for s in systems), TypeError("systems must be geobipy_amd.TdemSystem objects")
-        self.td_systems, self._offset = systems, tuple(float(v) for v in offset)
+        off = np.asarray(offset, dtype=np.float64)
+        if off.ndim == 2:
+            uniq, inverse = np.unique(off, axis=0, return_inverse=True)
+        else:
+            uniq, inverse = off[None, :], np.zeros(np.asarray(heights).size, dtype=np.int64)
+        self.td_systems, self._offset, self._offsets = systems, tuple(float(v) for v in uniq[0]), uniq
+        self._geom_id0 = inverse.ravel().astype(np.int32)
         nf = [s.n_components * s.node_frequencies().size for s in systems]          # "frequencies" per system
         nw = [s.n_components * s.nwindows for s in systems]
         nF, N = sum(nf), sum(nw)
@@ -583,10 +617,15 @@ class TdemDeviceChains(DeviceChains):
         class _Handle:                    # what DeviceChains asks of an acquisition system
             def handle(self_inner):
                 if getattr(outer, "_raw", None) is None:
-                    parts = [s.hankel_tables(*outer._offset) for s in systems]
-                    cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p[j] for p in parts], axis=ax))
-                    outer._raw = _RawHandle(cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1), eps=outer._hankel_eps,
-                                            bins=_altitude_bins(heights))
+                    def merged(off_):
+                        parts = [s.hankel_tables(*off_) for s in systems]
+                        cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p[j] for p in parts], axis=ax))
+                        return cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1)
+                    sets = [merged(o_) for o_ in outer._offsets]
+                    assert all(np.array_equal(t_[0], sets[0][0]) for t_ in sets), NotImplementedError(
+                        "offsets with the receiver on the transmitter's axis use other filters: invert them as a block of their own")
+                    outer._raw = _RawHandle(*sets[0], eps=outer._hankel_eps, bins=_altitude_bins(heights),
+                                            more_sets=[(t_[2], t_[4]) for t_ in sets[1:]])
                 return outer._raw
         kw.pop("exact_jacobian", None)
         kw.pop("hankel_eps_ppm", None)
@@ -597,6 +636,15 @@ class TdemDeviceChains(DeviceChains):
         kw.pop("min_altitude", None)
         super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=np.asarray(add_scale),
                          rel_group=np.asarray(rel_group, dtype=np.int32), add_group=np.asarray(add_group, dtype=np.int32), **kw)
+        if self._offsets.shape[0] > 1:       # carried with the chains' rows (infer() re-packs every tensor of self.t)
+            self.t["geom_id"] = torch.as_tensor(self._geom_id0, device=self.device)
+
+    def _set_row_map(self, index):
+        if self._offsets.shape[0] == 1:
+            return
+        t = self.__dict__.get("t")
+        g = t["geom_id"] if t is not None and "geom_id" in t else torch.as_tensor(self._geom_id0, device=self.device)
+        self._h.set_rows(g if index is None else g[index])
 
     def _td(self):
         if self._td_struct is None:

@@ -119,6 +119,16 @@ gbp_status gbp_fdem_system_create_binned(int nF, const int32_t *tid, const doubl
  */
 gbp_status gbp_hankel_system_add_bins(gbp_fdem_system *sys, double eps, int relative, int first_altitude_m, int n_bins);
 gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system *sys);
+/*
+ * Further table sets for one handle -- the same frequencies, weights and point counts as the tables it was created with, other
+ * altitude terms hd0[nF] and points tables[7][P]: e.g. the Hankel tables of other transmitter-receiver offsets of a time-domain
+ * system.  gbp_hankel_system_set_rows(sys, d_set_of_row) then makes row b of every launch on this handle use set
+ * d_set_of_row[b] (0 = the handle's own tables, k = the k-th added set; [dev] int32, B entries, owned by the caller and read at
+ * launch time; NULL = set 0 for every row), so soundings of different geometry run in ONE launch.  Call gbp_hankel_system_add_bins
+ * after the last add_set (eps = 0, n_bins = 0 for "no windows"): it builds every set's descriptors.  Set ids are not range-checked.
+ */
+gbp_status gbp_hankel_system_add_set(gbp_fdem_system *sys, const double *hd0, const double *tables);
+gbp_status gbp_hankel_system_set_rows(gbp_fdem_system *sys, const int32_t *d_set_of_row);
 /* abscissa points a sounding at (integer) altitude_m is evaluated with */
 gbp_status gbp_fdem_system_bin_points(const gbp_fdem_system *sys, int altitude_m, int *npts);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);

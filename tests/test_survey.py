@@ -123,9 +123,10 @@ def test_read_tempest_csv_with_per_sounding_geometry(tmp_path):
 
 @pytest.mark.gpu
 def test_time_domain_soundings_with_different_offsets():
-    """Soundings are evaluated, and inverted, in groups of equal transmitter-receiver offset: a batch with per-sounding
-    offsets returns what per-offset batches return, and in a survey the chains of a sounding do not depend on the other
-    soundings' geometry (streams keyed by the row of the data file)."""
+    """Per-sounding transmitter-receiver offsets: the handle holds one set of Hankel tables per distinct offset and every
+    sounding / chain is evaluated with its own, all in the same launches (gbp_hankel_system_add_set / _set_rows) -- a batch with
+    per-sounding offsets returns what per-offset batches return, bit for bit, and in a survey the chains of a sounding do not
+    depend on the other soundings' geometry (streams keyed by the row of the data file)."""
     import torch
     from geobipy_amd import synthetic
     from geobipy_amd.tdem import TdemBatch, TdemSystem
@@ -137,6 +138,7 @@ def test_time_domain_soundings_with_different_offsets():
     off = offs[np.arange(B) % 3]
     data = np.full((B, 30), 1.0)
     mixed = TdemBatch(systems, nl, sig, thk, h, off, data=data, relative_error=np.full((B, 2), 0.03), additive_error=np.full((B, 1), 0.01))
+    assert mixed._groups is None and mixed._h[0].n_sets == 3          # one launch sequence, three table sets
     pm = mixed.forward().clone()
     cm, lm = (t.clone() for t in mixed.forward_loglike())
     Jm = mixed.sensitivity()
