@@ -169,7 +169,14 @@ struct gbp_tdem_system {
     std::vector<double> w0, w1;                  // Hankel filter weights (J0: 120, J1: 140)
     std::vector<double> Wb;                      // block matrix for k_td_apply: [2 nc n_nodes][nc n_windows]
     double* d_Wb = nullptr;
-    std::map<std::tuple<double, double, double>, gbp_fdem_system*> handles;      // raw Hankel handles by receiver offset
+    // One raw Hankel handle per table layout (receiver off / on the transmitter's axis: J0 / J1 filter for the z component), holding
+    // one table set per receiver offset seen so far (gbp_hankel_system_add_set); rows of a call pick theirs by index.
+    struct Multi {
+        gbp_fdem_system* h = nullptr;
+        std::map<std::tuple<double, double, double>, int> set_of;
+    };
+    Multi multi[2];
+    std::vector<int32_t> h_set;                  // staging of the rows' set indices
     std::vector<double> h_height;                // staging of the altitudes of the last forward call
     double hankel_eps = 1.0e-12;                 // per-sounding abscissa windows (gbp_tdem_system_set_hankel_eps); 0: all abscissae
 };
@@ -303,13 +310,19 @@ inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
 }
 
 // raw Hankel tables of one receiver offset (geobipy_amd/tdem.py TdemSystem.hankel_tables without the abscissa window)
-inline gbp_status build_handle(gbp_tdem_system* s, double dx, double dy, double dz, gbp_fdem_system** out)
+struct RawTables {
+    std::vector<int32_t> npts;
+    std::vector<double> wmu, hd0, g, tables;
+};
+
+inline gbp_status build_tables(gbp_tdem_system* s, double dx, double dy, double dz, RawTables* out)
 {
     const double r = std::hypot(dx, dy), a = s->loop_radius;
     if (r == 0.0 && !(a > 0.0)) return fail(GBP_ERR_BAD_SYSTEM, "a receiver on the transmitter axis needs a finite ModellingLoopRadius%s");
     const double rs = r > 0.0 ? r : a;
-    std::vector<int32_t> npts;
-    std::vector<double> wmu, hd0, g, cols[GBP_PT_FIELDS];
+    std::vector<int32_t>& npts = out->npts;
+    std::vector<double>&wmu = out->wmu, &hd0 = out->hd0, &g = out->g;
+    std::vector<double> cols[GBP_PT_FIELDS];
     auto base0 = [](int j) { return std::pow(10.0, -8.3885 + 0.0904226468670 * (double)j); };        // FdemSystem.py:67-83
     auto base1 = [](int j) { return std::pow(10.0, -7.91001919 + 0.087967143957 * (double)j); };      // :85-101
     for (int comp = 0; comp < 2; ++comp) {                       // x then z, like the channel layout
@@ -341,9 +354,8 @@ inline gbp_status build_handle(gbp_tdem_system* s, double dx, double dy, double 
             }
         }
     }
-    std::vector<double> tables;
-    for (int f = 0; f < GBP_PT_FIELDS; ++f) tables.insert(tables.end(), cols[f].begin(), cols[f].end());
-    return gbp_hankel_system_create_raw((int)npts.size(), npts.data(), wmu.data(), hd0.data(), g.data(), tables.data(), out);
+    for (int f = 0; f < GBP_PT_FIELDS; ++f) out->tables.insert(out->tables.end(), cols[f].begin(), cols[f].end());
+    return GBP_OK;
 }
 
 }  // namespace td
@@ -370,7 +382,7 @@ gbp_status gbp_tdem_system_create(const char* stm_text, const double* w0, const 
 void gbp_tdem_system_destroy(gbp_tdem_system* s)
 {
     if (!s) return;
-    for (auto& kv : s->handles) gbp_fdem_system_destroy(kv.second);
+    for (auto& mu : s->multi) gbp_fdem_system_destroy(mu.h);
     if (s->d_Wb) (void)hipFree(s->d_Wb);
     delete s;
 }
@@ -380,7 +392,8 @@ gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system* s, double eps)
     if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (!(eps >= 0.0)) return fail(GBP_ERR_INVALID_ARG, "eps must be >= 0%s");
     if (eps != s->hankel_eps)                 // the cached tables were windowed for the old budget
-        for (auto& kv : s->handles) gbp_hankel_system_clear_bins(kv.second);
+        for (auto& mu : s->multi)
+            if (mu.h) gbp_hankel_system_clear_bins(mu.h);
     s->hankel_eps = eps;
     return GBP_OK;
 }
@@ -432,36 +445,65 @@ gbp_status gbp_tdem_forward(gbp_tdem_system* s, int B, const double* geometry, i
     GBP_HIP(hipMallocAsync((void**)&d_nodal, sizeof(double) * (size_t)B * n_nodal, q));
     GBP_HIP(hipMemcpyAsync(d_h, s->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
     gbp_status st = GBP_OK;
-    for (int b0 = 0; b0 < B && st == GBP_OK;) {                  // runs of soundings that share the receiver offset
-        const double* g0 = geometry + (size_t)b0 * 10;
+    // Every receiver offset has its own table set in the handle of its layout class; a row picks its set by index, so soundings
+    // of any geometry share one launch (runs of rows change launches only where the receiver moves on / off the transmitter's axis).
+    s->h_set.resize(B);
+    int32_t* d_set = nullptr;
+    GBP_HIP(hipMallocAsync((void**)&d_set, sizeof(int32_t) * (size_t)B, q));
+    auto on_axis = [&](int b) { return geometry[(size_t)b * 10 + 4] == 0.0 && geometry[(size_t)b * 10 + 5] == 0.0; };
+    for (int b0 = 0; b0 < B && st == GBP_OK;) {
+        const int cls = on_axis(b0) ? 1 : 0;
         int b1 = b0 + 1;
-        while (b1 < B && geometry[(size_t)b1 * 10 + 4] == g0[4] && geometry[(size_t)b1 * 10 + 5] == g0[5] && geometry[(size_t)b1 * 10 + 6] == g0[6]) ++b1;
-        const auto key = std::make_tuple(g0[4], g0[5], g0[6]);
-        auto it = s->handles.find(key);
-        if (it == s->handles.end()) {
-            gbp_fdem_system* h = nullptr;
-            st = td::build_handle(s, g0[4], g0[5], g0[6], &h);
-            if (st != GBP_OK) break;
-            it = s->handles.emplace(key, h).first;
+        while (b1 < B && (on_axis(b1) ? 1 : 0) == cls) ++b1;
+        gbp_tdem_system::Multi& mu = s->multi[cls];
+        bool grown = false;
+        double lo = s->h_height[b0], hi = lo;
+        for (int b = b0; b < b1 && st == GBP_OK; ++b) {
+            const double* gm = geometry + (size_t)b * 10;
+            lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]);
+            const auto key = std::make_tuple(gm[4], gm[5], gm[6]);
+            auto it = mu.set_of.find(key);
+            if (it == mu.set_of.end()) {
+                td::RawTables t;
+                st = td::build_tables(s, gm[4], gm[5], gm[6], &t);
+                if (st != GBP_OK) break;
+                if (mu.h == nullptr)
+                    st = gbp_hankel_system_create_raw((int)t.npts.size(), t.npts.data(), t.wmu.data(), t.hd0.data(), t.g.data(), t.tables.data(), &mu.h);
+                else
+                    st = gbp_hankel_system_add_set(mu.h, t.hd0.data(), t.tables.data());
+                if (st != GBP_OK) break;
+                it = mu.set_of.emplace(key, (int)mu.set_of.size()).first;
+                grown = true;
+            }
+            s->h_set[b] = it->second;
         }
-        const int n = b1 - b0;
+        if (st != GBP_OK) break;
+        gbp_fdem_system* h = mu.h;
+        const bool sets = mu.set_of.size() > 1;
         if (s->hankel_eps > 0.0) {        // per-sounding abscissa windows: 1 m altitude bins covering this run (kept, and widened, across calls)
-            double lo = s->h_height[b0], hi = lo;
-            for (int b = b0; b < b1; ++b) { lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]); }
-            gbp_fdem_system* h = it->second;
             int first = (int)std::floor(lo), last = std::min((int)std::floor(hi), first + 1023);
-            if (h->n_bins == 0 || first < h->bin0 || last >= h->bin0 + h->n_bins) {
+            if (grown || h->n_bins == 0 || first < h->bin0 || last >= h->bin0 + h->n_bins) {
                 if (h->n_bins > 0) { first = std::min(first, h->bin0); last = std::min(std::max(last, h->bin0 + h->n_bins - 1), first + 1023); }
                 st = gbp_hankel_system_add_bins(h, s->hankel_eps, 1, first, last - first + 1);
-                if (st != GBP_OK) break;
             }
+        } else if (sets && (grown || h->d_bins == nullptr)) {
+            st = gbp_hankel_system_add_bins(h, 0.0, 1, 0, 0);                 // descriptors of the sets' full tables
         }
-        st = gbp_fdem_forward_ex(it->second, n, Lmax, nlayers + b0, sigma + (size_t)b0 * Lmax, thk + (size_t)b0 * Lmax, d_h + b0,
+        if (st != GBP_OK) break;
+        const int n = b1 - b0;
+        if (sets) {
+            GBP_HIP(hipMemcpyAsync(d_set + b0, s->h_set.data() + b0, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, q));
+            st = gbp_hankel_system_set_rows(h, d_set + b0);
+            if (st != GBP_OK) break;
+        }
+        st = gbp_fdem_forward_ex(h, n, Lmax, nlayers + b0, sigma + (size_t)b0 * Lmax, thk + (size_t)b0 * Lmax, d_h + b0,
                                  d_nodal + (size_t)b0 * n_nodal, 0, stream);
+        if (sets) (void)gbp_hankel_system_set_rows(h, nullptr);
         if (st == GBP_OK)
             st = gbp_td_apply(n, Lmax, n_nodal, N, nlayers + b0, s->d_Wb, d_nodal + (size_t)b0 * n_nodal, nullptr, out + (size_t)b0 * N, nullptr, stream);
         b0 = b1;
     }
+    (void)hipFreeAsync(d_set, q);
     (void)hipFreeAsync(d_h, q);
     (void)hipFreeAsync(d_nodal, q);
     return st;

@@ -405,8 +405,8 @@ gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chain
  * gbp_tdem_system_create parses the TEXT of a .stm file ([host], NUL-terminated) and folds waveform, spline, low-pass
  * filters and windows into one matrix (geobipy_amd/csrc/gbp_tdem.h); w0[120] / w1[140]: the J0 / J1 Hankel filter weights
  * (the same [host] arrays gbp_fdem_system_create takes).  gbp_tdem_forward: geometry [host] f64[B, 10] as above -- level
- * flight only (non-zero attitude angles are refused), runs of soundings with the same receiver offset share one launch (a
- * survey flown with nominal geometry is one run); nlayers / sigma / thk [dev] as in gbp_fdem_forward; out [dev]
+ * flight only (non-zero attitude angles are refused); the receiver offset may change from row to row: the handle keeps one
+ * table set per offset it has seen and all rows share one launch (gbp_hankel_system_add_set / _set_rows); nlayers / sigma / thk [dev] as in gbp_fdem_forward; out [dev]
  * f64[B, n_components * n_windows], components x then z, in the reference's sign convention for predicted_secondary_field
  * (TdemDataPoint.py:1013-1015).  Stream-ordered; the handle must not be used from two threads at once.
  */

@@ -131,15 +131,28 @@ def test_c_level_forward_equals_the_python_host_path_and_the_reference_csv():
         for i in range(79):
             for j in range(c.n_components):
                 assert within_bar(out[i, j * n:(j + 1) * n], ref[i, j * n:(j + 1) * n], fam), (name, i, j)
-    # two receiver offsets in one call = two runs; each equals its own batch
+    # receiver offsets that change from row to row, interleaved, in one call (one table set per offset, one launch); a second call
+    # adds offsets and altitudes the handle has not seen; each row equals its own single-offset batch
     c = NativeTdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))
-    geom = np.zeros((40, 10))
-    geom[:, 0] = np.linspace(25.0, 45.0, 40)
-    geom[:20, 4:7], geom[20:, 4:7] = SKYTEM_OFFSET, (-17.0, 0.0, 2.5)
-    out = c.forward(geom, np.full(40, 3), sig[:40], thk[:40]).cpu().numpy()
-    for sl, off in ((slice(0, 20), SKYTEM_OFFSET), (slice(20, 40), (-17.0, 0.0, 2.5))):
-        py = TdemBatch(TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm")), np.full(20, 3), sig[sl], thk[sl], geom[sl, 0], off).forward().cpu().numpy()
-        assert np.abs(out[sl] - py).max() <= 1e-10 * np.abs(py).max()
+    py_sys = TdemSystem(os.path.join(GOLDEN, "SkytemLM.stm"))
+    offs = [SKYTEM_OFFSET, (-17.0, 0.0, 2.5), (-13.0, 1.5, 2.0)]
+    for call, (n_off, alt0) in enumerate(((2, 25.0), (3, 18.0))):
+        geom = np.zeros((40, 10))
+        geom[:, 0] = np.linspace(alt0, alt0 + 20.0, 40)
+        which = np.arange(40) % n_off
+        geom[:, 4:7] = np.array(offs)[which]
+        out = c.forward(geom, np.full(40, 3), sig[:40], thk[:40]).cpu().numpy()
+        for g in range(n_off):
+            m = which == g
+            py = TdemBatch(py_sys, np.full(int(m.sum()), 3), sig[:40][m], thk[:40][m], geom[m, 0], offs[g]).forward().cpu().numpy()
+            assert np.abs(out[m] - py).max() <= 1e-10 * np.abs(py).max(), (call, g)
+    # and the Python host with the same per-row offsets
+    pym = TdemBatch(py_sys, np.full(40, 3), sig[:40], thk[:40], geom[:, 0], geom[:, 4:7]).forward().cpu().numpy()
+    assert np.abs(out - pym).max() <= 1e-10 * np.abs(pym).max()
+    for eps in (0.0, 1e-12):                                      # all abscissae / back to the default windows: same values to the budget
+        _lib.check(_lib.load().gbp_tdem_system_set_hankel_eps(c.ptr, eps))
+        again = c.forward(geom, np.full(40, 3), sig[:40], thk[:40]).cpu().numpy()
+        assert np.abs(again - out).max() <= 1e-10 * np.abs(out).max()
     geom[3, 2] = 1.5                                             # pitch
     with pytest.raises(_lib.NativeLibraryError):
         c.forward(geom, np.full(40, 3), sig[:40], thk[:40])
