@@ -28,7 +28,7 @@ def parse(argv=None):
     p.add_argument("--no-hitmap", action="store_true", help="skip the conductivity-depth hit map")
     p.add_argument("--hankel-eps", type=float, default=None,
                    help="accuracy budget of the Hankel-filter abscissa window: ppm for frequency-domain data (default 1e-10, 0 = all "
-                        "abscissae), relative for time-domain data (default off)")
+                        "abscissae), relative to the inductive-limit value for time-domain data (default 1e-12)")
     p.add_argument("--no-containers", action="store_true",
                    help="skip the reference-layout results containers (<line>.h5, or <line>.h5.npz without h5py); the per-line "
                         "summary files <line>.npz are always written")
@@ -61,9 +61,14 @@ def main(argv=None):
         print("Using user input file {}".format(a.options_file))
         print("Output files will be produced at {}".format(a.output_directory))
         shutil.copy(a.options_file, a.output_directory)            # kept with the results, like the reference does
+    containers = None if a.no_containers else a.output_directory
+    if containers is not None and survey.read_options(a.options_file)["data_type"] in ("TdemData", "TdemDataPoint"):
+        containers = None                   # (the reference-layout containers are written for frequency-domain surveys)
+        if rank == 0:
+            print("Time-domain survey: writing the per-line summary files only")
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
-                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=None if a.no_containers else a.output_directory,
+                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=containers,
                        data_directory=a.data_directory,
                        data_filename=a.data_filename)
     if rank == 0:
