@@ -41,9 +41,16 @@ class RjChains(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32)] + [(n, c_void_p) for n in RJ_CHAIN_FIELDS]
 
 
+class TdMix(ctypes.Structure):
+    """gbp_td_mix."""
+    _fields_ = [("n_in", ctypes.c_int32), ("terms", ctypes.c_int32), ("n_weights", ctypes.c_int32), ("src", c_void_p),
+                ("col", c_void_p), ("weights", c_void_p)]
+
+
 class TdOperator(ctypes.Structure):
     """gbp_td_operator."""
-    _fields_ = [("n_nodal", ctypes.c_int32), ("W", c_void_p), ("nodal", c_void_p), ("J_nodal", c_void_p)]
+    _fields_ = [("n_nodal", ctypes.c_int32), ("W", c_void_p), ("nodal", c_void_p), ("J_nodal", c_void_p), ("mix", TdMix),
+                ("table_set", c_void_p)]
 
 
 _rj_o, _rj_c = ctypes.POINTER(RjOptions), ctypes.POINTER(RjChains)
@@ -61,7 +68,9 @@ SIGNATURES = {
     "gbp_tdem_system_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_double_p]),
     "gbp_tdem_system_tables": (c_int, [c_void_p, c_double_p, c_double_p, c_double_p]),
     "gbp_tdem_forward": (c_int, [c_void_p, c_int, c_double_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gbp_tdem_fm_dlogc": (c_int, [c_void_p, c_int, c_double_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gbp_td_apply": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
+    "gbp_td_apply_mix": (c_int, [c_int, c_int, c_int, c_int] + [c_void_p] * 6 + [ctypes.POINTER(TdMix), c_void_p]),
     "gbp_rj_flush_posteriors": (c_int, [_rj_o, _rj_c, c_void_p]),
     "gbp_rj_run_td": (c_int, [c_void_p, ctypes.POINTER(TdOperator), _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),
     "gbp_rj_debug_random": (c_int, [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -77,7 +86,6 @@ SIGNATURES = {
     "gbp_hankel_system_add_bins": (c_int, [c_void_p, ctypes.c_double, c_int, c_int, c_int]),
     "gbp_hankel_system_clear_bins": (c_int, [c_void_p]),
     "gbp_hankel_system_add_set": (c_int, [c_void_p, c_double_p, c_double_p]),
-    "gbp_hankel_system_set_rows": (c_int, [c_void_p, c_void_p]),
     "gbp_tdem_system_set_hankel_eps": (c_int, [c_void_p, ctypes.c_double]),
     "gbp_hankel_system_create_raw": (c_int, [c_int, c_int32_p] + [c_double_p] * 4 + [ctypes.POINTER(c_void_p)]),
     "gbp_fdem_system_destroy": (None, [c_void_p]),
@@ -85,6 +93,8 @@ SIGNATURES = {
     "gbp_fdem_system_h0": (c_int, [c_void_p, c_double_p]),
     "gbp_fdem_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "gbp_fdem_forward_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
+    "gbp_fdem_forward_rows_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p, c_int, c_void_p]),
+    "gbp_fdem_fm_dlogc_rows_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p]),
     "gbp_fdem_validate": (c_int, [c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike_std": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_void_p]),

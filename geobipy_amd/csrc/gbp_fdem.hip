@@ -58,10 +58,20 @@ struct gbp_fdem_system {
     double* d_pts = nullptr;  // SoA, GBP_PT_FIELDS arrays of [npts] (gbp_fdem_point.h)
     int bin0 = 0, n_bins = 0;
     // Further table sets of the same layout (gbp_hankel_system_add_set: e.g. the tables of other transmitter-receiver offsets);
-    // row b of a launch uses set d_row_set[b] (gbp_hankel_system_set_rows; NULL: set 0).  Descriptor layout in d_bins: the n_bins
-    // altitude windows of set 0, then per further set its full tables followed by its n_bins windows.
+    // row b of a launch uses set set_of_row[b], an ARGUMENT of the *_rows_ex entries (NULL: set 0) -- the handle holds no per-call
+    // state, so host threads may share it.  Descriptor layout in d_bins: the n_bins altitude windows of set 0, then per further
+    // set its full tables followed by its n_bins windows.
     std::vector<gbp::SystemTables> extra_sets;
-    const int32_t* d_row_set = nullptr;
+    // host copies of every set's windowed tables for the current (eps, relative, first altitude, bin count): a handle that grows
+    // set by set (gbp_tdem_forward meeting new receiver offsets) windows only the NEW sets in gbp_hankel_system_add_bins
+    struct Pack {
+        std::vector<BinDesc> desc;      // offsets relative to the pack's own chans / pts
+        std::vector<Channel> chans;
+        std::vector<double> pts;
+    };
+    std::vector<Pack> packs;
+    double pack_eps = -1.0;
+    int pack_relative = -1, pack_first = -1, pack_bins = -1;
     BinDesc* d_bins = nullptr;
     Channel* d_bin_chan = nullptr;
     double* d_bin_pts = nullptr;
@@ -644,11 +654,19 @@ gbp_status check_batch(const gbp_fdem_system* sys, int B, int Lmax, const void* 
     return GBP_OK;
 }
 
+// per-row table sets need the descriptors gbp_hankel_system_add_bins builds after the last gbp_hankel_system_add_set
+gbp_status check_row_sets(const gbp_fdem_system* sys, const int32_t* set_of_row)
+{
+    if (set_of_row != nullptr && !sys->extra_sets.empty() && sys->d_bins == nullptr)
+        return fail(GBP_ERR_INVALID_ARG, "table sets need their descriptors: call gbp_hankel_system_add_bins after the last add_set%s");
+    return GBP_OK;
+}
+
 }  // namespace
 
 static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
                                   const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
-                                  int waves, int compact_rows, void* stream);
+                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream);
 
 extern "C" {
 
@@ -728,14 +746,21 @@ gbp_status gbp_fdem_system_create_binned(int nF, const int32_t* tid, const doubl
     return GBP_OK;
 }
 
-gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system* s)
+static void drop_device_bins(gbp_fdem_system* s)
 {
-    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (s->d_bins) { (void)hipFree(s->d_bins); s->d_bins = nullptr; }
     if (s->d_bin_chan) { (void)hipFree(s->d_bin_chan); s->d_bin_chan = nullptr; }
     if (s->d_bin_pts) { (void)hipFree(s->d_bin_pts); s->d_bin_pts = nullptr; }
     s->n_bins = 0;
     s->bin_npts.clear();
+}
+
+gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system* s)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    drop_device_bins(s);
+    s->packs.clear();
+    s->pack_eps = -1.0;
     return GBP_OK;
 }
 
@@ -745,42 +770,65 @@ gbp_status gbp_hankel_system_add_bins(gbp_fdem_system* s, double eps, int relati
     const bool sets_only = n_bins == 0 && eps == 0.0 && !s->extra_sets.empty();     // descriptors of the further sets' full tables
     if (!sets_only && (!(eps > 0.0) || first_altitude_m < 0 || n_bins < 1 || n_bins > 1024))
         return fail(GBP_ERR_INVALID_ARG, "eps > 0, first_altitude_m >= 0 and 1 <= n_bins <= 1024 are required%s");
-    (void)gbp_hankel_system_clear_bins(s);                                      // (replaces an earlier set)
-    std::vector<BinDesc> desc;
-    std::vector<Channel> chans;
-    std::vector<double> pts;
-    auto push = [&](const gbp::SystemTables& t) {
-        BinDesc d;
-        d.chan_off = (int)chans.size();
-        d.npts_total = t.npts;
-        d.pts_off = (long long)pts.size();
-        desc.push_back(d);
-        chans.insert(chans.end(), t.chan.begin(), t.chan.end());
-        pts.insert(pts.end(), t.soa.begin(), t.soa.end());
-    };
-    s->bin_npts.resize(n_bins);
-    for (int k = 0; k <= (int)s->extra_sets.size(); ++k) {
-        const gbp::SystemTables& full = k == 0 ? s->t : s->extra_sets[k - 1];
-        if (k > 0) push(full);                           // a further set's own tables (soundings below the first bin)
-        for (int i = 0; i < n_bins; ++i) {
-            gbp::SystemTables t = full;                  // the exact tables, then windowed for altitude >= first + i metres
-            gbp::window_system_tables(&t, eps, (double)(first_altitude_m + i), relative != 0);
-            if (k == 0) s->bin_npts[i] = t.npts;
-            push(t);
-        }
+    drop_device_bins(s);                                                        // (replaces an earlier set)
+    if (s->pack_eps != eps || s->pack_relative != (relative != 0) || s->pack_first != first_altitude_m || s->pack_bins != n_bins) {
+        s->packs.clear();
+        s->pack_eps = eps; s->pack_relative = relative != 0; s->pack_first = first_altitude_m; s->pack_bins = n_bins;
     }
+    try {
+        for (int k = (int)s->packs.size(); k <= (int)s->extra_sets.size(); ++k) {   // only the sets that are new since the last call
+            const gbp::SystemTables& full = k == 0 ? s->t : s->extra_sets[k - 1];
+            gbp_fdem_system::Pack pk;
+            auto push = [&](const gbp::SystemTables& t) {
+                BinDesc d;
+                d.chan_off = (int)pk.chans.size();
+                d.npts_total = t.npts;
+                d.pts_off = (long long)pk.pts.size();
+                pk.desc.push_back(d);
+                pk.chans.insert(pk.chans.end(), t.chan.begin(), t.chan.end());
+                pk.pts.insert(pk.pts.end(), t.soa.begin(), t.soa.end());
+            };
+            if (k > 0) push(full);                           // a further set's own tables (soundings below the first bin)
+            for (int i = 0; i < n_bins; ++i) {
+                gbp::SystemTables t = full;                  // the exact tables, then windowed for altitude >= first + i metres
+                gbp::window_system_tables(&t, eps, (double)(first_altitude_m + i), relative != 0);
+                push(t);
+            }
+            s->packs.push_back(std::move(pk));
+        }
+    } catch (const std::bad_alloc&) {
+        s->packs.clear();
+        s->pack_eps = -1.0;
+        return fail(GBP_ERR_INVALID_ARG, "out of host memory for the abscissa windows of the table sets%s");
+    }
+    std::vector<BinDesc> desc;
+    size_t n_chan = 0, n_pts = 0;
+    for (const auto& pk : s->packs) {
+        for (BinDesc d : pk.desc) { d.chan_off += (int)n_chan; d.pts_off += (long long)n_pts; desc.push_back(d); }
+        n_chan += pk.chans.size();
+        n_pts += pk.pts.size();
+    }
+    s->bin_npts.resize(n_bins);
+    for (int i = 0; i < n_bins; ++i) s->bin_npts[i] = s->packs[0].desc[i].npts_total;
     s->bin0 = first_altitude_m;
-    s->n_bins = n_bins;
-    hipError_t e = hipMalloc((void**)&s->d_bins, sizeof(BinDesc) * desc.size());
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_chan, sizeof(Channel) * chans.size());
-    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_pts, sizeof(double) * pts.size());
-    if (e == hipSuccess) e = hipMemcpy(s->d_bins, desc.data(), sizeof(BinDesc) * desc.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(s->d_bin_chan, chans.data(), sizeof(Channel) * chans.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(s->d_bin_pts, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void**)&s->d_bins, sizeof(BinDesc) * std::max<size_t>(desc.size(), 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_chan, sizeof(Channel) * std::max<size_t>(n_chan, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->d_bin_pts, sizeof(double) * std::max<size_t>(n_pts, 1));
+    if (e == hipSuccess && !desc.empty()) e = hipMemcpy(s->d_bins, desc.data(), sizeof(BinDesc) * desc.size(), hipMemcpyHostToDevice);
+    n_chan = n_pts = 0;
+    for (const auto& pk : s->packs) {
+        if (e == hipSuccess && !pk.chans.empty())
+            e = hipMemcpy(s->d_bin_chan + n_chan, pk.chans.data(), sizeof(Channel) * pk.chans.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess && !pk.pts.empty())
+            e = hipMemcpy(s->d_bin_pts + n_pts, pk.pts.data(), sizeof(double) * pk.pts.size(), hipMemcpyHostToDevice);
+        n_chan += pk.chans.size();
+        n_pts += pk.pts.size();
+    }
     if (e != hipSuccess) {
-        s->n_bins = 0;
+        drop_device_bins(s);
         return fail(GBP_ERR_HIP, "bin table upload failed: %s", hipGetErrorString(e));
     }
+    s->n_bins = n_bins;
     return GBP_OK;
 }
 
@@ -791,16 +839,8 @@ gbp_status gbp_hankel_system_add_set(gbp_fdem_system* s, const double* hd0, cons
     for (int f = 0; f < t.nF; ++f) t.chan[f].hd0 = hd0[f];
     t.soa.assign(tables, tables + (size_t)GBP_PT_FIELDS * t.npts);
     s->extra_sets.push_back(std::move(t));
-    (void)gbp_hankel_system_clear_bins(s);               // descriptors are rebuilt by the next gbp_hankel_system_add_bins
-    return GBP_OK;
-}
-
-gbp_status gbp_hankel_system_set_rows(gbp_fdem_system* s, const int32_t* d_set_of_row)
-{
-    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
-    if (d_set_of_row != nullptr && !s->extra_sets.empty() && s->d_bins == nullptr)
-        return fail(GBP_ERR_INVALID_ARG, "table sets need their descriptors: call gbp_hankel_system_add_bins after the last add_set%s");
-    s->d_row_set = d_set_of_row;
+    drop_device_bins(s);                                 // descriptors are rebuilt by the next gbp_hankel_system_add_bins (the
+                                                         // windows of the sets that were there are kept on the host)
     return GBP_OK;
 }
 
@@ -896,16 +936,24 @@ gbp_status gbp_fdem_forward_ex(const gbp_fdem_system* sys, int B, int Lmax, cons
                                const double* sigma, const double* thk, const double* height, double* pred,
                                int waves, void* stream)
 {
+    return gbp_fdem_forward_rows_ex(sys, B, Lmax, nlayers, sigma, thk, height, pred, nullptr, waves, stream);
+}
+
+gbp_status gbp_fdem_forward_rows_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                    const double* sigma, const double* thk, const double* height, double* pred,
+                                    const int32_t* set_of_row, int waves, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
     if (B == 0) return GBP_OK;
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
+    if ((st = check_row_sets(sys, set_of_row)) != GBP_OK) return st;
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts,
-                       sys->d_row_set);
+                       set_of_row);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -957,7 +1005,7 @@ gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lm
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
-                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts, sys->d_row_set);
+                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts, nullptr);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1033,7 +1081,14 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
                                 const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
                                 int waves, void* stream)
 {
-    return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, stream);
+    return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, nullptr, stream);
+}
+
+gbp_status gbp_fdem_fm_dlogc_rows_ex(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                                     const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                                     const int32_t* set_of_row, int waves, void* stream)
+{
+    return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, set_of_row, stream);
 }
 
 }  // extern "C"
@@ -1041,12 +1096,13 @@ gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system* sys, int B, int Lmax, con
 // compact_rows != 0 (the sampler's launches): only the columns up to the layer count rounded up to 8 are written
 static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
                                   const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
-                                  int waves, int compact_rows, void* stream)
+                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream)
 {
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (B == 0) return GBP_OK;
     if (!J) return fail(GBP_ERR_INVALID_ARG, "J is NULL%s");
+    if ((st = check_row_sets(sys, set_of_row)) != GBP_OK) return st;
     if (max_layers < 1 || max_layers > Lmax) max_layers = Lmax;
     const size_t per_wave = (size_t)max_layers * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK));
     if (per_wave + (size_t)max_layers * 8 > 150000)
@@ -1062,7 +1118,7 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
                            Lmax, max_layers, nlayers, sigma, thk, height, J, pred, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                           sys->d_bin_pts, compact_rows, sys->d_row_set);
+                           sys->d_bin_pts, compact_rows, set_of_row);
         return GBP_OK;
     };
     // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs

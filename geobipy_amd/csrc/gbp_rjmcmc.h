@@ -1254,10 +1254,13 @@ __global__ void k_rj_debug_random(uint64_t seed, uint32_t chain, uint32_t iter, 
 // matrix turns it into window values (geobipy_amd/tdem.py: windows = nodal @ W).  One workgroup per sounding; soundings
 // with 0 layers are skipped like everywhere else.
 // ---------------------------------------------------------------------------------------------------------------
+// Geometry mixing (gbp_td_mix, geobipy_amd/tdem_geometry.py): the kernels' nodal spectra are those of the BASIS INTEGRALS of the
+// rho-frame; the spectrum of output component m is the per-row real combination  sum_t weights[b, col[m, t]] * in[src[m, t]]
+// (transmitter / receiver attitude, azimuth of the offset, output sign and scaling) -- formed while the row is staged in LDS.
 template <bool WITH_J>
 __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int N, const int* __restrict__ nl, const double* __restrict__ W,
                                                  const double* __restrict__ nodal, const double* __restrict__ J_nodal,
-                                                 double* __restrict__ pred, double* __restrict__ J)
+                                                 double* __restrict__ pred, double* __restrict__ J, gbp_td_mix mix)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // nodal[n_nodal] | J_nodal[n_nodal][k]
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1265,9 +1268,32 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
     if (k <= 0) return;
     double* sn = reinterpret_cast<double*>(sh_dyn);
     double* sj = sn + n_nodal;
-    for (int m = lane; m < n_nodal; m += 64) sn[m] = nodal[(size_t)b * n_nodal + m];
-    if (WITH_J)
-        for (int q = lane; q < n_nodal * k; q += 64) sj[q] = J_nodal[((size_t)b * n_nodal + q / k) * K + q % k];
+    if (mix.n_in <= 0) {
+        for (int m = lane; m < n_nodal; m += 64) sn[m] = nodal[(size_t)b * n_nodal + m];
+        if (WITH_J)
+            for (int q = lane; q < n_nodal * k; q += 64) sj[q] = J_nodal[((size_t)b * n_nodal + q / k) * K + q % k];
+    } else {
+        const double* w = mix.weights + (size_t)b * mix.n_weights;
+        const double* in = nodal + (size_t)b * mix.n_in;
+        for (int m = lane; m < n_nodal; m += 64) {
+            double acc = 0.0;
+            for (int t = 0; t < mix.terms; ++t) {
+                const int s = mix.src[m * mix.terms + t];
+                if (s >= 0) acc += w[mix.col[m * mix.terms + t]] * in[s];
+            }
+            sn[m] = acc;
+        }
+        if (WITH_J)
+            for (int q = lane; q < n_nodal * k; q += 64) {
+                const int m = q / k, l = q % k;
+                double acc = 0.0;
+                for (int t = 0; t < mix.terms; ++t) {
+                    const int s = mix.src[m * mix.terms + t];
+                    if (s >= 0) acc += w[mix.col[m * mix.terms + t]] * J_nodal[((size_t)b * mix.n_in + s) * K + l];
+                }
+                sj[q] = acc;
+            }
+    }
     __syncthreads();
     for (int g = lane; g < N; g += 64) {
         double acc = 0.0;
@@ -1849,8 +1875,11 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         if (o->n_rel_groups != 1 || o->n_add_groups != 1)
             return fail(GBP_ERR_INVALID_ARG, "frequency-domain data: one relative and one additive error level%s");
     } else {
-        if (td->n_nodal != 2 * sys->t.nF) return fail(GBP_ERR_INVALID_ARG, "n_nodal must be 2 * nF of the system%s");
+        if ((td->mix.n_in > 0 ? td->mix.n_in : td->n_nodal) != 2 * sys->t.nF)
+            return fail(GBP_ERR_INVALID_ARG, "the nodal vector the kernels write (n_nodal, or mix.n_in with geometry mixing) must be 2 * nF of the system%s");
         if (!td->W || !td->nodal || !td->J_nodal) return fail(GBP_ERR_INVALID_ARG, "NULL pointer in gbp_td_operator%s");
+        if (td->mix.n_in > 0 && (!td->mix.src || !td->mix.col || !td->mix.weights || td->mix.terms < 1 || td->mix.n_weights < 1))
+            return fail(GBP_ERR_INVALID_ARG, "incomplete gbp_td_mix%s");
     }
     const int B = c->B, K = o->max_layers;
     if (B == 0) return GBP_OK;
@@ -1874,10 +1903,10 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");
         if (with_j)
             hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, q, B, K, td->n_nodal, N, nl, td->W,
-                               td->nodal, td->J_nodal, pred, J);
+                               td->nodal, td->J_nodal, pred, J, td->mix);
         else
             hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, q, B, K, td->n_nodal, N, nl, td->W,
-                               td->nodal, td->J_nodal, pred, J);
+                               td->nodal, td->J_nodal, pred, J, td->mix);
         GBP_HIP(hipGetLastError());
         return GBP_OK;
     };
@@ -1886,7 +1915,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         for (int i = 0; i < nb; ++i) {
             // (compact rows: the consumers read columns < layer count only, so the columns beyond it rounded up to 8 are not touched)
             gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
-                                            td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, q);
+                                            td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, td ? td->table_set : nullptr, q);
             if (s2 != GBP_OK) return s2;
         }
         return td ? td_apply(nl, true, pred, J, q) : GBP_OK;
@@ -1952,7 +1981,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if ((st = gbp_fdem_forward_loglike_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
                                                   c->pred_p, c->misfit_p, c->like_p, fw, stream)) != GBP_OK) return st;
         } else {
-            if ((st = gbp_fdem_forward_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, fw, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_forward_rows_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, td->table_set, fw, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr, main_q)) != GBP_OK) return st;
             hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, rj::extend(*o), *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
                                c->misfit_p, c->like_p);
@@ -1974,17 +2003,29 @@ extern "C" {
 gbp_status gbp_td_apply(int B, int K, int n_nodal, int N, const int32_t* nlayers, const double* W, const double* nodal,
                         const double* J_nodal, double* pred, double* J, void* stream)
 {
+    return gbp_td_apply_mix(B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J, nullptr, stream);
+}
+
+gbp_status gbp_td_apply_mix(int B, int K, int n_nodal, int N, const int32_t* nlayers, const double* W, const double* nodal,
+                            const double* J_nodal, double* pred, double* J, const gbp_td_mix* mix, void* stream)
+{
     if (B < 0 || K < 1 || n_nodal < 1 || N < 1) return fail(GBP_ERR_INVALID_ARG, "B >= 0 and K, n_nodal, N >= 1 are required%s");
     if (B == 0) return GBP_OK;
     if (!nlayers || !W || !nodal || !pred) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
     const bool with_j = J_nodal != nullptr || J != nullptr;
     if (with_j && (!J_nodal || !J)) return fail(GBP_ERR_INVALID_ARG, "J_nodal and J come together%s");
+    gbp_td_mix mx;
+    std::memset(&mx, 0, sizeof(mx));
+    if (mix != nullptr && mix->n_in > 0) {
+        if (!mix->src || !mix->col || !mix->weights || mix->terms < 1 || mix->n_weights < 1) return fail(GBP_ERR_INVALID_ARG, "incomplete gbp_td_mix%s");
+        mx = *mix;
+    }
     const size_t lds = ((size_t)n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
     if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");
     if (with_j)
-        hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J);
+        hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J, mx);
     else
-        hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J);
+        hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J, mx);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }

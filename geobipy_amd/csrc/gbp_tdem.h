@@ -9,8 +9,10 @@
 #pragma once
 
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
+#include <utility>
 
 namespace td {
 
@@ -159,29 +161,46 @@ inline std::vector<double> numbers(const std::string& s)
 
 }  // namespace td
 
+// Geometry (geobipy_amd/tdem_geometry.py is the same statement in numpy; tests hold the two together): GA-AEM's frame x = flight
+// direction, y = left, z = up; roll / pitch / yaw in degrees = right-handed rotations about x / y / z, body -> earth matrix
+// R = Rz(yaw) Ry(pitch) Rx(roll).  In the frame whose x' axis points from the transmitter to the receiver the secondary field is a
+// combination of five Hankel integrals per spline node -- the basis integrals B0L, B1L (vertical moment: the system's loop), B0, B1,
+// BA (horizontal moment: a dipole) -- which are the "frequencies" of the raw Hankel handle; a row's geometry is the small real
+// matrix that mixes their nodal spectra into those of the output components (gbp_td_mix).
+#define GBP_TD_NBASIS 5
 struct gbp_tdem_system {
     td::Stm stm;
-    double f0 = 0, fs = 0, moment = 1, loop_radius = 0, scale_x = 0, scale_z = 0;
+    double f0 = 0, fs = 0, moment = 1, loop_radius = 0;
+    double scale[3] = {0, 0, 0};                 // X / Y / ZOutputScaling
+    int comp[3] = {0, 0, 0};                     // the output components in channel order: 0 = x, 1 = y, 2 = z
     bool dbdt = true, area = false;
     int n_samples = 0, n_windows = 0, n_components = 0, n_nodes = 0;
-    bool has_x = false, has_z = false;
     std::vector<double> nodes, centres, W;       // W[2 n_nodes][n_windows] of ONE component (components share it)
     std::vector<double> w0, w1;                  // Hankel filter weights (J0: 120, J1: 140)
     std::vector<double> Wb;                      // block matrix for k_td_apply: [2 nc n_nodes][nc n_windows]
     double* d_Wb = nullptr;
-    // One raw Hankel handle per table layout (receiver off / on the transmitter's axis: J0 / J1 filter for the z component), holding
-    // one table set per receiver offset seen so far (gbp_hankel_system_add_set); rows of a call pick theirs by index.
-    struct Multi {
+    // One raw Hankel handle per table layout = (set of basis integrals, receiver on / off the transmitter's axis), holding one table
+    // set per (horizontal distance, dz) seen so far (gbp_hankel_system_add_set); rows of a call pick theirs by index.
+    struct Layout {
         gbp_fdem_system* h = nullptr;
-        std::map<std::tuple<double, double, double>, int> set_of;
+        std::map<std::pair<double, double>, int> set_of;
+        int basis[GBP_TD_NBASIS], n_basis = 0;
+        int32_t *d_src = nullptr, *d_col = nullptr;      // index maps of gbp_td_mix for this layout
     };
-    Multi multi[2];
-    std::vector<int32_t> h_set;                  // staging of the rows' set indices
-    std::vector<double> h_height;                // staging of the altitudes of the last forward call
+    std::map<int, Layout> layouts;               // key: basis mask | on-axis << 8
+    // staging + device scratch, grown as needed and kept (no allocation per call once warm)
+    std::vector<int32_t> h_set;
+    std::vector<double> h_height, h_weights;
+    double *d_height = nullptr, *d_nodal = nullptr, *d_weights = nullptr, *d_jnodal = nullptr;
+    int32_t* d_set = nullptr;
+    size_t cap_rows = 0, cap_set = 0, cap_nodal = 0, cap_weights = 0, cap_jnodal = 0;
     double hankel_eps = 1.0e-12;                 // per-sounding abscissa windows (gbp_tdem_system_set_hankel_eps); 0: all abscissae
 };
 
 namespace td {
+
+constexpr int MAX_TABLE_SETS = 4096;             // table sets one layout keeps; a call that needs more is refused (bin the offsets)
+constexpr double ON_AXIS_RHO = 1.0e-2;           // tdem_geometry.ON_AXIS_RHO
 
 inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
 {
@@ -191,11 +210,12 @@ inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
     if (!(s->f0 > 0.0) || !(s->fs > 2.0 * s->f0)) { *msg = "BaseFrequency / WaveformDigitisingFrequency missing or inconsistent"; return GBP_ERR_BAD_SYSTEM; }
     s->moment = m.num("NumberOfTurns", 1.0) * m.num("PeakCurrent", 1.0) * m.num("LoopArea", 1.0);
     s->loop_radius = m.num("ModellingLoopRadius", 0.0);
-    s->scale_x = m.num("XOutputScaling", 0.0);
-    s->scale_z = m.num("ZOutputScaling", 0.0);
-    if (m.num("YOutputScaling", 0.0) != 0.0) { *msg = "Y component output is not supported"; return GBP_ERR_BAD_SYSTEM; }
-    s->has_x = s->scale_x != 0.0; s->has_z = s->scale_z != 0.0;
-    s->n_components = (int)s->has_x + (int)s->has_z;
+    s->scale[0] = m.num("XOutputScaling", 0.0);
+    s->scale[1] = m.num("YOutputScaling", 0.0);
+    s->scale[2] = m.num("ZOutputScaling", 0.0);
+    s->n_components = 0;
+    for (int k = 0; k < 3; ++k)
+        if (s->scale[k] != 0.0) s->comp[s->n_components++] = k;
     if (s->n_components == 0) { *msg = "no output component has a non-zero scaling"; return GBP_ERR_BAD_SYSTEM; }
     const std::string ot = m.str("OutputType", "dB/dt");
     s->dbdt = ot.size() >= 2 && (ot[0] == 'd' || ot[0] == 'D') && (ot[1] == 'b' || ot[1] == 'B');
@@ -214,7 +234,7 @@ inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
     s->nodes.clear();
     for (int i = -1; i < n_up; ++i) s->nodes.push_back(s->f0 * std::pow(10.0, (double)i / fpd));
     const int n = s->n_nodes = (int)s->nodes.size();
-    if (2 * n * s->n_components > 2 * GBP_MAX_FREQ) { *msg = "too many spline nodes x components (limit 128)"; return GBP_ERR_BAD_SYSTEM; }
+    if (n * s->n_components > GBP_MAX_FREQ) { *msg = "too many spline nodes x components (limit 128)"; return GBP_ERR_BAD_SYSTEM; }
     // digitised current over one period (a table spanning half a period continues with opposite polarity)
     const double dt = 1.0 / s->fs, T = 1.0 / s->f0, t0 = m.wt.front();
     std::vector<zc> cur(N, zc(0, 0));
@@ -309,45 +329,92 @@ inline gbp_status build_operator(gbp_tdem_system* s, const char** msg)
     return GBP_OK;
 }
 
-// raw Hankel tables of one receiver offset (geobipy_amd/tdem.py TdemSystem.hankel_tables without the abscissa window)
+// body -> earth rotation, degrees (tdem_geometry.rotation)
+inline void rotation(double roll, double pitch, double yaw, double R[3][3])
+{
+    const double d = PI / 180.0;
+    const double cr = std::cos(roll * d), sr = std::sin(roll * d), cp = std::cos(pitch * d), sp = std::sin(pitch * d);
+    const double cy = std::cos(yaw * d), sy = std::sin(yaw * d);
+    R[0][0] = cy * cp; R[0][1] = cy * sp * sr - sy * cr; R[0][2] = cy * sp * cr + sy * sr;
+    R[1][0] = sy * cp; R[1][1] = sy * sp * sr + cy * cr; R[1][2] = sy * sp * cr - cy * sr;
+    R[2][0] = -sp;     R[2][1] = cp * sr;                R[2][2] = cp * cr;
+}
+
+// w[3][5]: field along the receiver's axis k = sum_i w[k][i] * basis integral i, before output sign and scaling
+// (tdem_geometry.basis_weights: the two must agree)
+inline void basis_weights(const double* gm, bool loop, double w[3][GBP_TD_NBASIS])
+{
+    const double rho = std::hypot(gm[4], gm[5]);
+    const bool on = rho == 0.0;
+    const double c = on ? 1.0 : gm[4] / rho, s = on ? 0.0 : gm[5] / rho;
+    double Rt[3][3], Rr[3][3];
+    rotation(gm[1], gm[2], gm[3], Rt);
+    rotation(gm[7], gm[8], gm[9], Rr);
+    const double Rz[3][3] = {{c, -s, 0.0}, {s, c, 0.0}, {0.0, 0.0, 1.0}};
+    double u[3], V[3][3];
+    for (int i = 0; i < 3; ++i) {          // u = Rz^T (R_tx z^),  V = R_rx^T Rz
+        u[i] = 0.0;
+        for (int j = 0; j < 3; ++j) u[i] += Rz[j][i] * Rt[j][2];
+        for (int k = 0; k < 3; ++k) {
+            V[i][k] = 0.0;
+            for (int j = 0; j < 3; ++j) V[i][k] += Rr[j][i] * Rz[j][k];
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        w[k][0] = V[k][2] * u[2];
+        w[k][1] = V[k][0] * u[2];
+        w[k][2] = V[k][0] * u[0];
+        w[k][3] = -V[k][2] * u[0];
+        w[k][4] = -V[k][0] * u[0] + V[k][1] * u[1];
+        if (!loop) { w[k][0] += w[k][2]; w[k][1] += w[k][3]; w[k][2] = w[k][3] = 0.0; }
+        if (on) { w[k][2] += 0.5 * w[k][4]; w[k][1] = w[k][3] = w[k][4] = 0.0; }
+    }
+}
+
+// raw Hankel tables of one table set (rho, dz) for the basis integrals of a layout (TdemSystem.hankel_tables, all abscissae)
 struct RawTables {
     std::vector<int32_t> npts;
     std::vector<double> wmu, hd0, g, tables;
 };
 
-inline gbp_status build_tables(gbp_tdem_system* s, double dx, double dy, double dz, RawTables* out)
+inline gbp_status build_tables(const gbp_tdem_system* s, double rho, double dz, const int* basis, int n_basis, RawTables* out)
 {
-    const double r = std::hypot(dx, dy), a = s->loop_radius;
-    if (r == 0.0 && !(a > 0.0)) return fail(GBP_ERR_BAD_SYSTEM, "a receiver on the transmitter axis needs a finite ModellingLoopRadius%s");
-    const double rs = r > 0.0 ? r : a;
-    std::vector<int32_t>& npts = out->npts;
-    std::vector<double>&wmu = out->wmu, &hd0 = out->hd0, &g = out->g;
+    const double a = s->loop_radius, k4 = 1.0 / (4.0 * PI);
+    const bool on_axis = rho == 0.0;
+    if (on_axis && !(a > 0.0)) return fail(GBP_ERR_BAD_SYSTEM, "a receiver on the transmitter axis needs a finite ModellingLoopRadius%s");
     std::vector<double> cols[GBP_PT_FIELDS];
     auto base0 = [](int j) { return std::pow(10.0, -8.3885 + 0.0904226468670 * (double)j); };        // FdemSystem.py:67-83
     auto base1 = [](int j) { return std::pow(10.0, -7.91001919 + 0.087967143957 * (double)j); };      // :85-101
-    for (int comp = 0; comp < 2; ++comp) {                       // x then z, like the channel layout
-        const bool is_z = comp == 1;
-        if ((is_z && !s->has_z) || (!is_z && !s->has_x)) continue;
-        const bool on_axis = r == 0.0;
-        const bool use_j1 = !is_z || on_axis;
+    auto srcz = [&](double lam) { return a > 0.0 ? lam * std::cyl_bessel_j(1.0, lam * a) / (2.0 * PI * a) : lam * lam * k4; };
+    for (int q = 0; q < n_basis; ++q) {
+        const int i = basis[q];
+        bool use_j1;
+        double div;
+        if (on_axis) {
+            if (i == 0) { use_j1 = true; div = a; }                 // B0L: J0(0) = 1, the loop's own J1(lam a) is the filter kernel
+            else if (i == 2) { use_j1 = false; div = ON_AXIS_RHO; } // B0 (and BA -> B0 / 2) a hair off the axis
+            else return fail(GBP_ERR_INVALID_ARG, "basis integral vanishes on the axis%s");
+        } else {
+            use_j1 = i == 1 || i == 3 || i == 4;
+            div = rho;
+        }
         const int np = use_j1 ? GBP_NC1 : GBP_NC0;
-        const double div = (on_axis && is_z) ? a : rs;
-        const double sc = is_z ? s->scale_z : s->scale_x;
         std::vector<double> lam(np), coef(np);
         for (int j = 0; j < np; ++j) {
             lam[j] = (use_j1 ? base1(j) : base0(j)) / div;
-            double w = (use_j1 ? s->w1[j] : s->w0[j]) / div;
-            if (!is_z) w *= r > 0.0 ? -dx / r : 0.0;
+            const double w = (use_j1 ? s->w1[j] : s->w0[j]) / div;
             double src;
-            if (on_axis && is_z) src = lam[j] / (2.0 * PI * a);
-            else src = a > 0.0 ? lam[j] * std::cyl_bessel_j(1.0, lam[j] * a) / (2.0 * PI * a) : lam[j] * lam[j] / (4.0 * PI);
-            coef[j] = src * w * sc;
+            if (on_axis) src = i == 0 ? lam[j] / (2.0 * PI * a) : lam[j] * lam[j] * k4;
+            else if (i <= 1) src = srcz(lam[j]);
+            else if (i <= 3) src = lam[j] * lam[j] * k4;
+            else src = lam[j] * k4 / rho;
+            coef[j] = src * w;
         }
         for (int nd = 0; nd < s->n_nodes; ++nd) {
-            npts.push_back(np);
-            wmu.push_back(2.0 * PI * s->nodes[nd] * MU0);
-            hd0.push_back(-dz);
-            g.push_back(1.0); g.push_back(0.0);
+            out->npts.push_back(np);
+            out->wmu.push_back(2.0 * PI * s->nodes[nd] * MU0);
+            out->hd0.push_back(-dz);
+            out->g.push_back(1.0); out->g.push_back(0.0);
             for (int j = 0; j < np; ++j) {
                 cols[0].push_back(lam[j] * lam[j]); cols[1].push_back(lam[j]); cols[2].push_back(0.0); cols[3].push_back(coef[j]);
                 cols[4].push_back(0.0); cols[5].push_back(lam[j]); cols[6].push_back(0.0);
@@ -355,6 +422,176 @@ inline gbp_status build_tables(gbp_tdem_system* s, double dx, double dy, double 
         }
     }
     for (int f = 0; f < GBP_PT_FIELDS; ++f) out->tables.insert(out->tables.end(), cols[f].begin(), cols[f].end());
+    return GBP_OK;
+}
+
+template <class T>
+inline gbp_status grow(T** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return GBP_OK;
+    if (*p) { (void)hipDeviceSynchronize(); (void)hipFree(*p); *p = nullptr; *cap = 0; }   // (work of earlier calls may still read it)
+    const size_t n = need + need / 4;
+    const hipError_t e = hipMalloc((void**)p, sizeof(T) * n);
+    if (e != hipSuccess) return fail(GBP_ERR_HIP, "scratch allocation failed: %s", hipGetErrorString(e));
+    *cap = n;
+    return GBP_OK;
+}
+
+// windows (and, with J, their derivatives with respect to ln sigma) of B soundings: the body of gbp_tdem_forward / _fm_dlogc
+inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lmax, const int32_t* nlayers, const double* sigma,
+                      const double* thk, double* out, double* J, void* stream)
+{
+    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
+    if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
+    if (B == 0) return GBP_OK;
+    if (!geometry || !nlayers || !sigma || !thk || !out) return fail(GBP_ERR_INVALID_ARG, "NULL pointer%s");
+    for (int b = 0; b < B; ++b) {
+        const double* gm = geometry + (size_t)b * 10;
+        for (int i = 0; i < 10; ++i)
+            if (!std::isfinite(gm[i])) return fail(GBP_ERR_INVALID_ARG, "geometry must be finite%s");
+        if (!(gm[0] >= 0.0)) return fail(GBP_ERR_INVALID_ARG, "transmitter height must be >= 0%s");
+    }
+    const hipStream_t q = (hipStream_t)stream;
+    const bool loop = s->loop_radius > 0.0;
+    const int nc = s->n_components, n = s->n_nodes, N = nc * s->n_windows, n_out = 2 * nc * n;
+    try {
+        if (s->d_Wb == nullptr) {
+            hipError_t e = hipMalloc((void**)&s->d_Wb, sizeof(double) * s->Wb.size());
+            if (e == hipSuccess) e = hipMemcpy(s->d_Wb, s->Wb.data(), sizeof(double) * s->Wb.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { if (s->d_Wb) (void)hipFree(s->d_Wb); s->d_Wb = nullptr; return fail(GBP_ERR_HIP, "window operator upload failed: %s", hipGetErrorString(e)); }
+        }
+        s->h_height.resize(B);
+        s->h_set.resize(B);
+        for (int b = 0; b < B; ++b) s->h_height[b] = geometry[(size_t)b * 10];
+        gbp_status st;
+        if ((st = grow(&s->d_height, &s->cap_rows, (size_t)B)) != GBP_OK) return st;
+        if ((st = grow(&s->d_set, &s->cap_set, (size_t)B)) != GBP_OK) return st;
+        GBP_HIP(hipMemcpyAsync(s->d_height, s->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
+        auto on_axis = [&](int b) { return geometry[(size_t)b * 10 + 4] == 0.0 && geometry[(size_t)b * 10 + 5] == 0.0; };
+        // Jacobians go through the window stage in chunks of rows so that the nodal Jacobian scratch stays bounded
+        const int chunk_rows = J != nullptr ? 2048 : B;
+        for (int b0 = 0; b0 < B;) {
+            const bool ax = on_axis(b0);
+            int b1 = b0 + 1;
+            while (b1 < B && on_axis(b1) == ax && b1 - b0 < chunk_rows) ++b1;
+            const int nr = b1 - b0;
+            // the basis integrals some row of this run needs, and every row's weights for all five
+            std::vector<double> wall((size_t)nr * nc * GBP_TD_NBASIS);
+            bool used[GBP_TD_NBASIS] = {true, false, false, false, false};
+            for (int b = b0; b < b1; ++b) {
+                double w[3][GBP_TD_NBASIS];
+                basis_weights(geometry + (size_t)b * 10, loop, w);
+                for (int c = 0; c < nc; ++c) {
+                    const int k = s->comp[c];
+                    const double f = (k == 2 ? 1.0 : -1.0) * s->scale[k];      // the reference negates GA-AEM's z (TdemDataPoint.py:1013-1015)
+                    for (int i = 0; i < GBP_TD_NBASIS; ++i) {
+                        const double v = f * w[k][i];
+                        wall[((size_t)(b - b0) * nc + c) * GBP_TD_NBASIS + i] = v;
+                        if (v != 0.0) used[i] = true;
+                    }
+                }
+            }
+            int mask = 0;
+            for (int i = 0; i < GBP_TD_NBASIS; ++i) if (used[i]) mask |= 1 << i;
+            gbp_tdem_system::Layout& ly = s->layouts[mask | ((int)ax << 8)];
+            if (ly.n_basis == 0)
+                for (int i = 0; i < GBP_TD_NBASIS; ++i) if (used[i]) ly.basis[ly.n_basis++] = i;
+            const int nb = ly.n_basis, nF_in = nb * n, n_in = 2 * nF_in, n_w = nc * nb;
+            if (nF_in > GBP_MAX_FREQ) return fail(GBP_ERR_INVALID_ARG, "spline nodes x basis integrals of this geometry exceed the limit of 128 frequencies%s");
+            // table sets: one per distinct (rho, dz); consecutive rows with the same key share one look-up
+            bool grown = false;
+            double lo = s->h_height[b0], hi = lo, last_rho = -1.0, last_dz = 0.0;
+            int last_set = -1;
+            for (int b = b0; b < b1; ++b) {
+                const double* gm = geometry + (size_t)b * 10;
+                lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]);
+                const double rho = std::hypot(gm[4], gm[5]);
+                if (last_set < 0 || rho != last_rho || gm[6] != last_dz) {
+                    const auto key = std::make_pair(rho, gm[6]);
+                    auto it = ly.set_of.find(key);
+                    if (it == ly.set_of.end()) {
+                        if ((int)ly.set_of.size() >= MAX_TABLE_SETS)
+                            return fail(GBP_ERR_INVALID_ARG, "more than 4096 distinct (horizontal distance, dz) receiver offsets on one handle: bin the offsets (e.g. to 0.1 m)%s");
+                        RawTables t;
+                        st = build_tables(s, rho, gm[6], ly.basis, nb, &t);
+                        if (st != GBP_OK) return st;
+                        if (ly.h == nullptr)
+                            st = gbp_hankel_system_create_raw((int)t.npts.size(), t.npts.data(), t.wmu.data(), t.hd0.data(), t.g.data(), t.tables.data(), &ly.h);
+                        else
+                            st = gbp_hankel_system_add_set(ly.h, t.hd0.data(), t.tables.data());
+                        if (st != GBP_OK) return st;
+                        it = ly.set_of.emplace(key, (int)ly.set_of.size()).first;
+                        grown = true;
+                    }
+                    last_rho = rho; last_dz = gm[6]; last_set = it->second;
+                }
+                s->h_set[b] = last_set;
+            }
+            gbp_fdem_system* h = ly.h;
+            const bool sets = ly.set_of.size() > 1;
+            if (s->hankel_eps > 0.0) {        // per-sounding abscissa windows: 1 m altitude bins covering this run (kept, and widened, across calls)
+                int first = (int)std::floor(lo), last = std::min((int)std::floor(hi), first + 1023);
+                if (grown || h->n_bins == 0 || first < h->bin0 || last >= h->bin0 + h->n_bins) {
+                    if (h->n_bins > 0) { first = std::min(first, h->bin0); last = std::min(std::max(last, h->bin0 + h->n_bins - 1), first + 1023); }
+                    st = gbp_hankel_system_add_bins(h, s->hankel_eps, 1, first, last - first + 1);
+                }
+            } else if (sets && (grown || h->d_bins == nullptr)) {
+                st = gbp_hankel_system_add_bins(h, 0.0, 1, 0, 0);                 // descriptors of the sets' full tables
+            }
+            if (st != GBP_OK) return st;
+            // index maps of the mix (per layout, once)
+            if (ly.d_src == nullptr) {
+                std::vector<int32_t> src((size_t)n_out * nb, -1), col((size_t)n_out * nb, 0);
+                for (int c = 0; c < nc; ++c)
+                    for (int t = 0; t < nb; ++t)
+                        for (int j = 0; j < n; ++j) {
+                            const int m = c * n + j;
+                            src[(size_t)m * nb + t] = t * n + j;
+                            src[(size_t)(nc * n + m) * nb + t] = nF_in + t * n + j;
+                            col[(size_t)m * nb + t] = col[(size_t)(nc * n + m) * nb + t] = c * nb + t;
+                        }
+                hipError_t e = hipMalloc((void**)&ly.d_src, sizeof(int32_t) * src.size());
+                if (e == hipSuccess) e = hipMalloc((void**)&ly.d_col, sizeof(int32_t) * col.size());
+                if (e == hipSuccess) e = hipMemcpy(ly.d_src, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(ly.d_col, col.data(), sizeof(int32_t) * col.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) {
+                    if (ly.d_src) (void)hipFree(ly.d_src);
+                    if (ly.d_col) (void)hipFree(ly.d_col);
+                    ly.d_src = ly.d_col = nullptr;
+                    return fail(GBP_ERR_HIP, "mix tables upload failed: %s", hipGetErrorString(e));
+                }
+            }
+            // this run's weights (the layout's basis integrals only), set indices, scratch
+            s->h_weights.resize((size_t)nr * n_w);
+            for (int r = 0; r < nr; ++r)
+                for (int c = 0; c < nc; ++c)
+                    for (int t = 0; t < nb; ++t)
+                        s->h_weights[((size_t)r * nc + c) * nb + t] = wall[((size_t)r * nc + c) * GBP_TD_NBASIS + ly.basis[t]];
+            if ((st = grow(&s->d_weights, &s->cap_weights, (size_t)nr * n_w)) != GBP_OK) return st;
+            if ((st = grow(&s->d_nodal, &s->cap_nodal, (size_t)nr * n_in)) != GBP_OK) return st;
+            if (J != nullptr && (st = grow(&s->d_jnodal, &s->cap_jnodal, (size_t)nr * n_in * Lmax)) != GBP_OK) return st;
+            // (the staging vector is reused by the next run: the copy must have left the host before that)
+            GBP_HIP(hipMemcpyAsync(s->d_weights, s->h_weights.data(), sizeof(double) * (size_t)nr * n_w, hipMemcpyHostToDevice, q));
+            if (b1 < B) GBP_HIP(hipStreamSynchronize(q));
+            if (sets) GBP_HIP(hipMemcpyAsync(s->d_set + b0, s->h_set.data() + b0, sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, q));
+            const int32_t* rows = sets ? s->d_set + b0 : nullptr;
+            const size_t ro = (size_t)b0 * Lmax;
+            if (J == nullptr)
+                st = gbp_fdem_forward_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, s->d_height + b0, s->d_nodal, rows, 0, stream);
+            else
+                st = gbp_fdem_fm_dlogc_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, s->d_height + b0, s->d_nodal, s->d_jnodal, Lmax, 1,
+                                               rows, 0, stream);
+            if (st != GBP_OK) return st;
+            gbp_td_mix mix;
+            mix.n_in = n_in; mix.terms = nb; mix.n_weights = n_w; mix.src = ly.d_src; mix.col = ly.d_col; mix.weights = s->d_weights;
+            st = gbp_td_apply_mix(nr, Lmax, n_out, N, nlayers + b0, s->d_Wb, s->d_nodal, J ? s->d_jnodal : nullptr, out + (size_t)b0 * N,
+                                  J ? J + (size_t)b0 * N * Lmax : nullptr, &mix, stream);
+            if (st != GBP_OK) return st;
+            b0 = b1;
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(GBP_ERR_INVALID_ARG, "out of host memory%s");
+    }
     return GBP_OK;
 }
 
@@ -382,8 +619,13 @@ gbp_status gbp_tdem_system_create(const char* stm_text, const double* w0, const 
 void gbp_tdem_system_destroy(gbp_tdem_system* s)
 {
     if (!s) return;
-    for (auto& mu : s->multi) gbp_fdem_system_destroy(mu.h);
-    if (s->d_Wb) (void)hipFree(s->d_Wb);
+    for (auto& kv : s->layouts) {
+        gbp_fdem_system_destroy(kv.second.h);
+        if (kv.second.d_src) (void)hipFree(kv.second.d_src);
+        if (kv.second.d_col) (void)hipFree(kv.second.d_col);
+    }
+    for (void* p : {(void*)s->d_Wb, (void*)s->d_height, (void*)s->d_nodal, (void*)s->d_weights, (void*)s->d_jnodal, (void*)s->d_set})
+        if (p) (void)hipFree(p);
     delete s;
 }
 
@@ -392,8 +634,8 @@ gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system* s, double eps)
     if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (!(eps >= 0.0)) return fail(GBP_ERR_INVALID_ARG, "eps must be >= 0%s");
     if (eps != s->hankel_eps)                 // the cached tables were windowed for the old budget
-        for (auto& mu : s->multi)
-            if (mu.h) gbp_hankel_system_clear_bins(mu.h);
+        for (auto& kv : s->layouts)
+            if (kv.second.h) gbp_hankel_system_clear_bins(kv.second.h);
     s->hankel_eps = eps;
     return GBP_OK;
 }
@@ -420,93 +662,14 @@ gbp_status gbp_tdem_system_tables(const gbp_tdem_system* s, double* window_centr
 gbp_status gbp_tdem_forward(gbp_tdem_system* s, int B, const double* geometry, int Lmax, const int32_t* nlayers, const double* sigma,
                             const double* thk, double* out, void* stream)
 {
-    if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
-    if (B < 0 || Lmax < 1) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0 and Lmax >= 1%s");
-    if (B == 0) return GBP_OK;
-    if (!geometry || !nlayers || !sigma || !thk || !out) return fail(GBP_ERR_INVALID_ARG, "NULL pointer%s");
-    // Geometry(tx_height, tx_roll, -tx_pitch, -tx_yaw, dx, dy, dz, rx_roll, -rx_pitch, -rx_yaw)  (system/Loop_pair.py:70-77)
-    s->h_height.resize(B);
-    for (int b = 0; b < B; ++b) {
-        const double* gm = geometry + (size_t)b * 10;
-        if (gm[1] != 0.0 || gm[2] != 0.0 || gm[3] != 0.0 || gm[7] != 0.0 || gm[8] != 0.0 || gm[9] != 0.0)
-            return fail(GBP_ERR_INVALID_ARG, "only level flight is supported: roll / pitch / yaw of both loops must be 0%s");
-        if (!(gm[0] >= 0.0) || !std::isfinite(gm[0])) return fail(GBP_ERR_INVALID_ARG, "transmitter height must be finite and >= 0%s");
-        s->h_height[b] = gm[0];
-    }
-    if (s->d_Wb == nullptr) {
-        hipError_t e = hipMalloc((void**)&s->d_Wb, sizeof(double) * s->Wb.size());
-        if (e == hipSuccess) e = hipMemcpy(s->d_Wb, s->Wb.data(), sizeof(double) * s->Wb.size(), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { s->d_Wb = nullptr; return fail(GBP_ERR_HIP, "window operator upload failed: %s", hipGetErrorString(e)); }
-    }
-    const hipStream_t q = (hipStream_t)stream;
-    const int nF = s->n_components * s->n_nodes, n_nodal = 2 * nF, N = s->n_components * s->n_windows;
-    double *d_h = nullptr, *d_nodal = nullptr;
-    GBP_HIP(hipMallocAsync((void**)&d_h, sizeof(double) * (size_t)B, q));
-    GBP_HIP(hipMallocAsync((void**)&d_nodal, sizeof(double) * (size_t)B * n_nodal, q));
-    GBP_HIP(hipMemcpyAsync(d_h, s->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
-    gbp_status st = GBP_OK;
-    // Every receiver offset has its own table set in the handle of its layout class; a row picks its set by index, so soundings
-    // of any geometry share one launch (runs of rows change launches only where the receiver moves on / off the transmitter's axis).
-    s->h_set.resize(B);
-    int32_t* d_set = nullptr;
-    GBP_HIP(hipMallocAsync((void**)&d_set, sizeof(int32_t) * (size_t)B, q));
-    auto on_axis = [&](int b) { return geometry[(size_t)b * 10 + 4] == 0.0 && geometry[(size_t)b * 10 + 5] == 0.0; };
-    for (int b0 = 0; b0 < B && st == GBP_OK;) {
-        const int cls = on_axis(b0) ? 1 : 0;
-        int b1 = b0 + 1;
-        while (b1 < B && (on_axis(b1) ? 1 : 0) == cls) ++b1;
-        gbp_tdem_system::Multi& mu = s->multi[cls];
-        bool grown = false;
-        double lo = s->h_height[b0], hi = lo;
-        for (int b = b0; b < b1 && st == GBP_OK; ++b) {
-            const double* gm = geometry + (size_t)b * 10;
-            lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]);
-            const auto key = std::make_tuple(gm[4], gm[5], gm[6]);
-            auto it = mu.set_of.find(key);
-            if (it == mu.set_of.end()) {
-                td::RawTables t;
-                st = td::build_tables(s, gm[4], gm[5], gm[6], &t);
-                if (st != GBP_OK) break;
-                if (mu.h == nullptr)
-                    st = gbp_hankel_system_create_raw((int)t.npts.size(), t.npts.data(), t.wmu.data(), t.hd0.data(), t.g.data(), t.tables.data(), &mu.h);
-                else
-                    st = gbp_hankel_system_add_set(mu.h, t.hd0.data(), t.tables.data());
-                if (st != GBP_OK) break;
-                it = mu.set_of.emplace(key, (int)mu.set_of.size()).first;
-                grown = true;
-            }
-            s->h_set[b] = it->second;
-        }
-        if (st != GBP_OK) break;
-        gbp_fdem_system* h = mu.h;
-        const bool sets = mu.set_of.size() > 1;
-        if (s->hankel_eps > 0.0) {        // per-sounding abscissa windows: 1 m altitude bins covering this run (kept, and widened, across calls)
-            int first = (int)std::floor(lo), last = std::min((int)std::floor(hi), first + 1023);
-            if (grown || h->n_bins == 0 || first < h->bin0 || last >= h->bin0 + h->n_bins) {
-                if (h->n_bins > 0) { first = std::min(first, h->bin0); last = std::min(std::max(last, h->bin0 + h->n_bins - 1), first + 1023); }
-                st = gbp_hankel_system_add_bins(h, s->hankel_eps, 1, first, last - first + 1);
-            }
-        } else if (sets && (grown || h->d_bins == nullptr)) {
-            st = gbp_hankel_system_add_bins(h, 0.0, 1, 0, 0);                 // descriptors of the sets' full tables
-        }
-        if (st != GBP_OK) break;
-        const int n = b1 - b0;
-        if (sets) {
-            GBP_HIP(hipMemcpyAsync(d_set + b0, s->h_set.data() + b0, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, q));
-            st = gbp_hankel_system_set_rows(h, d_set + b0);
-            if (st != GBP_OK) break;
-        }
-        st = gbp_fdem_forward_ex(h, n, Lmax, nlayers + b0, sigma + (size_t)b0 * Lmax, thk + (size_t)b0 * Lmax, d_h + b0,
-                                 d_nodal + (size_t)b0 * n_nodal, 0, stream);
-        if (sets) (void)gbp_hankel_system_set_rows(h, nullptr);
-        if (st == GBP_OK)
-            st = gbp_td_apply(n, Lmax, n_nodal, N, nlayers + b0, s->d_Wb, d_nodal + (size_t)b0 * n_nodal, nullptr, out + (size_t)b0 * N, nullptr, stream);
-        b0 = b1;
-    }
-    (void)hipFreeAsync(d_set, q);
-    (void)hipFreeAsync(d_h, q);
-    (void)hipFreeAsync(d_nodal, q);
-    return st;
+    return td::run(s, B, geometry, Lmax, nlayers, sigma, thk, out, nullptr, stream);
+}
+
+gbp_status gbp_tdem_fm_dlogc(gbp_tdem_system* s, int B, const double* geometry, int Lmax, const int32_t* nlayers, const double* sigma,
+                             const double* thk, double* out, double* J, void* stream)
+{
+    if (!J) return fail(GBP_ERR_INVALID_ARG, "J is NULL%s");
+    return td::run(s, B, geometry, Lmax, nlayers, sigma, thk, out, J, stream);
 }
 
 }  // extern "C"

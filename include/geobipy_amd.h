@@ -122,13 +122,14 @@ gbp_status gbp_hankel_system_clear_bins(gbp_fdem_system *sys);
 /*
  * Further table sets for one handle -- the same frequencies, weights and point counts as the tables it was created with, other
  * altitude terms hd0[nF] and points tables[7][P]: e.g. the Hankel tables of other transmitter-receiver offsets of a time-domain
- * system.  gbp_hankel_system_set_rows(sys, d_set_of_row) then makes row b of every launch on this handle use set
- * d_set_of_row[b] (0 = the handle's own tables, k = the k-th added set; [dev] int32, B entries, owned by the caller and read at
- * launch time; NULL = set 0 for every row), so soundings of different geometry run in ONE launch.  Call gbp_hankel_system_add_bins
- * after the last add_set (eps = 0, n_bins = 0 for "no windows"): it builds every set's descriptors.  Set ids are not range-checked.
+ * system.  The `set_of_row` ARGUMENT of gbp_fdem_forward_rows_ex / gbp_fdem_fm_dlogc_rows_ex (and gbp_td_operator.table_set for
+ * the sampler) then makes row b of that launch use set set_of_row[b] (0 = the handle's own tables, k = the k-th added set; [dev]
+ * int32, B entries, owned by the caller, read by the kernels; NULL = set 0 for every row), so soundings of different geometry
+ * run in ONE launch.  The handle keeps no per-call state: host threads may share one handle, each with its own rows (SURVEY 8b
+ * "Threading"; tests/c_abi/two_threads.cpp).  Call gbp_hankel_system_add_bins after the last add_set (eps = 0, n_bins = 0 for "no
+ * windows"): it builds every set's descriptors.  Set ids are not range-checked.
  */
 gbp_status gbp_hankel_system_add_set(gbp_fdem_system *sys, const double *hd0, const double *tables);
-gbp_status gbp_hankel_system_set_rows(gbp_fdem_system *sys, const int32_t *d_set_of_row);
 /* abscissa points a sounding at (integer) altitude_m is evaluated with */
 gbp_status gbp_fdem_system_bin_points(const gbp_fdem_system *sys, int altitude_m, int *npts);
 void gbp_fdem_system_destroy(gbp_fdem_system *sys);
@@ -159,6 +160,11 @@ gbp_status gbp_fdem_forward(const gbp_fdem_system *sys, int B, int Lmax, const i
 gbp_status gbp_fdem_forward_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
                                const double *sigma, const double *thk, const double *height,
                                double *pred, int waves, void *stream);
+
+/* Same with a table set per row (gbp_hankel_system_add_set): set_of_row [dev] int32[B] or NULL. */
+gbp_status gbp_fdem_forward_rows_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                    const double *sigma, const double *thk, const double *height,
+                                    double *pred, const int32_t *set_of_row, int waves, void *stream);
 
 /*
  * Per-sounding status word (SURVEY 8b "Errors"; the reference asserts on the host, FD/fdem1d.py:29,
@@ -241,6 +247,12 @@ gbp_status gbp_fdem_fm_dlogc(const gbp_fdem_system *sys, int B, int Lmax, const 
 gbp_status gbp_fdem_fm_dlogc_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
                                 const double *sigma, const double *thk, const double *height,
                                 double *pred, double *J, int max_layers, int exact, int waves, void *stream);
+
+/* Same with a table set per row (gbp_hankel_system_add_set): set_of_row [dev] int32[B] or NULL. */
+gbp_status gbp_fdem_fm_dlogc_rows_ex(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                     const double *sigma, const double *thk, const double *height,
+                                     double *pred, double *J, int max_layers, int exact, const int32_t *set_of_row,
+                                     int waves, void *stream);
 
 /* NOT part of the product interface -- timing helper for bench.py: average kernel time (ms) of `reps` launches of the
  * fused kernel, measured with hipEvents recorded on `stream` around the launches. */
@@ -380,11 +392,26 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system *sys, const gbp_rj_options *opt
  * forwardmodel / derivative, TD/tdem1d.py:89-154).  opt->n_channels = the number of windows; chains->add_scale carries the
  * time-dependent additive error, rel_group / add_group the level of each channel.
  */
+/* Geometry mixing (transmitter / receiver attitude, azimuth of the receiver offset, X / Y / Z outputs; geobipy_amd/tdem_geometry.py):
+ * the frequency-domain kernels then produce the nodal spectra of the BASIS INTEGRALS of the transmitter-receiver frame
+ * (n_in values per row) and the spectrum entry m of the output components is the per-row real combination
+ *     out[m] = sum_{t < terms} weights[b, col[m, t]] * in[src[m, t]]        (src < 0: no term)
+ * formed inside gbp_td_apply_mix / the sampler's window stage.  n_in = 0: no mixing (the kernels' spectra are the outputs'). */
+typedef struct gbp_td_mix {
+    int32_t n_in;           /* nodal values per row written by the kernels = 2 * nF of `sys`; 0 = no mixing   */
+    int32_t terms;          /* T                                                                              */
+    int32_t n_weights;      /* weights per row                                                                */
+    const int32_t *src;     /* [dev] int32[n_nodal, T]                                                        */
+    const int32_t *col;     /* [dev] int32[n_nodal, T]                                                        */
+    const double *weights;  /* [dev] f64[B, n_weights]                                                        */
+} gbp_td_mix;
 typedef struct gbp_td_operator {
-    int32_t n_nodal;        /* rows of W = 2 * nF of `sys`                                                   */
+    int32_t n_nodal;        /* rows of W (= 2 * nF of `sys` without mixing)                                   */
     const double *W;        /* [dev] f64[n_nodal, n_channels], row-major                                      */
-    double *nodal;          /* [dev] scratch f64[B, n_nodal]                                                  */
-    double *J_nodal;        /* [dev] scratch f64[B, n_nodal, K]                                               */
+    double *nodal;          /* [dev] scratch f64[B, max(n_nodal, mix.n_in)]                                   */
+    double *J_nodal;        /* [dev] scratch f64[B, max(n_nodal, mix.n_in), K]                                */
+    gbp_td_mix mix;         /* geometry mixing, or n_in = 0                                                   */
+    const int32_t *table_set;  /* [dev] int32[B] or NULL: table set of every chain (gbp_hankel_system_add_set)  */
 } gbp_td_operator;
 /* The time-domain stage on its own (what TdemDataPoint.forward / sensitivity add to the frequency-domain kernels): for every
  * sounding with nlayers[b] > 0,  pred[b, :] = nodal[b, :] @ W  and, when J_nodal / J are given,
@@ -393,6 +420,9 @@ typedef struct gbp_td_operator {
  * pred f64[B, N], J f64[B, N, K]. */
 gbp_status gbp_td_apply(int B, int K, int n_nodal, int N, const int32_t *nlayers, const double *W, const double *nodal,
                         const double *J_nodal, double *pred, double *J, void *stream);
+/* Same with geometry mixing: nodal f64[B, mix->n_in], J_nodal f64[B, mix->n_in, K] (mix NULL or n_in = 0: as gbp_td_apply). */
+gbp_status gbp_td_apply_mix(int B, int K, int n_nodal, int N, const int32_t *nlayers, const double *W, const double *nodal,
+                            const double *J_nodal, double *pred, double *J, const gbp_td_mix *mix, void *stream);
 gbp_status gbp_rj_run_td(const gbp_fdem_system *sys, const gbp_td_operator *td, const gbp_rj_options *opt,
                          const gbp_rj_chains *c, int64_t first_iteration, int n_iterations, int accumulate, void *stream);
 /* Adds what the chains' current models are still owed to the hit maps (see hit_dwell); call before reading them. */
@@ -404,11 +434,21 @@ gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chain
  *   Geometry(tx_height, tx_roll, -tx_pitch, -tx_yaw, txrx_dx, txrx_dy, txrx_dz, rx_roll, -rx_pitch, -rx_yaw)   system/Loop_pair.py:70-77
  * gbp_tdem_system_create parses the TEXT of a .stm file ([host], NUL-terminated) and folds waveform, spline, low-pass
  * filters and windows into one matrix (geobipy_amd/csrc/gbp_tdem.h); w0[120] / w1[140]: the J0 / J1 Hankel filter weights
- * (the same [host] arrays gbp_fdem_system_create takes).  gbp_tdem_forward: geometry [host] f64[B, 10] as above -- level
- * flight only (non-zero attitude angles are refused); the receiver offset may change from row to row: the handle keeps one
- * table set per offset it has seen and all rows share one launch (gbp_hankel_system_add_set / _set_rows); nlayers / sigma / thk [dev] as in gbp_fdem_forward; out [dev]
- * f64[B, n_components * n_windows], components x then z, in the reference's sign convention for predicted_secondary_field
- * (TdemDataPoint.py:1013-1015).  Stream-ordered; the handle must not be used from two threads at once.
+ * (the same [host] arrays gbp_fdem_system_create takes).
+ * gbp_tdem_forward: geometry [host] f64[B, 10] = GA-AEM's tuple above, angles in degrees in GA-AEM's convention (x = flight
+ * direction, y = left, z = up; roll "left side up", pitch "nose down", yaw "turn left" positive; body -> earth matrix
+ * Rz(yaw) Ry(pitch) Rx(roll)) -- the reference's sign changes of pitch and yaw are the caller's, as they are in Loop_pair.py.
+ * Any attitude and any receiver offset per row, all rows in one launch: the handle keeps one table set per (horizontal
+ * distance, dz) it has seen (at most 4096 per layout: bin measured offsets, e.g. to 0.1 m) and a row's azimuth and attitude
+ * enter as a per-row mixing matrix of the nodal spectra (gbp_td_mix; geobipy_amd/tdem_geometry.py).  The conventions are restated
+ * from GA-AEM's published description and held against closed forms (tests/test_tdem_attitude.py), not against gatdaem1d:
+ * parity unpinned for non-zero angles.  nlayers / sigma / thk [dev] as in gbp_fdem_forward; out [dev] f64[B, n_components *
+ * n_windows], components x, y, z (those with a non-zero output scaling), in the reference's sign convention for
+ * predicted_secondary_field (TdemDataPoint.py:1004-1015).
+ * gbp_tdem_fm_dlogc: the same plus J [dev] f64[B, n_components * n_windows, Lmax] = d out / d ln sigma (columns >= nlayers[b]
+ * are 0) -- what the reference gets from gatdaem1d's fm_dlogc / derivative(CONDUCTIVITYDERIVATIVE, layer) x sigma
+ * (TD/tdem1d.py:98-154), here the exact derivative through the same kernels.
+ * Stream-ordered; the handle caches tables and scratch, so use it from one thread and one stream at a time.
  */
 typedef struct gbp_tdem_system gbp_tdem_system;
 gbp_status gbp_tdem_system_create(const char *stm_text, const double *w0, const double *w1, gbp_tdem_system **out);
@@ -422,6 +462,8 @@ gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system *sys, double eps);
 gbp_status gbp_tdem_system_tables(const gbp_tdem_system *sys, double *window_centres, double *node_frequencies, double *W);
 gbp_status gbp_tdem_forward(gbp_tdem_system *sys, int B, const double *geometry, int Lmax, const int32_t *nlayers,
                             const double *sigma, const double *thk, double *out, void *stream);
+gbp_status gbp_tdem_fm_dlogc(gbp_tdem_system *sys, int B, const double *geometry, int Lmax, const int32_t *nlayers,
+                             const double *sigma, const double *thk, double *out, double *J, void *stream);
 
 /* Diagnostics: [host] out[8] = accumulated 100 MHz clock ticks of chain 0 in the persistent kernel's stages (propose, fm_dlogc at
  * the remapped model, newton, forward / fm_dlogc at the proposal, accept), out[5] = iterations counted; synchronises the device.

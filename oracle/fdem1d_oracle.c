@@ -162,6 +162,13 @@ static void M1_0(coef_t *w, int nLayers, const double *thk, cx *rTE, cx *u0)
 static inline cx cpow2(cx a) { return cmul(a, a); }
 static inline cx cpow3(cx a) { return cmul(a, cmul(a, a)); }
 
+/* Test switch (NOT in the reference): 0 = the reference's M1_1 expression (FD:269-274), 1 = the true derivative of the forward
+ * recursion -- the reference's "(Y_2 - Yn_2) * tanuh + 2.0 * Yn_2" becomes "(Y_2 + Yn_2) * tanuh" (DESIGN.md 3.4).  Used by the CPU
+ * replays of device chains that run in exact-Jacobian mode (tests/config5_replay.py); checked against central differences of
+ * oracle_fdem1dfwd in tests/test_oracle_golden.py. */
+static int g_exact_jacobian = 0;
+void oracle_set_exact_jacobian(int exact) { g_exact_jacobian = exact != 0; }
+
 /* FD:222-303 M1_1: recursion + per-layer sensitivities sens[L,F,C] */
 static void M1_1(coef_t *w, int nLayers, const double *frequencies, const double *thk,
                  const double *par, const double *kappa, cx *u0, cx *sens)
@@ -200,6 +207,7 @@ static void M1_1(coef_t *w, int nLayers, const double *frequencies, const double
                 cx t2 = csub(cmul(kappaFactor, tanuh2), kappaFactor);
                 cx t3 = cmul(csub(Y_2, Yn_2), tanuh);
                 cx t4 = cscale(Yn_2, 2.0);
+                if (g_exact_jacobian) { t3 = cmul(cadd(Y_2, Yn_2), tanuh); t4 = cx_(0.0, 0.0); }
                 sens[(size_t)k2 * FC + (size_t)i * nC + jc] = cmul(lead, cadd(cadd(cadd(t1, t2), t3), t4));
             }
         }

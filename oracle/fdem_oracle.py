@@ -41,7 +41,14 @@ def lib():
         _LIB.oracle_fdem1dsen.restype = ctypes.c_int
         _LIB.oracle_fdem_forward_loglike_batch.restype = ctypes.c_int
         _LIB.oracle_gauss_loglike.restype = None
+        _LIB.oracle_set_exact_jacobian.restype = None
     return _LIB
+
+
+def set_exact_jacobian(exact):
+    """Test switch: ``sensitivity`` returns the true derivative of the forward recursion instead of the reference's M1_1
+    expression (which is not one).  Process-wide; the CPU replays of exact-Jacobian device chains set it."""
+    lib().oracle_set_exact_jacobian(ctypes.c_int(1 if exact else 0))
 
 
 def _d(a):

@@ -93,8 +93,8 @@ def secondary_fields(stm, sig, thk, alt, dx, dy, dz, freqs):
     return hz, hx
 
 
-def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=None):
-    """Window values in the reference's channel order (x windows then z windows, only scaled components)."""
+def _time_domain(stm, H_nodes, scale, fn):
+    """Windows of ONE component from its nodal spectrum: spline in log10 f -> waveform spectrum -> inverse FFT -> window averages."""
     f0, fs = float(stm["BaseFrequency"]), float(stm["WaveformDigitisingFrequency"])
     N = int(round(fs / f0))
     wt, wc = stm["wave"][:, 0], stm["wave"][:, 1]
@@ -106,8 +106,6 @@ def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=None):
         cur = np.interp(t, wt, wc)
     I = np.fft.rfft(cur)
     fk = np.arange(N // 2 + 1) * f0
-    fn = node_frequencies(stm, per_decade)
-    hz, hx = secondary_fields(stm, sig, thk, alt, dx, dy, dz, fn)
     moment = float(stm.get("NumberOfTurns", 1)) * float(stm.get("PeakCurrent", 1)) * float(stm.get("LoopArea", 1))
     fac = np.full(fk.size, MU0 * moment, dtype=complex)
     if stm.get("OutputType", "dB/dt").lower().startswith("db"):
@@ -115,22 +113,128 @@ def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=None):
     if "CutOffFrequency" in stm:
         for fc, n in zip(stm["CutOffFrequency"].split(), stm["Order"].split()):
             fac *= (1.0 / (1.0 + 1j * fk / float(fc))) ** int(float(n))
+    lf = np.log10(np.clip(fk[1:], fn[0], fn[-1]))
+    Hk = np.zeros(fk.size, complex)
+    Hk[1:] = CubicSpline(np.log10(fn), H_nodes.real, bc_type="natural")(lf) + 1j * CubicSpline(np.log10(fn), H_nodes.imag, bc_type="natural")(lf)
+    spec = I * fac * Hk * scale
+    spec[0] = 0.0
+    r = np.fft.irfft(spec, N)
+    out = []
+    for a, b in stm["windows"]:
+        if stm.get("WindowWeightingScheme", "Boxcar").lower().startswith("area"):
+            q = np.linspace(a, b, 257)
+            out.append(np.trapezoid(np.interp(q, t, r), q) / (b - a))
+        else:
+            m = (t >= a - BOXCAR_TOLERANCE) & (t <= b + BOXCAR_TOLERANCE)
+            out.append(r[m].mean())
+    return out
+
+
+def forward(stm, sig, thk, alt, dx, dy, dz, per_decade=None):
+    """Window values in the reference's channel order (x windows then z windows, only scaled components); level flight."""
+    fn = node_frequencies(stm, per_decade)
+    hz, hx = secondary_fields(stm, sig, thk, alt, dx, dy, dz, fn)
     out = []
     for comp, H in (("X", hx), ("Z", hz)):
         scale = float(stm.get(comp + "OutputScaling", 0.0))
-        if scale == 0.0:
-            continue
-        lf = np.log10(np.clip(fk[1:], fn[0], fn[-1]))
-        Hk = np.zeros(fk.size, complex)
-        Hk[1:] = CubicSpline(np.log10(fn), H.real, bc_type="natural")(lf) + 1j * CubicSpline(np.log10(fn), H.imag, bc_type="natural")(lf)
-        spec = I * fac * Hk * scale
-        spec[0] = 0.0
-        r = np.fft.irfft(spec, N)
-        for a, b in stm["windows"]:
-            if stm.get("WindowWeightingScheme", "Boxcar").lower().startswith("area"):
-                q = np.linspace(a, b, 257)
-                out.append(np.trapezoid(np.interp(q, t, r), q) / (b - a))
-            else:
-                m = (t >= a - BOXCAR_TOLERANCE) & (t <= b + BOXCAR_TOLERANCE)
-                out.append(r[m].mean())
+        if scale != 0.0:
+            out += _time_domain(stm, H, scale, fn)
+    return np.array(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Attitude (roll / pitch / yaw of both loops) and the Y component.  PARITY UNPINNED: every known answer the reference holds is
+# level flight, and the rotation conventions are those of the absent gatdaem1d behind Loop_pair.Geometry (system/Loop_pair.py:
+# 63-77).  Restated from GA-AEM's published geometry description: x = flight direction, y = left (port), z = up; roll
+# "left side up", pitch "nose down" and yaw "turn left" positive = right-handed rotations about x, y, z; body -> earth matrix
+# R = Rz(yaw) Ry(pitch) Rx(roll); the transmitter moment is R_tx z^, the receiver reports the field along its own rotated axes,
+# R_rx^T H.  This code is held against closed forms instead (tests/test_tdem_attitude.py): the image dipole of a perfect
+# conductor for any orientation, rigid rotations of the whole system about the vertical, the 90 degree identities.
+# Written in earth (x, y) coordinates with the second derivatives of the potential -- NOT the product's rho-frame basis
+# integrals (geobipy_amd/tdem_geometry.py) -- so the two are independent statements of the same physics.
+# ------------------------------------------------------------------------------------------------------------------------
+def rotation(roll, pitch, yaw):
+    """Body -> earth rotation matrix, angles in degrees (GA-AEM sign semantics)."""
+    r, p, y = np.deg2rad([roll, pitch, yaw])
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def field_vector(stm, sig, thk, geometry, freqs, rte_fn=None):
+    """Secondary magnetic field per unit moment along the RECEIVER's axes, complex [n_freq, 3], for GA-AEM's geometry tuple
+    (tx_height, tx_roll, tx_pitch, tx_yaw, dx, dy, dz, rx_roll, rx_pitch, rx_yaw).  Above the ground the secondary field is
+    -grad of  Phi = (1/4pi) (m_x d/dx + m_y d/dy - m_z d/dZ) G,  G(x, y, Z) = Int rTE e^{-lam Z} J0(lam rho) dlam,  Z = 2 h + dz;
+    the vertical part of the moment radiates as the horizontal loop of the system (ModellingLoopRadius), the horizontal part
+    as a dipole.  ``rte_fn(lam, omega)`` overrides the layered-earth reflection coefficient (tests: -1 = perfect conductor)."""
+    h, dx, dy, dz = geometry[0], geometry[4], geometry[5], geometry[6]
+    m = rotation(*geometry[1:4]) @ np.array([0.0, 0.0, 1.0])
+    Rrx = rotation(*geometry[7:10])
+    rho = np.hypot(dx, dy)
+    assert rho > 0.0, "oracle: general geometry needs an off-axis receiver"
+    a = float(stm.get("ModellingLoopRadius", 0.0))
+    l0, l1 = base_abscissae()
+    lam0, lam1 = l0 / rho, l1 / rho
+    Z = 2.0 * h + dz
+    out = np.empty((len(freqs), 3), complex)
+    for i, f in enumerate(freqs):
+        om = 2 * np.pi * f
+        K0 = (rte_fn(lam0, om) if rte_fn else rte(lam0, om, sig, thk)) * np.exp(-lam0 * Z)
+        K1 = (rte_fn(lam1, om) if rte_fn else rte(lam1, om, sig, thk)) * np.exp(-lam1 * Z)
+        I0 = np.sum(K0 * lam0 ** 2 * W0_J0_120) / rho                     # Int K lam^2 J0
+        I1 = np.sum(K1 * lam1 ** 2 * W1_J1_140) / rho                     # Int K lam^2 J1
+        A1 = np.sum(K1 * lam1 * W1_J1_140) / rho                          # Int K lam   J1
+        if a > 0:                                                        # loop source for the vertical moment
+            I0L = np.sum(K0 * lam0 * j1(lam0 * a) / (2 * np.pi * a) * W0_J0_120) / rho
+            I1L = np.sum(K1 * lam1 * j1(lam1 * a) / (2 * np.pi * a) * W1_J1_140) / rho
+        else:
+            I0L, I1L = I0 / (4 * np.pi), I1 / (4 * np.pi)
+        Grr = -I0 + A1 / rho                                              # d2G/drho2
+        Gr_r = -A1 / rho                                                  # (dG/drho) / rho
+        Gxx = (dx * dx * Grr + dy * dy * Gr_r) / rho ** 2
+        Gyy = (dy * dy * Grr + dx * dx * Gr_r) / rho ** 2
+        Gxy = dx * dy * (Grr - Gr_r) / rho ** 2
+        k = 1.0 / (4 * np.pi)
+        Hx = -k * (m[0] * Gxx + m[1] * Gxy) + m[2] * (dx / rho) * I1L
+        Hy = -k * (m[0] * Gxy + m[1] * Gyy) + m[2] * (dy / rho) * I1L
+        Hz = -k * (m[0] * dx + m[1] * dy) / rho * I1 + m[2] * I0L
+        out[i] = Rrx.T @ np.array([Hx, Hy, Hz])
+    return out
+
+
+OUTPUT_SIGN = {"X": -1.0, "Y": -1.0, "Z": 1.0}   # reference's predicted_secondary_field vs the physical frequency-domain field, with
+                                               # the -dB/dt convention of `_time_domain` (pinned on Z by the CSVs; TdemDataPoint.py:1013-1015)
+
+
+def forward_geometry(stm, sig, thk, geometry, per_decade=None):
+    """Windows for GA-AEM's geometry tuple with attitude; components X, Y, Z (those with a non-zero output scaling)."""
+    fn = node_frequencies(stm, per_decade)
+    c = field_vector(stm, sig, thk, np.asarray(geometry, dtype=float), fn)
+    out = []
+    for j, comp in enumerate("XYZ"):
+        scale = float(stm.get(comp + "OutputScaling", 0.0))
+        if scale != 0.0:
+            out += _time_domain(stm, OUTPUT_SIGN[comp] * c[:, j], scale, fn)
+    return np.array(out)
+
+
+def dipole_field(m, R):
+    """Free-space magnetic field (per 1/mu0) of a dipole with moment vector m at displacement R."""
+    Rn = np.linalg.norm(R)
+    return (3.0 * np.dot(m, R) * R / Rn ** 2 - m) / (4 * np.pi * Rn ** 3)
+
+
+def primary_field(stm, geometry):
+    """(PX, PY, PZ) in the reference's convention (TdemDataPoint.py:1004-1015: z negated), output units, scaled components only:
+    free-space field of the rotated transmitter dipole along the receiver's axes."""
+    g = np.asarray(geometry, dtype=float)
+    m = rotation(*g[1:4]) @ np.array([0.0, 0.0, 1.0])
+    moment = float(stm.get("NumberOfTurns", 1)) * float(stm.get("PeakCurrent", 1)) * float(stm.get("LoopArea", 1))
+    c = rotation(*g[7:10]).T @ dipole_field(m, g[4:7]) * MU0 * moment
+    out = []
+    for j, (comp, sgn) in enumerate((("X", 1.0), ("Y", 1.0), ("Z", -1.0))):
+        scale = float(stm.get(comp + "OutputScaling", 0.0))
+        if scale != 0.0:
+            out.append(sgn * scale * c[j])
     return np.array(out)

@@ -16,7 +16,8 @@ def _one(spec):
     from geobipy_amd import rjmcmc
     from conftest import oracle_system
     from oracle import fdem_oracle as fo
-    (o, seed, chain, system_name, z, data, sigma0, rel0, add0, log_mean, n_depth_bins, depth_bin_width, n_it, every, prior_kw) = spec
+    (o, seed, chain, system_name, z, data, sigma0, rel0, add0, log_mean, n_depth_bins, depth_bin_width, n_it, every, prior_kw) = spec[:15]
+    fo.set_exact_jacobian(bool(spec[15]) if len(spec) > 15 else False)      # (worker processes: one chain at a time)
 
     class Engine:
         def __init__(self):
@@ -48,9 +49,10 @@ def _one(spec):
     return dict(chain=chain, marks=np.array(marks), k_hist=c.k_hist, edge_hist=c.edge_hist, sigma=c.sigma, misfit=c.misfit)
 
 
-def specs_from_device(dc, rows, system_name, n_it, every, data, heights, system=None):
+def specs_from_device(dc, rows, system_name, n_it, every, data, heights, system=None, exact=False):
     """Build the worker arguments for the sampled ``rows`` of a DeviceChains block right after its initialisation.
-    ``system_name``: a system file of tests/golden, or None with ``system`` = a geobipy_amd.FdemSystem."""
+    ``system_name``: a system file of tests/golden, or None with ``system`` = a geobipy_amd.FdemSystem.  ``exact``: the CPU chain
+    uses the true-derivative Jacobian (oracle test switch) -- for device chains run with exact_jacobian=True."""
     if system_name is None:
         s = system
         system_name = (np.asarray(s.frequencies), list(s.transmitter.orientation), np.asarray(s.transmitter.moment),
@@ -69,7 +71,7 @@ def specs_from_device(dc, rows, system_name, n_it, every, data, heights, system=
     rel0, add0 = dc.rel[:, 0].cpu().numpy(), dc.add[:, 0].cpu().numpy()
     first = int(o.first_chain)
     return [(eo, int(o.seed), first + int(b), system_name, float(heights[b]), np.asarray(data[b], dtype=np.float64), float(sig0[b]),
-             float(rel0[b]), float(add0[b]), float(lm[b]), dc.n_depth_bins, dc.depth_bin_width, int(n_it), int(every), prior_kw)
+             float(rel0[b]), float(add0[b]), float(lm[b]), dc.n_depth_bins, dc.depth_bin_width, int(n_it), int(every), prior_kw, bool(exact))
             for b in rows]
 
 
