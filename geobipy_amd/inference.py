@@ -62,16 +62,23 @@ def _priors_from_options(o, value_mean):
                                 o["probability_of_no_change"]])
     vp = rjmcmc.ValuePrior(value_mean, o["factor"], o["gradient_standard_deviation"], o["solve_gradient"],
                            bool(o.get("solve_parameter", False)), o.get("parameter_limits"))
-    rp = rjmcmc.ErrorPrior(o["minimum_relative_error"], o["maximum_relative_error"], o["relative_error_proposal_variance"])
-    ap = rjmcmc.ErrorPrior(o["minimum_additive_error"], o["maximum_additive_error"], o["additive_error_proposal_variance"])
+    # error levels: scalars (frequency-domain data, one level each) or lists per level (time-domain options files:
+    # one relative level per system x component, one additive level per system)
+    lv = lambda key: o[key] if np.ndim(o[key]) == 0 else np.asarray(o[key], dtype=np.float64)
+    rp = rjmcmc.ErrorPrior(lv("minimum_relative_error"), lv("maximum_relative_error"), lv("relative_error_proposal_variance"))
+    ap = rjmcmc.ErrorPrior(lv("minimum_additive_error"), lv("maximum_additive_error"), lv("additive_error_proposal_variance"))
     return sp, vp, rp, ap
 
 
-def initial_state(engine, data, o):
+def initial_state(engine, data, o, error_model=None):
     """Inference1D.initialize (inversion/Inference1D.py:353-464, 485-535): best half-space out of 100 log-spaced
     conductivities (EmDataPoint.find_best_halfspace), its forward / Jacobian, prior and likelihood."""
     rel, add = o["initial_relative_error"], o["initial_additive_error"]
-    std = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+    if error_model is None:
+        std = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+    else:
+        rel, add = np.atleast_1d(np.asarray(rel, dtype=np.float64)), np.atleast_1d(np.asarray(add, dtype=np.float64))
+        std = error_model.std(data, rel, add)
     grid = np.logspace(-4.0, 4.0, 100)
     none = np.zeros(0)
     models = [(none, np.array([c])) for c in grid]
@@ -98,10 +105,12 @@ class Posteriors:
                  relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99):
         self.ratio = ratio
         # error levels (DataPoint.set_posteriors :651-694): n_error_bins cells, uniform in log10 between the prior bounds
-        self.rel_edges = None if relative_error_bounds is None else np.linspace(*np.log10(relative_error_bounds), n_error_bins + 1)
-        self.add_edges = None if additive_error_bounds is None else np.linspace(*np.log10(additive_error_bounds), n_error_bins + 1)
-        self.relative_error = np.zeros(n_error_bins, dtype=np.int64)
-        self.additive_error = np.zeros(n_error_bins, dtype=np.int64)
+        # (several levels -- time-domain data: bounds are arrays, one histogram per level: edges [G, n + 1], counts [G, n])
+        grid = lambda b: None if b is None else np.linspace(*np.log10(np.asarray(b, dtype=np.float64)), n_error_bins + 1).T
+        self.rel_edges, self.add_edges = grid(relative_error_bounds), grid(additive_error_bounds)
+        shape = lambda e: (n_error_bins,) if e is None or e.ndim == 1 else (e.shape[0], n_error_bins)
+        self.relative_error = np.zeros(shape(self.rel_edges), dtype=np.int64)
+        self.additive_error = np.zeros(shape(self.add_edges), dtype=np.int64)
         self.depth_edges = np.arange(0.0, 1.1 * max_edge, 0.5 * min_width)
         self.depth_centres = 0.5 * (self.depth_edges[:-1] + self.depth_edges[1:])
         half = 4.0 * np.sqrt(np.log(1.0 + factor) ** 2.0)           # MvNormal.bins(nBins, nStd=4): +- 4 std of ln sigma ...
@@ -119,7 +128,11 @@ class Posteriors:
         """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels."""
         for x, grid, hist in ((rel, self.rel_edges, self.relative_error), (add, self.add_edges, self.additive_error)):
             if x is not None and grid is not None:
-                hist[np.clip(np.searchsorted(grid, np.log10(x), side="right") - 1, 0, hist.size - 1)] += 1
+                if grid.ndim == 1:
+                    hist[np.clip(np.searchsorted(grid, np.log10(x), side="right") - 1, 0, hist.size - 1)] += 1
+                else:
+                    for g_, xv in enumerate(np.atleast_1d(x)):
+                        hist[g_, np.clip(np.searchsorted(grid[g_], np.log10(xv), side="right") - 1, 0, hist.shape[1] - 1)] += 1
         k = values.size
         self.n_cells[k] += 1
         if k > 1:
@@ -168,12 +181,22 @@ class Inference1D:
         self.on_update = None                      # optional callback(self) after every update of infer()'s schedule
 
     def initialize(self, datapoint):
-        """``datapoint``: geobipy_amd.FdemDataPoint (its data, altitude and system are used)."""
+        """``datapoint``: geobipy_amd.FdemDataPoint or TdemDataPoint (its data, altitude, geometry and systems are used).  A
+        time-domain data point brings its own engine (TdemEngine: the frequency-domain kernels on the spline nodes + the
+        window operator) and error model (a relative level per system x component, an additive level per system scaled by
+        sqrt(1e-3 / t) per gate: TdemDataPoint.py:361-365); the options then carry lists per level, as the reference's
+        skytem_options / tempest_options do."""
         self.datapoint = datapoint
         self.data = np.asarray(datapoint.data, dtype=np.float64)
+        self.error_model = datapoint.error_model() if hasattr(datapoint, "error_model") else None
         if self.engine is None:
-            self.engine = getattr(datapoint, "engine", None) or GpuEngine(datapoint.system[0], datapoint.z[0])
-        self.priors, self.state = initial_state(self.engine, self.data, self.options)
+            self.engine = getattr(datapoint, "engine", None)
+        if self.engine is None:
+            if hasattr(datapoint, "make_engine"):
+                self.engine = datapoint.make_engine(lmax=int(self.options["maximum_number_of_layers"]) + 2)
+            else:
+                self.engine = GpuEngine(datapoint.system[0], datapoint.z[0])
+        self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model)
         self.halfspace = self.state.values.copy()
         self.iteration = 0
         self.data_misfit_v = np.zeros(2 * self.n_markov_chains + 2)
@@ -211,7 +234,7 @@ class Inference1D:
     def accept_reject(self):
         sp, vp, rp, ap = self.priors
         self.accepted, self.state = rjmcmc.accept_reject(self.prng, self.state, self.data, self.engine, sp, vp, rp, ap,
-                                                         self.options["covariance_scaling"])
+                                                         self.options["covariance_scaling"], getattr(self, "error_model", None))
         return False
 
     def update(self):
@@ -290,7 +313,7 @@ class Inference1D:
     def reset(self):
         """Inference1D.reset (:984-999): back to the initial state of this sounding; the random stream is not rewound."""
         self.n_resets += 1
-        self.priors, self.state = initial_state(self.engine, self.data, self.options)
+        self.priors, self.state = initial_state(self.engine, self.data, self.options, getattr(self, "error_model", None))
         self.iteration = 0
         self.data_misfit_v[:] = 0.0
         self.data_misfit_v[0] = self.state.misfit

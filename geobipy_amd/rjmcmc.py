@@ -146,19 +146,35 @@ def propose_values(prng, mean, H):
 # ------------------------------------------------------------------------------------------------------------
 class ErrorPrior:
     """Log-uniform prior [lo, hi] and log-normal random-walk proposal of one error level
-    (DataPoint.set_priors / set_proposals, data/datapoint/DataPoint.py:575-644)."""
+    (DataPoint.set_priors / set_proposals, data/datapoint/DataPoint.py:575-644) -- or, with array arguments, of the error
+    levels of a time-domain data point (one relative level per system x component, one additive level per system:
+    TdemDataPoint.py:361-365), which the reference proposes and redraws JOINTLY (one multivariate draw, StatArray.propose)."""
 
     def __init__(self, lo, hi, proposal_variance):
-        self.lo, self.hi, self.var = np.log(lo), np.log(hi), proposal_variance
+        self.lo, self.hi = np.log(lo), np.log(hi)
+        self.var = proposal_variance if np.ndim(lo) == 0 else np.broadcast_to(np.asarray(proposal_variance, dtype=np.float64), np.shape(lo)).copy()
 
     def log_prior(self, x):
         lx = np.log(x)
+        if np.ndim(lx) > 0:
+            return -np.sum(np.log(self.hi - self.lo)) if np.all((self.lo <= lx) & (lx <= self.hi)) else -np.inf
         return -np.log(self.hi - self.lo) if (self.lo <= lx <= self.hi) else -np.inf
 
     def propose(self, prng, current):
         """StatArray.propose with imposePrior=True, log=True (statistics/StatArray.py:578-638).  The reference draws
         with Generator.multivariate_normal on a 1 x 1 covariance, which numpy evaluates as
         mean + standard_normal() * sqrt(var) (SVD of a positive 1 x 1 matrix: s = var, vh = 1)."""
+        if np.ndim(current) > 0:                 # several levels: the reference's own call, one joint draw per try
+            cur = np.asarray(current, dtype=np.float64)
+            draw_n = lambda: np.exp(prng.multivariate_normal(np.log(cur), np.diag(np.broadcast_to(self.var, cur.shape)), size=1)[0])
+            x = draw_n()
+            tries = 0
+            while self.log_prior(x) == -np.inf:
+                x = draw_n()
+                tries += 1
+                if tries == 10:
+                    return cur.copy()
+            return x
         lc, sd = np.log(current), np.sqrt(self.var)
         draw = lambda: float(np.exp(lc + prng.standard_normal() * sd))
         x = draw()
@@ -207,12 +223,37 @@ def gauss_loglike(pred, data, std):
     return chi2, float(-(0.5 * a.sum()) * np.log(2.0 * np.pi) - np.sum(np.log(std[a])) - 0.5 * chi2)
 
 
+class ErrorModel:
+    """Standard deviation of every channel from the error levels: DataPoint.std (data/datapoint/DataPoint.py:268-282: one
+    relative and one additive level) or, with channel -> level maps, TdemDataPoint.std (TdemDataPoint.py:361-365:
+    sigma_i^2 = (rel_{system, component} d_i)^2 + (add_system sqrt(1e-3 / t_i))^2)."""
+
+    def __init__(self, rel_group=None, add_group=None, add_scale=None, stale_prediction=False):
+        # stale_prediction: the reference's TdemDataPoint.fm_dlogc (TdemDataPoint.py:1031-1055) stores the Jacobian of the
+        # remapped model but NOT its prediction (the assignment is commented out there), so the stochastic-Newton gradient of a
+        # time-domain chain is formed with the prediction of the CURRENT model (Model.py:383-399) -- reproduced on request
+        self.stale_prediction = bool(stale_prediction)
+        self.rel_group = None if rel_group is None else np.asarray(rel_group, dtype=np.int64)
+        self.add_group = None if add_group is None else np.asarray(add_group, dtype=np.int64)
+        self.add_scale = None if add_scale is None else np.asarray(add_scale, dtype=np.float64)
+
+    def std(self, data, rel, add):
+        if self.rel_group is None:
+            return np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+        rel, add = np.atleast_1d(rel), np.atleast_1d(add)
+        return np.sqrt((rel[self.rel_group] * data) ** 2.0 + (add[self.add_group] * self.add_scale) ** 2.0)
+
+
+_PLAIN_ERRORS = ErrorModel()
+
+
 class ChainState:
     """What Inference1D carries between iterations for one sounding."""
 
     def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit):
         self.edges, self.values = np.array(edges, dtype=np.float64), np.array(values, dtype=np.float64)
-        self.rel, self.add = float(rel), float(add)
+        self.rel = float(rel) if np.ndim(rel) == 0 else np.array(rel, dtype=np.float64)
+        self.add = float(add) if np.ndim(add) == 0 else np.array(add, dtype=np.float64)
         self.pred, self.J = np.array(pred, dtype=np.float64), np.array(J, dtype=np.float64)
         self.prior, self.like, self.misfit = float(prior), float(like), float(misfit)
 
@@ -221,7 +262,7 @@ class ChainState:
         return self.values.size
 
 
-def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0):
+def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None):
     """One iteration of Inference1D.accept_reject (inversion/Inference1D.py:537-631) for the Resolve-style option
     set (solve_gradient, solve relative / additive error, no height move), written as a coroutine around the hot
     path: it yields ``(phase, (edges, values))`` whenever it needs the kernels --
@@ -237,13 +278,16 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
         pred_rem, J = yield (0, (edges, rem))
     else:
         pred_rem, J = state.pred, state.J
-    std = np.sqrt((state.rel * data) ** 2.0 + state.add ** 2.0)
+    em = _PLAIN_ERRORS if error_model is None else error_model
+    if em.stale_prediction:
+        pred_rem = state.pred
+    std = em.std(data, state.rel, state.add)
     mean, H = stochastic_newton(vp, edges, rem, J, pred_rem, data, std, alpha)
     prop = propose_values(prng, mean, H)
     rel = rel_prior.propose(prng, state.rel)                    # DataPoint.perturb, DataPoint.py:531-573
     add = add_prior.propose(prng, state.add)
     pred, _ = yield (1, (edges, prop))
-    std_t = np.sqrt((rel * data) ** 2.0 + add ** 2.0)
+    std_t = em.std(data, rel, add)
     misfit, like = gauss_loglike(pred, data, std_t)
     prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
     if prior == -np.inf:
@@ -277,10 +321,10 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit))
 
 
-def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0):
+def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None):
     """Drive ``accept_reject_phases`` for one chain with ``engine.forward(edges, values)`` /
     ``engine.sensitivity(edges, values)`` (GPU kernels in the product).  Returns (accepted, state)."""
-    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha)
+    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha, error_model)
     req = next(g)
     while req[0] != 3:
         phase, (e, v) = req

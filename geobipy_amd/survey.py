@@ -152,12 +152,15 @@ class TdemData:
     the window data of every system, columns ``S<system><component>_time_<t>`` of the reference's CSV files in file order
     (system 0 component X then Z windows, system 1 ...), which is TdemBatch's channel layout.  ``offset``: one (dx, dy, dz) for
     the set or one per sounding [nPoints, 3] (columns txrx_dx / dy / dz); the Hankel tables depend on it, so ``infer`` builds one
-    table set per distinct offset and every chain runs with its own.  ``primary_field`` [nPoints, components]: the PX / PY / PZ
-    columns of Tempest files (TempestData.py), kept for the caller, NaN when absent.  Attitude angles must be zero."""
+    table set per distinct (horizontal distance, dz) and every chain runs with its own.  ``primary_field`` [nPoints, components]:
+    the PX / PY / PZ columns of Tempest files (TempestData.py), kept for the caller, NaN when absent.  ``loop_angles``
+    [nPoints, 6]: the file's tx_pitch, tx_roll, tx_yaw, rx_pitch, rx_roll, rx_yaw columns (degrees, the reference's own
+    convention; TdemData.py:588-589); ``attitude`` is what Loop_pair.Geometry hands GA-AEM from them (roll, -pitch, -yaw per
+    loop, Loop_pair.py:70-77) and what the kernels' geometry mixing takes."""
 
     MAX_OFFSET_SETS = 4096
 
-    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset, primary_field=None):
+    def __init__(self, system, lineNumber, fiducial, x, y, z, elevation, data, offset, primary_field=None, loop_angles=None):
         from .tdem import TdemSystem
         systems = [system] if isinstance(system, (str, TdemSystem)) else list(system)
         self.system = [s if isinstance(s, TdemSystem) else TdemSystem(s) for s in systems]
@@ -168,6 +171,7 @@ class TdemData:
         off = np.asarray(offset, dtype=np.float64)
         self.offsets = np.array(np.broadcast_to(off, (self.x.size, 3)), dtype=np.float64)      # per sounding (own, writable copy)
         self.primary_field = None if primary_field is None else f64(primary_field)
+        self.loop_angles = np.zeros((self.x.size, 6)) if loop_angles is None else np.array(np.broadcast_to(f64(loop_angles), (self.x.size, 6)))
         n = sum(s.n_components * s.nwindows for s in self.system)
         assert self.data.shape == (self.nPoints, n), ValueError("data must have shape (nPoints, {})".format(n))
 
@@ -178,6 +182,12 @@ class TdemData:
     @property
     def nChannels(self):
         return self.data.shape[1]
+
+    @property
+    def attitude(self):
+        """[nPoints, 6] (tx roll, pitch, yaw, rx roll, pitch, yaw) in GA-AEM's convention (Loop_pair.py:70-77)."""
+        a = self.loop_angles
+        return np.stack([a[:, 1], -a[:, 0], -a[:, 2], a[:, 4], -a[:, 3], -a[:, 5]], axis=1)
 
     @property
     def offset(self):
@@ -212,18 +222,17 @@ class TdemData:
         table = np.atleast_2d(np.loadtxt(data_filename, delimiter=",", skiprows=1))
         off = np.stack([table[:, low.index(k)] for k in ("txrx_dx", "txrx_dy", "txrx_dz")], axis=1)
         pcols = sorted(j for j, h in enumerate(low) if h in ("px", "py", "pz"))            # TdemData.py:632, primary_channels.sort()
-        for k in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"):
-            if k in low:
-                assert not np.any(table[:, low.index(k)]), NotImplementedError("attitude angles are not supported (level flight)")
+        angles = np.stack([table[:, low.index(k)] if k in low else np.zeros(table.shape[0])
+                           for k in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw")], axis=1)
         c = lambda r: table[:, idx[r]]
         return cls(system_filename, c("line"), c("fid"), c("x"), c("y"), c("z"),
                    table[:, elev] if elev is not None else np.zeros(table.shape[0]), table[:, dcols], off,
-                   primary_field=table[:, pcols] if pcols else None)
+                   primary_field=table[:, pcols] if pcols else None, loop_angles=angles)
 
     def subset(self, rows):
         return type(self)(self.system, self.lineNumber[rows], self.fiducial[rows], self.x[rows], self.y[rows], self.z[rows],
                           self.elevation[rows], self.data[rows], self.offsets[rows],
-                          primary_field=None if self.primary_field is None else self.primary_field[rows])
+                          primary_field=None if self.primary_field is None else self.primary_field[rows], loop_angles=self.loop_angles[rows])
 
 
 class TempestData(TdemData):
@@ -419,7 +428,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             kw["chain_id"] = int(rows[0]) + idx
         if time_domain:
             from .tdem import TdemDeviceChains
-            dc = TdemDeviceChains(ds.system, ds.z[idx], ds.data[idx], offset, **kw)
+            dc = TdemDeviceChains(ds.system, ds.z[idx], ds.data[idx], offset, attitude=ds.attitude[idx] if idx.size else None, **kw)
         else:
             dc = DeviceChains(ds.system, ds.z[idx], ds.data[idx], exact_jacobian=exact_jacobian, **kw)
         dc.infer(check_every=check_every)
@@ -467,12 +476,13 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
         span = np.arange(first, first + count)
         if time_domain:
-            # the Hankel tables depend on the transmitter-receiver offset: the block's handle holds one table set per distinct
-            # offset and every chain runs with its own (TdemDeviceChains(offset=[n, 3])) -- one block whatever the geometry
-            n_off = len(ds.offset_groups(span)) if count > 0 else 1
+            # the Hankel tables depend on the horizontal transmitter-receiver distance and dz: the block's handle holds one table
+            # set per distinct pair and every chain runs with its own; azimuth and attitude are per-chain mixing weights
+            # (TdemDeviceChains(offset=[n, 3], attitude=[n, 6])) -- one block whatever the geometry
+            n_off = np.unique(np.c_[np.hypot(ds.offsets[span, 0], ds.offsets[span, 1]), ds.offsets[span, 2]], axis=0).shape[0] if count > 0 else 1
             if n_off > TdemData.MAX_OFFSET_SETS:
-                raise NotImplementedError("{} distinct transmitter-receiver offsets in {} soundings: the device sampler holds one set of "
-                                          "Hankel tables (~2 MB) per offset -- bin the offsets (e.g. to 0.1 m) first".format(n_off, count))
+                raise NotImplementedError("{} distinct (horizontal distance, dz) receiver offsets in {} soundings: the device sampler holds one "
+                                          "set of Hankel tables (~0.15 MB x (1 + altitude bins)) per pair -- bin the offsets (e.g. to 0.1 m) first".format(n_off, count))
             blocks = [(ds.offsets[span] if count > 0 else (0.0, 0.0, 0.0), span)]
         else:
             blocks = [(None, span)]

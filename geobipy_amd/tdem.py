@@ -24,7 +24,9 @@ Conventions recovered from the reference's fixtures: moment = NumberOfTurns * Pe
 an order-n ``LowPassFilter`` is n cascaded first-order sections; a waveform table that covers half a period
 is continued with opposite polarity; "dB/dt" output is the receiver voltage convention -dB/dt; the
 reference negates GA-AEM's z components (TdemDataPoint.py:1013-1015), which makes Z positive-up.
-Limitations: level flight (pitch = roll = yaw = 0); soundings are evaluated in groups of equal Tx-Rx offset.
+Geometry: any receiver offset and any attitude (roll / pitch / yaw of both loops) per sounding, X / Y / Z outputs -- the
+kernels evaluate the basis integrals of the transmitter-receiver frame and a per-row matrix mixes their spectra into the output
+components inside the window kernel (geobipy_amd/tdem_geometry.py); non-zero angles are unpinned by any reference vector.
 """
 import ctypes
 
@@ -34,6 +36,7 @@ import torch
 from . import _lib
 from .rjmcmc_gpu import DeviceChains
 from .filters import W0_J0_120, W1_J1_140, base_abscissae
+from .tdem_geometry import ON_AXIS_RHO, GeometryMix, from_loops, gaaem_geometry
 
 MU0 = 4.0e-7 * np.pi
 
@@ -102,7 +105,6 @@ class TdemSystem:
         self.output_type = d.get("OutputType", "dB/dt").strip()
         self.scaling = {c: float(d.get(c.upper() + "OutputScaling", 0.0)) for c in "xyz"}
         self._components = [c for c in "xyz" if self.scaling[c] != 0.0]
-        assert "y" not in self._components, NotImplementedError("Y component output is not supported")
         self.frequencies_per_decade = float(d.get("FrequenciesPerDecade", 5))
         # GA-AEM's Hankel quadrature size; this implementation evaluates the same integrals with the 120 / 140-point
         # digital filters of the FDEM path (difference < 2e-5 of the largest gate, scripts/tdem_study/README.md)
@@ -212,35 +214,53 @@ class TdemSystem:
         return W
 
     # -- Hankel tables of the frequency-domain stage ------------------------------------------------------
-    def hankel_tables(self, dx, dy, dz):
-        """Raw point tables for gbp_hankel_system_create_raw, one "frequency" per (component, node), all 120 / 140 filter
-        abscissae (the per-sounding abscissa windows are cut from them by gbp_hankel_system_add_bins).
+    def hankel_tables(self, rho, dz, basis=(0,)):
+        """Raw point tables for gbp_hankel_system_create_raw: one "frequency" per (basis integral, node), in that order, all
+        120 / 140 filter abscissae (the per-sounding abscissa windows are cut from them by gbp_hankel_system_add_bins).
+        ``rho``: horizontal transmitter-receiver distance, ``dz``: receiver height above the transmitter, ``basis``: indices
+        into tdem_geometry.BASIS -- with K = rTE e^{-lam (2 alt + dz)} and s(lam) = lam J1(lam a) / (2 pi a) the source term of
+        the system's horizontal loop of radius a (a = 0: lam^2 / 4 pi, a vertical dipole):
 
-        Vertical field of a horizontal loop of radius a carrying the current of a unit-moment dipole, at
-        horizontal distance r and total height (z_tx + z_rx) = 2*altitude + dz:
-            Hz = 1/(2 pi a) Int rTE e^{-lam (2 alt + dz)} lam J1(lam a) J0(lam r) dlam      (a -> 0: lam^2/4pi)
-            Hx = -(dx/r) * same with J1(lam r)
-        """
+            0 B0L = Int K s J0(lam rho)      1 B1L = Int K s J1(lam rho)           (vertical part of the moment)
+            2 B0  = Int K lam^2 J0 / 4 pi    3 B1  = Int K lam^2 J1 / 4 pi    4 BA = Int K lam J1 / (4 pi rho)   (horizontal part)
+
+        Level flight needs B0L (Z output) and B1L (X, Y); output sign and scaling are NOT in the tables (they are in the rows'
+        mixing weights).  A receiver on the transmitter's axis (rho = 0): B0L through the loop's own J1(lam a) as the filter
+        kernel, B0 at ``ON_AXIS_RHO``; the others vanish."""
         from scipy.special import j1
-        r = float(np.hypot(dx, dy))
-        a = self._loop_radius
-        rs = r if r > 0.0 else (a if a > 0.0 else 1.0)           # abscissa scale when the receiver is on the axis
+        rho, a, k4 = float(rho), self._loop_radius, 1.0 / (4.0 * np.pi)
+        on_axis = rho == 0.0
+        if on_axis and not a > 0.0:
+            raise ValueError("a receiver on the axis needs a finite ModellingLoopRadius")
         l0, l1 = base_abscissae()
         fn = self.node_frequencies()
+        srcz = (lambda lam: lam * j1(lam * a) / (2.0 * np.pi * a)) if a > 0.0 else (lambda lam: lam * lam * k4)
         npts, wmu, hd0, g, cols = [], [], [], [], []
-        for comp in self._components:
-            on_axis = r == 0.0                                     # J0(0) = 1: the loop's own J1(lam a) is the filter kernel
-            if on_axis and not a > 0.0:
-                raise ValueError("a receiver on the axis needs a finite ModellingLoopRadius")
-            if comp == "z":
-                lam, w = (l1 / a, W1_J1_140 / a) if on_axis else (l0 / rs, W0_J0_120 / rs)
+        for i in basis:
+            if on_axis:
+                if i == 0:                                   # J0(0) = 1: the loop's own J1(lam a) is the filter kernel
+                    lam = l1 / a
+                    coef = lam / (2.0 * np.pi * a) * W1_J1_140 / a
+                elif i == 2:
+                    lam = l0 / ON_AXIS_RHO
+                    coef = lam * lam * k4 * W0_J0_120 / ON_AXIS_RHO
+                else:
+                    raise ValueError("basis integral {} vanishes on the axis".format(i))
+            elif i == 0:
+                lam = l0 / rho
+                coef = srcz(lam) * W0_J0_120 / rho
+            elif i == 1:
+                lam = l1 / rho
+                coef = srcz(lam) * W1_J1_140 / rho
+            elif i == 2:
+                lam = l0 / rho
+                coef = lam * lam * k4 * W0_J0_120 / rho
+            elif i == 3:
+                lam = l1 / rho
+                coef = lam * lam * k4 * W1_J1_140 / rho
             else:
-                lam, w = l1 / rs, W1_J1_140 / rs * ((-dx / r) if r > 0.0 else 0.0)
-            if on_axis and comp == "z":
-                src = lam / (2.0 * np.pi * a)
-            else:
-                src = lam * j1(lam * a) / (2.0 * np.pi * a) if a > 0.0 else lam * lam / (4.0 * np.pi)
-            coef = src * w * self.scaling[comp]
+                lam = l1 / rho
+                coef = lam * k4 / rho * W1_J1_140 / rho
             for f in fn:
                 npts.append(lam.size)
                 wmu.append(2.0 * np.pi * f * MU0)
@@ -252,14 +272,11 @@ class TdemSystem:
         return (np.asarray(npts, np.int32), np.asarray(wmu), np.asarray(hd0), np.asarray(g),
                 np.ascontiguousarray(tables))
 
-    def primary_field(self, dx, dy, dz):
-        """Free-space dipole field at the receiver in the output units (x, then z with the reference's
-        negated-z convention), e.g. Tempest PX / PZ."""
-        R = np.sqrt(dx * dx + dy * dy + dz * dz)
-        k = MU0 * self.moment / (4.0 * np.pi)
-        bx = k * 3.0 * dx * dz / R ** 5 * self.scaling["x"]
-        bz = -k * (3.0 * dz * dz / R ** 5 - 1.0 / R ** 3) * self.scaling["z"]
-        return bx, bz
+    def primary_field(self, dx, dy, dz, attitude=None):
+        """Free-space field of the (rotated) transmitter dipole along the receiver's axes in the output units, one value per
+        output component in channel order, with the reference's negated-z convention (TdemDataPoint.py:1004-1015), e.g.
+        Tempest PX / PZ.  ``attitude``: (tx roll, pitch, yaw, rx roll, pitch, yaw) in GA-AEM's convention, or None."""
+        return GeometryMix([self], gaaem_geometry([0.0], (dx, dy, dz), attitude)).primary_field()[0]
 
 
 class NativeTdemSystem:
@@ -303,6 +320,25 @@ class NativeTdemSystem:
                                                   sg.data_ptr(), th.data_ptr(), out.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
         return out
 
+    def fm_dlogc(self, geometry, nlayers, sigma, thk, device=None):
+        """(windows [B, N], J [B, N, Lmax] = d windows / d ln sigma) -- gbp_tdem_fm_dlogc, the C-level counterpart of
+        ga_fm_dlogc / gatdaem1d's derivative call (TD/tdem1d.py:98-154)."""
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        geometry = np.ascontiguousarray(geometry, dtype=np.float64)
+        B = geometry.shape[0]
+        assert geometry.shape == (B, 10), ValueError("geometry must have shape [B, 10] (Loop_pair.py:70-77)")
+        sg = torch.as_tensor(np.asarray(sigma), dtype=torch.float64).to(device).contiguous()
+        th = torch.as_tensor(np.asarray(thk), dtype=torch.float64).to(device).contiguous()
+        nl = torch.as_tensor(np.broadcast_to(np.asarray(nlayers), (B,)).copy(), dtype=torch.int32).to(device)
+        N = self.n_components * self.nwindows
+        out = torch.empty((B, N), dtype=torch.float64, device=device)
+        J = torch.empty((B, N, sg.shape[1]), dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            _lib.check(self._lib.gbp_tdem_fm_dlogc(self.ptr, B, geometry.ctypes.data_as(_lib.c_double_p), sg.shape[1], nl.data_ptr(),
+                                                   sg.data_ptr(), th.data_ptr(), out.data_ptr(), J.data_ptr(),
+                                                   torch.cuda.current_stream(device).cuda_stream))
+        return out, J
+
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
@@ -328,7 +364,7 @@ class _RawHandle:
         """``eps`` > 0 and ``bins`` = (first altitude, count): per-sounding abscissa windows in 1 m altitude bins, each nodal
         sum within ``eps`` times its inductive-limit value of the full sum (gbp_hankel_system_add_bins, relative budget).
         ``more_sets``: [(hd0, tables), ...] further table sets of the same layout (other transmitter-receiver offsets,
-        gbp_hankel_system_add_set); ``set_rows`` then says which set every row of a launch uses."""
+        gbp_hankel_system_add_set); the launches' ``set_of_row`` argument then says which set every row uses."""
         lib = _lib.load()
         self._lib = lib
         h = ctypes.c_void_p()
@@ -341,7 +377,6 @@ class _RawHandle:
         self.npoints = int(npts.sum())      # abscissa points of the full tables
         self.bins = None
         self.n_sets = 1 + len(more_sets)
-        self._rows = None
         for hd0_k, tables_k in more_sets:
             hd0_k, tables_k = np.ascontiguousarray(hd0_k, dtype=np.float64), np.ascontiguousarray(tables_k, dtype=np.float64)
             assert tables_k.shape == tables.shape and hd0_k.shape == hd0.shape, ValueError("table sets must share one layout")
@@ -351,11 +386,6 @@ class _RawHandle:
             self.bins = (int(bins[0]), int(bins[1]))
         elif more_sets:
             _lib.check(lib.gbp_hankel_system_add_bins(h, 0.0, 1, 0, 0))      # descriptors of the sets' full tables only
-
-    def set_rows(self, set_of_row):
-        """Row b of the launches that follow uses table set ``set_of_row[b]`` (int32 device tensor, kept alive here; None: set 0)."""
-        self._rows = None if set_of_row is None else set_of_row.to(torch.int32).contiguous()
-        _lib.check(self._lib.gbp_hankel_system_set_rows(self.ptr, None if self._rows is None else self._rows.data_ptr()))
 
     def bin_points(self, altitude):
         """Abscissa points a sounding at this altitude is evaluated with."""
@@ -372,19 +402,51 @@ class _RawHandle:
             pass
 
 
+class _Mix:
+    """Device side of a tdem_geometry.GeometryMix for one raw handle: gbp_td_mix + the rows' table sets."""
+
+    def __init__(self, gm, device):
+        self.gm = gm
+        dev = lambda a, dt: torch.as_tensor(a, dtype=dt).to(device).contiguous()
+        self.weights = dev(gm.weights, torch.float64)
+        self.src, self.col = dev(gm.src, torch.int32), dev(gm.col, torch.int32)
+        self.set_of_row = dev(gm.set_of_row, torch.int32) if gm.set_keys.shape[0] > 1 else None
+        self.n_in, self.n_out = gm.n_in, gm.n_out
+
+    def struct(self, weights=None):
+        m = _lib.TdMix()
+        m.n_in, m.terms, m.n_weights = self.n_in, self.src.shape[1], self.weights.shape[1]
+        m.src, m.col = self.src.data_ptr(), self.col.data_ptr()
+        m.weights = (self.weights if weights is None else weights).data_ptr()
+        return m
+
+
+def _raw_handle(systems, gm, eps, bins):
+    """One raw Hankel handle for ``systems`` merged (all (system, basis integral, node) triples are its frequencies) with one
+    table set per distinct (rho, dz) of the geometry mix ``gm``."""
+    def merged(key):
+        parts = [gm.tables(s_, key) for s_ in systems]
+        cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p_[j] for p_ in parts], axis=ax))
+        return cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1)
+    sets = [merged(k_) for k_ in gm.set_keys]
+    return _RawHandle(*sets[0], eps=eps, bins=bins, more_sets=[(t_[2], t_[4]) for t_ in sets[1:]])
+
+
 class TdemBatch:
     """B TDEM soundings on one GPU, all systems of a (multi-moment) acquisition in one object.
 
-    ``systems``: list of TdemSystem (e.g. SkyTEM high and low moment); ``offset`` = (dx, dy, dz) of the
-    receiver relative to the transmitter (Loop_pair, system/Loop_pair.py:63-77): one triple shared by the batch, or one per
-    sounding ([B, 3]).  The Hankel tables depend on the offset, so soundings are evaluated in groups of equal offset (one
-    set of tables and one launch sequence per distinct offset; results come back in the caller's row order).
-    Channel layout of ``predicted``: system 0 components x then z, each over its windows, then system 1 ...
-    (the reference's ``predicted_secondary_field`` layout).
+    ``systems``: list of TdemSystem (e.g. SkyTEM high and low moment); ``offset`` = (dx, dy, dz) of the receiver relative to
+    the transmitter (Loop_pair, system/Loop_pair.py:63-77) and ``attitude`` = (tx roll, pitch, yaw, rx roll, pitch, yaw) in
+    degrees in GA-AEM's convention (what Loop_pair.Geometry passes: roll, -pitch, -yaw; None = level flight): one tuple shared
+    by the batch, or one per sounding ([B, 3] / [B, 6]).  All soundings run in the same launches whatever their geometry: a
+    handle holds one table set per distinct (horizontal distance, dz) and a row's azimuth, attitude, output signs and scalings
+    are its mixing weights (tdem_geometry.GeometryMix); only receivers exactly on the transmitter's axis (other filters) form a
+    group of their own.  Channel layout of ``predicted``: system 0 components x, y, z (those it outputs), each over its
+    windows, then system 1 ... (the reference's ``predicted_secondary_field`` layout).
     """
 
     def __init__(self, systems, nlayers, sigma, thk, height, offset, data=None, relative_error=None,
-                 additive_error=None, device=None, hankel_eps=None, min_altitude=None):
+                 additive_error=None, device=None, hankel_eps=None, min_altitude=None, attitude=None):
         """``hankel_eps``: accuracy budget of the abscissa window every sounding is evaluated with -- the filter abscissae whose
         terms can add up to more than that fraction of a nodal sum's inductive-limit value at the sounding's OWN altitude (1 m
         bins, |rTE| <= 1; the same bound as FdemBatch's), so a sounding's numbers do not depend on its batch.
@@ -394,54 +456,40 @@ class TdemBatch:
             raise _lib.NativeLibraryError("TdemBatch needs a HIP device; there is no CPU fallback")
         self.systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._groups, self._sets = None, None
-        off = np.asarray(offset, dtype=np.float64)
-        if off.ndim == 2:
-            uniq, inverse = np.unique(off, axis=0, return_inverse=True)
-            tabs = [[s_.hankel_tables(*uniq[g]) for g in range(uniq.shape[0])] for s_ in self.systems] if uniq.shape[0] > 1 else None
-            same_layout = tabs is not None and all(np.array_equal(t[0], ts[0][0]) for ts in tabs for t in ts)
-            if same_layout:                # one table set per distinct offset, all soundings in one launch
-                self._sets = (tabs, torch.as_tensor(inverse.ravel().astype(np.int32), device=self.device))
-                self.offsets = off
-                off = uniq[0]
-            elif uniq.shape[0] > 1:        # (an on-axis receiver among them: other filters, other layout) one child batch per offset
-                sub = lambda a, m: None if a is None else np.asarray(a)[m]
-                bc = lambda a, n: np.broadcast_to(np.asarray(a), (n,) + np.shape(a)[1:]) if np.ndim(a) >= 1 else np.full(n, a)
-                n_all = off.shape[0]
-                nl_all, h_all = bc(nlayers, n_all), bc(height, n_all)
-                self._groups = []
-                for g in range(uniq.shape[0]):
-                    m = np.nonzero(inverse.ravel() == g)[0]
-                    child = TdemBatch(self.systems, nl_all[m], np.asarray(sigma)[m], np.asarray(thk)[m], h_all[m], tuple(uniq[g]),
-                                      data=sub(data, m), relative_error=sub(relative_error, m), additive_error=sub(additive_error, m),
-                                      device=self.device, hankel_eps=hankel_eps)
-                    self._groups.append((torch.as_tensor(m, device=self.device), child))
-                self.offset = off
-                self.B, self.Lmax = np.asarray(sigma).shape
-                self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
-                self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
-                self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
-                self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
-                return
-            off = uniq[0]
-        self.offset = tuple(float(v) for v in off)
+        self._groups = None
+        self.B, self.Lmax = np.asarray(sigma).shape
+        h_all = np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,))
+        geom = gaaem_geometry(h_all, offset, attitude)
+        self.geometry = geom
+        self.offset = tuple(float(v) for v in np.asarray(offset, dtype=np.float64)) if np.ndim(offset) == 1 else np.asarray(offset, dtype=np.float64)
+        self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
+        on = np.hypot(geom[:, 4], geom[:, 5]) == 0.0
+        if on.any() and not on.all():      # receivers on and off the axis: other filters, other layout -> one child batch each
+            sub = lambda a, m: None if a is None else np.asarray(a)[m]
+            nl_all = np.broadcast_to(np.asarray(nlayers), (self.B,))
+            self._groups = []
+            for flag in (False, True):
+                m = np.nonzero(on == flag)[0]
+                child = TdemBatch(self.systems, nl_all[m], np.asarray(sigma)[m], np.asarray(thk)[m], h_all[m], geom[m, 4:7],
+                                  data=sub(data, m), relative_error=sub(relative_error, m), additive_error=sub(additive_error, m),
+                                  device=self.device, hankel_eps=hankel_eps, attitude=np.c_[geom[m, 1:4], geom[m, 7:10]])
+                self._groups.append((torch.as_tensor(m, device=self.device), child))
+            self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
+            self.chi2 = torch.empty(self.B, dtype=torch.float64, device=self.device)
+            self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
+            return
         dev = lambda a, dt=torch.float64: torch.as_tensor(np.array(a), dtype=dt).to(self.device).contiguous()
         self.sigma, self.thk = dev(sigma), dev(thk)
-        self.B, self.Lmax = self.sigma.shape
         self.nlayers = dev(np.broadcast_to(np.asarray(nlayers), (self.B,)), torch.int32)
-        self.height = dev(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,)))
-        self._h, self._W, self._nodal = [], [], []
+        self.height = dev(h_all)
+        self._h, self._W, self._nodal, self._mix = [], [], [], []
         self.hankel_eps = DEFAULT_TDEM_HANKEL_EPS if hankel_eps is None else float(hankel_eps)
-        bins = _altitude_bins(np.broadcast_to(np.asarray(height, dtype=np.float64), (self.B,))) if self.B > 0 else None
+        bins = _altitude_bins(h_all) if self.B > 0 else None
         with torch.cuda.device(self.device):
-            for i_sys, s in enumerate(self.systems):
-                if self._sets is None:
-                    h = _RawHandle(*s.hankel_tables(*self.offset), eps=self.hankel_eps, bins=bins)
-                else:
-                    ts = self._sets[0][i_sys]
-                    h = _RawHandle(*ts[0], eps=self.hankel_eps, bins=bins, more_sets=[(t[2], t[4]) for t in ts[1:]])
-                    h.set_rows(self._sets[1])
-                self._h.append(h)
+            for s in self.systems:
+                gm = GeometryMix([s], geom)
+                self._h.append(_raw_handle([s], gm, self.hankel_eps, bins))
+                self._mix.append(_Mix(gm, self.device))
                 n = s.node_frequencies().size
                 W = s.time_operator()
                 # block-diagonal over components: nodal layout is [Re(comp0 nodes), Re(comp1 nodes), Im(...), Im(...)]
@@ -451,8 +499,7 @@ class TdemBatch:
                     Wb[c * n:(c + 1) * n, c * s.nwindows:(c + 1) * s.nwindows] = W[:n]
                     Wb[nc * n + c * n: nc * n + (c + 1) * n, c * s.nwindows:(c + 1) * s.nwindows] = W[n:]
                 self._W.append(dev(Wb))
-                self._nodal.append(torch.empty((self.B, 2 * nc * n), dtype=torch.float64, device=self.device))
-        self.nChannels = sum(s.n_components * s.nwindows for s in self.systems)
+                self._nodal.append(torch.empty((self.B, gm.n_in), dtype=torch.float64, device=self.device))
         self.predicted = torch.empty((self.B, self.nChannels), dtype=torch.float64, device=self.device)
         # window blocks of the systems (k_td_apply writes dense [B, n_windows] rows; several systems are then laid side by side)
         self._win, c0 = {}, 0
@@ -468,8 +515,13 @@ class TdemBatch:
         self.logL = torch.empty(self.B, dtype=torch.float64, device=self.device)
         self._max_layers = None
 
+    def primary_field(self):
+        """[B, sum of the systems' components] free-space field at the receiver, reference convention (GeometryMix.primary_field)."""
+        return GeometryMix(self.systems, self.geometry).primary_field()
+
     def forward(self):
-        """predicted[B, nChannels]: frequency-domain HIP kernel per system, then the window operator (k_td_apply)."""
+        """predicted[B, nChannels]: frequency-domain HIP kernel per system (nodal spectra of the basis integrals), then geometry
+        mixing + the window operator (k_td_apply)."""
         if self._groups is not None:
             for rows, child in self._groups:
                 self.predicted[rows] = child.forward()
@@ -478,14 +530,16 @@ class TdemBatch:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         col = 0
         with torch.cuda.device(self.device):
-            for s, h, W, nodal in zip(self.systems, self._h, self._W, self._nodal):
-                _lib.check(lib.gbp_fdem_forward(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
-                                                self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
-                                                nodal.data_ptr(), stream))
+            for s, h, W, nodal, mix in zip(self.systems, self._h, self._W, self._nodal, self._mix):
+                rows = None if mix.set_of_row is None else mix.set_of_row.data_ptr()
+                _lib.check(lib.gbp_fdem_forward_rows_ex(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                        self.sigma.data_ptr(), self.thk.data_ptr(), self.height.data_ptr(),
+                                                        nodal.data_ptr(), rows, 0, stream))
                 n = W.shape[1]
                 out = self._win[col] if len(self.systems) > 1 else self.predicted
-                _lib.check(lib.gbp_td_apply(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
-                                            None, out.data_ptr(), None, stream))
+                mx = mix.struct()
+                _lib.check(lib.gbp_td_apply_mix(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
+                                                None, out.data_ptr(), None, ctypes.byref(mx), stream))
                 if out is not self.predicted:
                     self.predicted[:, col:col + n] = out
                 col += n
@@ -494,12 +548,17 @@ class TdemBatch:
     def sensitivity(self):
         """J[B, nChannels, Lmax] = d predicted / d ln(sigma) (the reference obtains it from gatdaem1d's
         derivative call, TD/tdem1d.py:98-154): exact frequency-domain Jacobian of the nodal values (Jacobian
-        kernel on the raw handle) pushed through the same linear time-domain operator (k_td_apply)."""
+        kernel on the raw handle) pushed through the same geometry mixing and linear time-domain operator (k_td_apply)."""
+        return self.fm_dlogc()[1]
+
+    def fm_dlogc(self):
+        """(predicted, J) from one pass (TdemDataPoint.fm_dlogc, data/datapoint/TdemDataPoint.py:1031-1055)."""
         if self._groups is not None:
             out = torch.empty((self.B, self.nChannels, self.Lmax), dtype=torch.float64, device=self.device)
             for rows, child in self._groups:
-                out[rows] = child.sensitivity()
-            return out
+                p, J = child.fm_dlogc()
+                out[rows], self.predicted[rows] = J, p
+            return self.predicted, out
         lib = _lib.load()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         out = torch.empty((self.B, self.nChannels, self.Lmax), dtype=torch.float64, device=self.device)
@@ -507,21 +566,23 @@ class TdemBatch:
             self._max_layers = int(self.nlayers.max().item()) if self.B > 0 else 1
         col = 0
         with torch.cuda.device(self.device):
-            for h, W in zip(self._h, self._W):
-                Jn = torch.empty((self.B, W.shape[0], self.Lmax), dtype=torch.float64, device=self.device)
-                _lib.check(lib.gbp_fdem_sensitivity_ex(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
-                                                       self.sigma.data_ptr(), self.thk.data_ptr(),
-                                                       self.height.data_ptr(), Jn.data_ptr(), self._max_layers, 1,
-                                                       stream))
+            for h, W, nodal, mix in zip(self._h, self._W, self._nodal, self._mix):
+                Jn = torch.empty((self.B, mix.n_in, self.Lmax), dtype=torch.float64, device=self.device)
+                rows = None if mix.set_of_row is None else mix.set_of_row.data_ptr()
+                _lib.check(lib.gbp_fdem_fm_dlogc_rows_ex(h.ptr, self.B, self.Lmax, self.nlayers.data_ptr(),
+                                                         self.sigma.data_ptr(), self.thk.data_ptr(),
+                                                         self.height.data_ptr(), nodal.data_ptr(), Jn.data_ptr(), self._max_layers, 1,
+                                                         rows, 0, stream))
                 n = W.shape[1]
                 Jw = torch.empty((self.B, n, self.Lmax), dtype=torch.float64, device=self.device)
                 pw = torch.empty((self.B, n), dtype=torch.float64, device=self.device)
-                nodal = torch.zeros((self.B, W.shape[0]), dtype=torch.float64, device=self.device)
-                _lib.check(lib.gbp_td_apply(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
-                                            Jn.data_ptr(), pw.data_ptr(), Jw.data_ptr(), stream))
+                mx = mix.struct()
+                _lib.check(lib.gbp_td_apply_mix(self.B, self.Lmax, W.shape[0], n, self.nlayers.data_ptr(), W.data_ptr(), nodal.data_ptr(),
+                                                Jn.data_ptr(), pw.data_ptr(), Jw.data_ptr(), ctypes.byref(mx), stream))
                 out[:, col:col + n, :] = Jw
+                self.predicted[:, col:col + n] = pw
                 col += n
-        return out
+        return self.predicted, out
 
     def std(self):
         """TdemDataPoint.std (data/datapoint/TdemDataPoint.py:361-365):
@@ -571,32 +632,31 @@ class TdemBatch:
 class TdemDeviceChains(DeviceChains):
     """Device-resident rjMCMC (rjmcmc_gpu.DeviceChains) for time-domain soundings: one system or the systems of a
     multi-moment acquisition (e.g. SkyTEM high + low moment).  ``offset``: the transmitter-receiver offset (dx, dy, dz) of the
-    block, or one per sounding [B, 3] -- the handle then holds one set of Hankel tables per distinct offset and every chain is
-    evaluated with its own (gbp_hankel_system_add_set / _set_rows): soundings of different geometry advance in the same launches.
+    block, or one per sounding [B, 3]; ``attitude``: (tx roll, pitch, yaw, rx roll, pitch, yaw) in GA-AEM's convention, one for
+    the block or one per sounding [B, 6] (None: level flight).  The handle holds one set of Hankel tables per distinct
+    (horizontal distance, dz) and every chain carries its table set and its geometry-mixing weights
+    (gbp_td_operator.table_set / .mix): soundings of different geometry advance in the same launches.
 
-    The systems' spline nodes are merged into ONE frequency-domain handle (all (system, component, node) triples are
+    The systems' spline nodes are merged into ONE frequency-domain handle (all (system, basis integral, node) triples are
     "frequencies" of the sampler's forward / Jacobian launches) and ``gbp_rj_run_td`` turns the nodal spectra -- and their
     Jacobians -- into the windows of all systems with one block matrix W.  Error model: TdemDataPoint.std
     (data/datapoint/TdemDataPoint.py:361-365): a relative level per (system, component), an additive level per system
     scaled by sqrt(1e-3 / t) per gate; the error options may be scalars or lists per level like in the reference's
-    skytem / tempest options files.  Channel layout = TdemBatch's (system 0: component x then z windows, system 1 ...).
+    skytem / tempest options files.  Channel layout = TdemBatch's (system 0: components x, y, z windows, system 1 ...).
     The Jacobian is the exact derivative (GA-AEM's is, too).  Parity is unpinned like the rest of the TDEM path (DESIGN.md
     3.7); the sampler logic itself is the FDEM-pinned one."""
 
-    def __init__(self, systems, heights, data, offset, **kw):
+    def __init__(self, systems, heights, data, offset, attitude=None, **kw):
         systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         assert all(isinstance(s, TdemSystem) for s in systems), TypeError("systems must be geobipy_amd.TdemSystem objects")
-        off = np.asarray(offset, dtype=np.float64)
-        if off.ndim == 2:
-            uniq, inverse = np.unique(off, axis=0, return_inverse=True)
-        else:
-            uniq, inverse = off[None, :], np.zeros(np.asarray(heights).size, dtype=np.int64)
-        self.td_systems, self._offset, self._offsets = systems, tuple(float(v) for v in uniq[0]), uniq
-        self._geom_id0 = inverse.ravel().astype(np.int32)
-        nf = [s.n_components * s.node_frequencies().size for s in systems]          # "frequencies" per system
+        heights = np.atleast_1d(np.asarray(heights, dtype=np.float64))
+        gm = GeometryMix(systems, gaaem_geometry(heights, offset, attitude))
+        self.td_systems, self._gm = systems, gm
+        nf = [s.n_components * s.node_frequencies().size for s in systems]          # output "frequencies" per system
         nw = [s.n_components * s.nwindows for s in systems]
         nF, N = sum(nf), sum(nw)
-        assert nF <= 128, ValueError("the merged systems have {} spline nodes x components (limit 128)".format(nF))
+        assert gm.n_in // 2 <= 128 and nF <= 128, ValueError(
+            "the merged systems have {} spline nodes x basis integrals (limit 128)".format(gm.n_in // 2))
         Wm = np.zeros((2 * nF, N))
         rel_group, add_group, add_scale = [], [], []
         f0 = c0 = g0 = 0
@@ -612,20 +672,13 @@ class TdemDeviceChains(DeviceChains):
             add_scale += list(np.sqrt(1e-3 / np.tile(s.off_time, nc)))
             f0, c0, g0 = f0 + nf[i], c0 + nw[i], g0 + nc
         self._W_host, self._td_struct = Wm, None
+        self._row_index = None
         outer = self
 
         class _Handle:                    # what DeviceChains asks of an acquisition system
             def handle(self_inner):
                 if getattr(outer, "_raw", None) is None:
-                    def merged(off_):
-                        parts = [s.hankel_tables(*off_) for s in systems]
-                        cat = lambda j, ax=0: np.ascontiguousarray(np.concatenate([p[j] for p in parts], axis=ax))
-                        return cat(0).astype(np.int32), cat(1), cat(2), cat(3), cat(4, 1)
-                    sets = [merged(o_) for o_ in outer._offsets]
-                    assert all(np.array_equal(t_[0], sets[0][0]) for t_ in sets), NotImplementedError(
-                        "offsets with the receiver on the transmitter's axis use other filters: invert them as a block of their own")
-                    outer._raw = _RawHandle(*sets[0], eps=outer._hankel_eps, bins=_altitude_bins(heights),
-                                            more_sets=[(t_[2], t_[4]) for t_ in sets[1:]])
+                    outer._raw = _raw_handle(systems, gm, outer._hankel_eps, _altitude_bins(heights))
                 return outer._raw
         kw.pop("exact_jacobian", None)
         kw.pop("hankel_eps_ppm", None)
@@ -634,39 +687,53 @@ class TdemDeviceChains(DeviceChains):
         eps = kw.pop("hankel_eps", None)
         self._hankel_eps = DEFAULT_TDEM_HANKEL_EPS if eps is None else float(eps)
         kw.pop("min_altitude", None)
+        dev = kw.get("device")
+        dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+        self._mix = _Mix(gm, dev)
         super().__init__(_Handle(), heights, data, exact_jacobian=True, add_scale=np.asarray(add_scale),
                          rel_group=np.asarray(rel_group, dtype=np.int32), add_group=np.asarray(add_group, dtype=np.int32), **kw)
-        if self._offsets.shape[0] > 1:       # carried with the chains' rows (infer() re-packs every tensor of self.t)
-            self.t["geom_id"] = torch.as_tensor(self._geom_id0, device=self.device)
+        # carried with the chains' rows (infer() re-packs every tensor of self.t)
+        self.t["mix_w"] = self._mix.weights
+        if self._mix.set_of_row is not None:
+            self.t["geom_id"] = self._mix.set_of_row
 
     def _set_row_map(self, index):
-        if self._offsets.shape[0] == 1:
-            return
+        self._row_index = index
+        self._td_struct = None            # pointers of the rows the next launches evaluate
+
+    def _rows(self, name, default):
         t = self.__dict__.get("t")
-        g = t["geom_id"] if t is not None and "geom_id" in t else torch.as_tensor(self._geom_id0, device=self.device)
-        self._h.set_rows(g if index is None else g[index])
+        v = t[name] if t is not None and name in t else default
+        return v if (v is None or self._row_index is None) else v[self._row_index].contiguous()
 
     def _td(self):
         if self._td_struct is None:
             dev = self.device
-            self._W = torch.as_tensor(self._W_host, dtype=torch.float64).to(dev).contiguous()
-            nn = self._W.shape[0]
-            self._nodal = torch.empty((self.B, nn), dtype=torch.float64, device=dev)
-            self._J_nodal = torch.empty((self.B, nn, self.K), dtype=torch.float64, device=dev)
+            if getattr(self, "_W", None) is None:
+                self._W = torch.as_tensor(self._W_host, dtype=torch.float64).to(dev).contiguous()
+            rows = self.t["k"].shape[0]          # scratch of the sampler's launches: the block's rows
+            n_in = self._mix.n_in
+            if getattr(self, "_nodal", None) is None or self._nodal.shape[0] < rows:
+                self._nodal = torch.empty((rows, n_in), dtype=torch.float64, device=dev)
+                self._J_nodal = torch.empty((rows, n_in, self.K), dtype=torch.float64, device=dev)
+            self._w_rows = self._rows("mix_w", self._mix.weights)
+            self._set_rows = self._rows("geom_id", self._mix.set_of_row)
             td = _lib.TdOperator()
-            td.n_nodal, td.W, td.nodal, td.J_nodal = nn, self._W.data_ptr(), self._nodal.data_ptr(), self._J_nodal.data_ptr()
+            td.n_nodal, td.W, td.nodal, td.J_nodal = self._W.shape[0], self._W.data_ptr(), self._nodal.data_ptr(), self._J_nodal.data_ptr()
+            td.mix = self._mix.struct(self._w_rows)
+            td.table_set = None if self._set_rows is None else self._set_rows.data_ptr()
             self._td_struct = td
         return self._td_struct
 
     def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
-        self._td()
+        td = self._td()
         lib, n = _lib.load(), k.numel()
-        nodal = torch.empty((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
-        _lib.check(lib.gbp_fdem_forward_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
-                                           nodal.data_ptr(), self.forward_waves, self._stream()))
+        nodal = torch.empty((n, self._mix.n_in), dtype=torch.float64, device=self.device)
+        _lib.check(lib.gbp_fdem_forward_rows_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
+                                                nodal.data_ptr(), td.table_set, self.forward_waves, self._stream()))
         p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
-        _lib.check(lib.gbp_td_apply(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(), nodal.data_ptr(),
-                                    None, p.data_ptr(), None, self._stream()))
+        _lib.check(lib.gbp_td_apply_mix(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(), nodal.data_ptr(),
+                                        None, p.data_ptr(), None, ctypes.byref(td.mix), self._stream()))
         rg = self.t["rel_group"].long() if self.t["rel_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         ag = self.t["add_group"].long() if self.t["add_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         sd = torch.sqrt((rel[:, rg] * data) ** 2 + (add[:, ag] * self.t["add_scale"][None, :]) ** 2).contiguous()
@@ -676,27 +743,75 @@ class TdemDeviceChains(DeviceChains):
             pred.copy_(p)
 
     def _eval_jacobian(self, k, sigma, thk, height, J, max_layers):
-        self._td()
+        td = self._td()
         n = k.numel()
-        Jn = torch.empty((n, self._W.shape[0], self.K), dtype=torch.float64, device=self.device)
-        _lib.check(_lib.load().gbp_fdem_sensitivity_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
-                                                       height.data_ptr(), Jn.data_ptr(), int(max_layers), 1, self._stream()))
-        nodal = torch.zeros((n, self._W.shape[0]), dtype=torch.float64, device=self.device)
+        Jn = torch.empty((n, self._mix.n_in, self.K), dtype=torch.float64, device=self.device)
+        nodal = torch.empty((n, self._mix.n_in), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().gbp_fdem_fm_dlogc_rows_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
+                                                         height.data_ptr(), nodal.data_ptr(), Jn.data_ptr(), int(max_layers), 1,
+                                                         td.table_set, 0, self._stream()))
         p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
-        _lib.check(_lib.load().gbp_td_apply(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(),
-                                            nodal.data_ptr(), Jn.data_ptr(), p.data_ptr(), J.data_ptr(), self._stream()))
+        _lib.check(_lib.load().gbp_td_apply_mix(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(),
+                                                nodal.data_ptr(), Jn.data_ptr(), p.data_ptr(), J.data_ptr(), ctypes.byref(td.mix), self._stream()))
 
     def _launch(self, n, accumulate):
         _lib.check(_lib.load().gbp_rj_run_td(self._h.ptr, self._td(), self._o, self._c, self.iteration, int(n), int(bool(accumulate)),
                                              self._stream()))
 
 
+class TdemEngine:
+    """forward(edges, values) / sensitivity(edges, values) of one sounding's geometry -- what the host sampler
+    (inference.Inference1D, rjmcmc.accept_reject) asks of a data point -- on persistent TdemBatch objects (tables, windows and
+    mixing weights are built once; a call refills the model tensors and launches)."""
+
+    def __init__(self, systems, height, offset, attitude=None, lmax=32, hankel_eps=None):
+        self.systems, self.height, self.offset, self.attitude = list(systems), float(height), tuple(offset), attitude
+        self.lmax, self.hankel_eps = int(lmax), hankel_eps
+        self._b = {}
+
+    def _batch(self, models):
+        n = len(models)
+        b = self._b.get(n)
+        if b is None:
+            b = self._b[n] = TdemBatch(self.systems, np.ones(n, dtype=np.int32), np.ones((n, self.lmax)), np.zeros((n, self.lmax)),
+                                       np.full(n, self.height), self.offset, attitude=self.attitude, hankel_eps=self.hankel_eps)
+        nl = np.array([v.size for _, v in models], dtype=np.int32)
+        assert nl.max() <= self.lmax, ValueError("model has more layers than the engine was sized for")
+        sig, thk = np.ones((n, self.lmax)), np.zeros((n, self.lmax))
+        for i, (e, v) in enumerate(models):
+            sig[i, : v.size] = v
+            thk[i, : v.size - 1] = np.diff(np.r_[0.0, e])
+        b.sigma.copy_(torch.as_tensor(sig))
+        b.thk.copy_(torch.as_tensor(thk))
+        b.nlayers.copy_(torch.as_tensor(nl))
+        b._max_layers = int(nl.max())
+        return b, nl
+
+    def forward_many(self, models):
+        return self._batch(models)[0].forward().cpu().numpy()
+
+    def forward(self, edges, values):
+        return self.forward_many([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])[0]
+
+    def sensitivity(self, edges, values):
+        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])
+        return b.sensitivity().cpu().numpy()[0][:, : nl[0]]
+
+    def fm_dlogc(self, edges, values):
+        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])
+        p, J = b.fm_dlogc()
+        return p.cpu().numpy()[0], J.cpu().numpy()[0][:, : nl[0]]
+
+
 class TdemDataPoint:
-    """Per-sounding TDEM interface mirroring the hot-path members of the reference's ``TdemDataPoint``
-    (data/datapoint/TdemDataPoint.py): ``forward`` (:997-1022), ``std`` (:329-376), ``active``, ``deltaD``,
-    ``data_misfit`` and ``likelihood`` (DataPoint.py:491-525).  ``system`` is a list of TdemSystem (or .stm
-    paths); the receiver offset comes from the loop pair (``receiver - transmitter``).  Every evaluation is a
-    B = 1 launch of the batched GPU path."""
+    """Per-sounding TDEM interface mirroring the members of the reference's ``TdemDataPoint``
+    (data/datapoint/TdemDataPoint.py) the sampler touches: ``forward`` (:997-1022), ``sensitivity`` (:1024-1029),
+    ``fm_dlogc`` (:1031-1055), ``std`` (:329-376), ``active``, ``deltaD``, ``data_misfit`` and ``likelihood``
+    (DataPoint.py:491-525), ``perturb`` (:681), ``probability``, ``set_priors`` / ``set_proposals`` (:950-985).  ``system``
+    is a list of TdemSystem (or .stm paths); the receiver offset and both loops' attitude come from the loop pair (offset =
+    receiver - transmitter; angles handed on as Loop_pair.Geometry does, Loop_pair.py:70-77).  Every evaluation is a B = 1
+    launch of the batched GPU path on a persistent engine (TdemEngine).  Geometry moves (solve_transmitter_* / solve_receiver_*,
+    all False in the reference's options files) are not proposed."""
 
     def __init__(self, x=0.0, y=0.0, z=0.0, elevation=0.0, data=None, std=None, predictedData=None, system=None,
                  transmitter_loop=None, receiver_loop=None, lineNumber=0.0, fiducial=0.0):
@@ -706,16 +821,27 @@ class TdemDataPoint:
         self.x, self.y, self.elevation = np.float64(x), np.float64(y), np.float64(elevation)
         self.z = np.atleast_1d(np.asarray(z, dtype=np.float64)).copy()
         self.lineNumber, self.fiducial = lineNumber, fiducial
-        tx, rx = transmitter_loop, receiver_loop
-        self.offset = (float(rx.x[0] - tx.x[0]), float(rx.y[0] - tx.y[0]), float(rx.z[0] - tx.z[0]))
-        assert all(float(v[0]) == 0.0 for lp in (tx, rx) for v in (lp.pitch, lp.roll, lp.yaw)), \
-            NotImplementedError("only level flight (pitch = roll = yaw = 0) is supported")
+        self.transmitter, self.receiver = transmitter_loop, receiver_loop
         n = self.nChannels
         self._data = np.zeros(n) if data is None else np.asarray(data, dtype=np.float64).copy()
         self._predictedData = np.zeros(n) if predictedData is None else np.asarray(predictedData, np.float64).copy()
         self._relative_error = np.full(self.n_error_groups, 0.01)      # one per (system, component), TdemDataPoint.py:362
         self._additive_error = np.zeros(self.nSystems)
         self.units = r"$\\frac{V}{m^{2}}$"
+        self._sensitivity_matrix = None
+        self._rel_prior = self._add_prior = None              # rjmcmc.ErrorPrior (vector) once set_priors ran
+        self._prng = None
+        self._engine, self._engine_key = None, None
+        self.engine = None                                    # TEST HOOK only (see FdemDataPoint.engine); the product never sets it
+
+    @property
+    def offset(self):
+        return from_loops(self.transmitter, self.receiver)[0]
+
+    @property
+    def attitude(self):
+        """(tx roll, -tx pitch, -tx yaw, rx roll, -rx pitch, -rx yaw): what Loop_pair.Geometry hands GA-AEM (Loop_pair.py:70-77)."""
+        return from_loops(self.transmitter, self.receiver)[1]
 
     @property
     def nSystems(self):
@@ -770,33 +896,84 @@ class TdemDataPoint:
     def deltaD(self):
         return self._predictedData - self._data
 
-    def _batch(self, mod=None):
-        if mod is None:
-            L, sig, thk = 1, np.ones((1, 1)), np.zeros((1, 1))
-        else:
-            assert np.isinf(mod.mesh.edges[-1]), ValueError("mod.edges must have last entry be infinity")
-            L = int(mod.mesh.nCells)
-            thk = np.array(mod.mesh.widths, dtype=np.float64)[None, :]
-            thk[0, -1] = 0.0
-            sig = np.asarray(mod.values, dtype=np.float64)[None, :]
-        return TdemBatch(self.system, np.array([L]), sig, thk, self.z[:1], self.offset, data=self._data[None, :],
-                         relative_error=self._relative_error[None, :], additive_error=self._additive_error[None, :])
+    # -- engine -------------------------------------------------------------------------------------------------------
+    def make_engine(self, lmax=32, hankel_eps=None):
+        """A TdemEngine for this data point's altitude and geometry (what Inference1D.initialize asks for)."""
+        return TdemEngine(self.system, self.z[0], self.offset, self.attitude, lmax=lmax, hankel_eps=hankel_eps)
+
+    def _eng(self, n_layers):
+        if self.engine is not None:
+            return self.engine
+        key = (float(self.z[0]), self.offset, self.attitude)
+        if self._engine is None or self._engine_key != key or self._engine.lmax < n_layers:
+            self._engine, self._engine_key = self.make_engine(lmax=max(32, int(n_layers))), key
+        return self._engine
+
+    def error_model(self, reference_fm_dlogc=True):
+        """rjmcmc.ErrorModel of TdemDataPoint.std: channel -> (system, component) relative level, channel -> system additive
+        level, sqrt(1e-3 / t) per gate.  ``reference_fm_dlogc``: the host sampler forms its stochastic-Newton gradient as the
+        reference does for time-domain data -- with the prediction of the current model next to the Jacobian of the remapped
+        one (TdemDataPoint.fm_dlogc :1031-1055 keeps only the Jacobian); False uses the remapped model's own prediction, as the
+        device sampler does (both are valid proposals: the acceptance ratio uses the density actually drawn from)."""
+        from . import rjmcmc
+        rg, ag, sc, g = [], [], [], 0
+        for i, s_ in enumerate(self.system):
+            for _ in range(s_.n_components):
+                rg += [g] * s_.nwindows
+                ag += [i] * s_.nwindows
+                sc += list(np.sqrt(1e-3 / s_.off_time))
+                g += 1
+        return rjmcmc.ErrorModel(rg, ag, sc, stale_prediction=reference_fm_dlogc)
+
+    @staticmethod
+    def _model_arrays(mod):
+        assert np.isinf(mod.mesh.edges[-1]), ValueError("mod.edges must have last entry be infinity")
+        return np.asarray(mod.mesh.edges[1:-1], dtype=np.float64), np.asarray(mod.values, dtype=np.float64)
 
     @property
     def std(self):
-        return self._batch().std().cpu().numpy()[0]
+        return self.error_model().std(self._data, self._relative_error, self._additive_error)
+
+    @property
+    def sensitivity_matrix(self):
+        return self._sensitivity_matrix
 
     def forward(self, mod):
-        self._predictedData[:] = self._batch(mod).forward().cpu().numpy()[0]
+        """TdemDataPoint.forward (:997-1022): predicted_secondary_field of every system, components x, y, z, z negated."""
+        e, v = self._model_arrays(mod)
+        assert self.z[0] >= mod.mesh.relative_to, "Sensor altitude must be above the top of the model"      # TD/tdem1d.py:28
+        self._predictedData[:] = self._eng(v.size).forward(e, v)
+
+    def sensitivity(self, mod, ix=None, model_changed=False):
+        """J[nChannels, nLayers] = d predicted / d ln(sigma) (TdemDataPoint.sensitivity :1024-1029 -> gaTdem1dsen,
+        TD/tdem1d.py:125-154: gatdaem1d's conductivity derivative x sigma); ``ix``: the layers wanted (default all)."""
+        e, v = self._model_arrays(mod)
+        J = np.asarray(self._eng(v.size).sensitivity(e, v))
+        self._sensitivity_matrix = J if ix is None else J[:, np.asarray(ix)]
+        return self._sensitivity_matrix
+
+    def fm_dlogc(self, mod):
+        """Prediction and Jacobian from one pass (TdemDataPoint.fm_dlogc :1031-1055 -> ga_fm_dlogc, TD/tdem1d.py:98-123).  The
+        reference keeps only the Jacobian from that call; here the prediction of the same pass is stored as well."""
+        e, v = self._model_arrays(mod)
+        eng = self._eng(v.size)
+        if hasattr(eng, "fm_dlogc"):
+            self._predictedData[:], self._sensitivity_matrix = eng.fm_dlogc(e, v)
+        else:
+            self._predictedData[:], self._sensitivity_matrix = eng.forward(e, v), np.asarray(eng.sensitivity(e, v))
 
     def _loglike(self):
-        b = self._batch()
-        b.predicted.copy_(torch.as_tensor(self._predictedData[None, :]))
-        sd = b.std()
-        _lib.check(_lib.load().gbp_gauss_loglike_std(1, self.nChannels, b.predicted.data_ptr(), b.data.data_ptr(),
-                                                     sd.data_ptr(), b.chi2.data_ptr(), b.logL.data_ptr(),
-                                                     torch.cuda.current_stream(b.device).cuda_stream))
-        return float(b.chi2.cpu()[0]), float(b.logL.cpu()[0])
+        if self.engine is not None:                      # CPU test tier
+            from . import rjmcmc
+            return rjmcmc.gauss_loglike(self._predictedData, self._data, self.std)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)[None, :]).to(dev)
+        p, d, sd = t(self._predictedData), t(self._data), t(self.std)
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        _lib.check(_lib.load().gbp_gauss_loglike_std(1, self.nChannels, p.data_ptr(), d.data_ptr(), sd.data_ptr(), out.data_ptr(),
+                                                     out.data_ptr() + 8, torch.cuda.current_stream(dev).cuda_stream))
+        o = out.cpu().numpy()
+        return float(o[0]), float(o[1])
 
     def data_misfit(self):
         return np.float64(self._loglike()[0])
@@ -804,3 +981,58 @@ class TdemDataPoint:
     def likelihood(self, log):
         ll = self._loglike()[1]
         return np.float64(ll) if log else np.float64(np.exp(ll))
+
+    # -- rjMCMC members (DataPoint.py:454-489, 531-644; TdemDataPoint.py:681, 950-985): error-level priors, proposals, moves -----
+    def set_priors(self, relative_error_prior=None, additive_error_prior=None, data_prior=None, **kwargs):
+        """TdemDataPoint.set_priors (:950-971) -> DataPoint.set_priors (:575-595): log-uniform priors [minimum, maximum] on the
+        error levels that are solved for -- lists per level in the time-domain options files (minimum_relative_error = [..] per
+        system x component, minimum_additive_error = [..] per system); scalars are broadcast.  ``prng`` is remembered for
+        perturb().  Transmitter / receiver priors (solve_transmitter_* / solve_receiver_*) are not supported: a True flag raises."""
+        from . import rjmcmc
+        for k_, v_ in kwargs.items():
+            if (k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and v_:
+                raise NotImplementedError(k_ + ": geometry moves of the loop pair are not sampled")
+        self._prng = kwargs.get("prng", self._prng)
+        if relative_error_prior is None and kwargs.get("solve_relative_error", False):
+            relative_error_prior = (kwargs["minimum_relative_error"], kwargs["maximum_relative_error"])
+        if additive_error_prior is None and kwargs.get("solve_additive_error", False):
+            additive_error_prior = (kwargs["minimum_additive_error"], kwargs["maximum_additive_error"])
+        var = lambda p_: p_.var if p_ is not None else 0.0
+        vec = lambda v_, n_: np.broadcast_to(np.asarray(v_, dtype=np.float64), (n_,)).copy()
+        if relative_error_prior is not None:
+            self._rel_prior = rjmcmc.ErrorPrior(vec(relative_error_prior[0], self.n_error_groups), vec(relative_error_prior[1], self.n_error_groups),
+                                                var(self._rel_prior))
+        if additive_error_prior is not None:
+            self._add_prior = rjmcmc.ErrorPrior(vec(additive_error_prior[0], self.nSystems), vec(additive_error_prior[1], self.nSystems),
+                                                var(self._add_prior))
+
+    def set_proposals(self, relative_error_proposal=None, additive_error_proposal=None, **kwargs):
+        """TdemDataPoint.set_proposals (:973-985) -> DataPoint.set_proposals (:597-644): log-normal random walks with the
+        options file's proposal variances (a list per level, or a scalar)."""
+        self._prng = kwargs.get("prng", self._prng)
+        if relative_error_proposal is None and kwargs.get("solve_relative_error", False):
+            relative_error_proposal = kwargs["relative_error_proposal_variance"]
+        if additive_error_proposal is None and kwargs.get("solve_additive_error", False):
+            additive_error_proposal = kwargs["additive_error_proposal_variance"]
+        for prior, v_, n_ in ((self._rel_prior, relative_error_proposal, self.n_error_groups), (self._add_prior, additive_error_proposal, self.nSystems)):
+            if v_ is not None:
+                assert prior is not None, ValueError("set_priors must come before set_proposals")
+                prior.var = np.broadcast_to(np.asarray(v_, dtype=np.float64), (n_,)).copy()
+
+    def perturb(self):
+        """TdemDataPoint.perturb (:681) -> DataPoint.perturb (:531-573): the relative levels, then the additive levels -- each
+        set proposed jointly and redrawn while outside its prior (the current values are kept at the 10th redraw)."""
+        if self._rel_prior is not None and np.any(np.asarray(self._rel_prior.var) > 0.0):
+            self._relative_error = np.atleast_1d(self._rel_prior.propose(self._prng, self._relative_error))
+        if self._add_prior is not None and np.any(np.asarray(self._add_prior.var) > 0.0):
+            self._additive_error = np.atleast_1d(self._add_prior.propose(self._prng, self._additive_error))
+
+    @property
+    def probability(self):
+        """DataPoint.probability (:454-489): sum of the log priors of the error levels that have one."""
+        p = np.float64(0.0)
+        if self._rel_prior is not None:
+            p += self._rel_prior.log_prior(self._relative_error)
+        if self._add_prior is not None:
+            p += self._add_prior.log_prior(self._additive_error)
+        return p

@@ -112,7 +112,7 @@ def test_c_level_system_builds_the_same_operator_as_the_python_host():
 @pytest.mark.gpu
 def test_c_level_forward_equals_the_python_host_path_and_the_reference_csv():
     """gbp_tdem_forward(handle, B, geometry[B, 10], ...): same windows as TdemBatch (the Python host over the same kernels),
-    inside the CSV bars; soundings with different receiver offsets in one call; attitude angles are refused."""
+    inside the CSV bars; soundings with different receiver offsets in one call."""
     torch = pytest.importorskip("torch")
     from geobipy_amd import _lib
     from geobipy_amd.tdem import NativeTdemSystem, TdemBatch, TdemSystem
@@ -153,7 +153,7 @@ def test_c_level_forward_equals_the_python_host_path_and_the_reference_csv():
         _lib.check(_lib.load().gbp_tdem_system_set_hankel_eps(c.ptr, eps))
         again = c.forward(geom, np.full(40, 3), sig[:40], thk[:40]).cpu().numpy()
         assert np.abs(again - out).max() <= 1e-10 * np.abs(out).max()
-    geom[3, 2] = 1.5                                             # pitch
+    geom[3, 2] = np.nan                                          # a non-finite geometry entry is refused (attitude itself: test_tdem_attitude.py)
     with pytest.raises(_lib.NativeLibraryError):
         c.forward(geom, np.full(40, 3), sig[:40], thk[:40])
 
