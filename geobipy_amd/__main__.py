@@ -61,11 +61,7 @@ def main(argv=None):
         print("Using user input file {}".format(a.options_file))
         print("Output files will be produced at {}".format(a.output_directory))
         shutil.copy(a.options_file, a.output_directory)            # kept with the results, like the reference does
-    containers = None if a.no_containers else a.output_directory
-    if containers is not None and survey.read_options(a.options_file)["data_type"] in ("TdemData", "TdemDataPoint"):
-        containers = None                   # (the reference-layout containers are written for frequency-domain surveys)
-        if rank == 0:
-            print("Time-domain survey: writing the per-line summary files only")
+    containers = None if a.no_containers else a.output_directory      # reference-layout containers: FdemData, TdemData, TempestData
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
                        exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=containers,

@@ -33,7 +33,7 @@ RJ_CHAIN_FIELDS = ("rel_group", "add_group", "add_scale", "chain_id", "data", "h
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
                    "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma",
-                   "iteration0")
+                   "best_rel", "best_add", "iteration0")
 
 
 class RjChains(ctypes.Structure):
@@ -44,7 +44,7 @@ class RjChains(ctypes.Structure):
 class TdMix(ctypes.Structure):
     """gbp_td_mix."""
     _fields_ = [("n_in", ctypes.c_int32), ("terms", ctypes.c_int32), ("n_weights", ctypes.c_int32), ("src", c_void_p),
-                ("col", c_void_p), ("weights", c_void_p)]
+                ("col", c_void_p), ("weights", c_void_p), ("offset", c_void_p)]
 
 
 class TdOperator(ctypes.Structure):

@@ -853,7 +853,13 @@ __device__ inline void bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint3
     }
     if (reset_best || post > best_prev) {
         for (int j = i; j < K; j += W) { c.best_edges[b * K + j] = ec[j]; c.best_sigma[b * K + j] = sc[j]; }
-        if (i == 0) { c.best_posterior[b] = post; c.best_k[b] = kc; }
+        if (i == 0) {
+            c.best_posterior[b] = post; c.best_k[b] = kc;
+            if (c.best_rel != nullptr)                           // the error levels of the highest-posterior state (Inference1D.update
+                for (int g = 0; g < o.n_rel_groups; ++g) c.best_rel[b * o.n_rel_groups + g] = lev.rel[g];   //  :741-745 keeps the data point)
+            if (c.best_add != nullptr)
+                for (int g = 0; g < o.n_add_groups; ++g) c.best_add[b * o.n_add_groups + g] = lev.add[g];
+        }
     }
     if (accumulate) {
         if (i == 0) {
@@ -1298,6 +1304,7 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
     for (int g = lane; g < N; g += 64) {
         double acc = 0.0;
         for (int m = 0; m < n_nodal; ++m) acc += sn[m] * W[(size_t)m * N + g];
+        if (mix.offset != nullptr) acc += mix.offset[(size_t)b * N + g];
         pred[(size_t)b * N + g] = acc;
         if (WITH_J) {
             for (int l = 0; l < k; ++l) {
@@ -2019,6 +2026,8 @@ gbp_status gbp_td_apply_mix(int B, int K, int n_nodal, int N, const int32_t* nla
     if (mix != nullptr && mix->n_in > 0) {
         if (!mix->src || !mix->col || !mix->weights || mix->terms < 1 || mix->n_weights < 1) return fail(GBP_ERR_INVALID_ARG, "incomplete gbp_td_mix%s");
         mx = *mix;
+    } else if (mix != nullptr) {
+        mx.offset = mix->offset;
     }
     const size_t lds = ((size_t)n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
     if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");

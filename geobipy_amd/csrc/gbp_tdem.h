@@ -584,6 +584,7 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
             if (st != GBP_OK) return st;
             gbp_td_mix mix;
             mix.n_in = n_in; mix.terms = nb; mix.n_weights = n_w; mix.src = ly.d_src; mix.col = ly.d_col; mix.weights = s->d_weights;
+            mix.offset = nullptr;
             st = gbp_td_apply_mix(nr, Lmax, n_out, N, nlayers + b0, s->d_Wb, s->d_nodal, J ? s->d_jnodal : nullptr, out + (size_t)b0 * N,
                                   J ? J + (size_t)b0 * N * Lmax : nullptr, &mix, stream);
             if (st != GBP_OK) return st;

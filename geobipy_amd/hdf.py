@@ -24,24 +24,50 @@ CONDUCTIVITY_UNITS = "$\\frac{S}{m}$"
 # fallback container with the h5py surface the writer uses
 # ---------------------------------------------------------------------------------------------------------------
 class _Dataset:
+    """Dataset of the fallback container.  A dataset created from a shape is LAZY: nothing is allocated until it is written or
+    read (a per-line container pre-allocates per-iteration traces -- ``acceptance_rate`` / ``phids``: 2 n_markov_chains values
+    per sounding, 1.8 MB at the reference's default -- that the device writer never fills; h5py allocates those lazily on
+    disk, and so does this).  Indexing follows h5py's rules for the cases the writer uses, so that what runs here runs there:
+    an index array must be strictly increasing (no duplicates) and at most one index array per selection."""
+
     def __init__(self, name, shape=None, dtype=None, data=None, fillvalue=None):
         self.name, self.attrs = name, {}
+        self._arr = None
         if data is not None:
             a = np.array(data)
-            self.arr = a.astype(dtype) if dtype is not None else a
+            self._arr = a.astype(dtype) if dtype is not None else a
+            self._shape, self._dtype, self._fill = self._arr.shape, self._arr.dtype, None
         else:
-            shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
-            self.arr = np.zeros(shape, dtype=np.dtype(dtype if dtype is not None else "f8"))
-            if fillvalue is not None and (self.arr.dtype.kind == "f" or np.isfinite(fillvalue)):
-                self.arr[...] = fillvalue
+            self._shape = (int(shape),) if np.isscalar(shape) else tuple(int(s_) for s_ in shape)
+            self._dtype = np.dtype(dtype if dtype is not None else "f8")
+            self._fill = fillvalue if (fillvalue is not None and (self._dtype.kind == "f" or np.isfinite(fillvalue))) else None
 
-    shape = property(lambda s: s.arr.shape)
-    dtype = property(lambda s: s.arr.dtype)
+    shape = property(lambda s: s._shape)
+    dtype = property(lambda s: s._dtype)
+    materialised = property(lambda s: s._arr is not None)
+
+    @property
+    def arr(self):
+        if self._arr is None:
+            self._arr = np.zeros(self._shape, dtype=self._dtype)
+            if self._fill is not None:
+                self._arr[...] = self._fill
+        return self._arr
+
+    @staticmethod
+    def _check(k):
+        keys = k if isinstance(k, tuple) else (k,)
+        lists = [np.asarray(q) for q in keys if isinstance(q, (list, np.ndarray)) and np.ndim(q) > 0 and np.asarray(q).dtype != bool]
+        assert len(lists) <= 1, TypeError("only one indexing vector or array is currently allowed for fancy indexing (h5py)")
+        for q in lists:
+            assert q.size < 2 or np.all(np.diff(q) > 0), TypeError("indexing elements must be in increasing order (h5py)")
 
     def __getitem__(self, k):
+        self._check(k)
         return self.arr[k]
 
     def __setitem__(self, k, v):
+        self._check(k)
         self.arr[k] = v
 
 
@@ -104,19 +130,50 @@ class NpzGroup:
                 out[v.name] = dict(kind="dataset", shape=list(v.shape), dtype=str(v.dtype), **({"attrs": dict(v.attrs)} if v.attrs else {}))
         return out
 
-    def arrays(self, out=None):
+    def arrays(self, out=None, materialised_only=False):
         out = {} if out is None else out
         for v in self._items.values():
             if isinstance(v, NpzGroup):
-                v.arrays(out)
-            else:
+                v.arrays(out, materialised_only)
+            elif v.materialised or not materialised_only:
                 out[v.name] = v.arr
         return out
 
+    def unwritten(self, out=None):
+        """{path: (shape, dtype, fill)} of the datasets nothing was ever written to (still lazy)."""
+        out = {} if out is None else out
+        for v in self._items.values():
+            if isinstance(v, NpzGroup):
+                v.unwritten(out)
+            elif not v.materialised:
+                out[v.name] = dict(shape=list(v.shape), dtype=str(v.dtype), fill=None if v._fill is None else (float(v._fill) if np.isfinite(v._fill) else "nan"))
+        return out
+
     def save(self, path):
-        np.savez_compressed(path, **self.arrays())
+        """``path`` (.npz): every dataset that was written; ``path + '.attrs.json'``: the attributes and, under the key
+        "__unwritten__", shape / dtype / fill value of the datasets that never were (they are all fill value; ``load_npz``
+        puts them back) -- so a container costs what was written to it, not what it pre-allocates."""
+        lazy = self.unwritten()
+        np.savez_compressed(path, **self.arrays(materialised_only=True))
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
+        attrs["__unwritten__"] = lazy
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
+
+
+def load_npz(path):
+    """{hdf path: array} of a container written by ``NpzGroup.save``, unwritten datasets expanded to their fill value."""
+    out = {}
+    with np.load(path if str(path).endswith(".npz") else str(path) + ".npz") as z:
+        for k in z.files:
+            out[k] = z[k]
+    side = str(path)[:-4] if str(path).endswith(".npz") else str(path)
+    meta = json.load(open(side + ".attrs.json")).get("__unwritten__", {})
+    for k, m in meta.items():
+        a = np.zeros(m["shape"], dtype=np.dtype(m["dtype"]))
+        if m["fill"] is not None:
+            a[...] = np.nan if m["fill"] == "nan" else m["fill"]
+        out[k] = a
+    return out
 
 
 def open_results(path, mode="w"):
@@ -169,9 +226,9 @@ def _index_axis(parent, n):
     return _mesh1d(parent, "x", np.arange(n + 1) - 0.5, 0)
 
 
-def _histogram(parent, n, shape, axes, mesh_repr):
+def _histogram(parent, n, shape, axes, mesh_repr, name="posterior"):
     """Histogram.createHdf: group 'posterior' = mesh (index axis x, then the histogram's own axes) + int32 counts."""
-    g = parent.create_group("posterior")
+    g = parent.create_group(name)
     _attrs(g, repr="Histogram")
     m = g.create_group("mesh")
     _attrs(m, repr=mesh_repr)
@@ -190,6 +247,28 @@ def _stat_array(parent, name, n, shape, label, units, hist_shape, hist_axes, mes
     return g
 
 
+def _stat_array_n(parent, name, n, n_levels, label, units, hist_axes_per_level):
+    """StatArray.createHdf of a vector with ONE POSTERIOR PER ENTRY (statistics/StatArray.py:738-800: n_posteriors > 1 ->
+    groups posterior0, posterior1, ...): the error levels of a time-domain data point."""
+    g = _data_array(parent, name, (n, n_levels) if n_levels > 1 else (n,), rep="StatArray", label=label, units=units)
+    g.create_dataset("n_posteriors", data=np.int64(n_levels))
+    for i, axes in enumerate(hist_axes_per_level):
+        _histogram(g, n, (99,), axes, "RectilinearMesh2D", name="posterior{}".format(i))
+    return g
+
+
+def _loop_rows(parent, name, n):
+    """CircularLoops.createHdf with an added axis (system/CircularLoop.py:95-110, EmLoop.py:421-431): one value per sounding."""
+    g = parent.create_group(name)
+    _attrs(g, repr="CircularLoops")
+    for key, label, units in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
+                              ("pitch", "Pitch", "$^{o}$"), ("roll", "Roll", "$^{o}$"), ("yaw", "Yaw", "$^{o}$"), ("moment", "Moment", ""),
+                              ("radius", "Radius", "m")):
+        _data_array(g, key, (n,), label=label, units=units)
+    _data_array(g, "orientation", (n,), dtype="i4", fill=None, label="Orientation")
+    return g
+
+
 def _loop(parent, name, loop):
     g = parent.create_group(name)
     _attrs(g, repr="CircularLoop")
@@ -204,26 +283,43 @@ def _loop(parent, name, loop):
 # ---------------------------------------------------------------------------------------------------------------
 # Inference1D.createHdf / writeHdf
 # ---------------------------------------------------------------------------------------------------------------
+def data_kind(dp):
+    """'fdem' | 'tdem' | 'tempest': which of the reference's data point classes a container is laid out for."""
+    return getattr(dp, "kind", "fdem")
+
+
+def level_axes(o, kind="fdem"):
+    """Posterior axes of the error levels (DataPoint.set_relative_error_posterior / set_additive_error_posterior :651-694;
+    Tempest_datapoint.set_additive_error_posterior :533-547): per level (edges [100], relative_to).  Relative and additive
+    levels: log10 bins between the prior bounds, stored relative to log10(0.5 (max - min)); the Tempest multiplier: the same bins
+    in linear units, relative to 0.5 (max - min)."""
+    def one(lo, hi, linear=False):
+        lo, hi = np.atleast_1d(np.asarray(lo, dtype=np.float64)), np.atleast_1d(np.asarray(hi, dtype=np.float64))
+        out = []
+        for a, b in zip(lo, hi):
+            e = np.linspace(np.log10(a), np.log10(b), 100)
+            if linear:
+                to = 0.5 * (b - a)
+                out.append((10.0 ** e - to, to))
+            else:
+                to = np.log10(0.5 * (b - a))
+                out.append((e - to, to))
+        return out
+    return one(o["minimum_relative_error"], o["maximum_relative_error"]), one(o["minimum_additive_error"], o["maximum_additive_error"], kind == "tempest")
+
+
 def _grids(inf):
     o = inf.options
     p = inf.posteriors
     K = int(o["maximum_number_of_layers"])
-    rel_b = np.linspace(np.log10(o["minimum_relative_error"]), np.log10(o["maximum_relative_error"]), 100)
-    add_b = np.linspace(np.log10(o["minimum_additive_error"]), np.log10(o["maximum_additive_error"]), 100)
-    # DataPoint.set_relative_error_posterior (:666-680): the axis is stored relative to 0.5 * (max - min) of the linear bins
-    rel_to = np.log10(0.5 * (o["maximum_relative_error"] - o["minimum_relative_error"]))
-    add_to = np.log10(0.5 * (o["maximum_additive_error"] - o["minimum_additive_error"]))
-    return dict(K=K, rel_edges=rel_b - rel_to, add_edges=add_b - add_to, rel_to=rel_to, add_to=add_to, depth_edges=p.depth_edges,
-                value_edges=p.value_edges, value_to=p.relative_to, layer_edges=np.arange(K + 2) - 0.5)
+    rel, add = level_axes(o, data_kind(inf.datapoint))
+    return dict(K=K, rel_edges=rel[0][0], add_edges=add[0][0], rel_to=rel[0][1], add_to=add[0][1], rel_axes=rel, add_axes=add,
+                depth_edges=p.depth_edges, value_edges=p.value_edges, value_to=p.relative_to, layer_edges=np.arange(K + 2) - 0.5)
 
 
-def create_inference1d(parent, inf, add_axis):
-    """Inference1D.createHdf(parent, add_axis=fiducials) as Inference2D.createHdf calls it, plus that method's own two writes
-    (line number, sorted fiducials).  ``inf``: an initialised geobipy_amd Inference1D; ``add_axis``: the line's fiducials."""
-    fid = np.sort(np.atleast_1d(np.asarray(add_axis, dtype=np.float64)))
-    n = fid.size
-    dp, g_ = inf.datapoint, _grids(inf)
-    N, K = dp.nChannels, g_["K"]
+def _create_fdem_data(parent, dp, g_, n, fid):
+    """FdemDataPoint.createHdf (data/datapoint/FdemDataPoint.py) under 'data'."""
+    N = dp.nChannels
     d = parent.create_group("data")
     _attrs(d, repr="FdemData")
     for key, label, units in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
@@ -244,6 +340,69 @@ def create_inference1d(parent, inf, add_axis):
     _data_array(s, "freq", None, data=system.frequencies, label="Frequencies", units="Hz")
     _loop(s, "T", system.transmitter)
     _loop(s, "R", system.receiver)
+
+
+TD_UNITS = {"tdem": "$\\frac{V}{m^{2}}$", "tempest": "fT"}
+
+
+def _create_tdem_data(parent, dp, g_, n, fid, kind):
+    """TdemDataPoint.createHdf (data/datapoint/TdemDataPoint.py:603-625) / Tempest_datapoint.createHdf (Tempest_datapoint.py:566-
+    572) under 'data', as recorded in tests/golden/hdf_schema_tdem.json: the DataPoint part (location, data, std, predicted data,
+    error levels with one posterior per level), the systems' .stm texts, the component indices, the loop pair (offset +
+    transmitter + receiver with attitude), primary / secondary fields and their predictions; Tempest: per-channel additive
+    errors and their per-component multiplier."""
+    N, units, tempest = dp.nChannels, TD_UNITS[kind], kind == "tempest"
+    d = parent.create_group("data")
+    _attrs(d, repr="TempestData" if tempest else "TdemData")
+    for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
+                          ("line_number", "Line number", None)):
+        _data_array(d, key, (n,), label=label, units=u)
+    _data_array(d, "fiducial", None, data=fid, label="fiducial")
+    _data_array(d, "data", (n, N), label="Data" if tempest else "Secondary field", units=units)
+    _data_array(d, "std", (n, N), label="Standard deviation", units=units)
+    _data_array(d, "predicted_data", (n, N), label="Predicted Data" if tempest else "Predicted secondary field", units=units)
+    rel_label = "$\\epsilon_{Relative}$" if tempest else "$\\epsilon_{Relative}x10^{2}$"
+    axes = lambda levels, label, u, log: [[("y", dict(edges=e, dimension=1, label=label, units=u, log=log, relative_to_rows=n, rel_label=label,
+                                                       rel_units=u))] for e, _ in levels]
+    n_rel, n_sys = len(g_["rel_axes"]), len(dp.system)
+    _stat_array_n(d, "relative_error", n, n_rel, rel_label, "%", axes(g_["rel_axes"], rel_label, "%", 10))
+    if tempest:
+        _data_array(d, "additive_error", (n, N), label="$\\epsilon_{additive}$", units=units)
+        _stat_array_n(d, "additive_error_multiplier", n, len(g_["add_axes"]), "Multiplier", None, axes(g_["add_axes"], "Multiplier", None, None))
+    else:
+        _stat_array_n(d, "additive_error", n, len(g_["add_axes"]), "$\\epsilon_{Additive}$", units, axes(g_["add_axes"], "$\\epsilon_{Additive}$", units, 10))
+    d.create_dataset("nSystems", data=np.int64(n_sys))
+    for i, s_ in enumerate(dp.system):
+        g = d.create_group("System{}".format(i))
+        with open(s_.filename) as f:
+            _attrs(g, repr="TdemSystem", data=f.readlines())
+    d.create_dataset("components", data=np.asarray(["xyz".index(c) for c in dp.system[0].components], dtype=np.int32))
+    lp = d.create_group("loop_pair")
+    _attrs(lp, repr="Loop_pair")
+    for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m")):
+        _data_array(lp, key, (n,), label=label, units=u)
+    _loop_rows(lp, "transmitter", n)
+    _loop_rows(lp, "receiver", n)
+    nc = dp.system[0].n_components
+    wide = lambda m: (n, m) if m > 1 else (n,)
+    _data_array(d, "primary_field", wide(n_sys * nc), label="Primary field", units=units)
+    _data_array(d, "secondary_field", (n, N), label="Secondary field", units=units)
+    _data_array(d, "predicted_primary_field", wide(nc), label="Predicted primary field", units=units)
+    _data_array(d, "predicted_secondary_field", (n, N), label="Predicted secondary field", units=units)
+
+
+def create_inference1d(parent, inf, add_axis):
+    """Inference1D.createHdf(parent, add_axis=fiducials) as Inference2D.createHdf calls it, plus that method's own two writes
+    (line number, sorted fiducials).  ``inf``: an initialised geobipy_amd Inference1D; ``add_axis``: the line's fiducials."""
+    fid = np.sort(np.atleast_1d(np.asarray(add_axis, dtype=np.float64)))
+    n = fid.size
+    dp, g_ = inf.datapoint, _grids(inf)
+    N, K = dp.nChannels, g_["K"]
+    kind = data_kind(dp)
+    if kind == "fdem":
+        _create_fdem_data(parent, dp, g_, n, fid)
+    else:
+        _create_tdem_data(parent, dp, g_, n, fid, kind)
 
     parent.create_dataset("update_plot_every", data=np.int32(inf.options.get("update_plot_every") or 5000))
     parent.create_dataset("interactive_plot", data=np.bool_(inf.interactive_plot))
@@ -300,15 +459,18 @@ def write_inference1d(parent, inf, index=None):
     for key, v in (("x", dp.x), ("y", dp.y), ("z", dp.z[0]), ("elevation", dp.elevation), ("line_number", np.ravel(dp.lineNumber)[0])):
         d[key + "/data"][i] = float(v)
     data = np.asarray(dp.data, dtype=np.float64)
-    d["data/data"][i, :] = data
-    d["std/data"][i, :] = np.sqrt((best.rel * data) ** 2.0 + best.add ** 2.0)
-    d["predicted_data/data"][i, :] = best.pred
-    d["relative_error/data"][i] = best.rel
-    d["additive_error/data"][i] = best.add
-    d["relative_error/posterior/values/data"][i, :] = p.relative_error
-    d["additive_error/posterior/values/data"][i, :] = p.additive_error
-    d["relative_error/posterior/mesh/y/relative_to/data"][i] = g_["rel_to"]
-    d["additive_error/posterior/mesh/y/relative_to/data"][i] = g_["add_to"]
+    if data_kind(dp) != "fdem":
+        _write_tdem_point(d, i, dp, data, best, p, g_, inf.error_model)
+    else:
+        d["data/data"][i, :] = data
+        d["std/data"][i, :] = np.sqrt((best.rel * data) ** 2.0 + best.add ** 2.0)
+        d["predicted_data/data"][i, :] = best.pred
+        d["relative_error/data"][i] = best.rel
+        d["additive_error/data"][i] = best.add
+        d["relative_error/posterior/values/data"][i, :] = p.relative_error
+        d["additive_error/posterior/values/data"][i, :] = p.additive_error
+        d["relative_error/posterior/mesh/y/relative_to/data"][i] = g_["rel_to"]
+        d["additive_error/posterior/mesh/y/relative_to/data"][i] = g_["add_to"]
     m = parent["model"]
     k = best.values.size
     m["mesh/nCells/data"][i] = k
@@ -324,22 +486,63 @@ def write_inference1d(parent, inf, index=None):
     m["values/posterior/mesh/y/relative_to/data"][i] = g_["value_to"]
 
 
+def _write_loop_pair(d, i, x, y, z, offset, loop_angles, radius):
+    """Loop_pair.writeHdf (system/Loop_pair.py:305-315): the pair's offset, the transmitter at the sounding, the receiver at
+    transmitter + offset, both loops' pitch / roll / yaw (the file's convention), radius, unit moment, z orientation."""
+    lp = d["loop_pair"]
+    for key, v in (("x", offset[0]), ("y", offset[1]), ("z", offset[2]), ("elevation", 0.0)):
+        lp[key + "/data"][i] = v
+    a = np.asarray(loop_angles, dtype=np.float64)
+    for name, dx, ang in (("transmitter", (0.0, 0.0, 0.0), a[..., 0:3]), ("receiver", offset, a[..., 3:6])):
+        g = lp[name]
+        for key, v in (("x", x + dx[0]), ("y", y + dx[1]), ("z", z + dx[2]), ("elevation", 0.0), ("pitch", ang[..., 0]), ("roll", ang[..., 1]),
+                       ("yaw", ang[..., 2]), ("moment", 1.0), ("radius", radius)):
+            g[key + "/data"][i] = v
+        g["orientation/data"][i] = 2
+
+
+def _write_tdem_point(d, i, dp, data, best, p, g_, error_model):
+    """TdemDataPoint.writeHdf (data/datapoint/TdemDataPoint.py:627-645) for one host-sampled sounding."""
+    rel, add = np.atleast_1d(best.rel), np.atleast_1d(best.add)
+    d["data/data"][i, :] = data
+    d["secondary_field/data"][i, :] = data
+    d["std/data"][i, :] = error_model.std(data, rel, add)
+    d["predicted_data/data"][i, :] = best.pred
+    d["predicted_secondary_field/data"][i, :] = best.pred
+    d["relative_error/data"][i] = rel if rel.size > 1 else rel[0]
+    d["additive_error/data"][i] = add if add.size > 1 else add[0]
+    for g in range(rel.size):
+        d["relative_error/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.relative_error)[g]
+        d["relative_error/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["rel_axes"][g][1]
+    for g in range(add.size):
+        d["additive_error/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.additive_error)[g]
+        d["additive_error/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["add_axes"][g][1]
+    off = dp.offset
+    ang = [float(np.atleast_1d(getattr(lp_, k_))[0]) for lp_ in (dp.transmitter, dp.receiver) for k_ in ("pitch", "roll", "yaw")]
+    _write_loop_pair(d, i, float(dp.x), float(dp.y), float(dp.z[0]), off, ang, dp.system[0].loopRadius())
+    nc = dp.system[0].n_components
+    pf = np.concatenate([s_.primary_field(*off, attitude=dp.attitude) for s_ in dp.system])
+    d["primary_field/data"][i] = getattr(dp, "primary_field", np.zeros(pf.size)) if pf.size > 1 else 0.0
+    d["predicted_primary_field/data"][i] = pf[:nc] if nc > 1 else pf[0]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Per-line containers from the device sampler (survey.infer(results_directory=...)): the same tree, one row per sounding,
 # filled from the chains' device-resident posteriors instead of a host Inference1D
 # ---------------------------------------------------------------------------------------------------------------
 class LineSpec:
     """What ``create_inference1d`` reads of an initialised Inference1D, built from a DeviceChains block instead: the
-    acquisition system, the options, and the posterior grids (the device accumulators bin on the reference's grids:
-    RectilinearMesh1D.set_posteriors :1438-1455, Model.set_posteriors)."""
+    acquisition system(s), the options, the kind of data point ('fdem' | 'tdem' | 'tempest') and the posterior grids (the device
+    accumulators bin on the reference's grids: RectilinearMesh1D.set_posteriors :1438-1455, Model.set_posteriors)."""
 
-    def __init__(self, system, n_channels, options, n_value_bins=250):
+    def __init__(self, system, n_channels, options, n_value_bins=250, kind="fdem"):
         from types import SimpleNamespace
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in dict(options).items() if v is not None})
         self.options = o
-        self.datapoint = SimpleNamespace(nChannels=int(n_channels), system=[system], nSystems=1)
+        systems = list(system) if isinstance(system, (list, tuple)) else [system]
+        self.datapoint = SimpleNamespace(nChannels=int(n_channels), system=systems, nSystems=len(systems), kind=kind)
         min_width = float(o["minimum_thickness"])
         half = 4.0 * np.log(1.0 + float(o["factor"]))
         self.posteriors = SimpleNamespace(depth_edges=np.arange(0.0, 1.1 * float(o["maximum_depth"]), 0.5 * min_width),
@@ -350,20 +553,32 @@ class LineSpec:
 
 
 # per-sounding fields of a finished block, as survey.infer ships them to the writing rank: (name, columns, kind)
-def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True):
+def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0):
+    """``n_rel`` / ``n_add``: error levels per sounding (time-domain data: one relative level per system x component, one additive
+    level -- or Tempest multiplier -- per system / component); ``time_domain``: the loop pair's offset and both loops' angles, the
+    per-channel standard deviation and the (file, predicted) primary fields travel too."""
     f64 = [("x", 1), ("y", 1), ("z", 1), ("elevation", 1), ("line_number", 1), ("fiducial", 1), ("data", N), ("predicted", N),
-           ("relative_error", 1), ("additive_error", 1), ("log_mean_prior", 1), ("best_edges", K), ("best_sigma", K)]
+           ("relative_error", n_rel), ("additive_error", n_add), ("log_mean_prior", 1), ("best_edges", K), ("best_sigma", K)]
+    if time_domain:
+        f64 += [("std", N), ("offset", 3), ("loop_angles", 6), ("primary", n_primary), ("predicted_primary", n_primary)]
     i32 = [("status", 1), ("burned_in_iteration", 1), ("iterations", 1), ("best_k", 1), ("k_hist", K + 1), ("edge_hist", n_depth),
-           ("rel_hist", n_err), ("add_hist", n_err)] + ([("hitmap", n_value * n_depth)] if hitmap else [])
+           ("rel_hist", n_rel * n_err), ("add_hist", n_add * n_err)] + ([("hitmap", n_value * n_depth)] if hitmap else [])
     return f64, i32
 
 
-def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True):
+def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True, kind="fdem", n_rel=1, n_add=1, n_primary=0,
+                      loop_radius=0.0, channel_additive=None):
     """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
     LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  Not written: the
     per-iteration traces ``acceptance_rate`` / ``phids`` (the device sampler keeps no per-iteration history), ``best_iteration``,
-    the wall-clock fields."""
-    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap)
+    the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
+    wants increasing indices).  ``channel_additive`` (Tempest): the per-channel additive errors of the options file."""
+    td = kind != "fdem"
+    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary)
+    order = np.argsort(np.asarray(index), kind="stable")
+    idx = np.asarray(index)[order]
+    assert idx.size == 0 or np.all(np.diff(idx) > 0), ValueError("a sounding may be written once per call")
+    f64, i32 = np.asarray(f64)[order], np.asarray(i32)[order]
     col, F, I = 0, {}, {}
     for name, w in ff:
         F[name] = f64[:, col:col + w]
@@ -373,9 +588,7 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
         I[name] = i32[:, col:col + w]
         col += w
     o = options
-    rel_to = np.log10(0.5 * (o["maximum_relative_error"] - o["minimum_relative_error"]))
-    add_to = np.log10(0.5 * (o["maximum_additive_error"] - o["minimum_additive_error"]))
-    idx = np.asarray(index)
+    rel_axes, add_axes = level_axes(o, kind)
     parent["iteration"][idx] = I["iterations"][:, 0]
     parent["burned_in_iteration"][idx] = np.maximum(I["burned_in_iteration"][:, 0], 0)
     parent["burned_in"][idx] = I["status"][:, 0] == 1
@@ -386,13 +599,42 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
         d[key + "/data"][idx] = F[key][:, 0]
     d["data/data"][idx, :] = F["data"]
     d["predicted_data/data"][idx, :] = F["predicted"]
-    d["std/data"][idx, :] = np.sqrt((F["relative_error"] * F["data"]) ** 2.0 + F["additive_error"] ** 2.0)
-    d["relative_error/data"][idx] = F["relative_error"][:, 0]
-    d["additive_error/data"][idx] = F["additive_error"][:, 0]
-    d["relative_error/posterior/values/data"][idx, :] = I["rel_hist"]
-    d["additive_error/posterior/values/data"][idx, :] = I["add_hist"]
-    d["relative_error/posterior/mesh/y/relative_to/data"][idx] = rel_to
-    d["additive_error/posterior/mesh/y/relative_to/data"][idx] = add_to
+    if not td:
+        d["std/data"][idx, :] = np.sqrt((F["relative_error"] * F["data"]) ** 2.0 + F["additive_error"] ** 2.0)
+        d["relative_error/data"][idx] = F["relative_error"][:, 0]
+        d["additive_error/data"][idx] = F["additive_error"][:, 0]
+        d["relative_error/posterior/values/data"][idx, :] = I["rel_hist"]
+        d["additive_error/posterior/values/data"][idx, :] = I["add_hist"]
+        d["relative_error/posterior/mesh/y/relative_to/data"][idx] = rel_axes[0][1]
+        d["additive_error/posterior/mesh/y/relative_to/data"][idx] = add_axes[0][1]
+    else:
+        tempest = kind == "tempest"
+        one = lambda a: a if a.shape[1] > 1 else a[:, 0]
+        d["std/data"][idx, :] = F["std"]
+        d["relative_error/data"][idx] = one(F["relative_error"])
+        add_name = "additive_error_multiplier" if tempest else "additive_error"
+        d[add_name + "/data"][idx] = one(F["additive_error"])
+        if tempest and channel_additive is not None:
+            d["additive_error/data"][idx, :] = np.broadcast_to(np.asarray(channel_additive, dtype=np.float64), (idx.size, N))
+        rh, ah = I["rel_hist"].reshape(idx.size, n_rel, -1), I["add_hist"].reshape(idx.size, n_add, -1)
+        for g in range(n_rel):
+            d["relative_error/posterior{}/values/data".format(g)][idx, :] = rh[:, g]
+            d["relative_error/posterior{}/mesh/y/relative_to/data".format(g)][idx] = rel_axes[g][1]
+        for g in range(n_add):
+            d[add_name + "/posterior{}/values/data".format(g)][idx, :] = ah[:, g]
+            d[add_name + "/posterior{}/mesh/y/relative_to/data".format(g)][idx] = add_axes[g][1]
+        # Tempest channels hold primary + secondary (Tempest_datapoint.py:106-123); the fields are stored apart as well
+        nc = max(1, n_primary)
+        per = N // nc
+        prim = np.repeat(F["primary"], per, axis=1) if (tempest and n_primary) else 0.0
+        ppri = np.repeat(F["predicted_primary"], per, axis=1) if (tempest and n_primary) else 0.0
+        d["secondary_field/data"][idx, :] = F["data"] - prim
+        d["predicted_secondary_field/data"][idx, :] = F["predicted"] - ppri
+        if n_primary and tempest:                # (SkyTEM files carry no primary-field columns; the reference leaves those rows at their fill)
+            d["primary_field/data"][idx] = one(F["primary"])
+            d["predicted_primary_field/data"][idx] = one(F["predicted_primary"])
+        _write_loop_pair(d, idx, F["x"][:, 0], F["y"][:, 0], F["z"][:, 0], (F["offset"][:, 0], F["offset"][:, 1], F["offset"][:, 2]),
+                         F["loop_angles"], loop_radius)
     m = parent["model"]
     k = I["best_k"][:, 0]
     m["mesh/nCells/data"][idx] = k

@@ -178,7 +178,8 @@ class DeviceChains:
             hitmap=z(B, self.n_value_bins, self.n_depth_bins, dt=i32) if hitmap else None,
             hit_dwell=z(B, dt=i32) if hitmap else None,
             burned_in_iteration=torch.full((B,), -1, dtype=i32, device=dev), status=z(B, dt=i32),
-            best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K), iteration0=z(B, dt=i32))
+            best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K), best_rel=z(B, Gr), best_add=z(B, Ga),
+            iteration0=z(B, dt=i32))
         self._bind()
         self.iteration = 0
         self.forward_waves = int(forward_waves)      # also passed explicitly to the forward calls of the initialisation
@@ -209,6 +210,15 @@ class DeviceChains:
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def channel_std(self, data, rel, add):
+        """[rows, N] standard deviation of every channel from error levels [rows, groups] (DataPoint.std / TdemDataPoint.std)."""
+        t, N = self.t, data.shape[1]
+        zero = torch.zeros(N, dtype=torch.long, device=self.device)
+        rg = t["rel_group"].long() if t["rel_group"] is not None else zero
+        ag = t["add_group"].long() if t["add_group"] is not None else zero
+        sc = t["add_scale"][None, :] if t["add_scale"] is not None else 1.0
+        return torch.sqrt((rel[:, rg] * data) ** 2 + (add[:, ag] * sc) ** 2).contiguous()
 
     # -- Inference1D.initialize (:353-464): best half-space, its forward / Jacobian, prior and likelihood ----------------
     def _initialize(self):
@@ -253,6 +263,8 @@ class DeviceChains:
         t["best_sigma"].copy_(t["sigma"])
         t["best_edges"].copy_(t["edges"])
         t["best_k"].copy_(t["k"])
+        t["best_rel"].copy_(t["rel"])
+        t["best_add"].copy_(t["add"])
         # host-side bookkeeping of infer()'s restarts (not part of gbp_rj_chains; re-packed with the rest): the state the
         # chains start from and the reference's counters _n_zero_acceptance / _n_resets / "limiters armed"
         zi = lambda dt: torch.zeros(B, dtype=dt, device=self.device)
@@ -382,6 +394,8 @@ class DeviceChains:
         t["iteration0"][r] = self.iteration
         t["best_posterior"][r] = t["init_like"][r] + t["init_prior"][r]
         t["best_k"][r] = 1
+        t["best_rel"][r] = rel0
+        t["best_add"][r] = add0
         t["best_sigma"][r] = t["sigma"][r]
         t["best_edges"][r] = float("inf")
         t["status"].copy_(torch.where(give_up, torch.full_like(t["status"], 2), torch.where(reset, torch.zeros_like(t["status"]), t["status"])))

@@ -37,6 +37,12 @@ def _value(node):
         raise ValueError("unknown name {!r} in options file".format(node.id))
     if isinstance(node, (ast.List, ast.Tuple)):
         return [_value(e) for e in node.elts]
+    if (isinstance(node, ast.Subscript) and isinstance(node.value, ast.Attribute) and node.value.attr == "r_"
+            and isinstance(node.value.value, ast.Name) and node.value.value.id in ("np", "numpy")):
+        # np.r_[a, b, ...] of the reference's tempest_options (per-channel additive errors): a flat list of numbers
+        sl = node.slice
+        parts = [_value(e) for e in sl.elts] if isinstance(sl, ast.Tuple) else [_value(sl)]
+        return [float(x) for q in parts for x in (q if isinstance(q, list) else [q])]
     if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
         v = _value(node.operand)
         return -v if isinstance(node.op, ast.USub) else v
@@ -237,7 +243,17 @@ class TdemData:
 
 class TempestData(TdemData):
     """Fixed-wing Tempest soundings (classes/data/dataset/TempestData.py): the same file layout with X and Z components, the
-    per-sounding transmitter-receiver offsets and the primary-field columns PX / PZ."""
+    per-sounding transmitter-receiver offsets and the primary-field columns PX / PZ.  The reference's Tempest data point works
+    on TOTAL fields -- channel = secondary + the component's primary (Tempest_datapoint.py:106-123) -- with per-channel
+    additive errors scaled by a multiplier per component (:161-176): ``total_field`` gives those channels."""
+
+    def total_field(self, rows=None):
+        rows = slice(None) if rows is None else rows
+        d = self.data[rows]
+        if self.primary_field is None:
+            return d
+        nc = self.primary_field.shape[1]
+        return d + np.repeat(self.primary_field[rows], d.shape[1] // nc, axis=1)
 
 
 class SurveyResult(dict):
@@ -298,38 +314,61 @@ def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     return mean, pct
 
 
+def _container_kind(ds):
+    return "tempest" if isinstance(ds, TempestData) else ("tdem" if isinstance(ds, TdemData) else "fdem")
+
+
 def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
-    """Rank 0 receives every rank's rows chunk by chunk and fills one container per flight line (geobipy_amd.hdf)."""
+    """Rank 0 receives every rank's rows chunk by chunk and fills one container per flight line (geobipy_amd.hdf); a line's
+    container is written out and dropped as soon as its last sounding has arrived, so rank 0 holds the open lines only."""
     import torch
     from . import hdf
     from .distributed import stream_rows_to_root
+    os.makedirs(directory, exist_ok=True)
     K, N, nd, nv = dc.K, dc.N, dc.n_depth_bins, dc.n_value_bins
-    wf = sum(w for _, w in hdf.device_row_fields(N, K, nd, nv, hitmap=hitmap)[0])
-    wi = sum(w for _, w in hdf.device_row_fields(N, K, nd, nv, hitmap=hitmap)[1])
-    dev = dc.device
-    cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt, device=dev)
+    kind = _container_kind(ds)
+    td = kind != "fdem"
+    n_primary = (ds.primary_field.shape[1] if getattr(ds, "primary_field", None) is not None else 0) if td else 0
+    fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary)
+    ff, fi = hdf.device_row_fields(N, K, nd, nv, **fkw)
+    wf, wi = sum(w for _, w in ff), sum(w for _, w in fi)
+    line_col = [n_ for n_, _ in ff].index("line_number")
+    fid_col = [n_ for n_, _ in ff].index("fiducial")
+    # the blocks were moved to host memory when they finished (payload): concatenating them costs host memory only
+    cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt)
     rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, wf, torch.float64), cat(2, wi, torch.int32)
     assert f_t.shape[1] == wf and i_t.shape[1] == wi
-    lines = {}
-    for rows_np, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
-        for ln in np.unique(f[:, 4]):
-            if ln not in lines:
-                fid = np.sort(ds.fiducial[ds.lineNumber == ln])
-                path = os.path.join(directory, "{}.h5".format(ln))
-                root = hdf.open_results(path)
-                hdf.create_inference1d(root, hdf.LineSpec(ds.system, N, o, n_value_bins=nv), add_axis=fid)
-                lines[ln] = (root, fid, path)
-            root, fid, _ = lines[ln]
-            m = f[:, 4] == ln
-            hdf.write_device_rows(root, np.searchsorted(fid, f[m, 5]), f[m], i[m], N, K, nd, nv, o, hitmap=hitmap)
-    paths = []
-    for ln, (root, fid, path) in lines.items():
+    if dc.device.type != "cpu" and torch.distributed.is_initialized() and torch.distributed.get_backend() != "gloo":
+        rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
+    lines, paths = {}, []
+    wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
+               loop_radius=ds.system[0].loopRadius() if td else 0.0, channel_additive=o.get("initial_additive_error") if kind == "tempest" else None)
+
+    def close(ln):
+        root, fid, path, _ = lines.pop(ln)
         if isinstance(root, hdf.NpzGroup):
             root.save(path)                        # numpy appends .npz: <line>.h5.npz (+ <line>.h5.attrs.json)
             paths.append(path + ".npz")
         else:
             root.close()
             paths.append(path)
+
+    for rows_np, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
+        for ln in np.unique(f[:, line_col]):
+            if ln not in lines:
+                fid = np.sort(ds.fiducial[ds.lineNumber == ln])
+                path = os.path.join(directory, "{}.h5".format(ln))
+                root = hdf.open_results(path)
+                hdf.create_inference1d(root, hdf.LineSpec(ds.system, N, o, n_value_bins=nv, kind=kind), add_axis=fid)
+                lines[ln] = [root, fid, path, 0]
+            root, fid, _, _ = lines[ln]
+            m = f[:, line_col] == ln
+            hdf.write_device_rows(root, np.searchsorted(fid, f[m, fid_col]), f[m], i[m], N, K, nd, nv, o, **wkw)
+            lines[ln][3] += int(m.sum())
+            if lines[ln][3] >= fid.size:
+                close(ln)
+    for ln in list(lines):
+        close(ln)
     return paths
 
 
@@ -378,9 +417,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     from .rjmcmc_gpu import DeviceChains
 
     o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
-    time_domain = o["data_type"] in ("TdemData", "TdemDataPoint")
+    tempest = o["data_type"] in ("TempestData", "Tempest_datapoint")
+    time_domain = tempest or o["data_type"] in ("TdemData", "TdemDataPoint")
     if not time_domain and o["data_type"] not in ("FdemData", "FdemDataPoint"):
-        raise NotImplementedError("the device sampler handles FdemData and TdemData; {} is not supported".format(o["data_type"]))
+        raise NotImplementedError("the device sampler handles FdemData, TdemData and TempestData; {} is not supported".format(o["data_type"]))
+    for k_ in [k_ for k_ in o if (k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and o[k_]]:
+        raise NotImplementedError(k_ + ": geometry moves of the loop pair are not sampled")
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
     if o.get("ignore_likelihood"):
@@ -391,7 +433,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     if data is not None:
         ds = data
     elif time_domain:
-        ds = TdemData.read_csv(o["data_filename"], o["system_filename"])
+        ds = (TempestData if tempest else TdemData).read_csv(o["data_filename"], o["system_filename"])
     else:
         ds = FdemData.read_csv(o["data_filename"], o["system_filename"])
     rows = select_soundings(ds, index, fiducial, line_number)
@@ -428,7 +470,14 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             kw["chain_id"] = int(rows[0]) + idx
         if time_domain:
             from .tdem import TdemDeviceChains
-            dc = TdemDeviceChains(ds.system, ds.z[idx], ds.data[idx], offset, attitude=ds.attitude[idx] if idx.size else None, **kw)
+            if isinstance(ds, TempestData):
+                # Tempest_datapoint (data/datapoint/Tempest_datapoint.py:106-123, 161-176): the channels hold primary + secondary
+                # field, the options file's additive errors are per channel and the sampled level is their multiplier per component
+                nc = ds.system[0].n_components
+                kw.update(channel_additive=np.asarray(o["initial_additive_error"], dtype=np.float64), initial_additive_error=[1.0] * nc,
+                          primary_field=ds.primary_field[idx] if ds.primary_field is not None else None)
+            dc = TdemDeviceChains(ds.system, ds.z[idx], ds.total_field(idx) if isinstance(ds, TempestData) else ds.data[idx], offset,
+                                  attitude=ds.attitude[idx] if idx.size else None, **kw)
         else:
             dc = DeviceChains(ds.system, ds.z[idx], ds.data[idx], exact_jacobian=exact_jacobian, **kw)
         dc.infer(check_every=check_every)
@@ -445,13 +494,11 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         return dc, named
 
     state = dict(iterations=0, dc=None, named=None)
-    if results_directory is not None and time_domain:
-        raise NotImplementedError("results containers are written for frequency-domain surveys (FdemData)")
-    shipped = []                                   # per block: (rows, float64 block, int32 block) of hdf.device_row_fields
+    shipped = []                                   # per block: (rows, float64 block, int32 block) of hdf.device_row_fields, on the HOST
 
     def payload(dc, idx):
-        """The rows of hdf.device_row_fields for a finished block (device tensors)."""
-        from .batch import FdemBatch
+        """The rows of hdf.device_row_fields for a finished block, moved to host memory at once (the hit maps are 440 KB per
+        sounding: what stays on the GPU is the running block, not every block a rank has finished)."""
         from .rjmcmc_gpu import layer_widths
         t, dev = dc.t, dc.device
         n_mc = int(o["n_markov_chains"])
@@ -459,18 +506,32 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         bk = torch.where(none, t["k"], t["best_k"])
         be = torch.where(none[:, None], t["edges"], t["best_edges"])
         bs = torch.where(none[:, None], t["sigma"], t["best_sigma"])
-        pred = FdemBatch(ds.system, bk, bs, layer_widths(be, bk.to(torch.int64)), t["height"], device=dev).forward()
+        # the error levels of the highest-posterior state, like Inference1D.writeHdf's best data point (:1076-1088)
+        brel = torch.where(none[:, None], t["rel"], t["best_rel"]).contiguous()
+        badd = torch.where(none[:, None], t["add"], t["best_add"]).contiguous()
+        pred = torch.empty_like(t["data"])
+        chi2, logl = torch.empty_like(t["misfit"]), torch.empty_like(t["misfit"])
+        with torch.cuda.device(dev):                # one batched forward at the best models, through the sampler's own entry
+            dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(), t["height"], t["data"],
+                             brel, badd, pred, chi2, logl)
         host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
-        f64_block = torch.cat([host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
-                               t["rel"][:, :1], t["add"][:, :1], t["log_mean_prior"][:, None], be, bs], dim=1).contiguous()
+        cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
+                  brel, badd, t["log_mean_prior"][:, None], be, bs]
+        if time_domain:
+            n_pf = ds.primary_field.shape[1] if ds.primary_field is not None else 0
+            cols_f += [dc.channel_std(t["data"], brel, badd), host(ds.offsets), host(ds.loop_angles)]
+            if n_pf:
+                cols_f += [host(ds.primary_field), torch.as_tensor(dc.predicted_primary(), device=dev).reshape(idx.size, -1)]
+        f64_block = torch.cat(cols_f, dim=1).contiguous()
         st, bi = t["status"].to(torch.int32), t["burned_in_iteration"].to(torch.int32)
         ran = torch.where(st == 1, bi + n_mc + 1, torch.where(st == 2, torch.full_like(bi, n_mc), torch.full_like(bi, dc.iteration)))
         cols = [st[:, None], bi[:, None], ran[:, None], bk.to(torch.int32)[:, None], t["k_hist"], t["edge_hist"], t["rel_hist"].flatten(1),
                 t["add_hist"].flatten(1)]
         if hitmap:
             cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
-        return (torch.as_tensor(np.asarray(idx), dtype=torch.int64, device=dev), f64_block,
-                torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous())
+        to_host = lambda x: x.cpu()
+        return (torch.as_tensor(np.asarray(idx), dtype=torch.int64), to_host(f64_block),
+                to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
 
     def process(first, count):
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""

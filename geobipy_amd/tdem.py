@@ -646,7 +646,12 @@ class TdemDeviceChains(DeviceChains):
     The Jacobian is the exact derivative (GA-AEM's is, too).  Parity is unpinned like the rest of the TDEM path (DESIGN.md
     3.7); the sampler logic itself is the FDEM-pinned one."""
 
-    def __init__(self, systems, heights, data, offset, attitude=None, **kw):
+    def __init__(self, systems, heights, data, offset, attitude=None, channel_additive=None, primary_field=None, **kw):
+        """``channel_additive`` [N] + ``primary_field`` [B, components] (or True): the Tempest data point's model
+        (data/datapoint/Tempest_datapoint.py:106-123, 161-176) -- ``data`` then holds TOTAL fields (secondary + the component's
+        primary), the predicted primary field of each row's geometry is added to the predicted windows, the additive error of a
+        channel is ``channel_additive`` times a sampled multiplier per component (options initial / minimum / maximum
+        _additive_error = the multiplier's), the relative error multiplies the total field."""
         systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         assert all(isinstance(s, TdemSystem) for s in systems), TypeError("systems must be geobipy_amd.TdemSystem objects")
         heights = np.atleast_1d(np.asarray(heights, dtype=np.float64))
@@ -671,6 +676,13 @@ class TdemDeviceChains(DeviceChains):
             add_group += [i] * nw[i]
             add_scale += list(np.sqrt(1e-3 / np.tile(s.off_time, nc)))
             f0, c0, g0 = f0 + nf[i], c0 + nw[i], g0 + nc
+        if channel_additive is not None:              # Tempest: per-channel additive errors x a multiplier per (system, component)
+            add_group, add_scale = list(rel_group), list(np.broadcast_to(np.asarray(channel_additive, dtype=np.float64), (N,)))
+        self._pred_offset0 = None
+        if primary_field is not None:                 # total-field channels: predicted primary of every row's geometry, per window
+            pp = gm.primary_field()                                                  # [B, sum of the systems' components]
+            reps = np.concatenate([[s.nwindows] * s.n_components for s in systems])
+            self._pred_offset0 = np.repeat(pp, reps, axis=1)
         self._W_host, self._td_struct = Wm, None
         self._row_index = None
         outer = self
@@ -697,6 +709,15 @@ class TdemDeviceChains(DeviceChains):
         if self._mix.set_of_row is not None:
             self.t["geom_id"] = self._mix.set_of_row
 
+    def _bind(self):
+        if self._pred_offset0 is not None and "pred_offset" not in self.t:    # (before the first launch: _initialize evaluates with it)
+            self.t["pred_offset"] = torch.as_tensor(self._pred_offset0, dtype=torch.float64).to(self.device).contiguous()
+        super()._bind()
+
+    def predicted_primary(self):
+        """[B, components] predicted primary field of every row's geometry (reference convention), or None."""
+        return None if self._pred_offset0 is None else self._gm.primary_field()
+
     def _set_row_map(self, index):
         self._row_index = index
         self._td_struct = None            # pointers of the rows the next launches evaluate
@@ -718,9 +739,11 @@ class TdemDeviceChains(DeviceChains):
                 self._J_nodal = torch.empty((rows, n_in, self.K), dtype=torch.float64, device=dev)
             self._w_rows = self._rows("mix_w", self._mix.weights)
             self._set_rows = self._rows("geom_id", self._mix.set_of_row)
+            self._off_rows = self._rows("pred_offset", None)
             td = _lib.TdOperator()
             td.n_nodal, td.W, td.nodal, td.J_nodal = self._W.shape[0], self._W.data_ptr(), self._nodal.data_ptr(), self._J_nodal.data_ptr()
             td.mix = self._mix.struct(self._w_rows)
+            td.mix.offset = None if self._off_rows is None else self._off_rows.data_ptr()
             td.table_set = None if self._set_rows is None else self._set_rows.data_ptr()
             self._td_struct = td
         return self._td_struct
@@ -812,6 +835,8 @@ class TdemDataPoint:
     receiver - transmitter; angles handed on as Loop_pair.Geometry does, Loop_pair.py:70-77).  Every evaluation is a B = 1
     launch of the batched GPU path on a persistent engine (TdemEngine).  Geometry moves (solve_transmitter_* / solve_receiver_*,
     all False in the reference's options files) are not proposed."""
+
+    kind = "tdem"          # which of the reference's container layouts hdf.create_inference1d builds for it
 
     def __init__(self, x=0.0, y=0.0, z=0.0, elevation=0.0, data=None, std=None, predictedData=None, system=None,
                  transmitter_loop=None, receiver_loop=None, lineNumber=0.0, fiducial=0.0):

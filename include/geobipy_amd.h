@@ -362,6 +362,7 @@ typedef struct gbp_rj_chains {
     double *best_posterior;        /* [B]                                                              */
     int32_t *best_k;
     double *best_edges, *best_sigma;          /* [B, K]                                                */
+    double *best_rel, *best_add;   /* [B, n_rel_groups], [B, n_add_groups] or NULL: error levels of the highest-posterior state */
     int32_t *iteration0;           /* [B] or NULL (= 0)  schedule 1: the iteration at which the chain (re)started -- the schedule
                                       counts from there (Inference1D.reset :984-999 restarts a chain that accepted nothing over a
                                       whole window; the host does the restart between calls, rjmcmc_gpu.DeviceChains.infer) */
@@ -404,6 +405,9 @@ typedef struct gbp_td_mix {
     const int32_t *src;     /* [dev] int32[n_nodal, T]                                                        */
     const int32_t *col;     /* [dev] int32[n_nodal, T]                                                        */
     const double *weights;  /* [dev] f64[B, n_weights]                                                        */
+    const double *offset;   /* [dev] f64[B, n_channels] or NULL: added to the windows of every row -- the predicted PRIMARY
+                               field of data whose channels hold primary + secondary (Tempest_datapoint.py:106-123);
+                               honoured with or without mixing (n_in = 0)                                      */
 } gbp_td_mix;
 typedef struct gbp_td_operator {
     int32_t n_nodal;        /* rows of W (= 2 * nF of `sys` without mixing)                                   */
