@@ -58,6 +58,7 @@ _rj_o, _rj_c = ctypes.POINTER(RjOptions), ctypes.POINTER(RjChains)
 # name -> (restype, argtypes); must list every symbol include/geobipy_amd.h declares
 SIGNATURES = {
     "gbp_rj_propose": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
+    "gbp_rj_debug_propose_variant": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
     "gbp_rj_newton": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_void_p]),
     "gbp_rj_accept": (c_int, [_rj_o, _rj_c, ctypes.c_int64, c_int, c_void_p]),
     "gbp_rj_run": (c_int, [c_void_p, _rj_o, _rj_c, ctypes.c_int64, c_int, c_int, c_void_p]),

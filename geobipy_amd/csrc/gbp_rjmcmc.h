@@ -10,7 +10,25 @@
 //   k_rj_accept   one wave per chain:  priors, reversible-jump proposal ratio, Metropolis test, state update, posteriors
 #pragma once
 
-#define GBP_RJ_PERSISTENT_CUS 256    /* compute units assumed by gbp_rj_run's choice between its two drivers (MI355X) */
+// Register budget of the two per-chain physics kernels (k_rj_physics, k_rj_persistent): they are launched with at most 4 waves
+// per workgroup, so they are declared __launch_bounds__(256) and amdgpu_waves_per_eu picks the VGPR cap: 4 waves per SIMD = 128
+// VGPRs, 3 = 168, 2 = 256 (gfx950: 512 VGPRs per SIMD lane).  Measured in profiles/r3/rj_register_budget.md.
+// Measured (same box, scripts/bench_rj_modes.py through scripts/ab builds; chain-iterations/s, reference-Jacobian mode):
+//     waves per SIMD (VGPR cap, spills physics / persistent)   4 (128; 25-27 / 9)   3 (168; 0 / 7)   2 (256; 0 / 0)
+//     k_rj_physics,    8 192 Resolve chains, lock-step                37.6 M             35.7 M          28.5 M
+//     k_rj_persistent, 1 024 Resolve chains                           16.9 M             18.3 M          19.2 M
+//     k_rj_persistent, 1 024 ten-frequency chains                     15.5 M             16.6 M          17.4 M
+// The lock-step physics kernel is throughput-bound: the fourth wave per SIMD buys more than the 25 spilled registers cost (they sit
+// outside the layer loops).  The persistent kernel is a latency chain per workgroup with at most 4 workgroups of 2 waves resident per
+// CU (LDS): it never uses more than 2 waves per SIMD, so the whole register file is free -- no spills, +13 %.
+#ifndef GBP_RJ_PHYSICS_WAVES_PER_EU
+#define GBP_RJ_PHYSICS_WAVES_PER_EU 4
+#endif
+#ifndef GBP_RJ_PERSISTENT_WAVES_PER_EU
+#define GBP_RJ_PERSISTENT_WAVES_PER_EU 2
+#endif
+#define GBP_RJ_PHYSICS_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_RJ_PHYSICS_WAVES_PER_EU, GBP_RJ_PHYSICS_WAVES_PER_EU)))
+#define GBP_RJ_PERSISTENT_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_RJ_PERSISTENT_WAVES_PER_EU, GBP_RJ_PERSISTENT_WAVES_PER_EU)))
 
 namespace rj {
 
@@ -1453,7 +1471,7 @@ __device__ GBP_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t ite
 __device__ long long GBP_RJ_TICKS[8];
 
 template <bool EXACT>
-__global__ __launch_bounds__(1024) void k_rj_persistent(RjOpt o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
+__global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
                                                        const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                        uint32_t iter0, int n_iter, int accumulate, int nw_deep,
                                                        unsigned char* deep_scratch, size_t deep_bytes, const BinDesc* __restrict__ bins,
@@ -1591,7 +1609,7 @@ __global__ __launch_bounds__(1024) void k_rj_persistent(RjOpt o_arg, gbp_rj_chai
 // keep their Jacobian working set in a per-chain global block (as in the persistent kernel), so the LDS block is the small one.
 // ---------------------------------------------------------------------------------------------------------------
 template <bool EXACT>
-__global__ __launch_bounds__(1024) void k_rj_physics(RjOpt o, gbp_rj_chains c, const Channel* __restrict__ chan,
+__global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, const Channel* __restrict__ chan,
                                                     const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                     int stage, unsigned char* deep_scratch, size_t deep_bytes,
                                                     const BinDesc* __restrict__ bins, int bin0, int n_bins,
@@ -1688,26 +1706,26 @@ extern "C" {
 
 gbp_status gbp_rj_propose(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
 {
+    return gbp_rj_debug_propose_variant(o, c, iteration, 0, stream);
+}
+
+// variant 0: the product's choice -- one thread per chain, rows staged through LDS (the faster variant at every block size
+// measured, 256 ... 65536 chains; the unstaged kernel when max_layers > 42 rows do not fit); 1: unstaged thread per chain;
+// 2: cooperative one wave per chain.  The three are independent implementations of the same draws (tests hold them bit-equal).
+gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int variant, void* stream)
+{
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    // one thread per chain (rows staged through LDS) is the faster variant at every block size measured (256 ... 65536 chains);
-    // the unstaged kernel and the cooperative one-wave-per-chain kernel are kept as independent implementations of the same
-    // draws (test hooks: GBP_RJ_PROPOSE=thread / wave)
-    const char* force = std::getenv("GBP_RJ_PROPOSE");
-    if (force && force[0] == 'w')
+    if (variant < 0 || variant > 2) return fail(GBP_ERR_INVALID_ARG, "variant must be 0, 1 or 2%s");
+    const size_t lds = (size_t)3 * GBP_RJ_PROPOSE_ROWS * (o->max_layers | 1) * sizeof(double);
+    if (variant == 2)
         hipLaunchKernelGGL(rj::k_rj_propose_wave, dim3((c->B + 3) / 4), dim3(256), 0, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration);
-    else if (force && force[0] == 't')
+    else if (variant == 1 || lds > 64 * 1024)          // (rows too long to stage 64 of them: the unstaged kernel)
         hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rj::extend(*o), *c,
                            (uint32_t)iteration);
-    else {
-        const size_t lds = (size_t)3 * GBP_RJ_PROPOSE_ROWS * (o->max_layers | 1) * sizeof(double);
-        if (lds > 64 * 1024)          // rows too long to stage 64 of them (max_layers > 42): the unstaged kernel
-            hipLaunchKernelGGL(rj::k_rj_propose_thread, dim3((c->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rj::extend(*o), *c,
-                               (uint32_t)iteration);
-        else
-            hipLaunchKernelGGL(rj::k_rj_propose_staged, dim3((c->B + GBP_RJ_PROPOSE_ROWS - 1) / GBP_RJ_PROPOSE_ROWS),
-                               dim3(GBP_RJ_PROPOSE_THREADS), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration);
-    }
+    else
+        hipLaunchKernelGGL(rj::k_rj_propose_staged, dim3((c->B + GBP_RJ_PROPOSE_ROWS - 1) / GBP_RJ_PROPOSE_ROWS),
+                           dim3(GBP_RJ_PROPOSE_THREADS), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1742,6 +1760,19 @@ gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
 static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
                                   int64_t first_iteration, int n_iterations, int accumulate, bool fused, void* stream);
 
+// compute units of the current device (the persistent kernel's capacity: one query per process and device)
+static int device_cus()
+{
+    static thread_local int cached_dev = -1, cached = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return cached;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) { cached = n; cached_dev = dev; }
+    }
+    return cached;
+}
+
 static size_t sens_lds_bytes(int nw, int Lalloc)
 {
     return (size_t)nw * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)) + (size_t)Lalloc * sizeof(double);
@@ -1764,7 +1795,7 @@ static long long persistent_capacity(const gbp_fdem_system* sys, const gbp_rj_op
 {
     const size_t lds = persistent_lds_bytes(sys, o, nw);
     if (lds > 64 * 1024) return 0;
-    return (long long)GBP_RJ_PERSISTENT_CUS * std::min<long long>(160 * 1024 / (long long)(lds + 4864), 16 / nw);
+    return (long long)device_cus() * std::min<long long>(160 * 1024 / (long long)(lds + 4864), 4 * GBP_RJ_PERSISTENT_WAVES_PER_EU / nw);
 }
 
 // Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind.

@@ -84,10 +84,17 @@ class ChunkQueue:
     chains, not one sounding).  Iterating yields (start, size); without an initialised process group it runs through all chunks.
     """
 
-    def __init__(self, n_items, chunk, key="gbp_chunk_queue", store=None):
+    _jobs = 0          # queues made so far in this process: every rank makes them in the same order, so the n-th queue of a job is
+                       # the n-th on every rank and gets its own counter in the store (a second dynamic infer() -- a per-line loop --
+                       # must not find the first one's counter already past its chunks)
+
+    def __init__(self, n_items, chunk, key=None, store=None):
         assert chunk >= 1
         self.n_items, self.chunk = int(n_items), int(chunk)
         self.n_chunks = (self.n_items + self.chunk - 1) // self.chunk
+        if key is None:
+            key = "gbp_chunk_queue/{}".format(ChunkQueue._jobs)
+            ChunkQueue._jobs += 1
         self.key = key
         self._local = 0
         self.store = store
@@ -120,7 +127,8 @@ def gather_rows(rows, values, N, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev, C = values.device, values.shape[1]
     if world == 1:
-        out = torch.empty((N, C), dtype=torch.float64, device=dev)
+        assert int(rows.numel()) == N and int(torch.unique(rows).numel()) == N, ValueError("gather_rows: every row must arrive exactly once")
+        out = torch.full((N, C), float("nan"), dtype=torch.float64, device=dev)
         out[rows] = values
         return out
     counts = torch.empty(world, dtype=torch.int64, device=dev)
@@ -133,11 +141,17 @@ def gather_rows(rows, values, N, group=None):
     dist.all_gather_into_tensor(recv, send, group=group)
     if rank != 0:
         return None
-    out = torch.empty((N, C), dtype=torch.float64, device=dev)
+    # every row exactly once: a queue that handed out nothing (or a chunk twice) must not come back as uninitialised memory
+    assert int(counts.sum()) == N, RuntimeError("gather_rows: {} rows arrived for {} soundings".format(int(counts.sum()), N))
+    out = torch.full((N, C), float("nan"), dtype=torch.float64, device=dev)
+    seen = torch.zeros(N, dtype=torch.bool, device=dev)
     for r in range(world):
         n = int(counts[r])
         block = recv[r * max(pad, 1): r * max(pad, 1) + n]
-        out[block[:, 0].to(torch.int64)] = block[:, 1:]
+        idx = block[:, 0].to(torch.int64)
+        out[idx] = block[:, 1:]
+        seen[idx] = True
+    assert bool(seen.all()), RuntimeError("gather_rows: some soundings never arrived (and others twice)")
     return out
 
 
@@ -165,21 +179,32 @@ def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
         stage = lambda x: x.cpu()
     else:
         stage = lambda x: x.contiguous()
+    # Rounds: in round i every peer that still has a chunk i sends it, and rank 0 has receives posted for ALL of them at once
+    # (one reusable buffer set per peer: (world - 1) x chunk_rows rows of memory), so no rank waits for another rank to be
+    # drained completely -- at config 5's 3.5 GB of hit maps per GPU the peers' sends overlap instead of queueing behind rank 1.
+    n_rounds = max((c_ + chunk_rows - 1) // chunk_rows for c_ in counts) if counts else 0
     if rank == 0:
         for a in range(0, m, chunk_rows):
             yield to_host(rows, blocks, a, min(m, a + chunk_rows))
-        rbuf = torch.empty(chunk_rows, dtype=torch.int64, device=dev)
-        bufs = [torch.empty((chunk_rows,) + tuple(b.shape[1:]), dtype=b.dtype, device=dev) for b in blocks]
-        for r in range(1, world):
-            for a in range(0, counts[r], chunk_rows):
+        peers = [r for r in range(1, world) if counts[r] > 0]
+        rbuf = {r: torch.empty(chunk_rows, dtype=torch.int64, device=dev) for r in peers}
+        bufs = {r: [torch.empty((chunk_rows,) + tuple(b.shape[1:]), dtype=b.dtype, device=dev) for b in blocks] for r in peers}
+        for i in range(n_rounds):
+            posted = []
+            for r in peers:
+                a = i * chunk_rows
+                if a >= counts[r]:
+                    continue
                 n = min(chunk_rows, counts[r] - a)
-                dist.recv(rbuf[:n], src=r, group=group)
-                for buf in bufs:
-                    dist.recv(buf[:n], src=r, group=group)
-                yield to_host(rbuf, bufs, 0, n)
+                works = [dist.irecv(rbuf[r][:n], src=r, group=group)] + [dist.irecv(buf[:n], src=r, group=group) for buf in bufs[r]]
+                posted.append((r, n, works))
+            for r, n, works in posted:
+                for w in works:
+                    w.wait()
+                yield to_host(rbuf[r], bufs[r], 0, n)
     else:
         for a in range(0, m, chunk_rows):
             b = min(m, a + chunk_rows)
-            dist.send(stage(rows[a:b]), dst=0, group=group)
-            for x in blocks:
-                dist.send(stage(x[a:b]), dst=0, group=group)
+            works = [dist.isend(stage(rows[a:b]), dst=0, group=group)] + [dist.isend(stage(x[a:b]), dst=0, group=group) for x in blocks]
+            for w in works:
+                w.wait()

@@ -474,6 +474,10 @@ gbp_status gbp_tdem_fm_dlogc(gbp_tdem_system *sys, int B, const double *geometry
  * reset: 0 read only, 1 zero the counters and arm the clock (off by default: it costs chain 0 a few global updates per iteration),
  * 2 zero and disarm. */
 gbp_status gbp_rj_debug_stage_ticks(int64_t *out, int reset);
+/* Test hook: the proposal stage through one of its three independent implementations of the same draws (0 = gbp_rj_propose's:
+ * thread per chain, rows staged through LDS; 1 = unstaged thread per chain; 2 = one wave per chain); an explicit argument, no
+ * environment variable or other hidden state. */
+gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options *opt, const gbp_rj_chains *c, int64_t iteration, int variant, void *stream);
 /* Test hook: n uniforms and n standard normals of stream (chain, iteration, stream_id) as the kernels draw them. */
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);

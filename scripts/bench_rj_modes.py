@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from geobipy_amd import _lib
+if os.environ.get("GBP_AB_LIB"):                     # A/B builds of the library (scripts/ab/*.so): this script only, never the product
+    _lib.LIB_PATH = os.path.abspath(os.environ["GBP_AB_LIB"])
 from geobipy_amd import DeviceChains, FdemBatch, FdemSystem, synthetic
 
 which = sys.argv[1] if len(sys.argv) > 1 else "resolve"

@@ -81,3 +81,19 @@ def test_cpp_host_runs_the_sampler_through_the_c_abi(tmp_path):
     td = nxt(B * 19).reshape(B, 19)
     assert np.abs(td - py).max() <= 1e-10 * np.abs(py).max()
     assert off == r.size and dc.n_accepted.sum() > 1000
+
+
+@pytest.mark.gpu
+def test_two_host_threads_share_one_system_handle(tmp_path):
+    """SURVEY 8b "Threading": the compute entries are re-entrant.  tests/c_abi/two_threads.cpp runs two host threads on ONE handle
+    with table sets and abscissa windows, each thread with its own stream, batch and per-row set indices (an argument of
+    gbp_fdem_forward_rows_ex / gbp_fdem_fm_dlogc_rows_ex; the handle holds no per-call state): 2 x 200 rounds, every result
+    bit-equal to the single-threaded one."""
+    from geobipy_amd import _lib
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "two_threads")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", os.path.join(HERE, "c_abi", "two_threads.cpp"), "-o", exe,
+                           "-L" + os.path.dirname(_lib.LIB_PATH), "-lgeobipy_amd", "-lpthread", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 mismatching results" in out.stdout

@@ -70,34 +70,40 @@ def _queue_worker(rank, world, port, N, chunk, ret):
     try:
         import time
         from geobipy_amd.distributed import ChunkQueue, gather_rows
-        q = ChunkQueue(N, chunk)
-        rows, vals, mine = [], [], []
-        for s, m in q:
-            mine.append((s, m))
-            idx = torch.arange(s, s + m, dtype=torch.int64)
-            rows.append(idx)
-            vals.append(torch.stack([idx.double() * 3.0 - 1.0, torch.full((m,), float(rank), dtype=torch.float64)], dim=1))
-            time.sleep(0.002 * (1 + 3 * rank))          # a slow rank: the others take what it leaves
-        r = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.int64)
-        v = torch.cat(vals) if vals else torch.zeros((0, 2), dtype=torch.float64)
-        out = gather_rows(r, v, N)
-        counts = [None] * world
-        dist.all_gather_object(counts, len(mine))
+        all_counts, ok = [], True
+        for job in range(2):                                # two dynamic jobs in one process group: each queue has its own counter
+            q = ChunkQueue(N, chunk)
+            dist.barrier()                                  # (the ranks of a job start together: spawn / import times differ by seconds)
+            rows, vals, mine = [], [], []
+            for s, m in q:
+                mine.append((s, m))
+                idx = torch.arange(s, s + m, dtype=torch.int64)
+                rows.append(idx)
+                vals.append(torch.stack([idx.double() * 3.0 - 1.0, torch.full((m,), float(rank), dtype=torch.float64)], dim=1))
+                time.sleep(0.004 * (1 + 4 * rank))          # uneven chunk times: the slow ranks leave work to the fast one
+            r = torch.cat(rows) if rows else torch.zeros(0, dtype=torch.int64)
+            v = torch.cat(vals) if vals else torch.zeros((0, 2), dtype=torch.float64)
+            out = gather_rows(r, v, N)
+            counts = [None] * world
+            dist.all_gather_object(counts, len(mine))
+            all_counts.append(counts)
+            if rank == 0:
+                ref = torch.arange(N, dtype=torch.float64) * 3.0 - 1.0
+                ok = ok and bool(torch.equal(out[:, 0], ref)) and sum(counts) == q.n_chunks
+                owners = out[:, 1].reshape(-1)
+            else:
+                assert out is None
         if rank == 0:
-            ref = torch.arange(N, dtype=torch.float64) * 3.0 - 1.0
-            ok = bool(torch.equal(out[:, 0], ref)) and sum(counts) == q.n_chunks
-            owners = out[:, 1].reshape(-1)
-            ret.put((ok, counts, sorted(set(owners.tolist()))))
-        else:
-            assert out is None
+            ret.put((ok, all_counts, sorted(set(owners.tolist()))))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N,chunk", [(2, 1000, 64), (3, 130, 16)])
+@pytest.mark.parametrize("world,N,chunk", [(2, 1000, 64), (3, 130, 16), (4, 2000, 25)])
 def test_dynamic_chunk_queue_gloo(world, N, chunk):
     """Every chunk is taken exactly once (atomic counter in the job's store), whichever rank gets to it; rank 0 assembles
-    the rows wherever they were computed.  The slow rank ends up with fewer chunks."""
+    the rows wherever they were computed; a second job in the same process group starts from its own counter (a per-line loop of
+    dynamic infer() calls); with uneven chunk times the fast rank ends up with more chunks than the slowest (world 4: 80 chunks)."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
@@ -107,18 +113,25 @@ def test_dynamic_chunk_queue_gloo(world, N, chunk):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    ok, counts, owners = ret.get(timeout=5)
-    assert ok is True and sum(counts) == (N + chunk - 1) // chunk
-    assert counts[0] >= counts[-1]                     # the fastest rank did not do less than the slowest
-    print("chunks per rank:", counts, "owners seen:", owners)
+    ok, all_counts, owners = ret.get(timeout=5)
+    assert ok is True and len(all_counts) == 2
+    for counts in all_counts:
+        assert sum(counts) == (N + chunk - 1) // chunk
+    if (N + chunk - 1) // chunk >= 40:                 # enough chunks for the timing to show: 1 : 5 : 9 : 13 sleep per chunk
+        assert all_counts[0][0] > all_counts[0][-1] and all_counts[1][0] > all_counts[1][-1]
+    print("chunks per rank:", all_counts, "owners seen:", owners)
 
 
 def test_chunk_queue_without_a_process_group():
     from geobipy_amd.distributed import ChunkQueue, gather_rows
     assert list(ChunkQueue(10, 4)) == [(0, 4), (4, 4), (8, 2)] and list(ChunkQueue(0, 4)) == []
+    a, b = ChunkQueue(10, 4), ChunkQueue(10, 4)
+    assert a.key != b.key                               # every queue of a process its own counter key
     rows = torch.tensor([2, 0, 1])
     out = gather_rows(rows, torch.tensor([[2.0], [0.0], [1.0]], dtype=torch.float64), 3)
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0]
+    with pytest.raises(AssertionError):                  # a row missing / twice is an error, never uninitialised memory
+        gather_rows(torch.tensor([0, 0, 1]), torch.zeros((3, 1), dtype=torch.float64), 3)
 
 
 def _stream_worker(rank, world, port, N, ret):
@@ -146,7 +159,7 @@ def _stream_worker(rank, world, port, N, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,N", [(2, 50), (3, 20)])
+@pytest.mark.parametrize("world,N", [(2, 50), (3, 20), (4, 123)])
 def test_stream_rows_to_root_gloo(world, N):
     """Bounded-memory exchange of per-sounding payloads: rank 0 sees every rank's rows in chunks of at most chunk_rows."""
     ctx = mp.get_context("spawn")

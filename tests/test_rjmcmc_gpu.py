@@ -203,15 +203,11 @@ def test_propose_kernel_matches_the_emulation():
     # (one thread per chain, rows staged through LDS)
     names = ("action", "k_r", "nl_a", "nl_c", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p")
     out = {}
-    for variant in ("wave", "thread", "default"):
-        os.environ["GBP_RJ_PROPOSE"] = variant
-        try:
-            for n in names:
-                getattr(dc, n).fill_(-7)
-            _lib.check(_lib.load().gbp_rj_propose(dc._o, dc._c, 6, None))
-            out[variant] = {n: getattr(dc, n).clone() for n in names}
-        finally:
-            del os.environ["GBP_RJ_PROPOSE"]
+    for variant, code in (("wave", 2), ("thread", 1), ("default", 0)):
+        for n in names:
+            getattr(dc, n).fill_(-7)
+        _lib.check(_lib.load().gbp_rj_debug_propose_variant(dc._o, dc._c, 6, code, None))
+        out[variant] = {n: getattr(dc, n).clone() for n in names}
     for n in names:
         assert torch.equal(out["wave"][n], out["thread"][n]) and torch.equal(out["default"][n], out["thread"][n]), n
     assert np.array_equal(out["wave"]["action"].cpu().numpy(), act)
