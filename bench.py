@@ -4,11 +4,14 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 Workload (BASELINE.json configs[2]): 65 536 soundings x 10 zz frequencies x 8 layers, fp64,
-sharded in contiguous blocks over the N ranks (strong scaling: the total is fixed).  One STEP = one
-proposal round over the whole batch: every sounding gets a fresh conductivity vector (one of R
-pre-generated sets resident in HBM, so nothing can be cached), the fused kernel evaluates forward
-solve + chi^2 + log-likelihood, and the per-sounding summaries are gathered to rank 0 (RCCL, on a side
-stream so that it overlaps the next round).  Inputs are resident in HBM before the timed region.
+sharded in contiguous blocks over the N ranks (strong scaling: the total is fixed).  One proposal ROUND
+over the whole batch: every sounding gets a fresh conductivity vector (one of R pre-generated sets
+resident in HBM, so nothing can be cached), the fused kernel evaluates forward solve + chi^2 +
+log-likelihood, and the per-sounding summaries are gathered to rank 0 (RCCL, on a side stream so that it
+overlaps the next round).  One STEP = ``rounds_per_step`` rounds, chosen from the warm-up's round time so
+that the K timed steps last at least 1 s (R >= 8 rounds, wall >= 1 s; a 1 ms round x the
+driver's 20 steps would be a 20 ms region); value = soundings x K x rounds_per_step / elapsed.  Inputs
+are resident in HBM before the timed region.
 
 The JSON line also carries
   roofline      min-flop algorithmic FLOPs of SURVEY 8(d) / kernel time (HIP events on the launch
@@ -34,11 +37,23 @@ N_LAYERS = 8
 N_SIGMA_SETS = 4
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X datasheet, per GPU
 HBM_PEAK_GBPS = 8000.0
+MIN_TIMED_SECONDS = 1.0          # R >= 8 rounds and wall >= 1 s
 
 
 def flop_per_eval(L, F):
     """SURVEY 8(d) min-flop convention: (72 L + 33) flop per (frequency, abscissa) point, 120 points per zz frequency."""
     return (72 * L + 33) * F * 120
+
+
+def flop_per_jacobian_point(L, exact):
+    """Min-flop count (SURVEY 8d convention: real op 1, cadd 2, c x real 2, cmul 6, cdiv 11, cexp 5, csqrt 10) of ONE abscissa point
+    of the prediction + Jacobian pass (gbp_fdem_point.h sens_point = calcFdemSensitivity1D + M1_1, fdem1d_numba.py:130-154, 222-303):
+    basement layer 18; per layer above it 138 (csqrt 10, cexp 7, S / De / e De / Dd / Nn 14, 1 / Dd 11, its square 6, u e 6, the two
+    bracket products 21 + 15, accumulate 14, dY 8, i b / 2u and W 14, Y 12; + 9 for the reference's extra term), suffix propagation
+    6 per (layer, deeper layer) pair = 3 L (L - 1), surface factor + forward term 57, Hankel factor 13, row sums 2 L + 2."""
+    if L == 1:
+        return 80
+    return 18 + (138 + (0 if exact else 9)) * (L - 1) + 3 * L * (L - 1) + 57 + 13 + 2 * L + 2
 
 
 def bytes_per_eval(L, F, with_pred):
@@ -72,6 +87,24 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def rjmcmc_traffic(n_chains):
+    """HBM bytes per lock-step iteration of the sampler from the committed PMC passes (profiles/r*/summary_rjmcmc_<chains>.json)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_rjmcmc_{n_chains}.json")))
+    if not found:
+        return None
+    d = json.load(open(found[-1]))
+    return d.get("derived", {}).get("hbm_bytes_per_iteration")
+
+
+def tdem_traffic():
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary_tdem_config4.json")))
+    if not found:
+        return None
+    return json.load(open(found[-1])).get("derived", {}).get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(system, nl, sigma, thk, height, obs, sample, threads):
@@ -113,6 +146,31 @@ def rjmcmc_extra(system, height, obs, device, Btot):
         t0 = time.perf_counter(); dc.run(n); torch.cuda.synchronize(device)
         return time.perf_counter() - t0
 
+    F = system.nFrequencies
+
+    def evaluation_census(dc, exact, n_count=64):
+        """What one lock-step iteration evaluates, counted on the device over n_count further iterations: proposals that keep their
+        dimension run the fused forward (nl_b), chains whose structure changed the prediction + Jacobian pass at the remapped model
+        (nl_a) and dimension changes the same pass at the proposal (nl_c); every array holds the layer count of the chains that
+        need the stage, 0 for the others.  -> evaluations and algorithmic flops per chain-iteration."""
+        acc = torch.zeros(3, dtype=torch.float64, device=device)
+        fl = torch.zeros(2, dtype=torch.float64, device=device)
+        Lmax = dc.K
+        fwd_tab = torch.tensor([0.0] + [flop_per_eval(L_, F) for L_ in range(1, Lmax + 1)], dtype=torch.float64, device=device)
+        jac_tab = torch.tensor([0.0] + [flop_per_jacobian_point(L_, exact) * F * 120 for L_ in range(1, Lmax + 1)], dtype=torch.float64, device=device)
+        ksum = torch.zeros(1, dtype=torch.float64, device=device)
+        for _ in range(n_count):
+            dc.run(1)
+            a, b_, c_ = dc.t["nl_a"][0].long(), dc.t["nl_b"].long(), dc.t["nl_c"][0].long()
+            acc += torch.stack([(a > 0).sum(), (b_ > 0).sum(), (c_ > 0).sum()]).double()
+            fl += torch.stack([fwd_tab[b_].sum(), jac_tab[a].sum() + jac_tab[c_].sum()])
+            ksum += dc.t["k"].double().sum()
+        n = float(dc.B * n_count)
+        acc, fl = acc.cpu().numpy() / n, fl.cpu().numpy() / n
+        return {"forward_evals_per_chain_iteration": float(acc[1]), "jacobian_passes_per_chain_iteration": float(acc[0] + acc[2]),
+                "jacobian_at_remapped_model": float(acc[0]), "jacobian_at_proposal": float(acc[2]), "mean_layers": float(ksum.item() / n),
+                "flop_forward": float(fl[0]), "flop_jacobian": float(fl[1]), "flop_per_chain_iteration": float(fl[0] + fl[1])}
+
     for key, exact in (("reference_jacobian", False), ("exact_jacobian", True)):
         dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=exact, device=device, **opts)
         dt = timed(dc, n_it)
@@ -120,7 +178,19 @@ def rjmcmc_extra(system, height, obs, device, Btot):
         out[key] = {"value": nrj * n_it / dt, "seconds": dt, "ms_per_lockstep_iteration": 1e3 * dt / n_it,
                     "acceptance": float(sm[:, 4].mean()), "mean_layers": float(sm[:, 3].mean()),
                     "median_misfit": float(np.median(dc.misfit.cpu().numpy()))}
+        cen = evaluation_census(dc, exact)
+        ach = out[key]["value"] * cen["flop_per_chain_iteration"] / 1e12
+        win = dc._h.bin_points(35.0) / float(dc._h.npoints) if hasattr(dc._h, "bin_points") else 1.0
+        out[key]["roofline"] = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": rjmcmc_traffic(nrj),
+                                "frac_of_evaluated_flops": ach * win / FP64_VECTOR_PEAK_TFLOPS,
+                                "kernel": "k_rj_physics (fm_dlogc at the remapped models; fused forward / fm_dlogc at the proposals) "
+                                          "+ propose / newton / accept stages", **cen,
+                                "note": "algorithmic min-flop count of all 120 abscissae per frequency (as the headline's) x the evaluations "
+                                        "one iteration makes, counted on the device over 64 iterations; wall time of the whole iteration "
+                                        "(physics + per-chain stages)"}
         del dc
+    out["roofline"] = out["reference_jacobian"]["roofline"]
     out["value"] = out["reference_jacobian"]["value"]          # the pinned parity mode is the headline of this object
     # config 5 over 8 GPUs = 1 024 chains per GPU: the small-block regime
     small = {}
@@ -131,32 +201,49 @@ def rjmcmc_extra(system, height, obs, device, Btot):
         del dc
     out["block_of_1024"] = dict(small, unit="chain-iterations/s", note="one GPU's block when config 5 is spread over 8 GPUs; "
                                 "gbp_rj_run_mode 1 / 2 walk bit-identical chains")
-    # bounded replay on the host cores: 16 chains x 1 500 iterations of the reference-Jacobian run
+    # bounded replays on the host cores: 16 chains x 1 500 iterations in both Jacobian modes (the checker; never the measurement)
     try:
         import config5_replay
         n_rep, it_rep, every = 16, 1500, 100
-        dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=False, device=device, **opts)
-        rows = np.linspace(0, nrj - 1, n_rep).astype(int)
-        specs = config5_replay.specs_from_device(dc, rows, None, it_rep, every, obs_np, height, system=system)
-        pool, pending = config5_replay.start(specs)
-        try:
-            rows_t = torch.as_tensor(rows, device=device)
-            marks = []
-            for _ in range(it_rep // every):
-                dc.run(every)
-                marks.append(torch.stack([dc.k[rows_t].double(), dc.n_accepted[rows_t].double(), dc.misfit[rows_t]], dim=1).cpu().numpy())
-            res = pending.get(timeout=600)
-        finally:
-            pool.terminate()
-        cmp = config5_replay.compare(res, np.array(marks), dc.k_hist[rows_t].cpu().numpy(), dc.edge_hist[rows_t].cpu().numpy(), rows)
-        out["cpu_replay"] = {"chains": n_rep, "iterations": it_rep,
-                             "exact_matches": int(sum(c["first_divergent_checkpoint"] < 0 and c["histograms_equal"] for c in cmp)),
-                             "first_divergence_iteration": [int((c["first_divergent_checkpoint"] + 1) * every) for c in cmp
-                                                            if c["first_divergent_checkpoint"] >= 0],
+        arms = {}
+        for arm, exact in (("reference_jacobian", False), ("exact_jacobian", True)):
+            dc = DeviceChains(system, height[:nrj], obs_np[:nrj], seed=1, exact_jacobian=exact, device=device, **opts)
+            rows = np.linspace(0, nrj - 1, n_rep).astype(int)
+            specs = config5_replay.specs_from_device(dc, rows, None, it_rep, every, obs_np, height, system=system, exact=exact)
+            pool, pending = config5_replay.start(specs)
+            try:
+                rows_t = torch.as_tensor(rows, device=device)
+                marks = []
+                for _ in range(it_rep // every):
+                    dc.run(every)
+                    marks.append(torch.stack([dc.k[rows_t].double(), dc.n_accepted[rows_t].double(), dc.misfit[rows_t]], dim=1).cpu().numpy())
+                res = pending.get(timeout=600)
+            finally:
+                pool.terminate()
+            cmp = config5_replay.compare(res, np.array(marks), dc.k_hist[rows_t].cpu().numpy(), dc.edge_hist[rows_t].cpu().numpy(), rows)
+            same = [c for c in cmp if c["first_divergent_checkpoint"] < 0 and c["histograms_equal"]]
+            arms[arm] = {"exact_matches": len(same), "first_divergence_iteration": [int((c["first_divergent_checkpoint"] + 1) * every) for c in cmp
+                                                                                  if c["first_divergent_checkpoint"] >= 0],
+                         "median_rel_misfit_diff_of_matching_chains": float(np.median([c["max_rel_misfit_diff"] for c in same])) if same else None}
+            del dc
+        full = {}
+        for name, path in (("gpu_vs_cpu_64_chains_x_10000", "replay_arms_gpu_vs_cpu.json"), ("cpu_vs_perturbed_cpu_48_chains_x_10000", "replay_sensitivity_cpu.json")):
+            q = os.path.join(ROOT, "profiles", "r3", path)
+            if os.path.exists(q):
+                d = json.load(open(q))
+                full[name] = ([{k: a[k] for k in ("exact_jacobian", "hankel_eps_ppm", "exact_matches", "chains", "drift_median_final")} for a in d]
+                              if isinstance(d, list) else d["summary"])
+        out["cpu_replay"] = {"chains": n_rep, "iterations": it_rep, "exact_matches": arms["reference_jacobian"]["exact_matches"],
+                             "first_divergence_iteration": arms["reference_jacobian"]["first_divergence_iteration"], "arms": arms,
+                             "full_size_arms_committed": full,
                              "note": "layer-count / interface-depth histograms and every checkpoint of (layers, accepted steps) equal to a CPU "
-                                     "replay (rjmcmc.py stage emulation + C oracle, same random streams); the GPU tier replays 64 chains x "
-                                     "10 000 iterations (tests/test_config5_gpu.py: 58 of 64 identical to the end)"}
-        del dc
+                                     "replay (rjmcmc.py stage emulation + C oracle, same random streams).  Full size (64 chains x 10 000 "
+                                     "iterations, profiles/r3/replay_arms_gpu_vs_cpu.json): 58 / 58 / 59 / 59 of 64 identical in the four arms "
+                                     "{reference, exact Jacobian} x {abscissa window, all abscissae}, matching chains drift by 5e-11 (median, "
+                                     "not growing) -- and two CPU runs that differ by 1e-10-level perturbations of the oracle part at the same "
+                                     "rate (40 of 48, replay_sensitivity_cpu.json): the divergences are the chain map's own sensitivity in "
+                                     "ill-conditioned stretches (cond of the Newton precision ~1e4 - 4e5), not a property of either Jacobian "
+                                     "expression, of the window, or of the device"}
     except Exception as e:                                       # the replay is a checker, never the measurement
         out["cpu_replay"] = {"error": repr(e)}
     out["note"] = ("BASELINE config 5 on ONE GPU: full birth/death/perturb rjMCMC (gbp_rj_run), 10-frequency synthetic survey; value = "
@@ -167,7 +254,9 @@ def rjmcmc_extra(system, height, obs, device, Btot):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)   # ~1.6 s timed (wall >= 1 s)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--rounds-per-step", type=int, default=0,
+                    help="proposal rounds per step (0 = chosen so that the timed region is >= 1 s, SURVEY 8d)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--soundings", type=int, default=B_TOTAL, help="total soundings (default: BASELINE config)")
     ap.add_argument("--layers", type=int, default=N_LAYERS)
@@ -226,7 +315,7 @@ def main():
     gather = SummaryGather(Btot, 2, device)
     side = torch.cuda.Stream(device=device) if world > 1 else None
 
-    def step(i, pending):
+    def round_(i, pending):
         b = batches[i % N_SIGMA_SETS]
         chi2, logl = b.forward_loglike(want_pred=False)
         if world == 1:
@@ -247,15 +336,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # One STEP = rounds_per_step proposal rounds over the whole batch.  SURVEY 8(d) wants R >= 8 rounds and a timed region of at
+    # least 1 s: the driver's --steps 20 of ONE 1 ms round would be a 20 ms region, so the rounds per step are chosen from the
+    # warm-up's measured round time such that steps x rounds_per_step x round >= 1 s (every rank computes the same number from
+    # the max over ranks).  evals = soundings x steps x rounds_per_step.
     pending = None
     for i in range(args.warmup):
-        pending = step(i, pending)
+        pending = round_(i, pending)
     if pending is not None:
         pending[0].wait()
         pending = None
     sync_all()
+    tw0 = time.perf_counter()
+    n_probe = 8
+    for i in range(n_probe):
+        pending = round_(i, pending)
+    if pending is not None:
+        pending[0].wait()
+        pending = None
+    sync_all()
+    t_round = (time.perf_counter() - tw0) / n_probe
+    if world > 1:
+        tr = torch.tensor([t_round], dtype=torch.float64, device=device)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        t_round = float(tr[0])
+    rounds_per_step = max(1, int(np.ceil(MIN_TIMED_SECONDS / (args.steps * t_round)))) if args.rounds_per_step <= 0 else args.rounds_per_step
+    if args.steps * rounds_per_step < 8:
+        rounds_per_step = int(np.ceil(8 / args.steps))
+
+    def step(i, pending):
+        for r in range(rounds_per_step):
+            pending = round_(i * rounds_per_step + r, pending)
+        return pending
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync_all()
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
@@ -265,7 +380,8 @@ def main():
         pending[0].wait()
     sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # launch stream only: the fused kernel (+ tiny copies)
+    n_rounds = args.steps * rounds_per_step
+    kernel_ms = ev0.elapsed_time(ev1) / n_rounds        # launch stream only: the fused kernel (+ tiny copies), per round
 
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
@@ -274,11 +390,11 @@ def main():
     if world > 1:
         result = gather.finish()
     else:
-        last = batches[(args.steps - 1) % N_SIGMA_SETS]
+        last = batches[(n_rounds - 1) % N_SIGMA_SETS]
         result = torch.stack([last.chi2, last.logL], dim=1)
 
     if rank == 0:
-        evals = Btot * args.steps
+        evals = Btot * n_rounds
         value = evals / elapsed
         fpe = flop_per_eval(L, F)
         per_launch_evals = int(np.ceil(Btot / world))
@@ -292,6 +408,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "rounds_per_step": rounds_per_step,
+            "ms_per_round": 1e3 * elapsed / n_rounds,
+            "timed_seconds": elapsed,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -300,7 +419,8 @@ def main():
             "config": {"workload": f"{Btot} FDEM soundings x {F} zz frequencies x {L} layers, fused forward+chi2+logL, "
                                    f"contiguous shards over {world} GPU(s), gather of (chi2, logL) to rank 0 per round",
                        "soundings": Btot, "frequencies": F, "layers": L, "seed": synthetic.SEED,
-                       "proposal_sets": N_SIGMA_SETS},
+                       "proposal_sets": N_SIGMA_SETS, "rounds_per_step": rounds_per_step,
+                       "step": "rounds_per_step proposal rounds over the whole batch (chosen so that the timed region is >= 1 s)"},
             "roofline": {
                 "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(Btot, L, world),
@@ -317,7 +437,7 @@ def main():
             # abscissa window leaves out is bounded by 1e-12 ppm per output (|rTE| <= 1); measured difference below
             xb = [FdemBatch(system, nl[sl], sg, thk[sl], height[sl], data=obs, relative_error=rel, additive_error=add,
                             device=device, hankel_eps_ppm=0.0) for sg in sig_sets]
-            xsteps = max(10, args.steps // 4)
+            xsteps = max(10, n_rounds // 4)
             for i in range(3):
                 xb[i % N_SIGMA_SETS].forward_loglike(want_pred=False)
             torch.cuda.synchronize(device)
@@ -414,7 +534,7 @@ def main():
             line["tdem"] = {"value": Bt / c4["ms"] * 1e3, "unit": "evals/s", "soundings": Bt, "layers": Lt, "gates": c4["gates"],
                             "spline_nodes": c4["nodes"], "ms_per_step": c4["ms"],
                             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": (72 * Lt + 33) * c4["points"],
+                                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": tdem_traffic(), "flop_per_eval": (72 * Lt + 33) * c4["points"],
                                          "evals_per_launch": Bt, "kernel_ms": c4["ms"],
                                          "evaluated_flop_per_eval_at_35_m": (72 * Lt + 33) * c4["points_at_35_m"],
                                          "frac_of_evaluated_flops": ach_eval / FP64_VECTOR_PEAK_TFLOPS,

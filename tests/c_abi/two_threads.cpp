@@ -78,7 +78,7 @@ int main()
         std::vector<double> sg((size_t)b.B * b.L), th((size_t)b.B * b.L), h(b.B);
         for (int i = 0; i < b.B; ++i) {
             nl[i] = 1 + (i * 7 + t) % b.L;
-            set[i] = (i * (3 + t) + t) % n_sets;
+            set[i] = (i * 7 + i / 3 + t) % n_sets;
             h[i] = 22.0 + (i * 13 % 170) * 0.1 + t;
             for (int k = 0; k < b.L; ++k) {
                 sg[(size_t)i * b.L + k] = std::pow(10.0, -3.0 + 3.0 * ((i * 31 + k * 17 + t * 5) % 97) / 96.0);
