@@ -581,14 +581,16 @@ def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
                                                   options=dict(n_markov_chains=150)))])
 def test_persistent_kernel_walks_the_same_chains(exact, kw):
     """gbp_rj_run_mode: the persistent per-chain kernel (one workgroup owns a chain and loops over the iterations in ONE launch)
-    and the two lock-step drivers (mode 1: seven launches per iteration, one fused physics launch per stage; mode 3: ten, one
-    per kind of evaluation and layer-count bucket) are the same device functions on the same arrays, and their results do not
+    and the lock-step drivers (mode 1: seven launches per iteration, one fused physics launch per stage; mode 3: ten, one
+    per kind of evaluation and layer-count bucket; mode 4: mode 1 on concurrent sub-blocks of the chains, each on its own stream)
+    are the same device functions on the same arrays, and their results do not
     depend on the wave counts -- the chains, their posteriors and every piece of carried state are bit-identical, also when
     the run is cut into launches of different lengths, for deep models (> 8 layers: the one-wave variants of the per-chain
     algebra and the 8-row-group Jacobian pass) and under the reference's burn-in schedule."""
     B, n_it = 300, 400
     runs = []
-    for mode, cuts in ((1, (n_it,)), (3, (n_it,)), (2, (n_it,)), (2, (1, 7, 150, n_it - 158))):
+    # (mode 4: the block cut into concurrent sub-blocks on streams of their own -- here two of 150 chains -- and a run cut in two)
+    for mode, cuts in ((1, (n_it,)), (3, (n_it,)), (2, (n_it,)), (2, (1, 7, 150, n_it - 158)), (4, (n_it,)), (4, (90, n_it - 90))):
         d, s, dc = _chains(B, 31, exact=exact, **{k: (dict(v) if isinstance(v, dict) else v) for k, v in kw.items()})
         rng = np.random.default_rng(4)
         data = np.tile(d["data"], (B, 1)) * rng.uniform(0.7, 1.4, (B, 1))
@@ -692,3 +694,33 @@ def test_stuck_chains_restart_and_give_up_like_the_reference():
     assert torch.all(a.n_resets == 0) and torch.all(a.iteration0 == 0)
     for n in ("k", "sigma", "k_hist", "edge_hist", "burned_in_iteration", "status", "best_sigma", "n_accepted"):
         assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
+@pytest.mark.gpu
+def test_concurrent_sub_blocks_walk_the_same_chains_at_size():
+    """Mode 4 at sizes gbp_rj_run picks it for (two concurrent sub-blocks from 2 048 chains; uneven split at 4 099; explicit chain ids):
+    every chain, posterior and piece of carried state bit-identical to the one-block lock-step run, and the automatic choice
+    (mode 0) takes it."""
+    from geobipy_amd import DeviceChains, FdemBatch, FdemSystem, synthetic
+    from test_rjmcmc import RESOLVE_OPTIONS
+    system = FdemSystem.read(os.path.join(GOLDEN, "resolve.stm"))
+    o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
+    names = ["k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit", "n_accepted", "k_hist", "edge_hist", "rel_hist",
+             "add_hist", "best_posterior", "best_k", "best_edges", "best_sigma", "best_rel", "best_add"]
+    for B, ids in ((4099, False), (2500, True)):
+        nl, sig, thk, h = synthetic.draw_models(B, 4, seed=11)
+        data = synthetic.noisy_observations(FdemBatch(system, nl, sig, thk, h, waves=2).forward().cpu().numpy(), seed=12)
+        runs = {}
+        for mode in (1, 4, 0):
+            kw = dict(chain_id=np.arange(B)[::-1].copy() * 3 + 7) if ids else dict(first_chain=1000)
+            dc = DeviceChains(system, h, data, seed=5, exact_jacobian=False, hitmap=(mode != 0 and B < 3000), **kw, **o)
+            dc.run_mode = mode
+            dc.run(150)
+            dc.run(37)
+            torch.cuda.synchronize()
+            runs[mode] = dc
+        assert int(runs[1].n_accepted.sum()) > 0.05 * B * 187
+        for mode in (4, 0):
+            for n in names + (["hitmap"] if (mode != 0 and B < 3000) else []):
+                a, b = getattr(runs[1], n), getattr(runs[mode], n)
+                assert torch.equal(torch.nan_to_num(a.double(), nan=-1.25), torch.nan_to_num(b.double(), nan=-1.25)), (B, mode, n)
