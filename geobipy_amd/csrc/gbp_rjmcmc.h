@@ -30,7 +30,10 @@
 #include <string>
 #include <thread>
 
-#define GBP_RJ_PHYSICS_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_RJ_PHYSICS_WAVES_PER_EU, GBP_RJ_PHYSICS_WAVES_PER_EU)))
+#ifndef GBP_RJ_PHYSICS_MAX_WAVES
+#define GBP_RJ_PHYSICS_MAX_WAVES 4
+#endif
+#define GBP_RJ_PHYSICS_BOUNDS __launch_bounds__(64 * GBP_RJ_PHYSICS_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(GBP_RJ_PHYSICS_WAVES_PER_EU, GBP_RJ_PHYSICS_WAVES_PER_EU)))
 #define GBP_RJ_PERSISTENT_BOUNDS __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_RJ_PERSISTENT_WAVES_PER_EU, GBP_RJ_PERSISTENT_WAVES_PER_EU)))
 
 namespace rj {
@@ -1785,7 +1788,10 @@ gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     if (st != GBP_OK || c->B == 0) return st;
     // chains with <= 8 layers: packed kernel (8 per wave); the others: one wave each.  (Folding the deep body into the packed kernel
     // -- one launch per stage -- was tried: inlined it takes k_rj_accept8 from 111 to 178 VGPRs, as a call it adds 1.1 - 1.3 KB of
-    // scratch per lane to every launch; the second launch stays.)
+    // scratch per lane to every launch; the second launch stays.  So was running the two deep bodies as calls in the workgroup that
+    // owns the chain in the stage-1 physics launch -- five launches per iteration instead of seven: k_rj_physics goes from 104 to
+    // 288 B of scratch per lane and the iteration is no faster, 39.7 vs 40.5 M chain-iterations/s at 8 192 ten-frequency chains,
+    // 48.2 vs 51.5 M at 16 384: with two sub-blocks in flight the empty launches of one hide behind the other's kernels.)
     hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
                        rj::extend(*o), *c, (uint32_t)iteration);
     if (o->max_layers > 8)
@@ -2048,15 +2054,16 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if (P > 1 && c->chain_id == nullptr) t.o.first_chain = o->first_chain + (uint64_t)b0;
             t.q = P > 1 ? bs->q[p] : main_q;
             t.deep = nullptr;
-            // waves per workgroup as the one-block run of this size would choose them (results do not depend on it)
-            int swp = 1;
-            {
-                const int F = sys->t.nF;
-                const double want = 7500.0 / (0.4 * n) * (1.0 + std::min(n, 16384) / 16384.0);
-                for (int d = 1; d <= F; ++d)
-                    if (F % d == 0 && d <= 16 && (double)d <= 1.15 * want) swp = d;
-            }
-            t.nw = std::max(1, std::min(P > 1 ? swp : sw, 4));
+            // Waves per workgroup of the physics launches (results do not depend on it).  Measured per sub-block size n
+            // (scripts/bench_rj_parts.py through -DGBP_RJ_PHYSICS_NW builds, M chain-iterations/s with 1 / 2 / 3 / 4 waves; ten
+            // frequencies | Resolve): n = 1 024: 11.9 15.3 16.5 17.1 | 14.6 17.5 18.5 19.6;  2 048: 20.4 25.9 27.0 27.5 | 25.7 30.1 31.0
+            // 31.7;  4 096: 31.9 40.6 40.4 38.5 | 41.0 47.0 45.8 45.2;  8 192: 48.7 51.5 48.1 44.9 | 61.2 61.3 56.3 53.1 -- a
+            // chain's frequencies spread over four waves while the launch would not fill the SIMDs otherwise (<= 8 192 waves), two
+            // beyond.  (More than four -- a 320- or 384-thread launch bound -- is 30 % slower at every size.)
+            t.nw = std::min(n <= 2048 ? 4 : 2, GBP_RJ_PHYSICS_MAX_WAVES);
+#ifdef GBP_RJ_PHYSICS_NW
+            t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
+#endif
             t.lds = std::max(dyn_lds_bytes(t.nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(t.nw, K < 8 ? K : 8));
         }
         (void)deep_per_chain;

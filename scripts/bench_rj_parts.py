@@ -3,15 +3,18 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from geobipy_amd import _lib
+if os.environ.get("GBP_AB_LIB"):                     # A/B builds of the library (scripts/ab/*.so): this script only, never the product
+    _lib.LIB_PATH = os.path.abspath(os.environ["GBP_AB_LIB"])
 from geobipy_amd import DeviceChains, FdemBatch, FdemSystem, synthetic
 from test_rjmcmc import RESOLVE_OPTIONS
-system = FdemSystem.read(os.path.join(ROOT, "tests", "golden", "resolve.stm"))
+system = synthetic.syn10_system() if os.environ.get("GBP_SYSTEM") == "syn10" else FdemSystem.read(os.path.join(ROOT, "tests", "golden", "resolve.stm"))
 o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 nl, sig, thk, h = synthetic.draw_models(B, 4, seed=synthetic.SEED + 5)
 data = synthetic.noisy_observations(FdemBatch(system, nl, sig, thk, h, waves=2).forward().cpu().numpy())
-for mode in (1, 4, 0, 1, 4, 0):
+for mode in [int(m) for m in os.environ.get("GBP_MODES", "1,4,0,1,4,0").split(",")]:
     dc = DeviceChains(system, h, data, seed=3, exact_jacobian=False, forward_waves=2, **o)
     dc.run_mode = mode
     dc.run(100); torch.cuda.synchronize()

@@ -6,12 +6,20 @@ death / perturb / none = 1/6, 1/6, 1/6, 1/2, up to 30 layers, reference-expressi
         forward and Jacobian, same counter-based random streams -- and compared at 100 checkpoints (layer count, accepted
         steps, misfit) and in their final layer-count / interface-depth histograms: exact-match count and first divergence
         are printed ("posterior histograms bit-matching CPU seeds").  Measured: 58 of 64 chains
-        identical over all 10 000 iterations, the other 6 part between iterations 3 700 and 9 500 -- the two arithmetics
-        (C oracle vs HIP kernels) differ by ~1e-9 relative per evaluation, and with the reference's Jacobian expression (which
-        is not the derivative of its forward model) the stochastic-Newton map does not contract such differences:
-        they grow to ~1e-4 of the misfit over thousands of iterations, until one accept / reject draw is straddled; from
-        there the two chains are different draws of the same sampler.  Required: every chain identical for the first 2 000
-        iterations, >= 48 of 64 to the end.
+        identical over all 10 000 iterations, the other 6 part between iterations 3 700 and 9 500.  WHY (round 3,
+        scripts/replay_arms.py -> profiles/r3/replay_arms_gpu_vs_cpu.json, scripts/replay_sensitivity.py ->
+        profiles/r3/replay_sensitivity_cpu.json): the same replay in four arms -- {reference Jacobian expression, exact
+        derivative} x {per-sounding abscissa window, all 120 abscissae} -- gives 58 / 58 / 59 / 59 of 64, so neither the
+        reference's non-derivative Jacobian (round 2's guess) nor the window is the cause; the chains that match carry a
+        relative misfit difference of 5e-11 (median) that does NOT grow over the 10 000 iterations.  And the CPU chain run
+        twice, once with the oracle's outputs perturbed at the level two correct implementations differ by (prediction +-
+        3e-9 ppm, Jacobian 1e-10 relative), parts from itself at the same rate: 8 of 48 chains in 10 000 iterations.  In the
+        ~50 iterations before such a split the log acceptance ratios of the two runs differ by up to O(1) where the
+        stochastic-Newton precision J'PJ + Wm'Wm is ill-conditioned (cond 1e4 ... 4e5): the chain map itself is expansive
+        there, whatever computes the forward.  SURVEY 7-5's estimate (one split per 1e8 iterations) assumed a
+        well-conditioned map; the measured rate, device-vs-CPU and CPU-vs-CPU alike, is ~1e-5 per iteration.  Required:
+        every chain identical for the first 2 000 iterations, >= 48 of 64 to the end, and the matching chains within 1e-8
+        (median) / 5e-3 (any checkpoint: the stretches above) of the CPU misfit.
   (ii)  invariants on all 8 192 chains: finite state, structural constraints, posterior counts, cached prediction / misfit /
         likelihood equal to a from-scratch evaluation.
   (iii) the same survey run as two blocks of 4 096 (what two GPUs would do) ends bit-identical, row for row.
@@ -104,3 +112,4 @@ def test_config5_at_size_matches_cpu_replays_and_is_shard_independent():
     assert len(exact) >= 48, cmp
     assert all(c["first_divergent_checkpoint"] < 0 or (c["first_divergent_checkpoint"] + 1) * EVERY > 2000 for c in cmp), cmp
     assert all(c["max_rel_misfit_diff"] < 5e-3 for c in exact)
+    assert np.median([c["max_rel_misfit_diff"] for c in exact]) < 1e-8
