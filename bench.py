@@ -206,6 +206,14 @@ def rjmcmc_extra(system, height, obs, device, Btot):
         del dc
     out["block_of_1024"] = dict(small, unit="chain-iterations/s", note="one GPU's block when config 5 is spread over 8 GPUs; "
                                 "gbp_rj_run_mode 1 / 2 walk bit-identical chains")
+    # one GPU's block at 2 and 4 GPUs (gbp_rj_run's own choice of driver): the measured inputs of DESIGN.md 7's projection table
+    blocks = {}
+    for nb in (4096, 2048):
+        if nb <= nrj:
+            dc = DeviceChains(system, height[:nb], obs_np[:nb], seed=1, exact_jacobian=False, device=device, **opts)
+            blocks[str(nb)] = nb * 3000 / timed(dc, 3000, warm=100)
+            del dc
+    out["blocks"] = dict(blocks, unit="chain-iterations/s", note="one GPU's block of config 5 at 2 / 4 GPUs, driver chosen by gbp_rj_run")
     # bounded replays on the host cores: 16 chains x 1 500 iterations in both Jacobian modes (the checker; never the measurement)
     try:
         import config5_replay
@@ -480,7 +488,12 @@ def main():
             # the rows either side of the headline path, measured in the same run and reported next to it: the Jacobian
             # kernel on the same batch, and the time-domain path (rows 13-14, BASELINE config 4 shape)
             def per_call(fn, n):
-                fn(); torch.cuda.synchronize(device)
+                # (the GPU idles while the host builds a case: warm the clocks for ~50 ms before timing, or launches of ~0.1 ms
+                #  read 8 % slow -- shard_8192 60 M evals/s cold against 66 M warm in the same process)
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < 0.05:
+                    fn()
+                torch.cuda.synchronize(device)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(n):
@@ -495,7 +508,9 @@ def main():
             # BASELINE config 2 (4 096 soundings x 10 frequencies x 5 layers, one GPU) and one GPU's shard of config 3 (8 192 of
             # the 65 536 soundings at 8 GPUs): same kernel, same generator, smaller launches
             for key, Bk, Lk, note in (("config2", 4096, 5, "BASELINE config 2: 4 096 soundings x 10 frequencies x 5 layers, 1 GPU"),
-                                      ("shard_8192", 8192, L, "one GPU's shard of the headline workload at 8 GPUs (8 192 soundings)")):
+                                      ("shard_8192", 8192, L, "one GPU's shard of the headline workload at 8 GPUs (8 192 soundings)"),
+                                      ("shard_16384", 16384, L, "one GPU's shard of the headline workload at 4 GPUs"),
+                                      ("shard_32768", 32768, L, "one GPU's shard of the headline workload at 2 GPUs")):
                 nlk, sgk, thkk, hk = synthetic.draw_models(Bk, Lk, seed=synthetic.SEED + 2)
                 cl = FdemBatch(system, nlk, sgk, thkk, hk, device=device).forward().cpu().numpy()
                 ob = synthetic.noisy_observations(cl, seed=synthetic.SEED + 3)

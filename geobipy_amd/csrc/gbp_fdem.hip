@@ -630,10 +630,12 @@ size_t dyn_lds_bytes(int nw, int Lmax, int passes)
 // caller's explicit choice (the *_ex entries).  Results do not depend on it (forward_passes).
 int pick_waves(int B, int F, int Lmax, int max_waves, int waves)
 {
-    // measured (scripts/sweep_waves.py, 10 frequencies x 8 layers): one wave per sounding is best once every SIMD has a
-    // queue of soundings (B >= 49152); below that 4 waves per sounding balance the tail better (+2..6 %), and small
-    // batches need 8192 / B waves to fill the chip at all
-    const int heuristic = B >= 49152 ? 1 : std::max(4, (8192 + B - 1) / B);
+    // measured (scripts/sweep_waves.py, 10 frequencies x 8 layers, default abscissa windows = 10 passes per sounding): one wave
+    // per sounding is best once every SIMD has a queue of soundings -- from 8 192 soundings (66.9 / 70.0 / 71.0 / 70.7 M evals/s at
+    // 8 192 / 16 384 / 32 768 / 65 536 against 65.5 / 67.6 / 67.5 / 69.6 M with four waves, whose 10 passes split 3 3 2 2); below
+    // that 4 waves per sounding balance the tail better (61.4 vs 60.9 M at 4 096, 56.7 vs 47.3 M at 2 048), and small batches need
+    // 8192 / B waves to fill the chip at all.  (Round 2 switched at 49 152, measured with 19 passes per sounding.)
+    const int heuristic = B >= 8192 ? 1 : std::max(4, (8192 + B - 1) / B);
     int nw = waves > 0 ? waves : heuristic;
     if (nw > max_waves) nw = max_waves;
     if (nw > 16) nw = 16;

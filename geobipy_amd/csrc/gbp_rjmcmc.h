@@ -1911,6 +1911,9 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
 // ~8 us each, serialised inside the runtime whether one host thread issues them or four).
 static int lockstep_parts(int B)
 {
+#ifdef GBP_RJ_LOCKSTEP_PARTS
+    return B >= 2048 ? GBP_RJ_LOCKSTEP_PARTS : 1;              // (A/B builds under scripts/ab only)
+#endif
     return B >= 2048 ? 2 : 1;
 }
 
@@ -1937,7 +1940,7 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         mode = lockstep_parts(c->B) > 1 ? 4 : 1;
     }
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, true, stream);
-    return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, mode == 4 ? 2 : 1, stream);
+    return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, mode == 4 ? std::max(2, lockstep_parts(c->B)) : 1, stream);
 }
 
 gbp_status gbp_rj_debug_stage_ticks(int64_t* out, int reset)

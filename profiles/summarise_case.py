@@ -80,4 +80,4 @@ if case.startswith("rjmcmc"):
 out["derived"] = der
 os.makedirs(os.path.join(R, "profiles", rnd), exist_ok=True)
 json.dump(out, open(os.path.join(R, "profiles", rnd, "summary_%s.json" % case), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+print(json.dumps(out, indent=1))
