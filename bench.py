@@ -433,6 +433,9 @@ def main():
                                    f"contiguous shards over {world} GPU(s), gather of (chi2, logL) to rank 0 per round",
                        "soundings": Btot, "frequencies": F, "layers": L, "seed": synthetic.SEED,
                        "proposal_sets": N_SIGMA_SETS, "rounds_per_step": rounds_per_step,
+                       "hankel_eps_ppm": batches[0].hankel_eps_ppm,
+                       "abscissa_points_per_sounding_at_35_m": batches[0]._h.bin_points(35.0) if hasattr(batches[0]._h, "bin_points") else batches[0]._h.npoints,
+                       "abscissa_points_all": batches[0]._h.npoints,
                        "step": "rounds_per_step proposal rounds over the whole batch (chosen so that the timed region is >= 1 s)"},
             "roofline": {
                 "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

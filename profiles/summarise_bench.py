@@ -24,11 +24,16 @@ m = {k: sum(v) / len(v) for k, v in pmc.items()}
 bench = json.loads(next(l for l in open(os.path.join(src, "bench_kt.log")).read().splitlines()[::-1] if l.startswith("{")))
 fetch, write = m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
 cycles = m["GRBM_GUI_ACTIVE"] / 8.0
-timed = dur[-bench["steps"]:]
+timed = dur[-bench["steps"] * bench.get("rounds_per_step", 1):]
+cfg = bench.get("config", {})
+pts, pts_all = cfg.get("abscissa_points_per_sounding_at_35_m"), cfg.get("abscissa_points_all", 1200)
+label = ("label unknown (bench line without config.abscissa_points_*)" if pts is None else
+         "all %d abscissa points per sounding (hankel_eps_ppm = 0)" % pts_all if pts == pts_all else
+         "default path: per-sounding abscissa window, eps = %g ppm, %d of %d abscissa points per sounding at 35 m" % (cfg.get("hankel_eps_ppm"), pts, pts_all))
 out = {
-    "command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-windowed --no-rjmcmc (under rocprofv3, profiles/run_profile.sh; reduced by profiles/summarise_bench.py)",
+    "command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-windowed --no-rjmcmc --no-extras (under rocprofv3, profiles/run_profile.sh; reduced by profiles/summarise_bench.py)",
     "kernel": KERNEL,
-    "workload": "65536 soundings x 10 zz freq x 8 layers, 1 GPU (exact mode, 1200 abscissa points per sounding)",
+    "workload": "65536 soundings x 10 zz freq x 8 layers, 1 GPU (%s)" % label,
     "kernel_trace": {"calls": len(dur), "avg_ns": sum(dur) / len(dur), "min_ns": min(dur), "max_ns": max(dur),
                      "timed_region_avg_ns": sum(timed) / len(timed),
                      "bench_kernel_ms_same_run_hip_events": bench["roofline"]["kernel_ms"],
