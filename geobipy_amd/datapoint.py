@@ -37,6 +37,7 @@ class FdemDataPoint:
         self._additive_error = np.zeros(self.nSystems)
         self._sensitivity_matrix = None
         self._rel_prior = self._add_prior = None              # rjmcmc.ErrorPrior once set_priors / set_proposals ran
+        self._z_move = None                                   # rjmcmc.HeightMove once set_priors(solve_z=True, ...) ran
         self._prng = None
         # TEST HOOK: an object with forward(edges, values) / sensitivity(edges, values) replaces the GPU launches (the CPU
         # tier passes the C oracle); the product never sets it -- without it a missing GPU / library raises
@@ -201,11 +202,14 @@ class FdemDataPoint:
         assert np.isinf(mod.mesh.edges[-1]), ValueError("mod.edges must have last entry be infinity for forward modelling.")
         return np.asarray(mod.mesh.edges[1:-1], dtype=np.float64), np.asarray(mod.values, dtype=np.float64)
 
+    def _engine_height(self):
+        return {} if self._z_move is None else {"z": float(self.z[0])}       # (a sampled height travels with every request)
+
     def forward(self, mod):
         """Forward model the data from the given model (FdemDataPoint.py:524-545)."""
         assert isinstance(mod, Model), TypeError("Invalid model class for forward modeling [1D]")
         if self.engine is not None:
-            self._predictedData[:] = self.engine.forward(*self._engine_model(mod))
+            self._predictedData[:] = self.engine.forward(*self._engine_model(mod), **self._engine_height())
             return
         import torch
         from . import _lib
@@ -233,7 +237,7 @@ class FdemDataPoint:
         """J[2F, L] = d predictedData / d ln(sigma) (FdemDataPoint.py:530-559)."""
         assert isinstance(mod, Model), TypeError("Invalid model class for sensitivity matrix [1D]")
         if self.engine is not None:
-            self._sensitivity_matrix = np.asarray(self.engine.sensitivity(*self._engine_model(mod)))
+            self._sensitivity_matrix = np.asarray(self.engine.sensitivity(*self._engine_model(mod), **self._engine_height()))
             return self._sensitivity_matrix
         self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0][:, : int(mod.mesh.nCells)]
         return self._sensitivity_matrix
@@ -298,6 +302,8 @@ class FdemDataPoint:
             relative_error_prior = (kwargs["minimum_relative_error"], kwargs["maximum_relative_error"])
         if additive_error_prior is None and kwargs.get("solve_additive_error", False):
             additive_error_prior = (kwargs["minimum_additive_error"], kwargs["maximum_additive_error"])
+        if kwargs.get("solve_z", False):                      # Point.set_priors (pointcloud/Point.py:949-965): uniform z +- maximum_z_change
+            self._z_move = rjmcmc.HeightMove(float(self.z[0]), kwargs["maximum_z_change"], self._z_move.scale if self._z_move is not None else 0.0)
         var = lambda p: p.var if p is not None else 0.0
         if relative_error_prior is not None:
             lo, hi = (np.atleast_1d(v).astype(np.float64)[0] for v in relative_error_prior)
@@ -309,6 +315,9 @@ class FdemDataPoint:
     def set_proposals(self, relative_error_proposal=None, additive_error_proposal=None, **kwargs):
         """DataPoint.set_proposals (:597-644): log-normal random walks with the options file's proposal variances."""
         self._prng = kwargs.get("prng", self._prng)
+        if kwargs.get("solve_z", False):                      # Point.set_proposals (:967-983): Normal(z, z_proposal_variance)
+            assert self._z_move is not None, ValueError("set_priors must come before set_proposals")
+            self._z_move.scale = float(kwargs["z_proposal_variance"])
         if relative_error_proposal is None and kwargs.get("solve_relative_error", False):
             relative_error_proposal = kwargs["relative_error_proposal_variance"]
         if additive_error_proposal is None and kwargs.get("solve_additive_error", False):
@@ -320,7 +329,10 @@ class FdemDataPoint:
 
     def perturb(self):
         """DataPoint.perturb (:531-573): relative then additive error, each redrawn while outside its prior (the current
-        value is kept at the 10th redraw, StatArray.propose :620-638)."""
+        value is kept at the 10th redraw, StatArray.propose :620-638) -- after the height, when it is sampled (Point.perturb,
+        pointcloud/Point.py:614-621, reached first through super().perturb())."""
+        if self._z_move is not None and self._z_move.scale > 0.0:
+            self.z[0] = self._z_move.propose(self._prng, float(self.z[0]))
         if self._rel_prior is not None and self._rel_prior.var > 0.0:
             self._relative_error = np.atleast_1d(self._rel_prior.propose(self._prng, float(self._relative_error[0])))
         if self._add_prior is not None and self._add_prior.var > 0.0:
@@ -330,6 +342,8 @@ class FdemDataPoint:
     def probability(self):
         """DataPoint.probability (:454-489): sum of the log priors of the error levels that have one."""
         p = np.float64(0.0)
+        if self._z_move is not None:                          # Point.probability (pointcloud/Point.py:159-197)
+            p += self._z_move.log_prior(float(self.z[0]))
         if self._rel_prior is not None:
             p += self._rel_prior.log_prior(float(self._relative_error[0]))
         if self._add_prior is not None:

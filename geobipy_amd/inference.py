@@ -44,11 +44,11 @@ class GpuEngine:
         J = b.sensitivity(max_layers=int(nl.max()), exact=self.exact).cpu().numpy()
         return [J[i][:, : nl[i]] for i in range(len(models))]
 
-    def forward(self, edges, values):
-        return self.forward_many([(edges, values)])[0]
+    def forward(self, edges, values, z=None):
+        return self.forward_many([(edges, values)], None if z is None else [z])[0]
 
-    def sensitivity(self, edges, values):
-        return self.sensitivity_many([(edges, values)])[0]
+    def sensitivity(self, edges, values, z=None):
+        return self.sensitivity_many([(edges, values)], None if z is None else [z])[0]
 
 
 OPTION_DEFAULTS = dict(covariance_scaling=1.0, gradient_standard_deviation=1.5, factor=10.0, minimum_thickness=1.0,
@@ -70,7 +70,15 @@ def _priors_from_options(o, value_mean):
     return sp, vp, rp, ap
 
 
-def initial_state(engine, data, o, error_model=None):
+def height_move_from_options(o, z0):
+    """HeightMove when the options carry the keys the reference's data point reads (``solve_z``, ``maximum_z_change``,
+    ``z_proposal_variance``: pointcloud/Point.py:949-983), else None."""
+    if not o.get("solve_z", False):
+        return None
+    return rjmcmc.HeightMove(z0, o["maximum_z_change"], o["z_proposal_variance"])
+
+
+def initial_state(engine, data, o, error_model=None, z_move=None):
     """Inference1D.initialize (inversion/Inference1D.py:353-464, 485-535): best half-space out of 100 log-spaced
     conductivities (EmDataPoint.find_best_halfspace), its forward / Jacobian, prior and likelihood."""
     rel, add = o["initial_relative_error"], o["initial_additive_error"]
@@ -89,7 +97,9 @@ def initial_state(engine, data, o, error_model=None):
     pred, J = engine.forward(none, sigma), engine.sensitivity(none, sigma)
     misfit, like = rjmcmc.gauss_loglike(pred, data, std)
     prior = rjmcmc.model_log_prior(sp, vp, none, sigma) + rp.log_prior(rel) + ap.log_prior(add)
-    return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit)
+    if z_move is not None:
+        prior += z_move.log_prior(z_move.z0)
+    return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit, None if z_move is None else z_move.z0)
 
 
 class Posteriors:
@@ -102,8 +112,11 @@ class Posteriors:
     (tests/test_rjmcmc.py)."""
 
     def __init__(self, max_cells, max_edge, min_width, value_mean, factor=10.0, n_value_bins=250, ratio=0.5,
-                 relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99):
+                 relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99, height_edges=None):
         self.ratio = ratio
+        # height (Point.set_z_posterior :1010-1017): the cells of the uniform prior, when the height is sampled
+        self.height_edges = None if height_edges is None else np.asarray(height_edges, dtype=np.float64)
+        self.height = np.zeros(0 if height_edges is None else self.height_edges.size - 1, dtype=np.int64)
         # error levels (DataPoint.set_posteriors :651-694): n_error_bins cells, uniform in log10 between the prior bounds
         # (several levels -- time-domain data: bounds are arrays, one histogram per level: edges [G, n + 1], counts [G, n])
         grid = lambda b: None if b is None else np.linspace(*np.log10(np.asarray(b, dtype=np.float64)), n_error_bins + 1).T
@@ -121,11 +134,13 @@ class Posteriors:
         self.values = np.zeros((n_value_bins, self.depth_centres.size), dtype=np.int64)
 
     def reset(self):
-        for a in (self.n_cells, self.edges, self.values, self.relative_error, self.additive_error):
+        for a in (self.n_cells, self.edges, self.values, self.relative_error, self.additive_error, self.height):
             a[:] = 0
 
-    def update(self, edges, values, rel=None, add=None):
-        """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels."""
+    def update(self, edges, values, rel=None, add=None, z=None):
+        """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels; ``z``: height."""
+        if z is not None and self.height_edges is not None and self.height_edges[0] <= z <= self.height_edges[-1]:
+            self.height[min(np.searchsorted(self.height_edges, z, side="right") - 1, self.height.size - 1)] += 1
         for x, grid, hist in ((rel, self.rel_edges, self.relative_error), (add, self.add_edges, self.additive_error)):
             if x is not None and grid is not None:
                 if grid.ndim == 1:
@@ -196,7 +211,8 @@ class Inference1D:
                 self.engine = datapoint.make_engine(lmax=int(self.options["maximum_number_of_layers"]) + 2)
             else:
                 self.engine = GpuEngine(datapoint.system[0], datapoint.z[0])
-        self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model)
+        self.z_move = height_move_from_options(self.options, float(np.atleast_1d(datapoint.z)[0]))
+        self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model, self.z_move)
         self.halfspace = self.state.values.copy()
         self.iteration = 0
         self.data_misfit_v = np.zeros(2 * self.n_markov_chains + 2)
@@ -207,7 +223,8 @@ class Inference1D:
         self.posteriors = Posteriors(o["maximum_number_of_layers"], o["maximum_depth"], o["minimum_thickness"],
                                      float(self.halfspace[0]), o["factor"],
                                      relative_error_bounds=(o["minimum_relative_error"], o["maximum_relative_error"]),
-                                     additive_error_bounds=(o["minimum_additive_error"], o["maximum_additive_error"]))
+                                     additive_error_bounds=(o["minimum_additive_error"], o["maximum_additive_error"]),
+                                     height_edges=None if self.z_move is None else self.z_move.edges)
 
     # the quantities the reference exposes on its Inference1D
     @property
@@ -234,7 +251,8 @@ class Inference1D:
     def accept_reject(self):
         sp, vp, rp, ap = self.priors
         self.accepted, self.state = rjmcmc.accept_reject(self.prng, self.state, self.data, self.engine, sp, vp, rp, ap,
-                                                         self.options["covariance_scaling"], getattr(self, "error_model", None))
+                                                         self.options["covariance_scaling"], getattr(self, "error_model", None),
+                                                         getattr(self, "z_move", None))
         return False
 
     def update(self):
@@ -245,7 +263,7 @@ class Inference1D:
         if self.posterior > self.best_posterior:
             self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
         self.acceptance_v[self.iteration] = self.accepted
-        self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
+        self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z)
 
     def infer(self, hdf_file_handle=None, n_iterations=None, burn_in_min_iterations=5000):
         """``failed = infer(hdf_file_handle)`` as the harness calls it (Inference3D.py:620, Inference1D.infer :633-688); with
@@ -288,7 +306,7 @@ class Inference1D:
                 self.burned_in, self.burned_in_iteration = True, self.iteration
                 self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
                 self.posteriors.reset()
-                self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add)
+                self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z)
             if window > 1 and self.iteration % window == 0 and not self.burned_in:                    # update :764-776
                 # the reference's window: the flags it stored at indices [iteration - window, iteration), i.e. without this step's
                 if self.acceptance_v[max(self.iteration - window, 0):self.iteration].sum() == 0:
@@ -313,7 +331,8 @@ class Inference1D:
     def reset(self):
         """Inference1D.reset (:984-999): back to the initial state of this sounding; the random stream is not rewound."""
         self.n_resets += 1
-        self.priors, self.state = initial_state(self.engine, self.data, self.options, getattr(self, "error_model", None))
+        self.priors, self.state = initial_state(self.engine, self.data, self.options, getattr(self, "error_model", None),
+                                                getattr(self, "z_move", None))
         self.iteration = 0
         self.data_misfit_v[:] = 0.0
         self.data_misfit_v[0] = self.state.misfit

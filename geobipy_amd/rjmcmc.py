@@ -187,6 +187,35 @@ class ErrorPrior:
         return x
 
 
+class HeightMove:
+    """The height move of a data point (``solve_z``; Point.set_priors / set_proposals / perturb, pointcloud/Point.py:614-621,
+    949-983): uniform prior ``z0 +- maximum_z_change``, random-walk proposal ``Normal(z, z_proposal_variance)`` redrawn up to 10
+    times while the prior gives -inf, then the current height is kept (StatArray.propose, statistics/StatArray.py:578-638).
+    One quirk is reproduced: NormalDistribution.rng hands the VARIANCE to numpy as the scale
+    (statistics/NormalDistribution.py:111: ``prng.normal(mean, variance, size)``), so the step's standard deviation is
+    ``z_proposal_variance`` itself, not its square root.  (No options file of the reference sets these keys -- its ``solve_height`` /
+    ``maximum_height_change`` / ``height_proposal_variance`` are never read -- so the move is off unless a user adds them.)"""
+
+    def __init__(self, z0, max_change, proposal_variance, n_bins=99):
+        self.z0, self.lo, self.hi = float(z0), float(z0) - float(max_change), float(z0) + float(max_change)
+        self.scale = float(proposal_variance)
+        self.edges = np.linspace(self.lo, self.hi, n_bins + 1)          # Point.set_z_posterior: Uniform.bins() = 99 cells
+
+    def log_prior(self, z):
+        return -np.log(self.hi - self.lo) if (self.lo <= z <= self.hi) else -np.inf      # scipy uniform.logpdf: closed support
+
+    def propose(self, prng, current):
+        draw = lambda: float(prng.normal(current, self.scale))
+        x = draw()
+        tries = 0
+        while self.log_prior(x) == -np.inf:
+            x = draw()
+            tries += 1
+            if tries == 10:
+                return float(current)
+        return x
+
+
 def mvn_logpdf(x, mean, cov):
     """MvNormal.probability(log=True) (statistics/MvNormalDistribution.py:201-216)."""
     d = x - mean
@@ -250,7 +279,8 @@ _PLAIN_ERRORS = ErrorModel()
 class ChainState:
     """What Inference1D carries between iterations for one sounding."""
 
-    def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit):
+    def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit, z=None):
+        self.z = None if z is None else float(z)               # the data point's height, when it is sampled (HeightMove)
         self.edges, self.values = np.array(edges, dtype=np.float64), np.array(values, dtype=np.float64)
         self.rel = float(rel) if np.ndim(rel) == 0 else np.array(rel, dtype=np.float64)
         self.add = float(add) if np.ndim(add) == 0 else np.array(add, dtype=np.float64)
@@ -262,7 +292,7 @@ class ChainState:
         return self.values.size
 
 
-def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None):
+def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None):
     """One iteration of Inference1D.accept_reject (inversion/Inference1D.py:537-631) for the Resolve-style option
     set (solve_gradient, solve relative / additive error, no height move), written as a coroutine around the hot
     path: it yields ``(phase, (edges, values))`` whenever it needs the kernels --
@@ -271,11 +301,14 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
         phase 2: Jacobian at the proposed model (reversible-jump step, Model.py:612)
     -- is sent back ``(predicted, J)``, and finally yields ``(3, accepted, state)``.  The random stream is consumed
     in exactly the reference's order, so a driver may interleave the coroutines of many chains and batch each
-    phase into one launch."""
+    phase into one launch.  With ``z_move`` (HeightMove) the data point's height is sampled too and the requests carry it as a
+    third entry, ``(phase, (edges, values), z)``: the current height for phase 0 -- Model.perturb works on the unperturbed copy of
+    the data point, Inference1D.py:547-560 --, the proposed one for phases 1 and 2."""
     prng.random()                                               # Inference1D.py:542
     action, _, _, edges, rem = perturb_structure(prng, sp, state.edges, state.values)
+    ask = (lambda ph, e, v, z: (ph, (e, v))) if z_move is None else (lambda ph, e, v, z: (ph, (e, v), z))
     if action != NONE:
-        pred_rem, J = yield (0, (edges, rem))
+        pred_rem, J = yield ask(0, edges, rem, state.z)
     else:
         pred_rem, J = state.pred, state.J
     em = _PLAIN_ERRORS if error_model is None else error_model
@@ -284,12 +317,15 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     std = em.std(data, state.rel, state.add)
     mean, H = stochastic_newton(vp, edges, rem, J, pred_rem, data, std, alpha)
     prop = propose_values(prng, mean, H)
-    rel = rel_prior.propose(prng, state.rel)                    # DataPoint.perturb, DataPoint.py:531-573
+    z = state.z if z_move is None else z_move.propose(prng, state.z)     # Point.perturb first (DataPoint.perturb :561) ...
+    rel = rel_prior.propose(prng, state.rel)                    # ... then the error levels, DataPoint.py:531-573
     add = add_prior.propose(prng, state.add)
-    pred, _ = yield (1, (edges, prop))
+    pred, _ = yield ask(1, edges, prop, z)
     std_t = em.std(data, rel, add)
     misfit, like = gauss_loglike(pred, data, std_t)
     prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
+    if z_move is not None:
+        prior += z_move.log_prior(z)                            # Point.probability, pointcloud/Point.py:159-197
     if prior == -np.inf:
         yield (3, False, state)
         return
@@ -299,7 +335,7 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
         return
     q_fwd = q_rev = 1.0
     if action in (INSERT, DELETE):                              # Model.proposal_probabilities, Model.py:577-659
-        _, J = yield (2, (edges, prop))
+        _, J = yield ask(2, edges, prop, z)
         a = data > 0.0
         grad = model_prior_derivative(vp, edges, prop, 1) + J[a].T @ ((pred[a] - data[a]) / std_t[a] ** 2.0)
         # ln sigma' - alpha * pk with pk = -H g; the reference exponentiates in long double (expReal,
@@ -318,17 +354,19 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     if not accepted:
         yield (3, False, state)
         return
-    yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit))
+    yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit, z))
 
 
-def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None):
+def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None):
     """Drive ``accept_reject_phases`` for one chain with ``engine.forward(edges, values)`` /
-    ``engine.sensitivity(edges, values)`` (GPU kernels in the product).  Returns (accepted, state)."""
-    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha, error_model)
+    ``engine.sensitivity(edges, values)`` (GPU kernels in the product; with a height move both take ``z=``).  Returns
+    (accepted, state)."""
+    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha, error_model, z_move)
     req = next(g)
     while req[0] != 3:
-        phase, (e, v) = req
-        F = engine.forward(e, v) if phase in (0, 1) else None
-        Jm = engine.sensitivity(e, v) if phase in (0, 2) else None
+        phase, (e, v) = req[0], req[1]
+        kw = {} if z_move is None else {"z": req[2]}
+        F = engine.forward(e, v, **kw) if phase in (0, 1) else None
+        Jm = engine.sensitivity(e, v, **kw) if phase in (0, 2) else None
         req = g.send((F, Jm))
     return req[1], req[2]

@@ -84,11 +84,11 @@ class _Holder:
     pass
 
 
-def _setup(dp, d):
+def _setup(dp, d, rng_state=None, **more):
     """Inference1D.initialize with the objects' own methods: best half-space, priors, proposals, initial probabilities."""
     from geobipy_amd import Model, RectilinearMesh1D
-    o = dict(RESOLVE_OPTIONS, solve_relative_error=True, solve_additive_error=True, factor=10.0, gradient_standard_deviation=1.5)
-    prng = generator_at(d["rng_state"][0])
+    o = dict(RESOLVE_OPTIONS, solve_relative_error=True, solve_additive_error=True, factor=10.0, gradient_standard_deviation=1.5, **more)
+    prng = generator_at(d["rng_state"][0] if rng_state is None else rng_state)
     dp.relative_error, dp.additive_error = o["initial_relative_error"], o["initial_additive_error"]
     dp.set_priors(prng=prng, **o)
     dp.set_proposals(prng=prng, **o)
@@ -120,6 +120,42 @@ def test_reference_accept_reject_body_on_these_objects_walks_the_reference_chain
     h = _setup(dp, d)
     assert np.isclose(h.prior, d["cur_prior"][0], rtol=1e-12) and np.isclose(h.likelihood, d["cur_like"][0], rtol=1e-12)
     _check_chain(h, d, 1000)
+
+
+def _height_chain(engine):
+    """The same body with the height sampled (``solve_z``, Point.perturb pointcloud/Point.py:614-621 reached through
+    DataPoint.perturb's super().perturb()): the reference's own 600-iteration run of tests/golden/mcmc_height.npz."""
+    from geobipy_amd import FdemDataPoint, FdemSystem
+    g = np.load(os.path.join(GOLDEN, "mcmc_height.npz"))
+    z0 = float(g["z0"])
+    dp = FdemDataPoint(x=30.0, y=0.0, z=z0, elevation=0.0, data=g["data"], system=FdemSystem.read(os.path.join(GOLDEN, "resolve.stm")),
+                       lineNumber=0.0, fiducial=30.0)
+    if engine:
+        dp.engine = OracleEngine("resolve", z0)
+    h = _setup(dp, g, rng_state=g["rng_state"], solve_z=True, maximum_z_change=1.0, z_proposal_variance=float(g["z_proposal_variance"]))
+    assert np.isclose(h.prior, float(g["prior0"]), rtol=1e-12)
+    return g, h
+
+
+def _check_height_chain(g, h, n):
+    rows = g["rows"]
+    for it in range(n):
+        _reference_accept_reject(h)
+        acc, k, misfit, z = rows[it, :4]
+        assert h.accepted == bool(acc) and int(h.model.nCells) == int(k) and np.isclose(h.data_misfit, misfit, rtol=1e-6), it
+        assert np.isclose(float(h.datapoint.z[0]), z, atol=1e-9), it
+
+
+def test_reference_accept_reject_body_with_the_height_move():
+    g, h = _height_chain(engine=True)
+    _check_height_chain(g, h, 600)
+
+
+@pytest.mark.gpu
+def test_reference_accept_reject_body_with_the_height_move_on_the_gpu_objects():
+    g, h = _height_chain(engine=False)
+    assert h.datapoint.engine is None
+    _check_height_chain(g, h, 300)
 
 
 @pytest.mark.gpu

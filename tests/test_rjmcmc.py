@@ -91,11 +91,11 @@ class OracleEngine:
     def _thk(self, edges):
         return np.r_[np.diff(np.r_[0.0, edges]), np.inf]
 
-    def forward(self, edges, values):
-        return self.fo.predicted_data(self.sys, values, self._thk(edges), self.z)
+    def forward(self, edges, values, z=None):
+        return self.fo.predicted_data(self.sys, values, self._thk(edges), self.z if z is None else z)
 
-    def sensitivity(self, edges, values):
-        J = self.fo.sensitivity(self.sys, values, self._thk(edges), self.z)
+    def sensitivity(self, edges, values, z=None):
+        J = self.fo.sensitivity(self.sys, values, self._thk(edges), self.z if z is None else z)
         return np.vstack([J.real, J.imag])
 
 
@@ -190,6 +190,38 @@ def test_long_chain_reproduces_the_reference_decisions_and_posteriors():
     assert np.array_equal(post.edges, d["post_edges"]) and post.edges.sum() == 1947
     assert np.array_equal(post.values, d["post_values"]) and post.values.sum() == 3000 * 440
     assert np.array_equal(post.relative_error, d["post_rel"]) and np.array_equal(post.additive_error, d["post_add"])
+
+
+def test_height_move_reproduces_the_reference_chain():
+    """``solve_z`` (Point.perturb, pointcloud/Point.py:614-621; the keys no options file of the reference sets, added the way a
+    user would): the reference's own Inference1D run with the height sampled (tests/golden/make_mcmc_height.py -> mcmc_height.npz,
+    600 iterations from its seed) -- every decision, layer count, misfit, height and both error levels, the prior / likelihood
+    it carries, and the height posterior it accumulates are reproduced by the host sampler with the C oracle as its engine."""
+    from geobipy_amd import FdemDataPoint, FdemSystem, Inference1D
+    g = np.load(os.path.join(GOLDEN, "mcmc_height.npz"))
+    rows = g["rows"]
+    z0 = float(g["z0"])
+    dp = FdemDataPoint(x=30.0, y=0.0, z=z0, elevation=0.0, data=g["data"], system=FdemSystem.read(os.path.join(GOLDEN, "resolve.stm")),
+                       lineNumber=0.0, fiducial=30.0)
+    dp.engine = OracleEngine("resolve", z0)
+    o = dict(RESOLVE_OPTIONS, n_markov_chains=rows.shape[0], solve_z=True, maximum_z_change=1.0, z_proposal_variance=float(g["z_proposal_variance"]))
+    inf = Inference1D(prng=generator_at(g["rng_state"]), world=None, **o)
+    inf.initialize(dp)
+    assert inf.state.values[0] == pytest.approx(float(g["halfspace"]), rel=1e-12)
+    assert inf.prior == pytest.approx(float(g["prior0"]), rel=1e-12) and inf.likelihood == pytest.approx(float(g["like0"]), rel=1e-9)
+    assert (inf.z_move.lo, inf.z_move.hi) == tuple(g["z_prior"])
+    for it in range(rows.shape[0]):
+        inf.accept_reject()
+        inf.update()
+        acc, k, misfit, z, rel, add, prior, like = rows[it]
+        assert bool(acc) == inf.accepted and int(k) == inf.state.k, it
+        assert inf.state.z == pytest.approx(z, abs=1e-12) and inf.state.rel == pytest.approx(rel, rel=1e-12) and inf.state.add == pytest.approx(add, rel=1e-12), it
+        assert inf.data_misfit == pytest.approx(misfit, rel=1e-8) and inf.prior == pytest.approx(prior, rel=1e-10, abs=1e-10), it
+        assert inf.likelihood == pytest.approx(like, rel=1e-8), it
+    assert rows[:, 0].sum() > 200 and np.ptp(rows[:, 3]) > 0.4                       # (the height really moved)
+    # the reference stores the posterior's cells relative to the starting height (RectilinearMesh1D(relative_to=z))
+    assert np.allclose(inf.posteriors.height_edges - z0, g["z_hist_edges"], atol=1e-12) and float(g["z_hist_relative_to"]) == z0
+    assert np.array_equal(inf.posteriors.height, g["z_hist_counts"])
 
 
 def test_host_inference1d_follows_the_reference_schedule():
