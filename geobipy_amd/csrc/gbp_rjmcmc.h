@@ -45,6 +45,7 @@ struct RjOpt : gbp_rj_options {
     double log_min_edge, log_max_edge, log_layers_m1, log_value_precision, log_gradient_precision;
     double log_rel_min[4], log_rel_max[4], log_add_min[4], log_add_max[4];
     double nlog_rel_span[4], nlog_add_span[4];               // -log(log(max) - log(min)): the log-uniform prior density
+    double nlog_height_span;                                 // -log(2 height_half_width): the uniform prior density of the height
 };
 
 inline RjOpt extend(const gbp_rj_options& o)
@@ -64,6 +65,7 @@ inline RjOpt extend(const gbp_rj_options& o)
         x.nlog_rel_span[g] = -std::log(x.log_rel_max[g] - x.log_rel_min[g]);
         x.nlog_add_span[g] = -std::log(x.log_add_max[g] - x.log_add_min[g]);
     }
+    x.nlog_height_span = o.solve_height ? -std::log(2.0 * o.height_half_width) : 0.0;
     std::memcpy(&last, &o, sizeof(o)); cached = x; have = true;
     return x;
 }
@@ -288,6 +290,18 @@ __device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r
     c.nl_b[b] = jump ? 0 : kr;          // jump proposals get their prediction from the Jacobian pass instead
     c.action[b] = action;
     c.k_r[b] = kr;
+    // the data point's height (Point.perturb, reached first through DataPoint.perturb's super().perturb(): pointcloud/Point.py
+    // :614-621): random walk redrawn while outside the uniform prior, the current height kept at the 10th redraw
+    if (o.solve_height) {
+        const double cur_h = c.height[b], lo_h = c.height0[b] - o.height_half_width, hi_h = c.height0[b] + o.height_half_width;
+        double x = cur_h + o.height_scale * r.normal();
+        int tries = 0;
+        while (!(x >= lo_h && x <= hi_h)) {
+            x = cur_h + o.height_scale * r.normal();
+            if (++tries == 10) { x = cur_h; break; }
+        }
+        c.height_p[b] = x;
+    }
     // error levels (DataPoint.perturb: relative then additive)
     const Levels cur = load_levels(o, c.rel, c.add, (size_t)b);
     Levels out = cur;
@@ -841,7 +855,7 @@ __device__ inline double group_sum8(double v)
 template <int W>
 __device__ inline void bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
                                    int kc, const double* ec, const double* sc, double post, double best_prev, double misfit_now,
-                                   const Levels& lev, double lmp, int dwell)
+                                   const Levels& lev, double lmp, int dwell, double height_now)
 {
     const int K = o.max_layers, N = o.n_channels;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
@@ -864,6 +878,8 @@ __device__ inline void bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint3
                 }
                 if (c.edge_hist != nullptr)
                     for (int q = i; q < o.n_depth_bins; q += W) c.edge_hist[b * o.n_depth_bins + q] = 0;
+                if (c.height_hist != nullptr)
+                    for (int q = i; q < o.n_error_bins; q += W) c.height_hist[b * o.n_error_bins + q] = 0;
                 if (c.hitmap != nullptr) {
                     for (size_t q = i; q < nh; q += W) c.hitmap[b * nh + q] = 0;
                     dwell = 0;
@@ -883,12 +899,17 @@ __device__ inline void bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint3
                 for (int g = 0; g < o.n_rel_groups; ++g) c.best_rel[b * o.n_rel_groups + g] = lev.rel[g];   //  :741-745 keeps the data point)
             if (c.best_add != nullptr)
                 for (int g = 0; g < o.n_add_groups; ++g) c.best_add[b * o.n_add_groups + g] = lev.add[g];
+            if (c.best_height != nullptr) c.best_height[b] = height_now;
         }
     }
     if (accumulate) {
         if (i == 0) {
             c.k_hist[b * (K + 1) + kc] += 1;
             error_hist_add(o, c, b, lev);
+            if (c.height_hist != nullptr) {                      // Point.set_z_posterior: the cells of the uniform prior
+                const double u = (height_now - (c.height0[b] - o.height_half_width)) / (2.0 * o.height_half_width);
+                if (u >= 0.0 && u <= 1.0) c.height_hist[b * o.n_error_bins + min((int)floor(u * (double)o.n_error_bins), o.n_error_bins - 1)] += 1;
+            }
         }
         if (c.edge_hist != nullptr && i < kc - 1) {              // interfaces across which sigma changes by > 50 %
             const double ratio = sc[i + 1] / sc[i];              //   (RectilinearMesh1D.update_posteriors :1595-1610)
@@ -941,6 +962,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, (size_t)b);
     if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
     if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    if (o.solve_height) prior_p += o.nlog_height_span;           // Point.probability: the proposal is inside the uniform prior by construction
     double dq = 0.0;
     if (action == INSERT || action == DELETE) {                  // Model.proposal_probabilities (model/Model.py:577-659)
         const double* Jp = c.J_p + (size_t)b * N * K;
@@ -1008,6 +1030,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) return;
     const Levels lev_c = load_levels(o, c.rel, c.add, (size_t)b);  // (read before the state is overwritten)
+    const double height_now = o.solve_height ? (accept ? c.height_p[b] : c.height[b]) : 0.0;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[b] : 0;        // iterations the current model is still owed to the hit map
     if (accept && dwell > 0) {                                   // the model changes: settle the old one first
@@ -1037,11 +1060,12 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
             }
             c.prior[b] = prior_p; c.like[b] = like_p; c.misfit[b] = misfit_p;
             c.n_accepted[b] += 1;
+            if (o.solve_height) const_cast<double*>(c.height)[b] = height_now;
         }
     }
     bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
                     accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
-                    accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
+                    accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now);
 }
 
 __global__ __launch_bounds__(64) void k_rj_accept(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
@@ -1121,6 +1145,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, bb);
     if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
     if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    if (o.solve_height) prior_p += o.nlog_height_span;           // Point.probability: the proposal is inside the uniform prior by construction
     // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian
     double* PR = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * N;
     double s2 = 0.0, logdet = 0.0, na = 0.0;
@@ -1210,6 +1235,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
     const double misfit_c = c.misfit[bb];
     const Levels lev_c = load_levels(o, c.rel, c.add, bb);       // (read before the state is overwritten)
+    const double height_now = o.solve_height ? (accept ? c.height_p[bb] : c.height[bb]) : 0.0;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     int dwell = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
     if (c.hitmap != nullptr) {                       // the model changes: settle the old one in the hit map first
@@ -1240,11 +1266,12 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
             }
             c.prior[bb] = prior_p; c.like[bb] = like_p; c.misfit[bb] = misfit_p;
             c.n_accepted[bb] += 1;
+            if (o.solve_height) const_cast<double*>(c.height)[bb] = height_now;
         }
     }
     bookkeeping<8>(o, c, iter, accumulate, bb, i, accept ? k : k_prev, accept ? e : c.edges + bb * K,
                    accept ? c.sigma_p + bb * K : c.sigma + bb * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
-                   accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell);
+                   accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now);
 }
 
 __global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate)
@@ -1628,7 +1655,8 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     const int action = c.action[b];
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
     const int K = o.max_layers, N = o.n_channels, L = c.k_r[b];
-    const double alt = c.height[b];
+    // (a sampled height: the remapped model is evaluated at the chain's current height, the proposal at the proposed one)
+    const double alt = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
     if (bins != nullptr && alt >= (double)bin0) {                 // the chain's abscissa window: the bin of its sounding's altitude
         const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
         chan = bin_chan + d.chan_off;
@@ -1721,6 +1749,7 @@ gbp_rj_chains slice_chains(const gbp_rj_options& o, const gbp_rj_chains& c, int 
     GBP_OFF(k_hist, K + 1) GBP_OFF(edge_hist, nd) GBP_OFF(rel_hist, Gr * nb) GBP_OFF(add_hist, Ga * nb) GBP_OFF(hitmap, nv * nd) GBP_OFF(hit_dwell, 1)
     GBP_OFF(burned_in_iteration, 1) GBP_OFF(status, 1) GBP_OFF(best_posterior, 1) GBP_OFF(best_k, 1) GBP_OFF(best_edges, K) GBP_OFF(best_sigma, K)
     GBP_OFF(best_rel, Gr) GBP_OFF(best_add, Ga) GBP_OFF(iteration0, 1)
+    GBP_OFF(height_p, 1) GBP_OFF(height0, 1) GBP_OFF(height_hist, nb) GBP_OFF(best_height, 1)
 #undef GBP_OFF
     return s;
 }
@@ -1741,6 +1770,9 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
     if (c->hitmap && !c->hit_dwell) return fail(GBP_ERR_INVALID_ARG, "hitmap needs hit_dwell%s");
     if (o->n_rel_groups < 1 || o->n_rel_groups > 4 || o->n_add_groups < 1 || o->n_add_groups > 4)
         return fail(GBP_ERR_INVALID_ARG, "n_rel_groups / n_add_groups must be in [1, 4]%s");
+    if (o->solve_height && (!c->height_p || !c->height0 || !(o->height_half_width > 0.0) || !(o->height_scale >= 0.0)))
+        return fail(GBP_ERR_INVALID_ARG, "solve_height needs height_p, height0, height_half_width > 0 and height_scale >= 0%s");
+    if (c->height_hist && (!o->solve_height || o->n_error_bins < 1)) return fail(GBP_ERR_INVALID_ARG, "height_hist needs solve_height and n_error_bins >= 1%s");
     if ((c->rel_hist != nullptr) != (c->add_hist != nullptr) || (c->rel_hist && o->n_error_bins < 1))
         return fail(GBP_ERR_INVALID_ARG, "rel_hist and add_hist come together, with n_error_bins >= 1%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,
@@ -1935,10 +1967,12 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
         const int nw = persistent_waves(sys, o, c->B, false);
         bool small = false;
-        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
+        if (nw > 0 && n_iterations >= 4 && !o->solve_height) small = (long long)c->B <= persistent_capacity(sys, o, nw);
         if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
         mode = lockstep_parts(c->B) > 1 ? 4 : 1;
     }
+    if (mode == 2 && o->solve_height)
+        return fail(GBP_ERR_INVALID_ARG, "the persistent kernel fixes a chain's abscissa window at launch: a sampled height (solve_height) runs under the lock-step drivers%s");
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, true, stream);
     return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, mode == 4 ? std::max(2, lockstep_parts(c->B)) : 1, stream);
 }
@@ -2018,10 +2052,11 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         return GBP_OK;
     };
     // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
-    auto fm_dlogc = [&](const int32_t* nl, const double* sigma, double* pred, double* J, hipStream_t q) -> gbp_status {
+    const double* height_prop = o->solve_height ? c->height_p : c->height;     // (a sampled height: proposals are evaluated at theirs)
+    auto fm_dlogc = [&](const int32_t* nl, const double* sigma, const double* height, double* pred, double* J, hipStream_t q) -> gbp_status {
         for (int i = 0; i < nb; ++i) {
             // (compact rows: the consumers read columns < layer count only, so the columns beyond it rounded up to 8 are not touched)
-            gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, c->height, td ? td->nodal : pred,
+            gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, height, td ? td->nodal : pred,
                                             td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, td ? td->table_set : nullptr, q);
             if (s2 != GBP_OK) return s2;
         }
@@ -2141,7 +2176,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
         // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
-        if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->pred_r, c->J_r, main_q)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->height, c->pred_r, c->J_r, main_q)) != GBP_OK) return st;
         if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->fork, main_q));
@@ -2150,17 +2185,17 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         // forward + chi^2 + logL of every proposal (Inference1D.py:572-597)
         //   ... of the proposals that keep their dimension
         if (td == nullptr) {
-            if ((st = gbp_fdem_forward_loglike_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, c->data, c->rel_p, c->add_p,
+            if ((st = gbp_fdem_forward_loglike_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, height_prop, c->data, c->rel_p, c->add_p,
                                                   c->pred_p, c->misfit_p, c->like_p, fw, stream)) != GBP_OK) return st;
         } else {
-            if ((st = gbp_fdem_forward_rows_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, c->height, td->nodal, td->table_set, fw, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_forward_rows_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, height_prop, td->nodal, td->table_set, fw, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr, main_q)) != GBP_OK) return st;
             hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, rj::extend(*o), *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
                                c->misfit_p, c->like_p);
             GBP_HIP(hipGetLastError());
         }
         //   ... and prediction + Jacobian (Model.py:612) of those that change it; their chi^2 / logL are formed in accept
-        if ((st = fm_dlogc(c->nl_c, c->sigma_p, c->pred_p, c->J_p, jump_q)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_c, c->sigma_p, height_prop, c->pred_p, c->J_p, jump_q)) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->join, ss->q));
             GBP_HIP(hipStreamWaitEvent(main_q, ss->join, 0));

@@ -429,7 +429,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         # the reference then samples the prior alone (Inference1D.py:394, 519, 551, 596: no stochastic Newton step, no data term)
         raise NotImplementedError("ignore_likelihood (prior-only sampling) is not supported by the device sampler")
     # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
-    # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- the height stays fixed there too
+    # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- with the files as shipped the height
+    # stays fixed there too.  An options file that DOES carry solve_z = True gets the move (frequency-domain data; DeviceChains).
+    if time_domain and o.get("solve_z"):
+        raise NotImplementedError("solve_z on time-domain data: the reference's forward takes the TRANSMITTER's z (system/Loop_pair.py:70), "
+                                  "which the data point's z move never touches -- the key that would matter is solve_transmitter_z, and the "
+                                  "geometry of the loop pair is not sampled")
     if data is not None:
         ds = data
     elif time_domain:
@@ -449,7 +454,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             "maximum_relative_error", "initial_additive_error", "minimum_additive_error", "maximum_additive_error",
             "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",
             "probability_of_death", "probability_of_perturb", "probability_of_no_change", "factor",
-            "gradient_standard_deviation", "covariance_scaling", "parameter_limits", "update_plot_every", "reset_limit")
+            "gradient_standard_deviation", "covariance_scaling", "parameter_limits", "update_plot_every", "reset_limit",
+            "solve_z", "maximum_z_change", "z_proposal_variance")
     # chains are keyed by the sounding's row in the data file, so a sounding inverted alone walks the chain it walks in the
     # full survey
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
@@ -488,6 +494,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                  ("best_conductivity", t["best_sigma"]), ("layer_count_posterior", f64(t["k_hist"])),
                  ("interface_posterior", f64(t["edge_hist"])), ("relative_error_posterior", f64(t["rel_hist"]).flatten(1)),
                  ("additive_error_posterior", f64(t["add_hist"]).flatten(1))]
+        if getattr(dc, "solve_height", False):     # the sampled height: final and highest-posterior values, posterior on the prior's 99 cells
+            named += [("height", col(t["height"])), ("best_height", col(t["best_height"])), ("height_posterior", f64(t["height_hist"]))]
         if hitmap:
             mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
             named += [("mean_log10_conductivity", mean)] + [("log10_conductivity_" + q, p) for q, p in zip(("p05", "p50", "p95"), pct)]
@@ -512,7 +520,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         pred = torch.empty_like(t["data"])
         chi2, logl = torch.empty_like(t["misfit"]), torch.empty_like(t["misfit"])
         with torch.cuda.device(dev):                # one batched forward at the best models, through the sampler's own entry
-            dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(), t["height"], t["data"],
+            dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(),
+                             t["best_height"] if t.get("best_height") is not None else t["height"], t["data"],
                              brel, badd, pred, chi2, logl)
         host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
         cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
@@ -596,7 +605,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                        depth_bin_width=np.float64(dc.depth_bin_width))
     c0 = 0
     ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
-            "relative_error_posterior", "additive_error_posterior")
+            "relative_error_posterior", "additive_error_posterior", "height_posterior")
     for name, v in named:
         w = v.shape[1]
         block = r[:, c0:c0 + w]

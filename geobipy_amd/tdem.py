@@ -692,6 +692,9 @@ class TdemDeviceChains(DeviceChains):
                 if getattr(outer, "_raw", None) is None:
                     outer._raw = _raw_handle(systems, gm, outer._hankel_eps, _altitude_bins(heights))
                 return outer._raw
+        if kw.get("solve_z"):
+            raise NotImplementedError("solve_z on time-domain chains: the reference's forward takes the transmitter's z (system/Loop_pair.py:70), "
+                                      "which the data point's z move never touches; the loop pair's geometry is not sampled")
         kw.pop("exact_jacobian", None)
         kw.pop("hankel_eps_ppm", None)
         # per-chain abscissa window (1 m altitude bins): hankel_eps relative to the inductive-limit value of every nodal sum;

@@ -318,6 +318,13 @@ typedef struct gbp_rj_options {
     uint64_t seed;
     uint64_t first_chain;        /* global index of chain 0 of this block: the random streams are keyed by
                                     first_chain + b, so a survey gives the same chains however it is sharded */
+    /* The height move of the data point (`solve_z`: Point.perturb / set_priors / set_proposals, pointcloud/Point.py:614-621,
+     * 949-983): uniform prior height0 +- height_half_width (maximum_z_change), random walk height + height_scale * N(0, 1)
+     * redrawn up to 10 times while outside the prior, then kept.  height_scale is the reference's `z_proposal_variance` AS IS:
+     * its NormalDistribution.rng passes the variance to numpy as the scale (statistics/NormalDistribution.py:111).  Needs
+     * chains->height_p and ->height0; chains->height is then STATE (written on acceptance).  Lock-step drivers only. */
+    int32_t solve_height;
+    double height_half_width, height_scale;
 } gbp_rj_options;
 
 typedef struct gbp_rj_chains {
@@ -328,7 +335,8 @@ typedef struct gbp_rj_chains {
                                       (TdemDataPoint.std, data/datapoint/TdemDataPoint.py:361-365: sqrt(1e-3 / t)); NULL = 1 (FDEM) */
     const int64_t *chain_id;       /* [B] or NULL  global index of each chain (keys its random streams); NULL: first_chain + b */
     const double *data;            /* [B, N]  observed data (<= 0: inactive channel)                   */
-    const double *height;          /* [B]                                                              */
+    const double *height;          /* [B]     sensor height; with opt->solve_height the chain's CURRENT height: state, written by the
+                                      sampler on acceptance (the const is dropped there)                 */
     const double *log_mean_prior;  /* [B]     ln of the best half-space conductivity                   */
     /* chain state */
     int32_t *k;                    /* [B]     layers                                                   */
@@ -366,6 +374,11 @@ typedef struct gbp_rj_chains {
     int32_t *iteration0;           /* [B] or NULL (= 0)  schedule 1: the iteration at which the chain (re)started -- the schedule
                                       counts from there (Inference1D.reset :984-999 restarts a chain that accepted nothing over a
                                       whole window; the host does the restart between calls, rjmcmc_gpu.DeviceChains.infer) */
+    /* height move (opt->solve_height; all NULL otherwise) */
+    double *height_p;              /* [B]  proposed height (scratch of the step)                                          */
+    const double *height0;         /* [B]  centre of the uniform prior = the sounding's measured height                   */
+    int32_t *height_hist;          /* [B, n_error_bins] or NULL  posterior of the height on the prior's cells (Point.set_z_posterior) */
+    double *best_height;           /* [B] or NULL  height of the highest-posterior state                                  */
 } gbp_rj_chains;
 
 /* The three host-logic stages of one iteration, exposed separately for the tests ... */

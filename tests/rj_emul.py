@@ -89,8 +89,9 @@ def levels_log_prior(x, lo, hi):
     return float(sum(rjmcmc.ErrorPrior(l, h, 1.0).log_prior(v) for v, l, h in zip(x, lo, hi)))
 
 
-def propose(o, seed, b, it, edges, sigma, rel, add):
-    """k_rj_propose for one chain.  edges: k - 1 interior depths.  Returns (action, idx, val, edges_r, sigma_r, rel_p, add_p)."""
+def propose(o, seed, b, it, edges, sigma, rel, add, height=None, height0=None):
+    """k_rj_propose for one chain.  edges: k - 1 interior depths.  Returns (action, idx, val, edges_r, sigma_r, rel_p, add_p) -- and,
+    with a sampled height (o["height_scale"], o["height_half_width"]; drawn before the error levels), the proposed height."""
     r = Rng(seed, b, it, 0)
     k, K, mw = sigma.size, o["K"], o["min_width"]
     lo, hi = math.log(o["min_edge"]), math.log(o["max_edge"])
@@ -139,8 +140,20 @@ def propose(o, seed, b, it, edges, sigma, rel, add):
         e_r[idx - 1] += val
     else:
         e_r, s_r = edges.copy(), sigma.copy()
+    if height is not None:
+        lo_h, hi_h = height0 - o["height_half_width"], height0 + o["height_half_width"]
+        height_p = height + o["height_scale"] * r.normal()
+        tries = 0
+        while not (lo_h <= height_p <= hi_h):
+            height_p = height + o["height_scale"] * r.normal()
+            tries += 1
+            if tries == 10:
+                height_p = height
+                break
     rel_p = propose_levels(r, rel, o["rel_sd"], o["rel_min"], o["rel_max"])
     add_p = propose_levels(r, add, o["add_sd"], o["add_min"], o["add_max"])
+    if height is not None:
+        return action, idx, val, e_r, s_r, rel_p, add_p, height_p
     return action, idx, val, e_r, s_r, rel_p, add_p
 
 
@@ -160,11 +173,12 @@ def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_sc
 
 
 def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, pred_p, data, rel_p, add_p, like_p, prior, like,
-           add_scale=1.0, groups=None):
-    """k_rj_accept for one chain: (log_ratio, accepted, prior_p)."""
+           add_scale=1.0, groups=None, prior_const=0.0):
+    """k_rj_accept for one chain: (log_ratio, accepted, prior_p).  prior_const: the density of the uniform height prior, when the
+    height is sampled (its proposals are inside the prior by construction)."""
     prop = np.exp(log_prop)
     prior_p = (rjmcmc.model_log_prior(sp, vp, edges_r, prop) + levels_log_prior(rel_p, o["rel_min"], o["rel_max"])
-               + levels_log_prior(add_p, o["add_min"], o["add_max"]))
+               + levels_log_prior(add_p, o["add_min"], o["add_max"])) + prior_const
     dq = 0.0
     if action in (rjmcmc.INSERT, rjmcmc.DELETE):
         k = prop.size
@@ -189,35 +203,54 @@ class Chain:
     with forward(edges, values) / sensitivity(edges, values) (the C oracle in the tests).  Carries the same state and
     posterior accumulators as one row of gbp_rj_chains."""
 
-    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0, groups=None):
+    def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0, groups=None,
+                 height=None):
         self.o, self.seed, self.b, self.engine, self.sp, self.vp, self.data = o, seed, b, engine, sp, vp, data
         self.add_scale, self.groups = add_scale, groups
         self.edges, self.sigma, self.rel, self.add = np.zeros(0), np.array([sigma0]), rel, add
-        self.pred, self.J = engine.forward(self.edges, self.sigma), engine.sensitivity(self.edges, self.sigma)
+        self.height, self.height0 = height, height          # a sampled height (engine.forward / sensitivity then take z=)
+        self.height_hist = np.zeros(99, dtype=int)
+        self.pred, self.J = self._fwd(self.edges, self.sigma, height), self._sen(self.edges, self.sigma, height)
         std = channel_std(data, rel, add, add_scale, groups)
         self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
         self.prior = (rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + levels_log_prior(rel, o["rel_min"], o["rel_max"])
                       + levels_log_prior(add, o["add_min"], o["add_max"]))
+        if height is not None:
+            self.prior -= math.log(2.0 * o["height_half_width"])
         self.k_hist = np.zeros(o["K"] + 1, dtype=int)
         self.edge_hist = np.zeros(n_depth_bins, dtype=int)
         self.w = depth_bin_width
         self.n_accepted = 0
         self.trace = []
 
+    def _fwd(self, e, s, z):
+        return self.engine.forward(e, s) if z is None else self.engine.forward(e, s, z=z)
+
+    def _sen(self, e, s, z):
+        return self.engine.sensitivity(e, s) if z is None else self.engine.sensitivity(e, s, z=z)
+
     def step(self, it):
         o, d = self.o, self.data
-        action, idx, val, e_r, s_r, rel_p, add_p = propose(o, self.seed, self.b, it, self.edges, self.sigma, self.rel, self.add)
+        height_p = None
+        if self.height is None:
+            action, idx, val, e_r, s_r, rel_p, add_p = propose(o, self.seed, self.b, it, self.edges, self.sigma, self.rel, self.add)
+        else:
+            action, idx, val, e_r, s_r, rel_p, add_p, height_p = propose(o, self.seed, self.b, it, self.edges, self.sigma, self.rel, self.add,
+                                                                         self.height, self.height0)
         if action != rjmcmc.NONE:
-            pred_r, J_r = self.engine.forward(e_r, s_r), self.engine.sensitivity(e_r, s_r)
+            pred_r, J_r = self._fwd(e_r, s_r, self.height), self._sen(e_r, s_r, self.height)
         else:
             pred_r, J_r = self.pred, self.J
         log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add, self.add_scale, self.groups)
         prop = np.exp(log_prop)
-        pred_p = self.engine.forward(e_r, prop)
+        pred_p = self._fwd(e_r, prop, height_p)
         misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, channel_std(d, rel_p, add_p, self.add_scale, self.groups))
-        J_p = self.engine.sensitivity(e_r, prop) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
+        J_p = self._sen(e_r, prop, height_p) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
         log_ratio, acc, prior_p = accept(o, self.seed, self.b, it, self.sp, self.vp, action, e_r, s_r, log_prop, C, J_p, pred_p, d,
-                                         rel_p, add_p, like_p, self.prior, self.like, self.add_scale, self.groups)
+                                         rel_p, add_p, like_p, self.prior, self.like, self.add_scale, self.groups,
+                                         0.0 if self.height is None else -math.log(2.0 * o["height_half_width"]))
+        if acc and self.height is not None:
+            self.height = height_p
         if acc:
             self.edges, self.sigma, self.rel, self.add, self.pred = e_r, prop, rel_p, add_p, pred_p
             self.prior, self.like, self.misfit = prior_p, like_p, misfit_p
@@ -225,6 +258,10 @@ class Chain:
             self.n_accepted += 1
         self.trace.append((action, acc, self.sigma.size))
         self.k_hist[self.sigma.size] += 1
+        if self.height is not None:
+            u = (self.height - (self.height0 - o["height_half_width"])) / (2.0 * o["height_half_width"])
+            if 0.0 <= u <= 1.0:
+                self.height_hist[min(int(math.floor(u * 99)), 98)] += 1
         ratio = self.sigma[1:] / self.sigma[:-1]
         for depth in self.edges[(ratio <= 0.5) | (ratio >= 1.5)]:
             self.edge_hist[min(int(depth // self.w), self.edge_hist.size - 1)] += 1

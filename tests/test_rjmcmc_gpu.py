@@ -87,7 +87,8 @@ def _emul_options(dc):
     o = dc._o
     return dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge,
                 p=[o.p_birth, o.p_death, o.p_perturb, o.p_none], rel_sd=o.rel_sd[0], rel_min=o.rel_min[0], rel_max=o.rel_max[0],
-                add_sd=o.add_sd[0], add_min=o.add_min[0], add_max=o.add_max[0], alpha=o.alpha)
+                add_sd=o.add_sd[0], add_min=o.add_min[0], add_max=o.add_max[0], alpha=o.alpha,
+                height_scale=o.height_scale, height_half_width=o.height_half_width)
 
 
 def _host_priors(dc, b):
@@ -572,6 +573,78 @@ def test_device_chains_equal_cpu_chains_with_the_same_seeds(priors):
         assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-6) and np.allclose(c.sigma, dc.sigma[b, : c.sigma.size].cpu().numpy(), rtol=1e-6)
     assert accs.sum() > 0.2 * accs.size and len(np.unique(ks)) >= 3 and set(np.unique(acts)) == {0, 1, 2, 3}
     assert ks.max() <= dc.K
+
+
+@pytest.mark.gpu
+def test_height_move_on_the_device_equals_cpu_chains_with_the_same_seeds():
+    """``solve_z`` on the device (gbp_rj_options.solve_height; the move is pinned to the reference on the host,
+    test_rjmcmc.py::test_height_move_reproduces_the_reference_chain): CPU chains with the same counter-based streams -- the stage
+    emulation with the C oracle evaluating the remapped model at the current height and the proposal at the proposed one -- walk
+    the same chains as the device: every move and decision, the heights to 1e-9 m, the height posterior, over 400 iterations,
+    under the fused lock-step driver, the ten-launch driver and concurrent sub-blocks; the persistent kernel refuses the option;
+    cached state equals a from-scratch evaluation at the final heights."""
+    from test_rjmcmc import OracleEngine
+    n_it, B = 400, 6
+    hopt = dict(solve_z=True, maximum_z_change=1.5, z_proposal_variance=0.15)
+    runs = {}
+    for mode in (1, 3):
+        d, s, dc = _chains(B, 2025, options=hopt)
+        dc.run_mode = mode
+        rng = np.random.default_rng(6)
+        data = np.tile(d["data"], (B, 1)) * np.r_[1.0, rng.uniform(0.8, 1.3, B - 1)][:, None]
+        dc.data.copy_(torch.as_tensor(data))
+        dc._initialize()
+        if mode == 1:
+            eo = _emul_options(dc)
+            sig0 = dc.sigma[:, 0].cpu().numpy()
+            eng = OracleEngine("resolve", float(d["z"]))
+            chains = []
+            for b in range(B):
+                sp, vp = _host_priors(dc, b)
+                chains.append(rj_emul.Chain(eo, 2025, b, eng, sp, vp, data[b], sig0[b], 0.05, 5.0, dc.n_depth_bins, dc.depth_bin_width,
+                                            height=float(d["z"])))
+                assert np.isclose(chains[b].prior, float(dc.prior[b]), rtol=1e-12)
+            accs, ks, hs = [], [], []
+            prev = dc.n_accepted.cpu().numpy().copy()
+            for it in range(n_it):
+                dc.step()
+                now = dc.n_accepted.cpu().numpy()
+                accs.append(now - prev); ks.append(dc.k.cpu().numpy().copy()); hs.append(dc.height.cpu().numpy().copy())
+                prev = now.copy()
+                for c in chains:
+                    c.step(it)
+                    assert abs(c.height - hs[-1][c.b]) < 1e-9, (it, c.b)
+            accs, ks, hs = np.array(accs), np.array(ks), np.array(hs)
+            for b, c in enumerate(chains):
+                tr = np.array(c.trace)
+                assert np.array_equal(tr[:, 1], accs[:, b]) and np.array_equal(tr[:, 2], ks[:, b]), b
+                assert np.array_equal(c.height_hist, dc.height_hist[b].cpu().numpy()) and np.array_equal(c.k_hist, dc.k_hist[b].cpu().numpy())
+                assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-6)
+            assert np.ptp(hs, axis=0).min() > 0.3 and np.all(np.abs(hs - float(d["z"])) <= 1.5) and accs.sum() > 0.2 * accs.size
+            assert torch.all(torch.abs(dc.best_height - float(d["z"])) <= 1.5)
+        else:
+            dc.run(n_it)
+        runs[mode] = dc
+    for n in ("k", "sigma", "edges", "height", "height_hist", "best_height", "rel", "add", "misfit", "k_hist", "n_accepted"):
+        assert torch.equal(getattr(runs[1], n), getattr(runs[3], n)), n
+    # concurrent sub-blocks (a block large enough for them), against the one-block driver; the persistent kernel says no
+    big = {}
+    for mode in (1, 4):
+        d, s, dc = _chains(2304, 11, options=hopt)
+        dc.run_mode = mode
+        dc.run(60)
+        big[mode] = dc
+    for n in ("k", "sigma", "height", "height_hist", "misfit", "n_accepted"):
+        assert torch.equal(getattr(big[1], n), getattr(big[4], n)), n
+    dc = big[4]
+    from geobipy_amd import FdemBatch
+    thk = torch.zeros_like(dc.sigma)
+    thk[:, :-1] = torch.diff(torch.cat([torch.zeros(dc.B, 1, dtype=torch.float64, device=dc.device), dc.edges], dim=1), dim=1)[:, :-1].nan_to_num(posinf=0.0)
+    fb = FdemBatch(s, dc.k.cpu().numpy(), dc.sigma.cpu().numpy(), thk.cpu().numpy(), dc.height.cpu().numpy(), hankel_eps_ppm=dc.hankel_eps_ppm)
+    assert torch.allclose(fb.forward(), dc.pred, rtol=1e-9, atol=1e-7)
+    dc.run_mode = 2
+    with pytest.raises(Exception, match="solve_height"):
+        dc.run(5)
 
 
 @pytest.mark.gpu

@@ -402,6 +402,38 @@ def test_invert_the_wedge_survey(tmp_path):
     assert np.array_equal(res2["interface_posterior"], res["interface_posterior"]) and np.array_equal(res2["misfit"], res["misfit"])
 
 
+@pytest.mark.gpu
+def test_survey_with_the_height_move_recovers_a_wrong_altitude():
+    """``solve_z`` end to end (the keys the reference's data point reads, added to the options): the wedge survey with every
+    sounding's recorded altitude 0.8 m too high -- data of a conductive-over-resistive ground computed at 29.2 m, file says 30 m.  With the height fixed the chains
+    cannot reach the noise level; with the height sampled (prior +- 1.5 m) they do, and the posterior height sits at the true
+    altitude.  Time-domain data refuse the key (the reference's forward takes the transmitter's z, which that move never touches)."""
+    from geobipy_amd import FdemBatch
+    ds = survey.FdemData.read_csv(os.path.join(GOLDEN, "resolve_glacial_clean.csv"), os.path.join(GOLDEN, "resolve.stm"))
+    S = ds.nPoints
+    true = np.linspace(50, 1, S) / 10
+    nl = np.full(S, 2, dtype=np.int32)
+    sig = np.tile([0.1, 0.02, 1.0], (S, 1))          # conductive ground at the surface: a resistive top layer would pass for altitude
+    thk = np.c_[3.0 * true, np.zeros(S), np.zeros(S)]
+    clean = FdemBatch(ds.system, nl, sig, thk, np.full(S, 29.2)).forward().cpu().numpy()
+    rng = np.random.default_rng(0)
+    ds.data[:] = clean + rng.normal(size=clean.shape) * np.sqrt((0.03 * clean) ** 2 + 3.0 ** 2)
+    kw = dict(data=ds, burn_in_min_iterations=800, check_every=400, exact_jacobian=True, n_markov_chains=4000)
+    fixed = survey.infer(OPTIONS, **kw)
+    moved = survey.infer(OPTIONS, solve_z=True, maximum_z_change=1.5, z_proposal_variance=0.05, **kw)
+    assert "height" not in fixed and moved["height_posterior"].shape == (S, 99)
+    done = moved["status"] == 1
+    zc = 30.0 - 1.5 + (np.arange(99) + 0.5) * (3.0 / 99)
+    mean_h = (moved["height_posterior"] * zc).sum(axis=1) / np.maximum(1, moved["height_posterior"].sum(axis=1))
+    print("height move: done", done.sum(), "of", S, "posterior mean height", np.median(mean_h[done]), "median misfit fixed / moved",
+          np.median(fixed["misfit"]), np.median(moved["misfit"][done]))
+    assert done.sum() >= 60 and abs(np.median(mean_h[done]) - 29.2) < 0.3 and np.all(np.abs(moved["best_height"] - 30.0) <= 1.5)
+    assert np.all(moved["height_posterior"][done].sum(axis=1) == 4002)
+    assert np.median(moved["misfit"][done]) < 20.0 and np.median(fixed["misfit"]) > 2.0 * np.median(moved["misfit"][done])
+    with pytest.raises(NotImplementedError, match="transmitter"):
+        survey.infer(os.path.join(GOLDEN, "skytem_options_small"), solve_z=True, maximum_z_change=1.0, z_proposal_variance=0.01)
+
+
 def test_survey_result_round_trip(tmp_path):
     """save / load and save_lines / load_lines of a SurveyResult (no GPU needed)."""
     rng = np.random.default_rng(0)
