@@ -1114,7 +1114,10 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
     if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
     int nw = pick_waves(B, sys->t.nF, Lmax, sys->t.nF, waves);
     if (nw > sys->t.nF) nw = sys->t.nF;
-    while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > 60000) --nw;
+    // LDS per workgroup: 60 KB keeps two workgroups per CU resident; small launches -- where a workgroup per CU is all there is, and a
+    // deep model on one wave is a long tail (22 frequencies x 30 layers in sequence) -- may take most of a CU's 160 KB
+    const size_t lds_cap = B <= 4096 ? 150000 : 60000;
+    while (nw > 1 && nw * per_wave + (size_t)max_layers * 8 > lds_cap) --nw;
     const size_t lds = nw * per_wave + (size_t)max_layers * 8;
     auto launch = [&](auto kernel) -> gbp_status {
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1352,20 +1352,28 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
             }
     }
     __syncthreads();
-    for (int g = lane; g < N; g += 64) {
+    // one output per lane and pass: (gate g, column l) with l = 0 the prediction and l >= 1 column l - 1 of the Jacobian -- N (k + 1)
+    // outputs over the 64 lanes (a lane per gate left two thirds of the wave idle at 19 gates and ran (k + 1) n_nodal multiply-adds in
+    // sequence); every output is the same sum over the nodal values in the same order
+    const int n_out = N * (WITH_J ? k + 1 : 1);
+    for (int q = lane; q < n_out; q += 64) {
+        const int l = q / N, g = q - l * N;
+        const double* src = l == 0 ? sn : sj + (l - 1);
+        const int stride = l == 0 ? 1 : k;
         double acc = 0.0;
-        for (int m = 0; m < n_nodal; ++m) acc += sn[m] * W[(size_t)m * N + g];
-        if (mix.offset != nullptr) acc += mix.offset[(size_t)b * N + g];
-        pred[(size_t)b * N + g] = acc;
-        if (WITH_J) {
-            for (int l = 0; l < k; ++l) {
-                double a = 0.0;
-                for (int m = 0; m < n_nodal; ++m) a += sj[m * k + l] * W[(size_t)m * N + g];
-                J[((size_t)b * N + g) * K + l] = a;
-            }
-            for (int l = k; l < K; ++l) J[((size_t)b * N + g) * K + l] = 0.0;
+        for (int m = 0; m < n_nodal; ++m) acc += src[m * stride] * W[(size_t)m * N + g];
+        if (l == 0) {
+            if (mix.offset != nullptr) acc += mix.offset[(size_t)b * N + g];
+            pred[(size_t)b * N + g] = acc;
+        } else {
+            J[((size_t)b * N + g) * K + (l - 1)] = acc;
         }
     }
+    if (WITH_J)
+        for (int q = lane; q < N * (K - k); q += 64) {
+            const int g = q / (K - k), l = k + q - g * (K - k);
+            J[((size_t)b * N + g) * K + l] = 0.0;
+        }
 }
 
 // chi^2 / logL with the per-channel additive scale, for the soundings with nl > 0 (one wave per sounding)
@@ -1703,6 +1711,27 @@ SideStream* side_stream()
         if (hipStreamCreateWithFlags(&s.q, hipStreamNonBlocking) != hipSuccess) { s.q = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &s;
+}
+
+// Two more streams (+ fork / join events) for the Jacobian launches of the models of more than 8 layers, see rj_run_lockstep.
+struct DeepStreams {
+    hipStream_t q[2] = {nullptr, nullptr};
+    hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
+};
+DeepStreams* deep_streams()
+{
+    static thread_local DeepStreams table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    DeepStreams& s = table[dev];
+    if (s.q[0] == nullptr) {
+        for (int i = 0; i < 2; ++i) {
+            if (hipStreamCreateWithFlags(&s.q[i], hipStreamNonBlocking) != hipSuccess) { s.q[0] = nullptr; return nullptr; }
+            if (hipEventCreateWithFlags(&s.fork[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) != hipSuccess) { s.q[0] = nullptr; return nullptr; }
+        }
     }
     return &s;
 }
@@ -2053,13 +2082,27 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
     };
     // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
     const double* height_prop = o->solve_height ? c->height_p : c->height;     // (a sampled height: proposals are evaluated at theirs)
-    auto fm_dlogc = [&](const int32_t* nl, const double* sigma, const double* height, double* pred, double* J, hipStream_t q) -> gbp_status {
-        for (int i = 0; i < nb; ++i) {
+    // The launch of the models of more than 8 layers holds few chains, but with the working set of a K-layer model in LDS (32 KB per
+    // wave at K = 30) each runs on ONE wave: all frequencies x up to 30 layers in sequence -- ~100 us for a 22-node time-domain system,
+    // 21 % of an iteration at 8 192 chains when it follows the launch of the shallow models.  The two launches touch disjoint chains:
+    // the deep one goes to a stream of its own (`slot`: one per evaluation that can be in flight) and overlaps the shallow one.
+    // (Its working set in a global block per chain, to give it more waves, was tried and is slower: 7.3 vs 8.6 M chain-iterations/s.)
+    DeepStreams* ds = (nb > 1 && td != nullptr) ? deep_streams() : nullptr;
+    auto fm_dlogc = [&](const int32_t* nl, const double* sigma, const double* height, double* pred, double* J, hipStream_t q, int slot) -> gbp_status {
+        for (int i = nb - 1; i >= 0; --i) {
             // (compact rows: the consumers read columns < layer count only, so the columns beyond it rounded up to 8 are not touched)
+            const bool aside = i == 1 && ds != nullptr;
+            if (aside) {
+                GBP_HIP(hipEventRecord(ds->fork[slot], q));
+                GBP_HIP(hipStreamWaitEvent(ds->q[slot], ds->fork[slot], 0));
+            }
             gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, height, td ? td->nodal : pred,
-                                            td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, td ? td->table_set : nullptr, q);
+                                            td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, td ? td->table_set : nullptr,
+                                            aside ? ds->q[slot] : q);
             if (s2 != GBP_OK) return s2;
+            if (aside) GBP_HIP(hipEventRecord(ds->join[slot], ds->q[slot]));
         }
+        if (nb > 1 && ds != nullptr) GBP_HIP(hipStreamWaitEvent(q, ds->join[slot], 0));
         return td ? td_apply(nl, true, pred, J, q) : GBP_OK;
     };
     // The two evaluations at the proposals work on disjoint chains (those that keep their dimension / those that change it)
@@ -2176,7 +2219,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         const int64_t iter = first_iteration + it;
         if ((st = gbp_rj_propose(o, c, iter, stream)) != GBP_OK) return st;
         // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
-        if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->height, c->pred_r, c->J_r, main_q)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->height, c->pred_r, c->J_r, main_q, 0)) != GBP_OK) return st;
         if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->fork, main_q));
@@ -2195,7 +2238,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipGetLastError());
         }
         //   ... and prediction + Jacobian (Model.py:612) of those that change it; their chi^2 / logL are formed in accept
-        if ((st = fm_dlogc(c->nl_c, c->sigma_p, height_prop, c->pred_p, c->J_p, jump_q)) != GBP_OK) return st;
+        if ((st = fm_dlogc(c->nl_c, c->sigma_p, height_prop, c->pred_p, c->J_p, jump_q, 1)) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->join, ss->q));
             GBP_HIP(hipStreamWaitEvent(main_q, ss->join, 0));
