@@ -678,9 +678,13 @@ __device__ __forceinline__ double group_bcast(double v, int base, int j)   // j:
 __device__ __forceinline__ double lane_up(double v) { return dpp_mov64<0x111>(v); }
 __device__ __forceinline__ double lane_dn(double v) { return dpp_mov64<0x101>(v); }
 
-// `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N]
-__device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
-                                             unsigned char* sh_dyn, int b_idle = 0)
+// `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N].
+// KM: the algebra runs on the leading KM x KM block -- every chain of the wave has at most KM layers.  Rows and columns >= k are
+// identity rows: their Cholesky column is a unit vector, they add 0 x (finite) to every substitution step, so leaving them out
+// changes no bit of rows < k; KM = 8 is the full group.
+template <int KM>
+__device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
+                                             unsigned char* sh_dyn, int b_idle)
 {
     const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
     const int K = o.max_layers, N = o.n_channels;
@@ -709,23 +713,23 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
     const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
     wave_sync();
-    double arow[8], acol[8];
+    double arow[KM], acol[KM];
     double g = 0.0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { arow[j] = 0.0; acol[j] = 0.0; }
+    for (int j = 0; j < KM; ++j) { arow[j] = 0.0; acol[j] = 0.0; }
     for (int n = 0; n < N; ++n) {                    // J'PJ and J'P r
         const double Ji = i < k ? J[(size_t)n * K + i] : 0.0;
         const double jp = Ji * P[n];
         g += Ji * PR[n];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) arow[j] += jp * group_bcast(Ji, base, j);
+        for (int j = 0; j < KM; ++j) arow[j] += jp * group_bcast(Ji, base, j);
     }
     {   // + Wm'Wm (tridiagonal), Wm'Wm (ln sigma - ln sigma_ref)
         const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
         const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
         g += diag * v - t2_up * v_up - t2 * v_dn;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KM; ++j) {
             if (j == i) arow[j] += diag;
             if (j == i - 1) arow[j] -= t2_up;
             if (i >= k) arow[j] = j == i ? 1.0 : 0.0;
@@ -733,12 +737,12 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                    // Cholesky, right-looking
+    for (int j = 0; j < KM; ++j) {                   // Cholesky, right-looking
         const double cjj = sqrt(group_bcast(arow[j], base, j));
         if (i == j) { arow[j] = cjj; acol[j] = cjj; }
         else if (i > j) arow[j] = arow[j] / cjj;
 #pragma unroll
-        for (int m = j + 1; m < 8; ++m) {
+        for (int m = j + 1; m < KM; ++m) {
             const double cmj = group_bcast(arow[j], base, m);       // C[m][j]
             if (i == j) acol[m] = cmj;
             if (i >= m) arow[m] -= arow[j] * cmj;
@@ -747,12 +751,12 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
     if (live && i < k) {
         double* C = c.chol + bb * K * K + (size_t)i * K;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < KM; ++j)
             if (j <= i) C[j] = arow[j];
     }
     auto forward = [&](double x) {                   // C y = x
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KM; ++j) {
             const double yj = group_bcast(x / arow[j], base, j);     // lane j holds C[j][j] in arow[j]
             if (i == j) x = yj;
             if (i > j) x -= arow[j] * yj;
@@ -761,7 +765,7 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
     };
     auto backward = [&](double x) {                  // C' y = x
 #pragma unroll
-        for (int j = 7; j >= 0; --j) {
+        for (int j = KM - 1; j >= 0; --j) {
             const double yj = group_bcast(x / acol[j], base, j);     // lane j holds C[j][j] in acol[j]
             if (i == j) x = yj;
             if (i < j) x -= acol[j] * yj;                            // C[j][i]
@@ -779,6 +783,19 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
         c.sigma_p[bb * K + i] = i < k ? rj_exp(lp) : 1.0;
         for (int j = i + 8; j < K; j += 8) { c.log_prop[bb * K + j] = 0.0; c.sigma_p[bb * K + j] = 1.0; }
     }
+}
+
+// The packed Newton stage, sized by the deepest chain of the wave (wave-uniform): 2, 4 or all 8 columns.  One chain per wave
+// (persistent kernel): the chain's own layer count -- a 2-layer model runs a quarter of the cross-lane algebra of the full group.
+__device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
+                                             unsigned char* sh_dyn, int b_idle = 0)
+{
+    const int kb = b < c.B ? c.k_r[b] : 0;
+    const int mine = kb <= 8 ? kb : 0;                            // (deeper chains are not this stage's)
+    const unsigned long long deep4 = __ballot(mine > 4), deep2 = __ballot(mine > 2);
+    if (deep4 != 0ull) newton8_core<8>(o, c, iter, lane, b, sh_dyn, b_idle);
+    else if (deep2 != 0ull) newton8_core<4>(o, c, iter, lane, b, sh_dyn, b_idle);
+    else newton8_core<2>(o, c, iter, lane, b, sh_dyn, b_idle);
 }
 
 __global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter)
@@ -1105,6 +1122,70 @@ __device__ inline void hitmap_add8(const RjOpt& o, int32_t* hm, const double* ec
     }
 }
 
+// Reverse-move proposal density of the packed accept stage (Model.proposal_probabilities :577-659) on the leading KM x KM block:
+// every dimension-changing proposal of the wave has at most KM layers (rows >= k are identity rows, as in newton8_core).
+template <int KM>
+__device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_chains& c, int i, int base, int k, size_t bb, bool jump,
+                                                  const double* e, double lpv, double lmp, const double* PR)
+{
+    const int K = o.max_layers, N = o.n_channels;
+    double t2 = 0.0;
+    if (i < k - 1 && o.solve_gradient) {
+        const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
+        t2 = o.gradient_precision / (c2c * c2c);
+    }
+    const double t2_sh = lane_up(t2);
+    const double t2_up = i > 0 ? t2_sh : 0.0;
+    const double v = i < k ? lpv - lmp : 0.0;
+    const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
+    const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
+    double arow[KM], acol[KM];
+    const bool row = jump && i < k;
+    {
+        const double* C = c.chol + bb * K * K;
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            arow[j] = (row && j <= i) ? C[(size_t)i * K + j] : (j == i ? 1.0 : 0.0);
+            acol[j] = (row && j >= i && j < k) ? C[(size_t)j * K + i] : (j == i ? 1.0 : 0.0);
+        }
+    }
+    double grad = 0.0;
+    if (row) {
+        const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
+        const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
+        grad = diag * v - t2_up * v_up - t2 * v_dn;
+        const double* Jp = c.J_p + bb * N * K;
+        for (int n = 0; n < N; ++n) grad += Jp[(size_t)n * K + i] * PR[n];
+    }
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {                   // C y = grad
+        const double yj = group_bcast(grad / arow[j], base, j);
+        if (i == j) grad = yj;
+        if (i > j) grad -= arow[j] * yj;
+    }
+#pragma unroll
+    for (int j = KM - 1; j >= 0; --j) {              // C' x = y
+        const double yj = group_bcast(grad / acol[j], base, j);
+        if (i == j) grad = yj;
+        if (i < j) grad -= acol[j] * yj;
+    }
+    const double mean_r = lpv + o.alpha * grad;
+    const bool bad = row && !(fabs(mean_r) < 11356.0);
+    const double lrem = row ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
+    const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
+    double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
+#pragma unroll
+    for (int m = 0; m < KM; ++m) {
+        const double d1m = group_bcast(d1, base, m), d2m = group_bcast(d2, base, m);
+        if (m >= i) { a1 += acol[m] * d1m; a2 += acol[m] * d2m; }
+    }
+    const double q1 = group_sum8(row ? a1 * a1 : 0.0), q2 = group_sum8(row ? a2 * a2 : 0.0);
+    const unsigned long long badmask = __ballot(bad);
+    double dq = jump ? -0.5 * q1 + 0.5 * q2 : 0.0;
+    if ((badmask >> base) & 0xFFull) dq = __builtin_nan("");
+    return dq;
+}
+
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: PR[8][N]
 __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle = 0)
@@ -1169,61 +1250,11 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     // reverse-move proposal density (Model.proposal_probabilities :577-659); executed by every group of a wave that holds a
     // dimension-changing proposal (wave-uniform branch: the cross-lane reads inside are issued by all 64 lanes), used by the jumps
     double dq = 0.0;
-    if (__ballot(jump) != 0ull) {
-    double t2 = 0.0;
-    if (i < k - 1 && o.solve_gradient) {
-        const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
-        t2 = o.gradient_precision / (c2c * c2c);
-    }
-    const double t2_sh = lane_up(t2);
-    const double t2_up = i > 0 ? t2_sh : 0.0;
-    const double v = i < k ? lpv - lmp : 0.0;
-    const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
-    const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
-    double arow[8], acol[8];
-    const bool row = jump && i < k;
-    {
-        const double* C = c.chol + bb * K * K;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            arow[j] = (row && j <= i) ? C[(size_t)i * K + j] : (j == i ? 1.0 : 0.0);
-            acol[j] = (row && j >= i && j < k) ? C[(size_t)j * K + i] : (j == i ? 1.0 : 0.0);
-        }
-    }
-    double grad = 0.0;
-    if (row) {
-        const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
-        const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
-        grad = diag * v - t2_up * v_up - t2 * v_dn;
-        const double* Jp = c.J_p + bb * N * K;
-        for (int n = 0; n < N; ++n) grad += Jp[(size_t)n * K + i] * PR[n];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {                    // C y = grad
-        const double yj = group_bcast(grad / arow[j], base, j);
-        if (i == j) grad = yj;
-        if (i > j) grad -= arow[j] * yj;
-    }
-#pragma unroll
-    for (int j = 7; j >= 0; --j) {                   // C' x = y
-        const double yj = group_bcast(grad / acol[j], base, j);
-        if (i == j) grad = yj;
-        if (i < j) grad -= acol[j] * yj;
-    }
-    const double mean_r = lpv + o.alpha * grad;
-    const bool bad = row && !(fabs(mean_r) < 11356.0);
-    const double lrem = row ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
-    const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
-    double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const double d1m = group_bcast(d1, base, m), d2m = group_bcast(d2, base, m);
-        if (m >= i) { a1 += acol[m] * d1m; a2 += acol[m] * d2m; }
-    }
-    const double q1 = group_sum8(row ? a1 * a1 : 0.0), q2 = group_sum8(row ? a2 * a2 : 0.0);
-    const unsigned long long badmask = __ballot(bad);
-    dq = jump ? -0.5 * q1 + 0.5 * q2 : 0.0;
-    if ((badmask >> base) & 0xFFull) dq = __builtin_nan("");
+    {   // (wave-uniform: the cross-lane reads inside are issued by all 64 lanes; sized by the deepest jump of the wave)
+        const unsigned long long any = __ballot(jump), deep4 = __ballot(jump && k > 4), deep2 = __ballot(jump && k > 2);
+        if (deep4 != 0ull) dq = accept8_reverse<8>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        else if (deep2 != 0ull) dq = accept8_reverse<4>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        else if (any != 0ull) dq = accept8_reverse<2>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
     }
     const double misfit_p = jump ? s2 : c.misfit_p[bb];
     const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : c.like_p[bb];
