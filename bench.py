@@ -572,6 +572,24 @@ def main():
                                     "counts the algorithmic flops of all 120 abscissae, as the headline's does; parity against the reference's CSV known "
                                     "answers: every gate within 1e-3 |ref| + 7e-5 peak (Tempest) / 1e-2 |ref| + 4e-5 peak, median 6e-4 (SkyTEM), "
                                     "tests/test_tdem.py, scripts/tdem_study/README.md"}
+            # the device sampler on time-domain data (gbp_rj_run_td): SkyTEM low moment (22 spline nodes, 19 gates), 3-layer synthetic
+            # soundings of tests/test_tdem_sampler.py, blocks of 8 192 and 1 024 chains
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from test_tdem_sampler import OFFSET, _survey
+                from geobipy_amd.tdem import TdemDeviceChains
+                smp = {}
+                for Bs in (8192, 1024):
+                    s_td, h_td, d_td, _, o_td, _ = _survey(Bs, seed=2)
+                    dct = TdemDeviceChains(s_td, h_td, d_td, OFFSET, seed=1, device=device, **o_td)
+                    dct.run(100); torch.cuda.synchronize(device)
+                    t0 = time.perf_counter(); dct.run(300); torch.cuda.synchronize(device)
+                    smp[str(Bs)] = Bs * 300 / (time.perf_counter() - t0)
+                    del dct
+                line["tdem"]["sampler"] = dict(smp, unit="chain-iterations/s", note="TdemDeviceChains (gbp_rj_run_td), SkyTEM low moment, "
+                                               "22 spline nodes x 19 gates, mean ~4 layers; blocks of 8 192 and 1 024 chains")
+            except Exception as e:                               # an extra, never the measurement
+                line["tdem"]["sampler"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))

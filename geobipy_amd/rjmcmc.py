@@ -187,19 +187,17 @@ class ErrorPrior:
         return x
 
 
-class HeightMove:
-    """The height move of a data point (``solve_z``; Point.set_priors / set_proposals / perturb, pointcloud/Point.py:614-621,
-    949-983): uniform prior ``z0 +- maximum_z_change``, random-walk proposal ``Normal(z, z_proposal_variance)`` redrawn up to 10
-    times while the prior gives -inf, then the current height is kept (StatArray.propose, statistics/StatArray.py:578-638).
-    One quirk is reproduced: NormalDistribution.rng hands the VARIANCE to numpy as the scale
-    (statistics/NormalDistribution.py:111: ``prng.normal(mean, variance, size)``), so the step's standard deviation is
-    ``z_proposal_variance`` itself, not its square root.  (No options file of the reference sets these keys -- its ``solve_height`` /
-    ``maximum_height_change`` / ``height_proposal_variance`` are never read -- so the move is off unless a user adds them.)"""
+class ScalarMove:
+    """One sampled scalar of the acquisition geometry with the reference's uniform prior ``centre +- max_change`` and random-walk
+    proposal (Point / EmLoop.set_priors / set_proposals / perturb: pointcloud/Point.py:614-621, 949-983, system/EmLoop.py:222-305):
+    the data point's height (``HeightMove``) or an attitude angle / offset of the loop pair.  See HeightMove for the proposal's
+    scale quirk; ``n_bins``: cells of the posterior histogram on the prior's support (99; EmLoop's pitch: 199, EmLoop.py:326)."""
 
-    def __init__(self, z0, max_change, proposal_variance, n_bins=99):
-        self.z0, self.lo, self.hi = float(z0), float(z0) - float(max_change), float(z0) + float(max_change)
+    def __init__(self, name, centre, max_change, proposal_variance, n_bins=99):
+        self.name = name
+        self.z0, self.lo, self.hi = float(centre), float(centre) - float(max_change), float(centre) + float(max_change)
         self.scale = float(proposal_variance)
-        self.edges = np.linspace(self.lo, self.hi, n_bins + 1)          # Point.set_z_posterior: Uniform.bins() = 99 cells
+        self.edges = np.linspace(self.lo, self.hi, n_bins + 1)
 
     def log_prior(self, z):
         return -np.log(self.hi - self.lo) if (self.lo <= z <= self.hi) else -np.inf      # scipy uniform.logpdf: closed support
@@ -214,6 +212,19 @@ class HeightMove:
             if tries == 10:
                 return float(current)
         return x
+
+
+class HeightMove(ScalarMove):
+    """The height move of a data point (``solve_z``; Point.set_priors / set_proposals / perturb, pointcloud/Point.py:614-621,
+    949-983): uniform prior ``z0 +- maximum_z_change``, random-walk proposal ``Normal(z, z_proposal_variance)`` redrawn up to 10
+    times while the prior gives -inf, then the current height is kept (StatArray.propose, statistics/StatArray.py:578-638).
+    One quirk is reproduced: NormalDistribution.rng hands the VARIANCE to numpy as the scale
+    (statistics/NormalDistribution.py:111: ``prng.normal(mean, variance, size)``), so the step's standard deviation is
+    ``z_proposal_variance`` itself, not its square root.  (No options file of the reference sets these keys -- its ``solve_height`` /
+    ``maximum_height_change`` / ``height_proposal_variance`` are never read -- so the move is off unless a user adds them.)"""
+
+    def __init__(self, z0, max_change, proposal_variance, n_bins=99):
+        super().__init__("z", z0, max_change, proposal_variance, n_bins)          # Point.set_z_posterior: Uniform.bins() = 99 cells
 
 
 def mvn_logpdf(x, mean, cov):
@@ -279,8 +290,9 @@ _PLAIN_ERRORS = ErrorModel()
 class ChainState:
     """What Inference1D carries between iterations for one sounding."""
 
-    def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit, z=None):
+    def __init__(self, edges, values, rel, add, pred, J, prior, like, misfit, z=None, geom=None):
         self.z = None if z is None else float(z)               # the data point's height, when it is sampled (HeightMove)
+        self.geom = None if geom is None else dict(geom)       # sampled scalars of the loop pair by name (ScalarMove)
         self.edges, self.values = np.array(edges, dtype=np.float64), np.array(values, dtype=np.float64)
         self.rel = float(rel) if np.ndim(rel) == 0 else np.array(rel, dtype=np.float64)
         self.add = float(add) if np.ndim(add) == 0 else np.array(add, dtype=np.float64)
@@ -292,7 +304,7 @@ class ChainState:
         return self.values.size
 
 
-def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None):
+def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None, geom_moves=None):
     """One iteration of Inference1D.accept_reject (inversion/Inference1D.py:537-631) for the Resolve-style option
     set (solve_gradient, solve relative / additive error, no height move), written as a coroutine around the hot
     path: it yields ``(phase, (edges, values))`` whenever it needs the kernels --
@@ -301,14 +313,26 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
         phase 2: Jacobian at the proposed model (reversible-jump step, Model.py:612)
     -- is sent back ``(predicted, J)``, and finally yields ``(3, accepted, state)``.  The random stream is consumed
     in exactly the reference's order, so a driver may interleave the coroutines of many chains and batch each
-    phase into one launch.  With ``z_move`` (HeightMove) the data point's height is sampled too and the requests carry it as a
-    third entry, ``(phase, (edges, values), z)``: the current height for phase 0 -- Model.perturb works on the unperturbed copy of
-    the data point, Inference1D.py:547-560 --, the proposed one for phases 1 and 2."""
+    phase into one launch.  With ``z_move`` (HeightMove) and / or ``geom_moves`` (ScalarMove list: sampled angles / offsets of a
+    time-domain loop pair, proposed after the error levels as TdemDataPoint.perturb does, TdemDataPoint.py:681-683) the geometry is
+    sampled too and the requests carry it as a third entry, ``(phase, (edges, values), {"z": z, "geometry": {name: value}})``:
+    the current geometry for phase 0 -- Model.perturb works on the unperturbed copy of the data point, Inference1D.py:547-560 --,
+    the proposed one for phases 1 and 2."""
     prng.random()                                               # Inference1D.py:542
     action, _, _, edges, rem = perturb_structure(prng, sp, state.edges, state.values)
-    ask = (lambda ph, e, v, z: (ph, (e, v))) if z_move is None else (lambda ph, e, v, z: (ph, (e, v), z))
+    moving = z_move is not None or bool(geom_moves)
+
+    def ask(ph, e, v, z, geom):
+        if not moving:
+            return (ph, (e, v))
+        kw = {}
+        if z_move is not None:
+            kw["z"] = z
+        if geom_moves:
+            kw["geometry"] = dict(geom)
+        return (ph, (e, v), kw)
     if action != NONE:
-        pred_rem, J = yield ask(0, edges, rem, state.z)
+        pred_rem, J = yield ask(0, edges, rem, state.z, state.geom)
     else:
         pred_rem, J = state.pred, state.J
     em = _PLAIN_ERRORS if error_model is None else error_model
@@ -320,12 +344,17 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     z = state.z if z_move is None else z_move.propose(prng, state.z)     # Point.perturb first (DataPoint.perturb :561) ...
     rel = rel_prior.propose(prng, state.rel)                    # ... then the error levels, DataPoint.py:531-573
     add = add_prior.propose(prng, state.add)
-    pred, _ = yield ask(1, edges, prop, z)
+    geom = state.geom
+    if geom_moves:                                              # Loop_pair.perturb (system/Loop_pair.py:161-164), after the error levels
+        geom = {m.name: m.propose(prng, state.geom[m.name]) for m in geom_moves}
+    pred, _ = yield ask(1, edges, prop, z, geom)
     std_t = em.std(data, rel, add)
     misfit, like = gauss_loglike(pred, data, std_t)
     prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
     if z_move is not None:
         prior += z_move.log_prior(z)                            # Point.probability, pointcloud/Point.py:159-197
+    if geom_moves:
+        prior += sum(m.log_prior(geom[m.name]) for m in geom_moves)          # Loop_pair.probability, system/Loop_pair.py:294-295
     if prior == -np.inf:
         yield (3, False, state)
         return
@@ -335,7 +364,7 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
         return
     q_fwd = q_rev = 1.0
     if action in (INSERT, DELETE):                              # Model.proposal_probabilities, Model.py:577-659
-        _, J = yield ask(2, edges, prop, z)
+        _, J = yield ask(2, edges, prop, z, geom)
         a = data > 0.0
         grad = model_prior_derivative(vp, edges, prop, 1) + J[a].T @ ((pred[a] - data[a]) / std_t[a] ** 2.0)
         # ln sigma' - alpha * pk with pk = -H g; the reference exponentiates in long double (expReal,
@@ -354,18 +383,18 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     if not accepted:
         yield (3, False, state)
         return
-    yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit, z))
+    yield (3, True, ChainState(edges, prop, rel, add, pred, J, prior, like, misfit, z, geom))
 
 
-def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None):
+def accept_reject(prng, state, data, engine, sp, vp, rel_prior, add_prior, alpha=1.0, error_model=None, z_move=None, geom_moves=None):
     """Drive ``accept_reject_phases`` for one chain with ``engine.forward(edges, values)`` /
-    ``engine.sensitivity(edges, values)`` (GPU kernels in the product; with a height move both take ``z=``).  Returns
-    (accepted, state)."""
-    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha, error_model, z_move)
+    ``engine.sensitivity(edges, values)`` (GPU kernels in the product; with a sampled geometry both take ``z=`` / ``geometry=``).
+    Returns (accepted, state)."""
+    g = accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha, error_model, z_move, geom_moves)
     req = next(g)
     while req[0] != 3:
         phase, (e, v) = req[0], req[1]
-        kw = {} if z_move is None else {"z": req[2]}
+        kw = req[2] if len(req) > 2 else {}
         F = engine.forward(e, v, **kw) if phase in (0, 1) else None
         Jm = engine.sensitivity(e, v, **kw) if phase in (0, 2) else None
         req = g.send((F, Jm))
