@@ -78,7 +78,7 @@ def height_move_from_options(o, z0):
     return rjmcmc.HeightMove(z0, o["maximum_z_change"], o["z_proposal_variance"])
 
 
-def initial_state(engine, data, o, error_model=None, z_move=None):
+def initial_state(engine, data, o, error_model=None, z_move=None, geom_moves=None):
     """Inference1D.initialize (inversion/Inference1D.py:353-464, 485-535): best half-space out of 100 log-spaced
     conductivities (EmDataPoint.find_best_halfspace), its forward / Jacobian, prior and likelihood."""
     rel, add = o["initial_relative_error"], o["initial_additive_error"]
@@ -99,7 +99,11 @@ def initial_state(engine, data, o, error_model=None, z_move=None):
     prior = rjmcmc.model_log_prior(sp, vp, none, sigma) + rp.log_prior(rel) + ap.log_prior(add)
     if z_move is not None:
         prior += z_move.log_prior(z_move.z0)
-    return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit, None if z_move is None else z_move.z0)
+    geom = None
+    if geom_moves:
+        prior += sum(m.log_prior(m.z0) for m in geom_moves)
+        geom = {m.name: m.z0 for m in geom_moves}
+    return (sp, vp, rp, ap), rjmcmc.ChainState(none, sigma, rel, add, pred, J, prior, like, misfit, None if z_move is None else z_move.z0, geom)
 
 
 class Posteriors:
@@ -112,11 +116,14 @@ class Posteriors:
     (tests/test_rjmcmc.py)."""
 
     def __init__(self, max_cells, max_edge, min_width, value_mean, factor=10.0, n_value_bins=250, ratio=0.5,
-                 relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99, height_edges=None):
+                 relative_error_bounds=None, additive_error_bounds=None, n_error_bins=99, height_edges=None, geometry_edges=None):
         self.ratio = ratio
         # height (Point.set_z_posterior :1010-1017): the cells of the uniform prior, when the height is sampled
         self.height_edges = None if height_edges is None else np.asarray(height_edges, dtype=np.float64)
         self.height = np.zeros(0 if height_edges is None else self.height_edges.size - 1, dtype=np.int64)
+        # sampled scalars of the loop pair (EmLoop.set_pitch_posterior ...: the cells of their uniform priors)
+        self.geometry_edges = {n_: np.asarray(e_, dtype=np.float64) for n_, e_ in (geometry_edges or {}).items()}
+        self.geometry = {n_: np.zeros(e_.size - 1, dtype=np.int64) for n_, e_ in self.geometry_edges.items()}
         # error levels (DataPoint.set_posteriors :651-694): n_error_bins cells, uniform in log10 between the prior bounds
         # (several levels -- time-domain data: bounds are arrays, one histogram per level: edges [G, n + 1], counts [G, n])
         grid = lambda b: None if b is None else np.linspace(*np.log10(np.asarray(b, dtype=np.float64)), n_error_bins + 1).T
@@ -134,11 +141,16 @@ class Posteriors:
         self.values = np.zeros((n_value_bins, self.depth_centres.size), dtype=np.int64)
 
     def reset(self):
-        for a in (self.n_cells, self.edges, self.values, self.relative_error, self.additive_error, self.height):
+        for a in (self.n_cells, self.edges, self.values, self.relative_error, self.additive_error, self.height) + tuple(self.geometry.values()):
             a[:] = 0
 
-    def update(self, edges, values, rel=None, add=None, z=None):
-        """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels; ``z``: height."""
+    def update(self, edges, values, rel=None, add=None, z=None, geom=None):
+        """``edges``: interior interface depths; ``values``: layer conductivities; ``rel`` / ``add``: error levels; ``z``: height;
+        ``geom``: sampled scalars of the loop pair."""
+        for n_, v_ in (geom or {}).items():
+            e_ = self.geometry_edges.get(n_)
+            if e_ is not None and e_[0] <= v_ <= e_[-1]:
+                self.geometry[n_][min(np.searchsorted(e_, v_, side="right") - 1, e_.size - 2)] += 1
         if z is not None and self.height_edges is not None and self.height_edges[0] <= z <= self.height_edges[-1]:
             self.height[min(np.searchsorted(self.height_edges, z, side="right") - 1, self.height.size - 1)] += 1
         for x, grid, hist in ((rel, self.rel_edges, self.relative_error), (add, self.add_edges, self.additive_error)):
@@ -212,7 +224,9 @@ class Inference1D:
             else:
                 self.engine = GpuEngine(datapoint.system[0], datapoint.z[0])
         self.z_move = height_move_from_options(self.options, float(np.atleast_1d(datapoint.z)[0]))
-        self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model, self.z_move)
+        # sampled scalars of a time-domain loop pair (solve_transmitter_* / solve_receiver_*: all False in the reference's options files)
+        self.geom_moves = datapoint.geometry_moves(**self.options) if hasattr(datapoint, "geometry_moves") else []
+        self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model, self.z_move, self.geom_moves)
         self.halfspace = self.state.values.copy()
         self.iteration = 0
         self.data_misfit_v = np.zeros(2 * self.n_markov_chains + 2)
@@ -224,7 +238,8 @@ class Inference1D:
                                      float(self.halfspace[0]), o["factor"],
                                      relative_error_bounds=(o["minimum_relative_error"], o["maximum_relative_error"]),
                                      additive_error_bounds=(o["minimum_additive_error"], o["maximum_additive_error"]),
-                                     height_edges=None if self.z_move is None else self.z_move.edges)
+                                     height_edges=None if self.z_move is None else self.z_move.edges,
+                                     geometry_edges={m.name: m.edges for m in self.geom_moves})
 
     # the quantities the reference exposes on its Inference1D
     @property
@@ -252,7 +267,7 @@ class Inference1D:
         sp, vp, rp, ap = self.priors
         self.accepted, self.state = rjmcmc.accept_reject(self.prng, self.state, self.data, self.engine, sp, vp, rp, ap,
                                                          self.options["covariance_scaling"], getattr(self, "error_model", None),
-                                                         getattr(self, "z_move", None))
+                                                         getattr(self, "z_move", None), getattr(self, "geom_moves", None))
         return False
 
     def update(self):
@@ -263,7 +278,7 @@ class Inference1D:
         if self.posterior > self.best_posterior:
             self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
         self.acceptance_v[self.iteration] = self.accepted
-        self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z)
+        self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z, self.state.geom)
 
     def infer(self, hdf_file_handle=None, n_iterations=None, burn_in_min_iterations=5000):
         """``failed = infer(hdf_file_handle)`` as the harness calls it (Inference3D.py:620, Inference1D.infer :633-688); with
@@ -306,7 +321,7 @@ class Inference1D:
                 self.burned_in, self.burned_in_iteration = True, self.iteration
                 self.best_state, self.best_posterior, self.best_iteration = self.state, self.posterior, self.iteration
                 self.posteriors.reset()
-                self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z)
+                self.posteriors.update(self.state.edges, self.state.values, self.state.rel, self.state.add, self.state.z, self.state.geom)
             if window > 1 and self.iteration % window == 0 and not self.burned_in:                    # update :764-776
                 # the reference's window: the flags it stored at indices [iteration - window, iteration), i.e. without this step's
                 if self.acceptance_v[max(self.iteration - window, 0):self.iteration].sum() == 0:
@@ -332,7 +347,7 @@ class Inference1D:
         """Inference1D.reset (:984-999): back to the initial state of this sounding; the random stream is not rewound."""
         self.n_resets += 1
         self.priors, self.state = initial_state(self.engine, self.data, self.options, getattr(self, "error_model", None),
-                                                getattr(self, "z_move", None))
+                                                getattr(self, "z_move", None), getattr(self, "geom_moves", None))
         self.iteration = 0
         self.data_misfit_v[:] = 0.0
         self.data_misfit_v[0] = self.state.misfit

@@ -36,7 +36,7 @@ import torch
 from . import _lib
 from .rjmcmc_gpu import DeviceChains
 from .filters import W0_J0_120, W1_J1_140, base_abscissae
-from .tdem_geometry import ON_AXIS_RHO, GeometryMix, from_loops, gaaem_geometry
+from .tdem_geometry import LOOP_PAIR_SCALARS, gaaem_tuple, loop_pair_moves, loop_pair_values, ON_AXIS_RHO, GeometryMix, from_loops, gaaem_geometry
 
 MU0 = 4.0e-7 * np.pi
 
@@ -790,17 +790,28 @@ class TdemEngine:
     (inference.Inference1D, rjmcmc.accept_reject) asks of a data point -- on persistent TdemBatch objects (tables, windows and
     mixing weights are built once; a call refills the model tensors and launches)."""
 
-    def __init__(self, systems, height, offset, attitude=None, lmax=32, hankel_eps=None):
+    def __init__(self, systems, height, offset, attitude=None, lmax=32, hankel_eps=None, loop_pair=None):
         self.systems, self.height, self.offset, self.attitude = list(systems), float(height), tuple(offset), attitude
         self.lmax, self.hankel_eps = int(lmax), hankel_eps
         self._b = {}
+        self.loop_pair = None if loop_pair is None else dict(loop_pair)      # tdem_geometry.loop_pair_values: base of geometry moves
 
-    def _batch(self, models):
+    def _batch(self, models, geometry=None):
+        """``geometry``: {name: value} overrides of the loop pair's scalars (a sampled geometry, rjmcmc.ScalarMove) -- a batch per
+        distinct geometry is built and kept while it is the current or the proposed one (two are alive at a time)."""
         n = len(models)
-        b = self._b.get(n)
+        height, offset, attitude, key = self.height, self.offset, self.attitude, n
+        if geometry:
+            assert self.loop_pair is not None, ValueError("geometry moves need the engine's loop pair (TdemDataPoint.make_engine)")
+            g = gaaem_tuple(dict(self.loop_pair, **geometry))
+            height, offset, attitude = float(g[0]), tuple(g[4:7]), tuple(np.r_[g[1:4], g[7:10]])
+            key = (n,) + tuple(float(x) for x in g)
+            if key not in self._b and len(self._b) > 8:
+                self._b = {k_: v_ for k_, v_ in list(self._b.items())[-4:]}
+        b = self._b.get(key)
         if b is None:
-            b = self._b[n] = TdemBatch(self.systems, np.ones(n, dtype=np.int32), np.ones((n, self.lmax)), np.zeros((n, self.lmax)),
-                                       np.full(n, self.height), self.offset, attitude=self.attitude, hankel_eps=self.hankel_eps)
+            b = self._b[key] = TdemBatch(self.systems, np.ones(n, dtype=np.int32), np.ones((n, self.lmax)), np.zeros((n, self.lmax)),
+                                         np.full(n, height), offset, attitude=attitude, hankel_eps=self.hankel_eps)
         nl = np.array([v.size for _, v in models], dtype=np.int32)
         assert nl.max() <= self.lmax, ValueError("model has more layers than the engine was sized for")
         sig, thk = np.ones((n, self.lmax)), np.zeros((n, self.lmax))
@@ -813,18 +824,18 @@ class TdemEngine:
         b._max_layers = int(nl.max())
         return b, nl
 
-    def forward_many(self, models):
-        return self._batch(models)[0].forward().cpu().numpy()
+    def forward_many(self, models, geometry=None):
+        return self._batch(models, geometry)[0].forward().cpu().numpy()
 
-    def forward(self, edges, values):
-        return self.forward_many([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])[0]
+    def forward(self, edges, values, geometry=None):
+        return self.forward_many([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))], geometry)[0]
 
-    def sensitivity(self, edges, values):
-        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])
+    def sensitivity(self, edges, values, geometry=None):
+        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))], geometry)
         return b.sensitivity().cpu().numpy()[0][:, : nl[0]]
 
-    def fm_dlogc(self, edges, values):
-        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))])
+    def fm_dlogc(self, edges, values, geometry=None):
+        b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))], geometry)
         p, J = b.fm_dlogc()
         return p.cpu().numpy()[0], J.cpu().numpy()[0][:, : nl[0]]
 
@@ -860,6 +871,7 @@ class TdemDataPoint:
         self._rel_prior = self._add_prior = None              # rjmcmc.ErrorPrior (vector) once set_priors ran
         self._prng = None
         self._engine, self._engine_key = None, None
+        self._geom_moves = []                                 # rjmcmc.ScalarMove list once set_priors saw solve_transmitter_* / solve_receiver_*
         self.engine = None                                    # TEST HOOK only (see FdemDataPoint.engine); the product never sets it
 
     @property
@@ -927,7 +939,13 @@ class TdemDataPoint:
     # -- engine -------------------------------------------------------------------------------------------------------
     def make_engine(self, lmax=32, hankel_eps=None):
         """A TdemEngine for this data point's altitude and geometry (what Inference1D.initialize asks for)."""
-        return TdemEngine(self.system, self.z[0], self.offset, self.attitude, lmax=lmax, hankel_eps=hankel_eps)
+        return TdemEngine(self.system, self.z[0], self.offset, self.attitude, lmax=lmax, hankel_eps=hankel_eps,
+                          loop_pair=loop_pair_values(self.transmitter, self.receiver))
+
+    def geometry_moves(self, **options):
+        """The loop pair's sampled scalars as rjmcmc.ScalarMove objects, in the reference's order (Loop_pair.set_priors /
+        set_proposals / perturb, system/Loop_pair.py:161-192), from the options' ``solve_transmitter_* / solve_receiver_*`` keys."""
+        return loop_pair_moves(loop_pair_values(self.transmitter, self.receiver), options)
 
     def _eng(self, n_layers):
         if self.engine is not None:
@@ -1015,11 +1033,13 @@ class TdemDataPoint:
         """TdemDataPoint.set_priors (:950-971) -> DataPoint.set_priors (:575-595): log-uniform priors [minimum, maximum] on the
         error levels that are solved for -- lists per level in the time-domain options files (minimum_relative_error = [..] per
         system x component, minimum_additive_error = [..] per system); scalars are broadcast.  ``prng`` is remembered for
-        perturb().  Transmitter / receiver priors (solve_transmitter_* / solve_receiver_*) are not supported: a True flag raises."""
+        perturb().  Transmitter / receiver priors (solve_transmitter_* / solve_receiver_*: Loop_pair.set_priors, system/Loop_pair.py
+        :166-178) become rjmcmc.ScalarMove objects centred on the loops' current values; their proposal scales come with set_proposals."""
         from . import rjmcmc
-        for k_, v_ in kwargs.items():
-            if (k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and v_:
-                raise NotImplementedError(k_ + ": geometry moves of the loop pair are not sampled")
+        if any((k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and v_ for k_, v_ in kwargs.items()):
+            stems = {stem for _, stem, _ in LOOP_PAIR_SCALARS if kwargs.get("solve_" + stem, False)}
+            self._geom_moves = loop_pair_moves(loop_pair_values(self.transmitter, self.receiver),
+                                               dict({st + "_proposal_variance": 0.0 for st in stems}, **kwargs))
         self._prng = kwargs.get("prng", self._prng)
         if relative_error_prior is None and kwargs.get("solve_relative_error", False):
             relative_error_prior = (kwargs["minimum_relative_error"], kwargs["maximum_relative_error"])
@@ -1036,8 +1056,12 @@ class TdemDataPoint:
 
     def set_proposals(self, relative_error_proposal=None, additive_error_proposal=None, **kwargs):
         """TdemDataPoint.set_proposals (:973-985) -> DataPoint.set_proposals (:597-644): log-normal random walks with the
-        options file's proposal variances (a list per level, or a scalar)."""
+        options file's proposal variances (a list per level, or a scalar); Loop_pair.set_proposals (:180-192) for the loop pair's moves."""
         self._prng = kwargs.get("prng", self._prng)
+        stem_of = {name: stem for name, stem, _ in LOOP_PAIR_SCALARS}
+        for m_ in self._geom_moves:
+            if stem_of[m_.name] + "_proposal_variance" in kwargs:
+                m_.scale = float(kwargs[stem_of[m_.name] + "_proposal_variance"])
         if relative_error_proposal is None and kwargs.get("solve_relative_error", False):
             relative_error_proposal = kwargs["relative_error_proposal_variance"]
         if additive_error_proposal is None and kwargs.get("solve_additive_error", False):
@@ -1054,11 +1078,35 @@ class TdemDataPoint:
             self._relative_error = np.atleast_1d(self._rel_prior.propose(self._prng, self._relative_error))
         if self._add_prior is not None and np.any(np.asarray(self._add_prior.var) > 0.0):
             self._additive_error = np.atleast_1d(self._add_prior.propose(self._prng, self._additive_error))
+        if self._geom_moves:                                  # self.loop_pair.perturb() (TdemDataPoint.py:683)
+            cur = loop_pair_values(self.transmitter, self.receiver)
+            self.set_loop_pair({m_.name: m_.propose(self._prng, cur[m_.name]) for m_ in self._geom_moves})
+
+    def set_loop_pair(self, values):
+        """Write sampled scalars {name: value} (tdem_geometry.LOOP_PAIR_SCALARS) back into the two loops; an offset component moves
+        the receiver (the pair's offset is receiver - transmitter)."""
+        tx, rx = self.transmitter, self.receiver
+        put = lambda loop, attr, v_: setattr(loop, attr, np.atleast_1d(np.float64(v_)))
+        for name, v_ in values.items():
+            if name in ("dx", "dy", "dz"):
+                ax = name[1]
+                put(rx, ax, float(np.atleast_1d(getattr(tx, ax))[0]) + v_)
+            elif name.startswith("tx_"):
+                if name[3:] in ("x", "y", "z"):               # (the offset stays: Loop_pair keeps it as its own Point)
+                    old = float(np.atleast_1d(getattr(tx, name[3:]))[0])
+                    put(rx, name[3:], float(np.atleast_1d(getattr(rx, name[3:]))[0]) + (v_ - old))
+                put(tx, name[3:], v_)
+            else:
+                put(rx, name[3:], v_)
 
     @property
     def probability(self):
-        """DataPoint.probability (:454-489): sum of the log priors of the error levels that have one."""
+        """DataPoint.probability (:454-489): sum of the log priors of the error levels that have one (+ the loop pair's,
+        Loop_pair.probability :294-295)."""
         p = np.float64(0.0)
+        if self._geom_moves:
+            cur = loop_pair_values(self.transmitter, self.receiver)
+            p += sum(m_.log_prior(cur[m_.name]) for m_ in self._geom_moves)
         if self._rel_prior is not None:
             p += self._rel_prior.log_prior(self._relative_error)
         if self._add_prior is not None:

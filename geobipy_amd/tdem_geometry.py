@@ -77,6 +77,38 @@ def from_loops(tx, rx):
     return off, att
 
 
+# The scalars of a loop pair the reference can sample, in the order Loop_pair.perturb visits them (system/Loop_pair.py:161-164:
+# the pair's own Point = the receiver offset, then the transmitter -- Point.perturb x, y, z, then EmLoop.perturb pitch, roll, yaw,
+# system/EmLoop.py:222-240 --, then the receiver, whose x / y / z priors go to the offset instead, Loop_pair.set_priors :172-178).
+# name -> (option-key stem, cells of the posterior: EmLoop.set_pitch_posterior uses Uniform.bins(199), everything else 99)
+LOOP_PAIR_SCALARS = (("dx", "receiver_x", 99), ("dy", "receiver_y", 99), ("dz", "receiver_z", 99),
+                     ("tx_x", "transmitter_x", 99), ("tx_y", "transmitter_y", 99), ("tx_z", "transmitter_z", 99),
+                     ("tx_pitch", "transmitter_pitch", 199), ("tx_roll", "transmitter_roll", 99), ("tx_yaw", "transmitter_yaw", 99),
+                     ("rx_pitch", "receiver_pitch", 199), ("rx_roll", "receiver_roll", 99), ("rx_yaw", "receiver_yaw", 99))
+
+
+def loop_pair_values(tx, rx):
+    """{name: value} of the scalars above for a loop pair, angles as the loops store them (the reference's own convention)."""
+    f = lambda v: float(np.atleast_1d(v)[0])
+    return dict(dx=f(rx.x) - f(tx.x), dy=f(rx.y) - f(tx.y), dz=f(rx.z) - f(tx.z), tx_x=f(tx.x), tx_y=f(tx.y), tx_z=f(tx.z),
+                tx_pitch=f(tx.pitch), tx_roll=f(tx.roll), tx_yaw=f(tx.yaw), rx_pitch=f(rx.pitch), rx_roll=f(rx.roll), rx_yaw=f(rx.yaw))
+
+
+def gaaem_tuple(values):
+    """Loop_pair.Geometry (system/Loop_pair.py:63-77) from such a dict: (tx height, tx roll, -tx pitch, -tx yaw, dx, dy, dz, rx roll,
+    -rx pitch, -rx yaw) -- the transmitter's x / y do not enter the forward."""
+    v = values
+    return np.array([v["tx_z"], v["tx_roll"], -v["tx_pitch"], -v["tx_yaw"], v["dx"], v["dy"], v["dz"], v["rx_roll"], -v["rx_pitch"], -v["rx_yaw"]])
+
+
+def loop_pair_moves(values, options):
+    """The ScalarMove list of a loop pair from the reference's option keys -- ``solve_<stem>``, ``maximum_<stem>_change``,
+    ``<stem>_proposal_variance`` (all False in the options files the reference ships) -- centred on the pair's current values."""
+    from .rjmcmc import ScalarMove
+    return [ScalarMove(name, values[name], options["maximum_" + stem + "_change"], options[stem + "_proposal_variance"], n_bins=nb)
+            for name, stem, nb in LOOP_PAIR_SCALARS if options.get("solve_" + stem, False)]
+
+
 def basis_weights(geometry, loop_radius):
     """w[B, 3, 5]: field along the receiver's axis k (x, y, z) = sum_i w[b, k, i] * BASIS_i, before output sign and scaling.
     For a dipole transmitter (loop_radius = 0) B0L / B1L ARE B0 / B1 and take their weights (B0, B1 get 0); for a receiver on

@@ -46,20 +46,28 @@ def test_joint_error_level_moves_reproduce_the_reference_statarray():
 class OracleTdEngine:
     """CPU stand-in for TdemEngine (tests only): oracle/tdem_oracle windows, Jacobian by central differences in ln sigma."""
 
-    def __init__(self, stms, geometry):
+    def __init__(self, stms, geometry, loop_pair=None):
         from oracle import tdem_oracle as to
         self.to, self.stms, self.g = to, stms, np.asarray(geometry, dtype=float)
+        self.loop_pair = loop_pair               # tdem_geometry.loop_pair_values: base of sampled geometries (geometry= overrides)
 
-    def forward(self, edges, values):
+    def _g(self, geometry):
+        if not geometry:
+            return self.g
+        from geobipy_amd.tdem_geometry import gaaem_tuple
+        return gaaem_tuple(dict(self.loop_pair, **geometry))
+
+    def forward(self, edges, values, geometry=None):
         thk = np.diff(np.r_[0.0, edges])
-        return np.concatenate([self.to.forward_geometry(s, values, thk, self.g) for s in self.stms])
+        g = self._g(geometry)
+        return np.concatenate([self.to.forward_geometry(s, values, thk, g) for s in self.stms])
 
-    def sensitivity(self, edges, values, eps=1e-4):
+    def sensitivity(self, edges, values, eps=1e-4, geometry=None):
         cols = []
         for m in range(values.size):
             vp, vm = values.copy(), values.copy()
             vp[m] *= np.exp(eps); vm[m] *= np.exp(-eps)
-            cols.append((self.forward(edges, vp) - self.forward(edges, vm)) / (2 * eps))
+            cols.append((self.forward(edges, vp, geometry) - self.forward(edges, vm, geometry)) / (2 * eps))
         return np.stack(cols, axis=1)
 
 
@@ -95,8 +103,16 @@ def test_tdem_datapoint_error_level_members_on_the_host():
     assert np.allclose(dp.std, ref, rtol=1e-14)
     dp.additive_error = [1e-20, 1e-13]                   # outside the prior
     assert dp.probability == -np.inf
-    with pytest.raises(NotImplementedError):
-        dp.set_priors(solve_receiver_pitch=True)
+    # the loop pair's moves at the object level (Loop_pair.set_priors / set_proposals / perturb / probability)
+    dp.additive_error = a0
+    mv = dict(solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.5)
+    dp.set_priors(prng=prng, **mv)
+    dp.set_proposals(**mv)
+    p0 = dp.probability
+    assert np.isclose(p0, lp - np.log(10.0), rtol=1e-13)
+    dp.perturb()
+    pitch = float(np.atleast_1d(dp.receiver.pitch)[0])
+    assert pitch != 0.0 and abs(pitch) <= 5.0 and np.isclose(dp.probability, p0, rtol=1e-13) and dp.attitude[4] == -pitch
 
 
 def test_inference1d_runs_a_time_domain_sounding_on_the_host_engine():
@@ -190,3 +206,81 @@ def test_host_sampler_walks_the_reference_time_domain_chain():
         assert abs(inf.data_misfit - ref[2]) <= 1e-7 * abs(ref[2]), (it, inf.data_misfit, ref[2])
         assert np.allclose(np.r_[inf.state.rel, inf.state.add], ref[3:], rtol=1e-11, atol=0.0), it
     assert rows[:, 0].sum() == 91 and inf.state.k == 5 and inf.data_misfit < 45.0
+
+
+def _loop_pair_move_run(engine):
+    import json
+    from geobipy_amd import CircularLoop, Inference1D, TdemDataPoint
+    from geobipy_amd.tdem_geometry import loop_pair_values
+    from oracle import tdem_oracle as to
+    from test_rjmcmc import generator_at
+    g = np.load(os.path.join(GOLDEN, "mcmc_geometry.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "hdf_schema_tdem.json")))["skytem"]["meta"]
+    txv, rxv = g["tx"], g["rx"]
+    tx = CircularLoop(x=[txv[0]], y=[txv[1]], z=[txv[2]], pitch=[txv[3]], roll=[txv[4]], yaw=[txv[5]], orientation=["z"], radius=[10.416])
+    rx = CircularLoop(x=[rxv[0]], y=[rxv[1]], z=[rxv[2]], pitch=[rxv[3]], roll=[rxv[4]], yaw=[rxv[5]], orientation=["z"], radius=[10.416])
+    dp = TdemDataPoint(z=float(g["z"]), data=g["data"], system=[os.path.join(GOLDEN, "SkytemHM.stm"), os.path.join(GOLDEN, "SkytemLM.stm")],
+                       transmitter_loop=tx, receiver_loop=rx)
+    base = loop_pair_values(tx, rx)
+    from geobipy_amd.tdem_geometry import gaaem_tuple
+    if engine:
+        dp.engine = OracleTdEngine([to.parse_stm(os.path.join(GOLDEN, n)) for n in ("SkytemHM.stm", "SkytemLM.stm")], gaaem_tuple(base), base)
+    keys = ("additive_error_proposal_variance", "covariance_scaling", "factor", "gradient_standard_deviation", "initial_additive_error",
+            "initial_relative_error", "maximum_additive_error", "maximum_depth", "maximum_number_of_layers", "maximum_relative_error",
+            "minimum_additive_error", "minimum_depth", "minimum_relative_error", "n_markov_chains", "probability_of_birth",
+            "probability_of_death", "probability_of_no_change", "probability_of_perturb", "relative_error_proposal_variance",
+            "solve_additive_error", "solve_gradient", "solve_parameter", "solve_relative_error")
+    o = {k: meta["options"][k] for k in keys}
+    mo = g["move_options"]
+    o.update(solve_transmitter_pitch=True, maximum_transmitter_pitch_change=mo[0, 0], transmitter_pitch_proposal_variance=mo[0, 1],
+             solve_receiver_pitch=True, maximum_receiver_pitch_change=mo[1, 0], receiver_pitch_proposal_variance=mo[1, 1],
+             solve_receiver_roll=True, maximum_receiver_roll_change=mo[2, 0], receiver_roll_proposal_variance=mo[2, 1])
+    inf = Inference1D(prng=generator_at(g["rng_state"]), world=None, **o)
+    inf.initialize(dp)
+    assert [m.name for m in inf.geom_moves] == ["tx_pitch", "rx_pitch", "rx_roll"]
+    assert np.allclose([[m.lo, m.hi] for m in inf.geom_moves], g["priors"]) and np.allclose([m.scale for m in inf.geom_moves], g["proposal_variances"])
+    assert np.isclose(inf.state.values[0], g["halfspace"], rtol=1e-14) and np.isclose(inf.prior, g["prior0"], rtol=1e-13)
+    return g, inf
+
+
+def test_host_sampler_walks_the_reference_chain_with_loop_pair_moves():
+    """``solve_transmitter_pitch / solve_receiver_pitch / solve_receiver_roll`` (Loop_pair.perturb, system/Loop_pair.py:161-192; EmLoop
+    priors / proposals / posteriors, system/EmLoop.py:222-335; all False in the options files the reference ships): the reference's own
+    Inference1D with those keys added, run on the stand-in for gatdaem1d (tests/golden/make_mcmc_geometry.py -> mcmc_geometry.npz; the
+    forward values are this repository's oracle with the full geometry tuple on both sides, so what is pinned is the host logic:
+    which scalars move, in which order they consume the random stream -- after the error levels --, their priors, the 199-cell pitch
+    posteriors) -- against geobipy_amd.Inference1D on geobipy_amd.TdemDataPoint: every decision, layer count, misfit, error level
+    and angle of 250 iterations, and the three angle posteriors."""
+    g, inf = _loop_pair_move_run(engine=True)
+    rows = g["rows"]
+    for it in range(rows.shape[0]):
+        inf.accept_reject()
+        inf.update()
+        ref = rows[it]
+        assert bool(ref[0]) == bool(inf.accepted) and int(ref[1]) == inf.state.k, it
+        assert abs(inf.data_misfit - ref[2]) <= 1e-7 * abs(ref[2]), (it, inf.data_misfit, ref[2])
+        assert np.allclose(np.r_[inf.state.rel, inf.state.add], ref[3:7], rtol=1e-11, atol=0.0), it
+        assert np.allclose([inf.state.geom[n] for n in ("tx_pitch", "rx_pitch", "rx_roll")], ref[7:10], rtol=0.0, atol=1e-12), it
+        assert np.isclose(inf.prior, ref[10], rtol=1e-10) and np.isclose(inf.likelihood, ref[11], rtol=1e-8), it
+    assert rows[:, 0].sum() > 60 and np.all(np.ptp(rows[:, 7:10], axis=0) > 2.0)
+    for n in ("tx_pitch", "rx_pitch", "rx_roll"):
+        centre = float(g[n + "_hist_relative_to"])
+        assert np.allclose(inf.posteriors.geometry_edges[n] - centre, g[n + "_hist_edges"], atol=1e-12), n
+        assert np.array_equal(inf.posteriors.geometry[n], g[n + "_hist_counts"]), n
+
+
+@pytest.mark.gpu
+def test_loop_pair_moves_on_the_gpu_engine():
+    """The same run with nothing injected: every evaluation a launch of TdemEngine on the geometry of the request (current geometry
+    for the remapped model, proposed geometry for the proposal) -- the decisions of the reference's first 80 iterations, angles to
+    1e-9 degrees (the draws do not depend on the forward values; the decisions do, at the 1e-8 level GPU and oracle differ by)."""
+    g, inf = _loop_pair_move_run(engine=False)
+    assert inf.datapoint.engine is None
+    rows = g["rows"]
+    for it in range(80):
+        inf.accept_reject()
+        inf.update()
+        ref = rows[it]
+        assert bool(ref[0]) == bool(inf.accepted) and int(ref[1]) == inf.state.k, it
+        assert abs(inf.data_misfit - ref[2]) <= 1e-5 * abs(ref[2]), (it, inf.data_misfit, ref[2])
+        assert np.allclose([inf.state.geom[n] for n in ("tx_pitch", "rx_pitch", "rx_roll")], ref[7:10], rtol=0.0, atol=1e-9), it
