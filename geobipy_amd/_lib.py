@@ -27,14 +27,15 @@ class RjOptions(ctypes.Structure):
                 + [(n, ctypes.c_double * 4) for n in ("rel_min", "rel_max", "rel_sd", "add_min", "add_max", "add_sd")]
                 + [("depth_bin_width", ctypes.c_double), ("value_half_width", ctypes.c_double)]
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)]
-                + [("solve_height", ctypes.c_int32), ("height_half_width", ctypes.c_double), ("height_scale", ctypes.c_double)])
+                + [("solve_height", ctypes.c_int32), ("height_half_width", ctypes.c_double), ("height_scale", ctypes.c_double),
+                   ("extra_log_prior", ctypes.c_double)])
 
 
 RJ_CHAIN_FIELDS = ("rel_group", "add_group", "add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
                    "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma",
-                   "best_rel", "best_add", "iteration0", "height_p", "height0", "height_hist", "best_height")
+                   "best_rel", "best_add", "iteration0", "height_p", "height0", "height_hist", "best_height", "step_flags")
 
 
 class RjChains(ctypes.Structure):
@@ -48,10 +49,20 @@ class TdMix(ctypes.Structure):
                 ("col", c_void_p), ("weights", c_void_p), ("offset", c_void_p)]
 
 
+class TdMoves(ctypes.Structure):
+    """gbp_td_moves."""
+    _fields_ = [("n_moves", ctypes.c_int32), ("entry", ctypes.c_int32 * 6), ("sign", ctypes.c_double * 6), ("half_width", ctypes.c_double * 6),
+                ("scale", ctypes.c_double * 6), ("n_bins", ctypes.c_int32 * 6), ("geom", c_void_p), ("geom_p", c_void_p), ("geom0", c_void_p),
+                ("weights", c_void_p), ("weights_p", c_void_p), ("offset", c_void_p), ("offset_p", c_void_p), ("hist", c_void_p),
+                ("best_geom", c_void_p), ("n_blocks", ctypes.c_int32), ("n_basis", ctypes.c_int32), ("loop", ctypes.c_int32),
+                ("on_axis", ctypes.c_int32), ("basis", ctypes.c_int32 * 5), ("block_comp", c_void_p), ("block_scale", c_void_p),
+                ("block_primary", c_void_p), ("block_windows", c_void_p)]
+
+
 class TdOperator(ctypes.Structure):
     """gbp_td_operator."""
     _fields_ = [("n_nodal", ctypes.c_int32), ("W", c_void_p), ("nodal", c_void_p), ("J_nodal", c_void_p), ("mix", TdMix),
-                ("table_set", c_void_p)]
+                ("table_set", c_void_p), ("moves", TdMoves)]
 
 
 _rj_o, _rj_c = ctypes.POINTER(RjOptions), ctypes.POINTER(RjChains)

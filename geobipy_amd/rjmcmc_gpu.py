@@ -85,7 +85,7 @@ class DeviceChains:
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
-                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, **options):
+                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, extra_log_prior=0.0, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -170,6 +170,7 @@ class DeviceChains:
         ro.height_half_width = self.height_half_width
         # (NormalDistribution.rng hands the variance to numpy as the scale, statistics/NormalDistribution.py:111: reproduced)
         ro.height_scale = float(o["z_proposal_variance"]) if self.solve_height else 0.0
+        ro.extra_log_prior = float(extra_log_prior)     # (priors of sampled scalars that live outside gbp_rj_chains: gbp_td_moves)
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
@@ -191,7 +192,8 @@ class DeviceChains:
             best_posterior=z(B), best_k=z(B, dt=i32), best_edges=z(B, K), best_sigma=z(B, K), best_rel=z(B, Gr), best_add=z(B, Ga),
             iteration0=z(B, dt=i32),
             height_p=heights.clone() if self.solve_height else None, height0=heights if self.solve_height else None,
-            height_hist=z(B, 99, dt=i32) if self.solve_height else None, best_height=heights.clone() if self.solve_height else None)
+            height_hist=z(B, 99, dt=i32) if self.solve_height else None, best_height=heights.clone() if self.solve_height else None,
+            step_flags=z(B, dt=i32))
         self._bind()
         self.iteration = 0
         self.forward_waves = int(forward_waves)      # also passed explicitly to the forward calls of the initialisation
@@ -272,6 +274,7 @@ class DeviceChains:
                                 for g in range(self.n_add_groups))
         if self.solve_height:
             prior = prior - math.log(2.0 * self.height_half_width)
+        prior = prior + self._o.extra_log_prior
         t["prior"].copy_(prior)
         t["best_posterior"].copy_(t["like"] + t["prior"])
         t["best_sigma"].copy_(t["sigma"])
@@ -407,6 +410,7 @@ class DeviceChains:
         if self.solve_height:
             t["height"][r] = t["height0"][r]
             t["best_height"][r] = t["height0"][r]
+        self._restart_more(r)
         t["burned_in_iteration"][r] = -1
         t["iteration0"][r] = self.iteration
         t["best_posterior"][r] = t["init_like"][r] + t["init_prior"][r]
@@ -416,6 +420,9 @@ class DeviceChains:
         t["best_sigma"][r] = t["sigma"][r]
         t["best_edges"][r] = float("inf")
         t["status"].copy_(torch.where(give_up, torch.full_like(t["status"], 2), torch.where(reset, torch.zeros_like(t["status"]), t["status"])))
+
+    def _restart_more(self, r):
+        """Hook: further per-chain state of a subclass going back to its initial values for the rows ``r``."""
 
     def _scatter(self, full, rows):
         """Working rows -> their places in the full-size tensors."""

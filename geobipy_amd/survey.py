@@ -421,8 +421,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     time_domain = tempest or o["data_type"] in ("TdemData", "TdemDataPoint")
     if not time_domain and o["data_type"] not in ("FdemData", "FdemDataPoint"):
         raise NotImplementedError("the device sampler handles FdemData, TdemData and TempestData; {} is not supported".format(o["data_type"]))
-    for k_ in [k_ for k_ in o if (k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and o[k_]]:
-        raise NotImplementedError(k_ + ": geometry moves of the loop pair are not sampled")
+    geometry_keys = [k_ for k_ in o if (k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and o[k_]]
+    if geometry_keys and not time_domain:
+        raise NotImplementedError(geometry_keys[0] + ": frequency-domain data points have no loop pair to sample")
+    # (time-domain data: the loops' attitude angles are sampled on the device, gbp_td_moves; position moves raise in TdemDeviceChains)
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
     if o.get("ignore_likelihood"):
@@ -456,6 +458,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             "probability_of_death", "probability_of_perturb", "probability_of_no_change", "factor",
             "gradient_standard_deviation", "covariance_scaling", "parameter_limits", "update_plot_every", "reset_limit",
             "solve_z", "maximum_z_change", "z_proposal_variance")
+    if time_domain:
+        from .tdem_geometry import LOOP_PAIR_SCALARS
+        keys = keys + tuple(k_ for _, stem, _ in LOOP_PAIR_SCALARS for k_ in ("solve_" + stem, "maximum_" + stem + "_change", stem + "_proposal_variance"))
     # chains are keyed by the sounding's row in the data file, so a sounding inverted alone walks the chain it walks in the
     # full survey
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
@@ -494,6 +499,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                  ("best_conductivity", t["best_sigma"]), ("layer_count_posterior", f64(t["k_hist"])),
                  ("interface_posterior", f64(t["edge_hist"])), ("relative_error_posterior", f64(t["rel_hist"]).flatten(1)),
                  ("additive_error_posterior", f64(t["add_hist"]).flatten(1))]
+        if getattr(dc, "_moves", None):            # sampled attitude angles (the loops' own convention): final, highest-posterior, posterior
+            cur, best = dc.sampled_angles("geom"), dc.sampled_angles("best_geom")
+            for q, m_ in enumerate(dc._moves):
+                named += [(m_[0], col(cur[m_[0]])), ("best_" + m_[0], col(best[m_[0]])), (m_[0] + "_posterior", f64(t["geom_hist"][:, q, :m_[5]]))]
         if getattr(dc, "solve_height", False):     # the sampled height: final and highest-posterior values, posterior on the prior's 99 cells
             named += [("height", col(t["height"])), ("best_height", col(t["best_height"])), ("height_posterior", f64(t["height_hist"]))]
         if hitmap:
@@ -605,7 +614,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                        depth_bin_width=np.float64(dc.depth_bin_width))
     c0 = 0
     ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
-            "relative_error_posterior", "additive_error_posterior", "height_posterior")
+            "relative_error_posterior", "additive_error_posterior", "height_posterior") + tuple(
+        n_ + "_posterior" for n_ in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"))
     for name, v in named:
         w = v.shape[1]
         block = r[:, c0:c0 + w]

@@ -109,6 +109,25 @@ def loop_pair_moves(values, options):
             for name, stem, nb in LOOP_PAIR_SCALARS if options.get("solve_" + stem, False)]
 
 
+# The angle moves the DEVICE sampler takes (gbp_td_moves): name -> (entry of the GA-AEM tuple, sign of Loop_pair.Geometry)
+DEVICE_ANGLE_MOVES = {"tx_pitch": (2, -1.0), "tx_roll": (1, 1.0), "tx_yaw": (3, -1.0), "rx_pitch": (8, -1.0), "rx_roll": (7, 1.0), "rx_yaw": (9, -1.0)}
+
+
+def device_angle_moves(options):
+    """[(name, tuple entry, sign, maximum change, proposal scale, posterior cells)] in the reference's order for the options'
+    solve_transmitter_* / solve_receiver_* keys; position moves (x, y, z of either loop: new Hankel tables per proposal) raise."""
+    out = []
+    for name, stem, nb in LOOP_PAIR_SCALARS:
+        if not options.get("solve_" + stem, False):
+            continue
+        if name not in DEVICE_ANGLE_MOVES:
+            raise NotImplementedError("solve_" + stem + ": the device sampler samples the loops' attitude angles; a position move needs new "
+                                      "Hankel tables for every proposal (the host sampler, inference.Inference1D, takes it)")
+        e, sg = DEVICE_ANGLE_MOVES[name]
+        out.append((name, e, sg, float(options["maximum_" + stem + "_change"]), float(options[stem + "_proposal_variance"]), nb))
+    return out
+
+
 def basis_weights(geometry, loop_radius):
     """w[B, 3, 5]: field along the receiver's axis k (x, y, z) = sum_i w[b, k, i] * BASIS_i, before output sign and scaling.
     For a dipole transmitter (loop_radius = 0) B0L / B1L ARE B0 / B1 and take their weights (B0, B1 get 0); for a receiver on
@@ -148,7 +167,8 @@ class GeometryMix:
                    in: per system (basis integral, node); out: per system (component, node)
     All rows must be on the same side of the axis (rho = 0 uses other filters): ``on_axis`` says which."""
 
-    def __init__(self, systems, geometry):
+    def __init__(self, systems, geometry, force_basis=()):
+        """``force_basis``: basis integrals to keep in the layout although no row's weights need them now (sampled attitudes)."""
         g = np.ascontiguousarray(np.asarray(geometry, dtype=np.float64).reshape(-1, 10))
         assert np.all(np.isfinite(g)), ValueError("geometry must be finite")
         self.geometry, self.systems = g, list(systems)
@@ -172,9 +192,16 @@ class GeometryMix:
                 used |= np.any(blk != 0.0, axis=0)
                 blocks.append(blk)
         used[0] = True                                                      # (an empty batch still has a layout)
+        used[list(force_basis)] = True
         self.basis = [i for i in range(5) if used[i]]
         nb = len(self.basis)
         self.weights = np.ascontiguousarray(np.concatenate([blk[:, self.basis] for blk in blocks], axis=1)) if blocks else np.zeros((g.shape[0], 0))
+        # per (system, component) block: component index, output sign x scaling, factor of the free-space field, windows (gbp_td_moves)
+        self.block_comp = np.array([COMPONENTS.index(c_) for s in self.systems for c_ in s.components], dtype=np.int32)
+        self.block_scale = np.array([OUTPUT_SIGN[COMPONENTS.index(c_)] * s.scaling[c_] for s in self.systems for c_ in s.components])
+        self.block_primary = np.array([(1.0 if COMPONENTS.index(c_) < 2 else -1.0) * s.scaling[c_] * 4.0e-7 * np.pi * s.moment
+                                       for s in self.systems for c_ in s.components])
+        self.block_windows = np.array([s.nwindows for s in self.systems for _ in s.components], dtype=np.int32)
         # index maps
         n_nodes = [s.node_frequencies().size for s in self.systems]
         nF_in = sum(nb * n for n in n_nodes)

@@ -325,6 +325,9 @@ typedef struct gbp_rj_options {
      * chains->height_p and ->height0; chains->height is then STATE (written on acceptance).  Lock-step drivers only. */
     int32_t solve_height;
     double height_half_width, height_scale;
+    double extra_log_prior;      /* constant added to every proposal's log prior: the densities of the uniform priors of sampled
+                                    scalars that live outside gbp_rj_chains (gbp_td_moves); cancels in the acceptance ratio, keeps
+                                    the stored prior / posterior values those of the full model                              */
 } gbp_rj_options;
 
 typedef struct gbp_rj_chains {
@@ -379,6 +382,10 @@ typedef struct gbp_rj_chains {
     const double *height0;         /* [B]  centre of the uniform prior = the sounding's measured height                   */
     int32_t *height_hist;          /* [B, n_error_bins] or NULL  posterior of the height on the prior's cells (Point.set_z_posterior) */
     double *best_height;           /* [B] or NULL  height of the highest-posterior state                                  */
+    int32_t *step_flags;           /* [B] or NULL  what the accept stage did with the chain in the last iteration: bit 0 accepted,
+                                      bit 1 the highest-posterior state was replaced, bit 2 the posteriors were reset (burn-in),
+                                      bit 3 the post-step state was added to the posteriors; 0 for a frozen chain.  Read by the
+                                      stages that carry further per-chain state (gbp_td_moves)                             */
 } gbp_rj_chains;
 
 /* The three host-logic stages of one iteration, exposed separately for the tests ... */
@@ -426,6 +433,37 @@ typedef struct gbp_td_mix {
                                field of data whose channels hold primary + secondary (Tempest_datapoint.py:106-123);
                                honoured with or without mixing (n_in = 0)                                      */
 } gbp_td_mix;
+/* Sampled attitude angles of the loop pair (the reference's solve_transmitter_pitch / _roll / _yaw and solve_receiver_pitch / _roll /
+ * _yaw: Loop_pair.perturb system/Loop_pair.py:161-164, EmLoop.perturb / set_priors / set_proposals system/EmLoop.py:222-305 -- the
+ * receiver pitch is the nuisance parameter of Tempest inversions).  A rotation changes neither the Hankel tables (they depend on the
+ * horizontal distance and dz) nor the kernels' nodal spectra of the basis integrals, only the per-row real mixing weights (and the
+ * primary field of total-field data): every chain carries its GA-AEM tuple, a proposal stage draws the angles -- uniform prior
+ * centre +- half_width, random walk redrawn up to 10 times while outside, scale = the reference's proposal "variance" as is (see
+ * solve_height) -- and forms the proposal's weights / offset; evaluations at proposals use those; the accept stage's decision
+ * (chains->step_flags) moves them into the state.  Needs mix.n_in > 0 and chains->step_flags.  n_moves = 0: fixed geometry. */
+typedef struct gbp_td_moves {
+    int32_t n_moves;             /* 0 .. 6                                                                              */
+    int32_t entry[6];            /* entry of the GA-AEM tuple a move samples: 1..3 transmitter roll, pitch, yaw; 7..9 receiver   */
+    double sign[6];              /* tuple entry = sign * sampled value (Loop_pair.Geometry negates pitch and yaw)        */
+    double half_width[6];        /* maximum_<..>_change                                                                  */
+    double scale[6];             /* <..>_proposal_variance, used as the standard deviation like the reference does       */
+    int32_t n_bins[6];           /* cells of the posterior on the prior's support: 199 for a pitch, 99 otherwise (<= 199) */
+    double *geom, *geom_p;       /* [dev] f64[B, 10] GA-AEM tuples: current (state) and proposed (scratch)                */
+    const double *geom0;         /* [dev] f64[B, 10] the measured geometry: prior centres                                */
+    double *weights;             /* [dev] f64[B, mix.n_weights] = mix.weights, writable (state)                          */
+    double *weights_p;           /* [dev] f64[B, mix.n_weights] (scratch)                                                */
+    double *offset, *offset_p;   /* [dev] f64[B, n_channels] = mix.offset writable / its proposal; both NULL without total-field data */
+    int32_t *hist;               /* [dev] int32[B, n_moves, 199] or NULL: posteriors                                     */
+    double *best_geom;           /* [dev] f64[B, 10] or NULL: tuple of the highest-posterior state                       */
+    /* how weights and offset follow from a tuple (geobipy_amd/tdem_geometry.py GeometryMix): one block of n_basis weights per
+     * (system, output component) */
+    int32_t n_blocks, n_basis, loop, on_axis;
+    int32_t basis[5];            /* the basis integrals of the layout, indices into (B0L, B1L, B0, B1, BA)               */
+    const int32_t *block_comp;   /* [dev] int32[n_blocks]  0 x, 1 y, 2 z                                                  */
+    const double *block_scale;   /* [dev] f64[n_blocks]    output sign * output scaling                                   */
+    const double *block_primary; /* [dev] f64[n_blocks]    factor of the free-space field in output units (with offset)   */
+    const int32_t *block_windows;/* [dev] int32[n_blocks]  windows of the block (with offset)                             */
+} gbp_td_moves;
 typedef struct gbp_td_operator {
     int32_t n_nodal;        /* rows of W (= 2 * nF of `sys` without mixing)                                   */
     const double *W;        /* [dev] f64[n_nodal, n_channels], row-major                                      */
@@ -433,6 +471,7 @@ typedef struct gbp_td_operator {
     double *J_nodal;        /* [dev] scratch f64[B, max(n_nodal, mix.n_in), K]                                */
     gbp_td_mix mix;         /* geometry mixing, or n_in = 0                                                   */
     const int32_t *table_set;  /* [dev] int32[B] or NULL: table set of every chain (gbp_hankel_system_add_set)  */
+    gbp_td_moves moves;     /* sampled attitude angles, or n_moves = 0                                        */
 } gbp_td_operator;
 /* The time-domain stage on its own (what TdemDataPoint.forward / sensitivity add to the frequency-domain kernels): for every
  * sounding with nlayers[b] > 0,  pred[b, :] = nodal[b, :] @ W  and, when J_nodal / J are given,

@@ -157,6 +157,25 @@ def propose(o, seed, b, it, edges, sigma, rel, add, height=None, height0=None):
     return action, idx, val, e_r, s_r, rel_p, add_p
 
 
+def propose_angles(moves, seed, b, it, current, centre):
+    """k_td_moves_propose for one chain: moves = [(name, half_width, scale)], drawn in that order from stream 3; random walk redrawn
+    up to 10 times while outside the uniform prior centre +- half_width, then the current value is kept."""
+    r = Rng(seed, b, it, 3)
+    out = {}
+    for name, hw, sc in moves:
+        cur, lo, hi = current[name], centre[name] - hw, centre[name] + hw
+        x = cur + sc * r.normal()
+        tries = 0
+        while not (lo <= x <= hi):
+            x = cur + sc * r.normal()
+            tries += 1
+            if tries == 10:
+                x = cur
+                break
+        out[name] = x
+    return out
+
+
 def newton(o, seed, b, it, vp, edges_r, sigma_r, J, pred, data, rel, add, add_scale=1.0, groups=None):
     """k_rj_newton for one chain: (log_prop, C) with precision = C C'."""
     k = sigma_r.size
@@ -204,12 +223,16 @@ class Chain:
     posterior accumulators as one row of gbp_rj_chains."""
 
     def __init__(self, o, seed, b, engine, sp, vp, data, sigma0, rel, add, n_depth_bins, depth_bin_width, add_scale=1.0, groups=None,
-                 height=None):
+                 height=None, angle_moves=None, angles=None):
         self.o, self.seed, self.b, self.engine, self.sp, self.vp, self.data = o, seed, b, engine, sp, vp, data
         self.add_scale, self.groups = add_scale, groups
         self.edges, self.sigma, self.rel, self.add = np.zeros(0), np.array([sigma0]), rel, add
         self.height, self.height0 = height, height          # a sampled height (engine.forward / sensitivity then take z=)
         self.height_hist = np.zeros(99, dtype=int)
+        # sampled attitude angles of a time-domain loop pair (engine.forward / sensitivity then take geometry={name: value})
+        self.angle_moves = angle_moves or []
+        self.angles, self.angles0 = (dict(angles) if angles else None), (dict(angles) if angles else None)
+        self.angle_hist = {m[0]: np.zeros(199, dtype=int) for m in self.angle_moves}
         self.pred, self.J = self._fwd(self.edges, self.sigma, height), self._sen(self.edges, self.sigma, height)
         std = channel_std(data, rel, add, add_scale, groups)
         self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
@@ -217,17 +240,25 @@ class Chain:
                       + levels_log_prior(add, o["add_min"], o["add_max"]))
         if height is not None:
             self.prior -= math.log(2.0 * o["height_half_width"])
+        self.prior_const_angles = -sum(math.log(2.0 * m[1]) for m in self.angle_moves)
+        self.prior += self.prior_const_angles
         self.k_hist = np.zeros(o["K"] + 1, dtype=int)
         self.edge_hist = np.zeros(n_depth_bins, dtype=int)
         self.w = depth_bin_width
         self.n_accepted = 0
         self.trace = []
 
-    def _fwd(self, e, s, z):
-        return self.engine.forward(e, s) if z is None else self.engine.forward(e, s, z=z)
+    def _fwd(self, e, s, z, geometry=None):
+        kw = ({} if z is None else {"z": z})
+        if self.angle_moves:
+            kw["geometry"] = self.angles if geometry is None else geometry
+        return self.engine.forward(e, s, **kw)
 
-    def _sen(self, e, s, z):
-        return self.engine.sensitivity(e, s) if z is None else self.engine.sensitivity(e, s, z=z)
+    def _sen(self, e, s, z, geometry=None):
+        kw = ({} if z is None else {"z": z})
+        if self.angle_moves:
+            kw["geometry"] = self.angles if geometry is None else geometry
+        return self.engine.sensitivity(e, s, **kw)
 
     def step(self, it):
         o, d = self.o, self.data
@@ -237,18 +268,21 @@ class Chain:
         else:
             action, idx, val, e_r, s_r, rel_p, add_p, height_p = propose(o, self.seed, self.b, it, self.edges, self.sigma, self.rel, self.add,
                                                                          self.height, self.height0)
+        angles_p = propose_angles(self.angle_moves, self.seed, self.b, it, self.angles, self.angles0) if self.angle_moves else None
         if action != rjmcmc.NONE:
             pred_r, J_r = self._fwd(e_r, s_r, self.height), self._sen(e_r, s_r, self.height)
         else:
             pred_r, J_r = self.pred, self.J
         log_prop, C = newton(o, self.seed, self.b, it, self.vp, e_r, s_r, J_r, pred_r, d, self.rel, self.add, self.add_scale, self.groups)
         prop = np.exp(log_prop)
-        pred_p = self._fwd(e_r, prop, height_p)
+        pred_p = self._fwd(e_r, prop, height_p, angles_p)
         misfit_p, like_p = rjmcmc.gauss_loglike(pred_p, d, channel_std(d, rel_p, add_p, self.add_scale, self.groups))
-        J_p = self._sen(e_r, prop, height_p) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
+        J_p = self._sen(e_r, prop, height_p, angles_p) if action in (rjmcmc.INSERT, rjmcmc.DELETE) else None
         log_ratio, acc, prior_p = accept(o, self.seed, self.b, it, self.sp, self.vp, action, e_r, s_r, log_prop, C, J_p, pred_p, d,
                                          rel_p, add_p, like_p, self.prior, self.like, self.add_scale, self.groups,
-                                         0.0 if self.height is None else -math.log(2.0 * o["height_half_width"]))
+                                         (0.0 if self.height is None else -math.log(2.0 * o["height_half_width"])) + self.prior_const_angles)
+        if acc and self.angle_moves:
+            self.angles = angles_p
         if acc and self.height is not None:
             self.height = height_p
         if acc:
@@ -258,6 +292,11 @@ class Chain:
             self.n_accepted += 1
         self.trace.append((action, acc, self.sigma.size))
         self.k_hist[self.sigma.size] += 1
+        for name, hw, _ in self.angle_moves:
+            u = (self.angles[name] - (self.angles0[name] - hw)) / (2.0 * hw)
+            nb = 199 if name.endswith("pitch") else 99
+            if 0.0 <= u <= 1.0:
+                self.angle_hist[name][min(int(math.floor(u * nb)), nb - 1)] += 1
         if self.height is not None:
             u = (self.height - (self.height0 - o["height_half_width"])) / (2.0 * o["height_half_width"])
             if 0.0 <= u <= 1.0:

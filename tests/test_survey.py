@@ -434,6 +434,41 @@ def test_survey_with_the_height_move_recovers_a_wrong_altitude():
         survey.infer(os.path.join(GOLDEN, "skytem_options_small"), solve_z=True, maximum_z_change=1.0, z_proposal_variance=0.01)
 
 
+@pytest.mark.gpu
+def test_tempest_survey_recovers_a_wrong_receiver_pitch():
+    """``solve_receiver_pitch`` end to end on the device sampler (gbp_td_moves): Tempest soundings whose receiver was pitched by 1.5
+    degrees -- secondary AND primary field computed with that attitude -- while the file records level flight.  With the geometry
+    fixed the predicted primary field is off by ~ 35 fT x sin(1.5 deg) on channels known to ~ 0.04 fT and the chains cannot fit;
+    with the pitch sampled (prior +- 5 degrees) they find it.  Position moves of the loops are refused by the device sampler."""
+    from geobipy_amd.tdem import TdemBatch
+    o = survey.read_options(os.path.join(GOLDEN, "tempest_options_small"))
+    ds = survey.TempestData.read_csv(o["data_filename"], o["system_filename"]).subset(np.arange(0, 79, 5))
+    S = ds.nPoints
+    rng = np.random.default_rng(3)
+    nl = np.full(S, 2, dtype=np.int32)
+    sig = np.tile([0.05, 0.005, 1.0], (S, 1))
+    thk = np.c_[rng.uniform(40.0, 80.0, S), np.zeros(S), np.zeros(S)]
+    ds.loop_angles[:, 3] = 1.5                                              # the truth (the loops' own convention)
+    tb = TdemBatch(ds.system, nl, sig, thk, ds.z, ds.offsets, attitude=ds.attitude)
+    sec, prim = tb.forward().cpu().numpy(), tb.primary_field()
+    tot = sec + np.repeat(prim, sec.shape[1] // prim.shape[1], axis=1)
+    noise = rng.normal(size=sec.shape) * np.sqrt((0.001 * tot) ** 2 + np.asarray(o["initial_additive_error"]) ** 2)
+    ds.data[:] = sec + noise
+    ds.primary_field[:] = prim
+    ds.loop_angles[:, 3] = 0.0                                              # what the file says
+    kw = dict(data=ds, burn_in_min_iterations=1500, check_every=500, n_markov_chains=2500)
+    fixed = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), **kw)
+    moved = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0,
+                         receiver_pitch_proposal_variance=0.2, **kw)
+    assert "rx_pitch" not in fixed and moved["rx_pitch_posterior"].shape == (S, 199)
+    print("receiver pitch: final", np.round(moved["rx_pitch"], 3), "median misfit fixed / moved", np.median(fixed["misfit"]), np.median(moved["misfit"]),
+          "done", int((moved["status"] == 1).sum()), "of", S)
+    assert np.mean(np.abs(moved["rx_pitch"] - 1.5) < 0.25) >= 0.8 and np.all(np.abs(moved["best_rx_pitch"]) <= 5.0)
+    assert np.median(moved["misfit"]) < 0.05 * np.median(fixed["misfit"])
+    with pytest.raises(NotImplementedError, match="position move"):
+        survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_x=True, maximum_receiver_x_change=5.0, receiver_x_proposal_variance=0.01, **kw)
+
+
 def test_survey_result_round_trip(tmp_path):
     """save / load and save_lines / load_lines of a SurveyResult (no GPU needed)."""
     rng = np.random.default_rng(0)

@@ -174,6 +174,111 @@ def test_tempest_two_components_one_system():
     assert acc.sum() > 10
 
 
+@pytest.mark.parametrize("case", ["skytem_tx_rx", "tempest_total_field"])
+def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
+    """gbp_td_moves -- the reference's solve_transmitter_pitch / solve_receiver_pitch / _roll (pinned to the reference on the host:
+    test_tdem_object_api.py::test_host_sampler_walks_the_reference_chain_with_loop_pair_moves): CPU chains with the same
+    counter-based streams, every evaluation a TdemBatch of the request's geometry (current angles for the remapped model, proposed
+    angles for the proposal; Tempest: + the free-space primary field of that geometry), walk the same chains as the device, whose
+    kernels never see a new table -- a rotation only changes the per-chain mixing weights (and primary-field offset) that
+    k_td_moves_propose forms: decisions, layer counts, angles to 1e-9 degrees, angle posteriors, highest-posterior angles."""
+    from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
+    from geobipy_amd.tdem_geometry import gaaem_tuple
+    if case == "skytem_tx_rx":
+        off, stm, alt, n_it = OFFSET, ("SkytemLM.stm",), (30.0, 40.0), 200
+        mv = dict(solve_transmitter_pitch=True, maximum_transmitter_pitch_change=4.0, transmitter_pitch_proposal_variance=0.4,
+                  solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.5)
+        moves = [("tx_pitch", 4.0, 0.4), ("rx_pitch", 5.0, 0.5)]
+        att0 = (1.0, 2.0, 0.0, -1.5, 1.0, 0.5)           # GA-AEM convention: tx roll, pitch, yaw, rx roll, pitch, yaw
+    else:
+        off, stm, alt, n_it = (-107.0, 0.0, -45.0), ("tempest.stm",), (115.0, 125.0), 150
+        mv = dict(solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.3,
+                  solve_receiver_roll=True, maximum_receiver_roll_change=3.0, receiver_roll_proposal_variance=0.2)
+        moves = [("rx_pitch", 5.0, 0.3), ("rx_roll", 3.0, 0.2)]
+        att0 = (0.0, 0.0, 0.0, 0.5, -1.0, 0.0)
+    B = 3
+    s, h, data, scale, opts, groups = _survey(B, seed=11, stm=stm, offset=off, alt=alt)
+    systems = s if isinstance(s, list) else [s]
+    base = dict(dx=off[0], dy=off[1], dz=off[2], tx_x=0.0, tx_y=0.0, tx_z=0.0, tx_roll=att0[0], tx_pitch=-att0[1], tx_yaw=-att0[2],
+                rx_roll=att0[3], rx_pitch=-att0[4], rx_yaw=-att0[5])          # the loops' own convention (Loop_pair.Geometry negates)
+    kw = {}
+    if case == "tempest_total_field":
+        opts = dict(opts, initial_relative_error=[0.05, 0.05], minimum_relative_error=[0.005, 0.005], maximum_relative_error=[0.5, 0.5],
+                    relative_error_proposal_variance=[1e-6, 1e-6], initial_additive_error=[1.0, 1.0], minimum_additive_error=[0.1, 0.1],
+                    maximum_additive_error=[10.0, 10.0], additive_error_proposal_variance=[1e-6, 1e-6])
+        chan_add = np.full(data.shape[1], 0.02 * np.abs(data).min())
+        pf = TdemBatch(systems, np.ones(B, dtype=np.int32), np.ones((B, 2)), np.zeros((B, 2)), h, off, attitude=att0).primary_field()
+        data = data + np.repeat(pf, [systems[0].nwindows] * systems[0].n_components, axis=1)      # total field
+        data = np.abs(data)
+        kw = dict(channel_additive=chan_add, primary_field=pf)
+        groups = (groups[0], groups[0])
+        scale = chan_add
+    dc = TdemDeviceChains(systems, h, data, off, attitude=att0, seed=41, **dict(opts, **mv), **kw)
+    assert [m_[0] for m_ in dc._moves] == [m_[0] for m_ in moves]
+
+    class Engine:
+        def __init__(self, z):
+            self.z = z
+
+        def _batch(self, e, v, geometry):
+            K = 20
+            sg, th = np.ones((1, K)), np.zeros((1, K))
+            sg[0, : v.size], th[0, : v.size - 1] = v, np.diff(np.r_[0.0, e])
+            g = gaaem_tuple(dict(base, tx_z=self.z, **geometry))
+            return TdemBatch(systems, np.array([v.size]), sg, th, np.array([self.z]), off, attitude=tuple(np.r_[g[1:4], g[7:10]]))
+
+        def forward(self, e, v, geometry):
+            b_ = self._batch(e, v, geometry)
+            p_ = b_.forward().cpu().numpy()[0].copy()
+            if case == "tempest_total_field":
+                p_ = p_ + np.repeat(b_.primary_field()[0], [systems[0].nwindows] * systems[0].n_components)
+            return p_
+
+        def sensitivity(self, e, v, geometry):
+            return self._batch(e, v, geometry).sensitivity().cpu().numpy()[0][:, : v.size].copy()
+
+    o = dc._o
+    Gr, Ga = dc.n_rel_groups, dc.n_add_groups
+    eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
+              rel_sd=np.array(o.rel_sd[:Gr]), rel_min=np.array(o.rel_min[:Gr]), rel_max=np.array(o.rel_max[:Gr]),
+              add_sd=np.array(o.add_sd[:Ga]), add_min=np.array(o.add_min[:Ga]), add_max=np.array(o.add_max[:Ga]), alpha=o.alpha)
+    sig0 = dc.sigma[:, 0].cpu().numpy()
+    chains = []
+    for b in range(B):
+        sp = rjmcmc.StructurePrior(dc.K, opts["minimum_depth"], opts["maximum_depth"], opts["minimum_thickness"], eo["p"])
+        vp = rjmcmc.ValuePrior(sig0[b], 10.0, 1.5, True)
+        rel0 = np.broadcast_to(np.atleast_1d(opts["initial_relative_error"]), (Gr,)).astype(float)
+        add0 = np.broadcast_to(np.atleast_1d(np.asarray(opts["initial_additive_error"], dtype=float)), (Ga,)).astype(float) if case != "tempest_total_field" else np.ones(Ga)
+        chains.append(rj_emul.Chain(eo, 41, b, Engine(h[b]), sp, vp, data[b], sig0[b], rel0, add0, dc.n_depth_bins, dc.depth_bin_width,
+                                    add_scale=scale, groups=groups, angle_moves=moves, angles={m_[0]: base[m_[0]] for m_ in moves}))
+        assert np.isclose(chains[b].misfit, float(dc.misfit[b]), rtol=1e-8) and np.isclose(chains[b].prior, float(dc.prior[b]), rtol=1e-12)
+    accs, ks = [], []
+    prev = dc.n_accepted.cpu().numpy().copy()
+    for it in range(n_it):
+        dc.step()
+        now = dc.n_accepted.cpu().numpy()
+        accs.append(now - prev); ks.append(dc.k.cpu().numpy().copy())
+        prev = now.copy()
+        ang = {n_: v_.cpu().numpy() for n_, v_ in dc.sampled_angles().items()}
+        for c in chains:
+            c.step(it)
+            for n_ in ang:
+                assert abs(c.angles[n_] - ang[n_][c.b]) < 1e-9, (it, c.b, n_)
+    accs, ks = np.array(accs), np.array(ks)
+    hist = dc.t["geom_hist"].cpu().numpy()
+    for b, c in enumerate(chains):
+        tr = np.array(c.trace)
+        assert np.array_equal(tr[:, 1], accs[:, b]) and np.array_equal(tr[:, 2], ks[:, b]), b
+        assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-5)
+        for q, (n_, _, _) in enumerate(moves):
+            assert np.array_equal(c.angle_hist[n_], hist[b, q]) and hist[b, q].sum() == n_it, (b, n_)
+    moved = np.array([[abs(c.angles[m_[0]] - base[m_[0]]) for m_ in moves] for c in chains])
+    assert accs.sum() > 0.1 * accs.size and moved.max() > 0.5
+    best = dc.sampled_angles("best_geom")
+    for m_ in moves:
+        assert torch.all(torch.abs(best[m_[0]] - base[m_[0]]) <= m_[1] + 1e-12)
+
+
 @pytest.mark.parametrize("stm", [("SkytemLM.stm",), ("SkytemHM.stm", "SkytemLM.stm")])
 def test_tdem_chains_fit_synthetic_soundings_and_stay_coherent(stm):
     from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
