@@ -326,7 +326,7 @@ typedef struct gbp_rj_options {
     int32_t solve_height;
     double height_half_width, height_scale;
     double extra_log_prior;      /* constant added to every proposal's log prior: the densities of the uniform priors of sampled
-                                    scalars that live outside gbp_rj_chains (gbp_td_moves); cancels in the acceptance ratio, keeps
+                                    scalars that live outside the chains struct, in gbp_td_moves; cancels in the acceptance ratio, keeps
                                     the stored prior / posterior values those of the full model                              */
 } gbp_rj_options;
 
