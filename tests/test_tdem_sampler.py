@@ -279,6 +279,34 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
         assert torch.all(torch.abs(best[m_[0]] - base[m_[0]]) <= m_[1] + 1e-12)
 
 
+def test_sampled_angles_survive_the_repacking_of_a_block():
+    """infer() re-packs the block when chains finish (and restarts stuck ones): the per-chain tuples, weights, proposals and
+    posteriors of gbp_td_moves travel with the rows -- the same chains, row for row, as a run that never re-packs."""
+    from geobipy_amd.tdem import TdemDeviceChains
+    B = 24
+    s, h, data, scale, opts, groups = _survey(B, seed=5)
+    mv = dict(solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.4,
+              solve_receiver_roll=True, maximum_receiver_roll_change=3.0, receiver_roll_proposal_variance=0.3)
+    runs = []
+    for compact in (0.0, 0.95):
+        dc = TdemDeviceChains(s, h, data, OFFSET, seed=9, reference_schedule=True,
+                              burn_in_min_iterations=250, **dict(opts, n_markov_chains=500, **mv))
+        sizes = []
+        run0 = dc.run
+        dc.run = lambda n, accumulate=True, dc=dc, run0=run0, sizes=sizes: (sizes.append(dc._c.B), run0(n, accumulate))[1]
+        dc.infer(check_every=40, compact_below=compact, min_rows=2)
+        runs.append((dc, sizes))
+    (a, sa), (b, sb) = runs
+    assert min(sa) == B and min(sb) < B                         # (the second run really re-packed)
+    assert (a.status == 1).sum() >= 3 and (a.status == 2).sum() >= 3          # (both ways out of the schedule occur)
+    for n in ("k", "sigma", "edges", "status", "burned_in_iteration", "n_accepted", "misfit", "geom", "best_geom", "geom_hist", "mix_w", "k_hist"):
+        assert torch.equal(a.t[n], b.t[n]), n
+    done = a.status == 1
+    assert torch.all(a.t["geom_hist"][done].sum(dim=2) == 502)
+    ang = a.sampled_angles()
+    assert float(ang["rx_pitch"].abs().max()) > 0.3 and float(ang["rx_pitch"].abs().max()) <= 5.0
+
+
 @pytest.mark.parametrize("stm", [("SkytemLM.stm",), ("SkytemHM.stm", "SkytemLM.stm")])
 def test_tdem_chains_fit_synthetic_soundings_and_stay_coherent(stm):
     from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
