@@ -12,10 +12,10 @@ from .system import CircularLoop, FdemSystem
 from .model import Model, RectilinearMesh1D
 from .datapoint import FdemDataPoint
 from .batch import FdemBatch
-from .tdem import TdemBatch, TdemDataPoint, TdemDeviceChains, TdemSystem
+from .tdem import TdemBatch, TdemDataPoint, TdemDeviceChains, TdemSystem, TempestDataPoint
 from .inference import BatchedInference, Inference1D
 from .rjmcmc_gpu import DeviceChains
 from . import rjmcmc, survey, synthetic
 
-__all__ = ["CircularLoop", "FdemSystem", "Model", "RectilinearMesh1D", "FdemDataPoint", "FdemBatch", "TdemSystem", "TdemDataPoint", "TdemBatch", "TdemDeviceChains",
+__all__ = ["CircularLoop", "FdemSystem", "Model", "RectilinearMesh1D", "FdemDataPoint", "FdemBatch", "TdemSystem", "TdemDataPoint", "TempestDataPoint", "TdemBatch", "TdemDeviceChains",
            "Inference1D", "BatchedInference", "DeviceChains", "rjmcmc", "survey", "synthetic"]

@@ -96,7 +96,9 @@ def initial_state(engine, data, o, error_model=None, z_move=None, geom_moves=Non
     sp, vp, rp, ap = _priors_from_options(o, sigma.item())
     pred, J = engine.forward(none, sigma), engine.sensitivity(none, sigma)
     misfit, like = rjmcmc.gauss_loglike(pred, data, std)
-    prior = rjmcmc.model_log_prior(sp, vp, none, sigma) + rp.log_prior(rel) + ap.log_prior(add)
+    prior = rjmcmc.model_log_prior(sp, vp, none, sigma) + rp.log_prior(rel)
+    if not (error_model is not None and error_model.tempest):           # (Tempest's multipliers: no prior term, rjmcmc.ErrorModel)
+        prior += ap.log_prior(add)
     if z_move is not None:
         prior += z_move.log_prior(z_move.z0)
     geom = None

@@ -160,14 +160,19 @@ class ErrorPrior:
             return -np.sum(np.log(self.hi - self.lo)) if np.all((self.lo <= lx) & (lx <= self.hi)) else -np.inf
         return -np.log(self.hi - self.lo) if (self.lo <= lx <= self.hi) else -np.inf
 
-    def propose(self, prng, current):
+    def propose(self, prng, current, redraw=True, centre=None):
         """StatArray.propose with imposePrior=True, log=True (statistics/StatArray.py:578-638).  The reference draws
         with Generator.multivariate_normal on a 1 x 1 covariance, which numpy evaluates as
-        mean + standard_normal() * sqrt(var) (SVD of a positive 1 x 1 matrix: s = var, vh = 1)."""
+        mean + standard_normal() * sqrt(var) (SVD of a positive 1 x 1 matrix: s = var, vh = 1).
+        ``redraw=False``: a single draw whatever the prior says (StatArray.perturb() without imposePrior -- the additive-error
+        multiplier of Tempest_datapoint.perturb :339-341); ``centre``: the proposal's mean when it is not the current value."""
         if np.ndim(current) > 0:                 # several levels: the reference's own call, one joint draw per try
             cur = np.asarray(current, dtype=np.float64)
-            draw_n = lambda: np.exp(prng.multivariate_normal(np.log(cur), np.diag(np.broadcast_to(self.var, cur.shape)), size=1)[0])
+            mean = cur if centre is None else np.asarray(centre, dtype=np.float64)
+            draw_n = lambda: np.exp(prng.multivariate_normal(np.log(mean), np.diag(np.broadcast_to(self.var, cur.shape)), size=1)[0])
             x = draw_n()
+            if not redraw:
+                return x
             tries = 0
             while self.log_prior(x) == -np.inf:
                 x = draw_n()
@@ -268,11 +273,20 @@ class ErrorModel:
     relative and one additive level) or, with channel -> level maps, TdemDataPoint.std (TdemDataPoint.py:361-365:
     sigma_i^2 = (rel_{system, component} d_i)^2 + (add_system sqrt(1e-3 / t_i))^2)."""
 
-    def __init__(self, rel_group=None, add_group=None, add_scale=None, stale_prediction=False):
+    def __init__(self, rel_group=None, add_group=None, add_scale=None, stale_prediction=False, tempest=False, add_centre=None):
         # stale_prediction: the reference's TdemDataPoint.fm_dlogc (TdemDataPoint.py:1031-1055) stores the Jacobian of the
         # remapped model but NOT its prediction (the assignment is commented out there), so the stochastic-Newton gradient of a
         # time-domain chain is formed with the prediction of the CURRENT model (Model.py:383-399) -- reproduced on request
         self.stale_prediction = bool(stale_prediction)
+        # tempest: the additive levels are Tempest_datapoint's MULTIPLIERS of per-channel additive errors (``add_scale``), which
+        # the reference treats unlike every other level (data/datapoint/Tempest_datapoint.py:339-341, 475-487): proposed last --
+        # after the loop pair --, with a single draw (no redraw against the prior), and their prior never enters
+        # Tempest_datapoint.probability (set_priors hands DataPoint.set_priors solve_additive_error = False); and their proposal
+        # stays centred on the values it was created with (``add_centre``): Tempest_datapoint.perturb does not move the proposal's
+        # mean to the new state as DataPoint.perturb does for the other levels -- an independence sampler around the initial
+        # multipliers, not a random walk.  All four reproduced (tests/golden/mcmc_trace_tempest.npz)
+        self.tempest = bool(tempest)
+        self.add_centre = None if add_centre is None else np.asarray(add_centre, dtype=np.float64).copy()
         self.rel_group = None if rel_group is None else np.asarray(rel_group, dtype=np.int64)
         self.add_group = None if add_group is None else np.asarray(add_group, dtype=np.int64)
         self.add_scale = None if add_scale is None else np.asarray(add_scale, dtype=np.float64)
@@ -343,14 +357,16 @@ def accept_reject_phases(prng, state, data, sp, vp, rel_prior, add_prior, alpha=
     prop = propose_values(prng, mean, H)
     z = state.z if z_move is None else z_move.propose(prng, state.z)     # Point.perturb first (DataPoint.perturb :561) ...
     rel = rel_prior.propose(prng, state.rel)                    # ... then the error levels, DataPoint.py:531-573
-    add = add_prior.propose(prng, state.add)
+    add = state.add if em.tempest else add_prior.propose(prng, state.add)
     geom = state.geom
     if geom_moves:                                              # Loop_pair.perturb (system/Loop_pair.py:161-164), after the error levels
         geom = {m.name: m.propose(prng, state.geom[m.name]) for m in geom_moves}
+    if em.tempest:                                              # Tempest_datapoint.perturb :339-341: the multipliers, last, one draw
+        add = add_prior.propose(prng, state.add, redraw=False, centre=em.add_centre)
     pred, _ = yield ask(1, edges, prop, z, geom)
     std_t = em.std(data, rel, add)
     misfit, like = gauss_loglike(pred, data, std_t)
-    prior = rel_prior.log_prior(rel) + add_prior.log_prior(add)
+    prior = rel_prior.log_prior(rel) + (0.0 if em.tempest else add_prior.log_prior(add))
     if z_move is not None:
         prior += z_move.log_prior(z)                            # Point.probability, pointcloud/Point.py:159-197
     if geom_moves:

@@ -842,9 +842,10 @@ class TdemEngine:
     (inference.Inference1D, rjmcmc.accept_reject) asks of a data point -- on persistent TdemBatch objects (tables, windows and
     mixing weights are built once; a call refills the model tensors and launches)."""
 
-    def __init__(self, systems, height, offset, attitude=None, lmax=32, hankel_eps=None, loop_pair=None):
+    def __init__(self, systems, height, offset, attitude=None, lmax=32, hankel_eps=None, loop_pair=None, total_field=False):
         self.systems, self.height, self.offset, self.attitude = list(systems), float(height), tuple(offset), attitude
         self.lmax, self.hankel_eps = int(lmax), hankel_eps
+        self.total_field = bool(total_field)      # Tempest: predictions = secondary + the free-space primary field of the geometry
         self._b = {}
         self.loop_pair = None if loop_pair is None else dict(loop_pair)      # tdem_geometry.loop_pair_values: base of geometry moves
 
@@ -877,7 +878,11 @@ class TdemEngine:
         return b, nl
 
     def forward_many(self, models, geometry=None):
-        return self._batch(models, geometry)[0].forward().cpu().numpy()
+        b = self._batch(models, geometry)[0]
+        out = b.forward().cpu().numpy()
+        if self.total_field:
+            out = out + np.repeat(b.primary_field(), [s_.nwindows for s_ in self.systems for _ in range(s_.n_components)], axis=1)
+        return out
 
     def forward(self, edges, values, geometry=None):
         return self.forward_many([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))], geometry)[0]
@@ -1164,3 +1169,108 @@ class TdemDataPoint:
         if self._add_prior is not None:
             p += self._add_prior.log_prior(self._additive_error)
         return p
+
+
+class TempestDataPoint(TdemDataPoint):
+    """The reference's ``Tempest_datapoint`` (data/datapoint/Tempest_datapoint.py) at the object level: the channels hold the TOTAL
+    field -- ``data = secondary_field + primary_field[component]`` (:106-113), ``predictedData = predicted secondary + predicted
+    primary`` of the loop pair's geometry (:119-124) --, the additive error is a per-channel array times a sampled MULTIPLIER per
+    component (:161-176), the relative error multiplies the total field.  The multipliers are the levels ``additive_error`` of this
+    class's sampler interface (error_model(): rjmcmc.ErrorModel(tempest=True) carries the reference's three quirks about them:
+    proposed last, one draw without redraw, no prior term in ``probability``)."""
+
+    kind = "tempest"
+
+    def __init__(self, *args, secondary_field=None, primary_field=None, channel_additive_error=None, additive_error_multiplier=None, **kw):
+        super().__init__(*args, data=secondary_field, **kw)
+        nc = self.n_error_groups
+        self.primary_field = np.zeros(nc) if primary_field is None else np.asarray(primary_field, dtype=np.float64).copy()
+        self.channel_additive_error = (np.ones(self.nChannels) if channel_additive_error is None
+                                       else np.broadcast_to(np.asarray(channel_additive_error, dtype=np.float64), (self.nChannels,)).copy())
+        self._additive_error = np.ones(nc) if additive_error_multiplier is None else np.asarray(additive_error_multiplier, dtype=np.float64).copy()
+        self._multiplier0 = self._additive_error.copy()       # where the multipliers' proposal stays centred (set_proposals re-centres it)
+        self._windows_per_group = [s_.nwindows for s_ in self.system for _ in range(s_.n_components)]
+
+    @property
+    def secondary_field(self):
+        return self._data
+
+    @property
+    def data(self):                                           # Tempest_datapoint.data :106-113
+        return self._data + np.repeat(self.primary_field, self._windows_per_group)
+
+    @property
+    def additive_error_multiplier(self):
+        return self._additive_error
+
+    @property
+    def additive_error(self):
+        return self._additive_error
+
+    @additive_error.setter
+    def additive_error(self, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        assert v.size == self.n_error_groups and np.all(v > 0.0), ValueError("one positive additive-error multiplier per (system, component)")
+        self._additive_error = v.copy()
+
+    @property
+    def predicted_primary_field(self):
+        """Free-space field of the transmitter dipole along the receiver's axes for the loops' current geometry, per component."""
+        g = gaaem_tuple(loop_pair_values(self.transmitter, self.receiver))
+        return GeometryMix(self.system, g[None, :]).primary_field()[0]
+
+    @property
+    def std(self):                                            # Tempest_datapoint.std :161-176
+        return self.error_model().std(self.data, self._relative_error, self._additive_error)
+
+    def make_engine(self, lmax=32, hankel_eps=None):
+        return TdemEngine(self.system, self.z[0], self.offset, self.attitude, lmax=lmax, hankel_eps=hankel_eps,
+                          loop_pair=loop_pair_values(self.transmitter, self.receiver), total_field=True)
+
+    def error_model(self, reference_fm_dlogc=True):
+        from . import rjmcmc
+        grp = np.repeat(np.arange(self.n_error_groups), self._windows_per_group)
+        return rjmcmc.ErrorModel(grp, grp, self.channel_additive_error, stale_prediction=reference_fm_dlogc, tempest=True,
+                                 add_centre=self._multiplier0)
+
+    def set_priors(self, relative_error_prior=None, additive_error_prior=None, data_prior=None, **kwargs):
+        """Tempest_datapoint.set_priors (:478-487): the options' additive-error bounds become the MULTIPLIERS' prior (which
+        Tempest_datapoint.probability never evaluates); everything else as TdemDataPoint."""
+        from . import rjmcmc
+        if additive_error_prior is None and kwargs.get("solve_additive_error", False):
+            additive_error_prior = (kwargs["minimum_additive_error"], kwargs["maximum_additive_error"])
+        super().set_priors(relative_error_prior, None, data_prior, **dict(kwargs, solve_additive_error=False))
+        if additive_error_prior is not None:
+            vec = lambda v_: np.broadcast_to(np.asarray(v_, dtype=np.float64), (self.n_error_groups,)).copy()
+            self._add_prior = rjmcmc.ErrorPrior(vec(additive_error_prior[0]), vec(additive_error_prior[1]),
+                                                self._add_prior.var if self._add_prior is not None else 0.0)
+
+    def set_proposals(self, relative_error_proposal=None, additive_error_proposal=None, **kwargs):
+        super().set_proposals(relative_error_proposal, None, **dict(kwargs, solve_additive_error=False))
+        if additive_error_proposal is None and kwargs.get("solve_additive_error", False):
+            additive_error_proposal = kwargs["additive_error_proposal_variance"]
+        if additive_error_proposal is not None:
+            assert self._add_prior is not None, ValueError("set_priors must come before set_proposals")
+            self._add_prior.var = np.broadcast_to(np.asarray(additive_error_proposal, dtype=np.float64), (self.n_error_groups,)).copy()
+            self._multiplier0 = self._additive_error.copy()   # (set_additive_error_proposal :503-508 centres it on the current multipliers)
+
+    def perturb(self):
+        """Tempest_datapoint.perturb (:339-341): TdemDataPoint.perturb (relative levels, loop pair), then the multipliers -- one
+        joint draw, no redraw against their prior, from a proposal that stays where set_proposals put it."""
+        add_prior, self._add_prior = self._add_prior, None
+        try:
+            super().perturb()
+        finally:
+            self._add_prior = add_prior
+        if add_prior is not None and np.any(np.asarray(add_prior.var) > 0.0):
+            self._additive_error = np.atleast_1d(add_prior.propose(self._prng, self._additive_error, redraw=False, centre=self._multiplier0))
+
+    @property
+    def probability(self):
+        """Tempest_datapoint.probability (:475-476) = TdemDataPoint.probability with no additive-error prior set: the relative
+        levels' (and the loop pair's) priors only."""
+        add_prior, self._add_prior = self._add_prior, None
+        try:
+            return TdemDataPoint.probability.fget(self)
+        finally:
+            self._add_prior = add_prior

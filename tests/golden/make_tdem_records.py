@@ -10,6 +10,10 @@ pins the reference's host logic around the forward operator, never GA-AEM's numb
                          TdemDataPoint.createHdf / writeHdf (data/datapoint/TdemDataPoint.py:603-645) and
                          Tempest_datapoint.createHdf (Tempest_datapoint.py:566-586) -- recorded with the in-memory h5py stand-in of
                          make_hdf_schema.py: groups, datasets, shapes, dtypes, fill values, attributes, small values;
+  mcmc_trace_tempest.npz the same for tempest_glacial.csv row 30 with tempest_options (200 iterations): decision, layer count, misfit, the
+                         two relative levels, the two additive-error MULTIPLIERS (Tempest_datapoint.py:94-104, 339-341), prior and
+                         likelihood, with the total-field model's inputs (secondary / primary / predicted primary field, per-channel
+                         additive errors) -- what a host twin of Tempest_datapoint has to reproduce;
   mcmc_trace_tdem.npz    a seeded run of the reference's sampler on skytem_glacial.csv row 30 with skytem_options: per iteration the
                          decision, layer count, misfit and the two sets of error levels (proposed JOINTLY, DataPoint.perturb
                          :531-573), the starting half-space, and the inputs (data, geometry) -- what geobipy_amd's host
@@ -66,14 +70,26 @@ def run(kind, n_it, trace):
     d = inf.datapoint
     rec = dict(halfspace=float(inf.model.values[0]), data=np.asarray(d.data, dtype=np.float64).copy(), z=float(d.z[0]),
                misfit0=float(inf.data_misfit), prior0=float(inf.prior), like0=float(inf.likelihood))
+    if kind == "tempest":            # the total-field model's inputs (Tempest_datapoint.py:106-176) and the generator state
+        st = inf.prng.bit_generator.state
+        sv, inc, m64 = st["state"]["state"], st["state"]["inc"], (1 << 64) - 1
+        rec.update(rng_state=np.array([sv >> 64, sv & m64, inc >> 64, inc & m64, st["has_uint32"], st["uinteger"]], dtype=np.uint64),
+                   secondary_field=np.asarray(d.secondary_field, dtype=np.float64).copy(), primary_field=np.asarray(d.primary_field, dtype=np.float64).copy(),
+                   predicted_primary_field=np.asarray(d.predicted_primary_field, dtype=np.float64).copy(),
+                   additive_error=np.asarray(d.additive_error, dtype=np.float64).copy(),
+                   multiplier0=np.asarray(d.additive_error_multiplier, dtype=np.float64).copy(),
+                   relative_error0=np.asarray(d.relative_error, dtype=np.float64).copy(),
+                   offset=np.array([float(np.squeeze(d.loop_pair.x)), float(np.squeeze(d.loop_pair.y)), float(np.squeeze(d.loop_pair.z))]),
+                   tx_z=float(np.squeeze(d.transmitter.z)))
     rows = []
     for _ in range(n_it):
         inf.accept_reject()
         inf.update()
         if trace:
             d = inf.datapoint
+            lev = np.asarray(d.additive_error_multiplier, dtype=np.float64) if kind == "tempest" else np.asarray(d.additive_error, dtype=np.float64)
             rows.append(np.r_[float(bool(inf.accepted)), float(inf.model.nCells.item()), float(inf.data_misfit),
-                              np.asarray(d.relative_error, dtype=np.float64), np.asarray(d.additive_error, dtype=np.float64)])
+                              np.asarray(d.relative_error, dtype=np.float64), lev, float(inf.prior), float(inf.likelihood)])
     inf.writeHdf(root, index=1)
     tree = {}
     root.walk(tree)
@@ -93,12 +109,15 @@ def main():
     import h5py
     h5py.Group, h5py.File, h5py.Dataset = Group, Group, Dataset
     out = {}
-    for kind, n_it, trace in (("skytem", N_TRACE, True), ("tempest", 60, False)):
+    # (the container trees come from the 300- / 60-iteration runs; the Tempest trace from a run of its own, 200 iterations)
+    for kind, n_it, trace, schema in (("skytem", N_TRACE, True, True), ("tempest", 60, False, True), ("tempest", 200, True, False)):
         meta, tree, rec, rows = run(kind, n_it, trace)
-        out[kind] = {"meta": meta, "tree": tree}
+        if schema:
+            out[kind] = {"meta": meta, "tree": tree}
         print(kind, len(tree), "entries;", sum(1 for v in tree.values() if v["kind"] == "dataset"), "datasets; k =", meta["k"])
         if trace:
-            np.savez_compressed(HERE + "/mcmc_trace_tdem.npz", rows=rows, **{k: np.asarray(v) for k, v in rec.items()})
+            np.savez_compressed(HERE + ("/mcmc_trace_tdem.npz" if kind == "skytem" else "/mcmc_trace_tempest.npz"), rows=rows,
+                                **{k: np.asarray(v) for k, v in rec.items()})
             print("trace", rows.shape, "accepted", int(rows[:, 0].sum()), "final k", rows[-1, 1], "misfit", rows[-1, 2])
     json.dump(out, open(HERE + "/hdf_schema_tdem.json", "w"), indent=0, sort_keys=True)
 

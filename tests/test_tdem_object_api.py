@@ -284,3 +284,61 @@ def test_loop_pair_moves_on_the_gpu_engine():
         assert bool(ref[0]) == bool(inf.accepted) and int(ref[1]) == inf.state.k, it
         assert abs(inf.data_misfit - ref[2]) <= 1e-5 * abs(ref[2]), (it, inf.data_misfit, ref[2])
         assert np.allclose([inf.state.geom[n] for n in ("tx_pitch", "rx_pitch", "rx_roll")], ref[7:10], rtol=0.0, atol=1e-9), it
+
+
+class OracleTempestEngine(OracleTdEngine):
+    """Total-field predictions: the oracle's secondary field + its free-space primary field of the same geometry."""
+
+    def forward(self, edges, values, geometry=None):
+        g = self._g(geometry)
+        sec = OracleTdEngine.forward(self, edges, values, geometry)
+        prim = np.concatenate([np.repeat(self.to.primary_field(s, g), int(s["windows"].shape[0])) for s in self.stms])
+        return sec + prim
+
+    def sensitivity(self, edges, values, eps=1e-4, geometry=None):
+        cols = []
+        for m in range(values.size):
+            vp, vm = values.copy(), values.copy()
+            vp[m] *= np.exp(eps); vm[m] *= np.exp(-eps)
+            cols.append((OracleTdEngine.forward(self, edges, vp, geometry) - OracleTdEngine.forward(self, edges, vm, geometry)) / (2 * eps))
+        return np.stack(cols, axis=1)
+
+
+def test_host_sampler_walks_the_reference_tempest_chain():
+    """The reference's OWN Inference1D on its Tempest_datapoint (tempest_options, tempest_glacial.csv row 30, its seed; run on the
+    gatdaem1d stand-in: tests/golden/make_tdem_records.py -> mcmc_trace_tempest.npz) against geobipy_amd.Inference1D on
+    geobipy_amd.TempestDataPoint: the total-field model -- data = secondary + measured primary, prediction = secondary + free-space
+    primary of the geometry, std from the relative levels on the TOTAL field and per-channel additive errors times a multiplier per
+    component -- and the reference's treatment of those multipliers (drawn last, one draw, no prior term): starting half-space,
+    misfit, prior, likelihood, then every decision, layer count, misfit, relative level and multiplier of 200 iterations."""
+    import json
+    from geobipy_amd import CircularLoop, Inference1D, TempestDataPoint
+    from geobipy_amd.tdem_geometry import gaaem_tuple, loop_pair_values
+    from oracle import tdem_oracle as to
+    from test_rjmcmc import generator_at
+    g = np.load(os.path.join(GOLDEN, "mcmc_trace_tempest.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "hdf_schema_tdem.json")))["tempest"]["meta"]
+    z, off = float(g["tx_z"]), g["offset"]
+    tx = CircularLoop(x=[0.0], y=[0.0], z=[z], orientation=["z"], radius=[1.0])
+    rx = CircularLoop(x=[off[0]], y=[off[1]], z=[z + off[2]], orientation=["x"], radius=[1.0])
+    dp = TempestDataPoint(z=float(g["z"]), system=[os.path.join(GOLDEN, "tempest.stm")], transmitter_loop=tx, receiver_loop=rx,
+                          secondary_field=g["secondary_field"], primary_field=g["primary_field"], channel_additive_error=g["additive_error"])
+    assert np.allclose(dp.data, g["data"], rtol=1e-14) and np.allclose(dp.predicted_primary_field, g["predicted_primary_field"], rtol=1e-9)
+    base = loop_pair_values(tx, rx)
+    dp.engine = OracleTempestEngine([to.parse_stm(os.path.join(GOLDEN, "tempest.stm"))], gaaem_tuple(base), base)
+    o = {k: v for k, v in meta["options"].items() if k not in ("n_markov_chains",)}
+    o.update(n_markov_chains=200, initial_additive_error=[1.0, 1.0])       # (the levels the sampler carries are the multipliers)
+    inf = Inference1D(prng=generator_at(g["rng_state"]), world=None, **o)
+    inf.initialize(dp)
+    assert np.isclose(inf.state.values[0], g["halfspace"], rtol=1e-14) and np.isclose(inf.data_misfit, g["misfit0"], rtol=1e-10)
+    assert np.isclose(inf.prior, g["prior0"], rtol=1e-13) and np.isclose(inf.likelihood, g["like0"], rtol=1e-10)
+    rows = g["rows"]
+    for it in range(rows.shape[0]):
+        inf.accept_reject()
+        inf.update()
+        ref = rows[it]
+        assert bool(ref[0]) == bool(inf.accepted) and int(ref[1]) == inf.state.k, it
+        assert abs(inf.data_misfit - ref[2]) <= 1e-7 * abs(ref[2]), (it, inf.data_misfit, ref[2])
+        assert np.allclose(np.r_[inf.state.rel, inf.state.add], ref[3:7], rtol=1e-11, atol=0.0), it
+        assert np.isclose(inf.prior, ref[7], rtol=1e-7) and np.isclose(inf.likelihood, ref[8], rtol=1e-6), it   # (1e-9 drifts: total-field sums)
+    assert rows[:, 0].sum() > 50
