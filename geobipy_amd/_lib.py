@@ -28,7 +28,7 @@ class RjOptions(ctypes.Structure):
                 + [("depth_bin_width", ctypes.c_double), ("value_half_width", ctypes.c_double)]
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)]
                 + [("solve_height", ctypes.c_int32), ("height_half_width", ctypes.c_double), ("height_scale", ctypes.c_double),
-                   ("extra_log_prior", ctypes.c_double)])
+                   ("additive_independent", ctypes.c_int32), ("add_centre", ctypes.c_double * 4), ("extra_log_prior", ctypes.c_double)])
 
 
 RJ_CHAIN_FIELDS = ("rel_group", "add_group", "add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",

@@ -306,7 +306,13 @@ __device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r
     const Levels cur = load_levels(o, c.rel, c.add, (size_t)b);
     Levels out = cur;
     if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.log_rel_min, o.log_rel_max, out.rel);
-    if (o.solve_additive_error) propose_levels(r, cur.add, o.n_add_groups, o.add_sd, o.log_add_min, o.log_add_max, out.add);
+    if (o.solve_additive_error && !o.additive_independent)
+        propose_levels(r, cur.add, o.n_add_groups, o.add_sd, o.log_add_min, o.log_add_max, out.add);
+    if (o.solve_additive_error && o.additive_independent) {      // Tempest's multipliers: one draw about a fixed centre (gbp_rj_options)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < o.n_add_groups) out.add[g] = rj_exp(rj_log(o.add_centre[g]) + o.add_sd[g] * r.normal());
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g < o.n_rel_groups) c.rel_p[(size_t)b * o.n_rel_groups + g] = out.rel[g];
@@ -981,7 +987,8 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     }
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, (size_t)b);
     if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
-    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    if (o.solve_additive_error && !o.additive_independent)
+        prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
     if (o.solve_height) prior_p += o.nlog_height_span;           // Point.probability: the proposal is inside the uniform prior by construction
     prior_p += o.extra_log_prior;
     double dq = 0.0;
@@ -1233,7 +1240,8 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     const Levels lev_p = load_levels(o, c.rel_p, c.add_p, bb);
     if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
-    if (o.solve_additive_error) prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    if (o.solve_additive_error && !o.additive_independent)
+        prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
     if (o.solve_height) prior_p += o.nlog_height_span;           // Point.probability: the proposal is inside the uniform prior by construction
     prior_p += o.extra_log_prior;
     // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian

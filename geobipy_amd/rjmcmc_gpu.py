@@ -85,7 +85,8 @@ class DeviceChains:
 
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
-                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, extra_log_prior=0.0, **options):
+                 min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, extra_log_prior=0.0,
+                 additive_independent=False, **options):
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -171,6 +172,9 @@ class DeviceChains:
         # (NormalDistribution.rng hands the variance to numpy as the scale, statistics/NormalDistribution.py:111: reproduced)
         ro.height_scale = float(o["z_proposal_variance"]) if self.solve_height else 0.0
         ro.extra_log_prior = float(extra_log_prior)     # (priors of sampled scalars that live outside gbp_rj_chains: gbp_td_moves)
+        # Tempest's additive-error multipliers as the reference samples them (gbp_rj_options.additive_independent)
+        ro.additive_independent = int(bool(additive_independent))
+        ro.add_centre = (ctypes.c_double * 4)(*(list(self._add0) + [1.0] * (4 - Ga)))
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
@@ -269,7 +273,7 @@ class DeviceChains:
         if self._o.solve_relative_error:
             prior = prior + sum(log_uniform_prior(t["rel"][:, g], self._bounds["rel"][0][g], self._bounds["rel"][1][g])
                                 for g in range(self.n_rel_groups))
-        if self._o.solve_additive_error:
+        if self._o.solve_additive_error and not self._o.additive_independent:
             prior = prior + sum(log_uniform_prior(t["add"][:, g], self._bounds["add"][0][g], self._bounds["add"][1][g])
                                 for g in range(self.n_add_groups))
         if self.solve_height:

@@ -687,6 +687,11 @@ class TdemDeviceChains(DeviceChains):
             f0, c0, g0 = f0 + nf[i], c0 + nw[i], g0 + nc
         if channel_additive is not None:              # Tempest: per-channel additive errors x a multiplier per (system, component)
             add_group, add_scale = list(rel_group), list(np.broadcast_to(np.asarray(channel_additive, dtype=np.float64), (N,)))
+            # the multipliers as the reference samples them (independence proposal about the initial values, one draw, no prior term:
+            # Tempest_datapoint.py:339-341, 475-487, 503-508; gbp_rj_options.additive_independent) unless the caller wants them as a
+            # random walk inside their log-uniform prior like every other level (reference_multipliers=False)
+            kw.setdefault("additive_independent", bool(kw.pop("reference_multipliers", True)))
+        kw.pop("reference_multipliers", None)
         self._pred_offset0 = None
         if primary_field is not None:                 # total-field channels: predicted primary of every row's geometry, per window
             pp = gm.primary_field()                                                  # [B, sum of the systems' components]

@@ -325,6 +325,13 @@ typedef struct gbp_rj_options {
      * chains->height_p and ->height0; chains->height is then STATE (written on acceptance).  Lock-step drivers only. */
     int32_t solve_height;
     double height_half_width, height_scale;
+    int32_t additive_independent;/* the additive levels as Tempest_datapoint treats its additive-error MULTIPLIERS (data/datapoint/
+                                    Tempest_datapoint.py:339-341, 475-487, 503-508): ONE joint draw per iteration from a log-normal
+                                    centred on add_centre (where set_proposals put it: the initial multipliers -- the proposal's mean
+                                    is never moved to the state, so this is an independence sampler, not a random walk), no redraw
+                                    against the prior, and no prior term in the acceptance ratio.  0: the levels of every other data
+                                    point (random walk, redrawn while outside the log-uniform prior, prior in the ratio)          */
+    double add_centre[4];
     double extra_log_prior;      /* constant added to every proposal's log prior: the densities of the uniform priors of sampled
                                     scalars that live outside the chains struct, in gbp_td_moves; cancels in the acceptance ratio, keeps
                                     the stored prior / posterior values those of the full model                              */

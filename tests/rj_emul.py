@@ -151,7 +151,10 @@ def propose(o, seed, b, it, edges, sigma, rel, add, height=None, height0=None):
                 height_p = height
                 break
     rel_p = propose_levels(r, rel, o["rel_sd"], o["rel_min"], o["rel_max"])
-    add_p = propose_levels(r, add, o["add_sd"], o["add_min"], o["add_max"])
+    if o.get("add_independent"):          # Tempest's multipliers: one draw per level about a fixed centre, no redraw (gbp_rj_options)
+        add_p = np.array([math.exp(math.log(c_) + sd_ * r.normal()) for c_, sd_ in zip(np.atleast_1d(o["add_centre"]), np.atleast_1d(o["add_sd"]))])
+    else:
+        add_p = propose_levels(r, add, o["add_sd"], o["add_min"], o["add_max"])
     if height is not None:
         return action, idx, val, e_r, s_r, rel_p, add_p, height_p
     return action, idx, val, e_r, s_r, rel_p, add_p
@@ -196,8 +199,10 @@ def accept(o, seed, b, it, sp, vp, action, edges_r, sigma_r, log_prop, C, J_p, p
     """k_rj_accept for one chain: (log_ratio, accepted, prior_p).  prior_const: the density of the uniform height prior, when the
     height is sampled (its proposals are inside the prior by construction)."""
     prop = np.exp(log_prop)
-    prior_p = (rjmcmc.model_log_prior(sp, vp, edges_r, prop) + levels_log_prior(rel_p, o["rel_min"], o["rel_max"])
-               + levels_log_prior(add_p, o["add_min"], o["add_max"])) + prior_const
+    prior_p = rjmcmc.model_log_prior(sp, vp, edges_r, prop) + levels_log_prior(rel_p, o["rel_min"], o["rel_max"])
+    if not o.get("add_independent"):
+        prior_p = prior_p + levels_log_prior(add_p, o["add_min"], o["add_max"])
+    prior_p = prior_p + prior_const
     dq = 0.0
     if action in (rjmcmc.INSERT, rjmcmc.DELETE):
         k = prop.size
@@ -236,8 +241,9 @@ class Chain:
         self.pred, self.J = self._fwd(self.edges, self.sigma, height), self._sen(self.edges, self.sigma, height)
         std = channel_std(data, rel, add, add_scale, groups)
         self.misfit, self.like = rjmcmc.gauss_loglike(self.pred, data, std)
-        self.prior = (rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + levels_log_prior(rel, o["rel_min"], o["rel_max"])
-                      + levels_log_prior(add, o["add_min"], o["add_max"]))
+        self.prior = rjmcmc.model_log_prior(sp, vp, self.edges, self.sigma) + levels_log_prior(rel, o["rel_min"], o["rel_max"])
+        if not o.get("add_independent"):
+            self.prior = self.prior + levels_log_prior(add, o["add_min"], o["add_max"])
         if height is not None:
             self.prior -= math.log(2.0 * o["height_half_width"])
         self.prior_const_angles = -sum(math.log(2.0 * m[1]) for m in self.angle_moves)

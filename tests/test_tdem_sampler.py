@@ -241,7 +241,9 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
     Gr, Ga = dc.n_rel_groups, dc.n_add_groups
     eo = dict(K=dc.K, min_width=o.min_width, min_edge=o.min_edge, max_edge=o.max_edge, p=[o.p_birth, o.p_death, o.p_perturb, o.p_none],
               rel_sd=np.array(o.rel_sd[:Gr]), rel_min=np.array(o.rel_min[:Gr]), rel_max=np.array(o.rel_max[:Gr]),
-              add_sd=np.array(o.add_sd[:Ga]), add_min=np.array(o.add_min[:Ga]), add_max=np.array(o.add_max[:Ga]), alpha=o.alpha)
+              add_sd=np.array(o.add_sd[:Ga]), add_min=np.array(o.add_min[:Ga]), add_max=np.array(o.add_max[:Ga]), alpha=o.alpha,
+              add_independent=bool(o.additive_independent), add_centre=np.array(o.add_centre[:Ga]))
+    assert bool(o.additive_independent) == (case == "tempest_total_field")       # (the reference's treatment of Tempest's multipliers)
     sig0 = dc.sigma[:, 0].cpu().numpy()
     chains = []
     for b in range(B):
