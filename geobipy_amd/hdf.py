@@ -502,26 +502,36 @@ def _write_loop_pair(d, i, x, y, z, offset, loop_angles, radius):
 
 
 def _write_tdem_point(d, i, dp, data, best, p, g_, error_model):
-    """TdemDataPoint.writeHdf (data/datapoint/TdemDataPoint.py:627-645) for one host-sampled sounding."""
+    """TdemDataPoint.writeHdf (data/datapoint/TdemDataPoint.py:627-645) / Tempest_datapoint.writeHdf for one host-sampled sounding."""
     rel, add = np.atleast_1d(best.rel), np.atleast_1d(best.add)
+    tempest = data_kind(dp) == "tempest"
+    off = dp.offset
+    nc = dp.system[0].n_components
+    pf = np.concatenate([s_.primary_field(*off, attitude=dp.attitude) for s_ in dp.system])          # predicted primary field per component
+    per = [s_.nwindows for s_ in dp.system for _ in range(s_.n_components)]
     d["data/data"][i, :] = data
-    d["secondary_field/data"][i, :] = data
     d["std/data"][i, :] = error_model.std(data, rel, add)
     d["predicted_data/data"][i, :] = best.pred
-    d["predicted_secondary_field/data"][i, :] = best.pred
+    if tempest:          # total-field channels: Tempest_datapoint.py:106-123 (data / predictedData), :94-104 (multipliers)
+        d["secondary_field/data"][i, :] = dp.secondary_field
+        d["predicted_secondary_field/data"][i, :] = best.pred - np.repeat(pf, per)
+        d["additive_error/data"][i, :] = dp.channel_additive_error
+        d["additive_error_multiplier/data"][i] = add
+        add_name = "additive_error_multiplier"
+    else:
+        d["secondary_field/data"][i, :] = data
+        d["predicted_secondary_field/data"][i, :] = best.pred
+        d["additive_error/data"][i] = add if add.size > 1 else add[0]
+        add_name = "additive_error"
     d["relative_error/data"][i] = rel if rel.size > 1 else rel[0]
-    d["additive_error/data"][i] = add if add.size > 1 else add[0]
     for g in range(rel.size):
         d["relative_error/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.relative_error)[g]
         d["relative_error/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["rel_axes"][g][1]
     for g in range(add.size):
-        d["additive_error/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.additive_error)[g]
-        d["additive_error/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["add_axes"][g][1]
-    off = dp.offset
+        d[add_name + "/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.additive_error)[g]
+        d[add_name + "/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["add_axes"][g][1]
     ang = [float(np.atleast_1d(getattr(lp_, k_))[0]) for lp_ in (dp.transmitter, dp.receiver) for k_ in ("pitch", "roll", "yaw")]
     _write_loop_pair(d, i, float(dp.x), float(dp.y), float(dp.z[0]), off, ang, dp.system[0].loopRadius())
-    nc = dp.system[0].n_components
-    pf = np.concatenate([s_.primary_field(*off, attitude=dp.attitude) for s_ in dp.system])
     d["primary_field/data"][i] = getattr(dp, "primary_field", np.zeros(pf.size)) if pf.size > 1 else 0.0
     d["predicted_primary_field/data"][i] = pf[:nc] if nc > 1 else pf[0]
 

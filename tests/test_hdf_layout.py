@@ -156,7 +156,7 @@ def test_device_rows_fill_the_reference_layout():
 TD_VALUE_SKIP = ("/invtime", "/savetime", "/radius/data", "/moment/data", "/orientation/data", "/data/predicted_primary_field/data")
 
 
-def _compare_tree(ours, arrays, ref, skip_values=TD_VALUE_SKIP, values=True):
+def _compare_tree(ours, arrays, ref, skip_values=TD_VALUE_SKIP, values=True, rtol=1e-7):
     assert sorted(ours) == sorted(ref), (sorted(set(ref) - set(ours)), sorted(set(ours) - set(ref)))
     for path, r in ref.items():
         o = ours[path]
@@ -173,10 +173,10 @@ def _compare_tree(ours, arrays, ref, skip_values=TD_VALUE_SKIP, values=True):
             assert np.array_equal(np.isfinite(a), np.isfinite(want)), (path, a, want)
             m = np.isfinite(want)
             exact = arrays[path].dtype.kind in "iub"
-            assert np.array_equal(a[m], want[m]) if exact else np.allclose(a[m], want[m], rtol=1e-7, atol=1e-300), (path, a[m][:5], want[m][:5])
+            assert np.array_equal(a[m], want[m]) if exact else np.allclose(a[m], want[m], rtol=rtol, atol=1e-300), (path, a[m][:5], want[m][:5])
         else:
             assert int(np.isfinite(a).sum()) == r["n_finite"], path
-            assert np.isclose(np.nansum(a[np.isfinite(a)]), r["nansum"], rtol=1e-9), (path, np.nansum(a[np.isfinite(a)]), r["nansum"])
+            assert np.isclose(np.nansum(a[np.isfinite(a)]), r["nansum"], rtol=max(1e-9, 1e-2 * rtol)), (path, np.nansum(a[np.isfinite(a)]), r["nansum"])
             if arrays[path].dtype.kind in "iub" and r.get("sha1_of_index_1"):
                 assert hashlib.sha1(np.ascontiguousarray(arrays[path][1]).tobytes()).hexdigest() == r["sha1_of_index_1"], path
 
@@ -213,6 +213,41 @@ def test_time_domain_container_matches_the_reference_layout_and_values():
         inf.update()
     inf.writeHdf(root)
     _compare_tree(root.walk(), root.arrays(), ref)
+    assert meta["iteration"] == inf.iteration and meta["k"] == inf.state.k
+
+
+def test_tempest_container_matches_the_reference_layout_and_values():
+    """Tempest (X and Z, total-field channels, primary field, additive-error multipliers): the tree Tempest_datapoint.createHdf /
+    writeHdf build, entry by entry, and -- with the host sampler on geobipy_amd.TempestDataPoint walking the reference's own chain
+    (test_tdem_object_api.py::test_host_sampler_walks_the_reference_tempest_chain) -- every number the reference wrote at index 1
+    after 60 iterations: counters, traces, data / secondary / primary fields, both relative levels and both multipliers with their
+    posteriors, best model (an unconstrained third layer carries 5e-7 of accumulated rounding: rtol 2e-6), hit map."""
+    from geobipy_amd import CircularLoop, Inference1D, TempestDataPoint, hdf
+    from geobipy_amd.tdem_geometry import gaaem_tuple, loop_pair_values
+    from oracle import tdem_oracle as to
+    from test_rjmcmc import generator_at
+    from test_tdem_object_api import OracleTempestEngine
+    schema = json.load(open(os.path.join(GOLDEN, "hdf_schema_tdem.json")))["tempest"]
+    ref, meta = schema["tree"], schema["meta"]
+    g = np.load(os.path.join(GOLDEN, "mcmc_trace_tempest.npz"))
+    z, off = float(g["tx_z"]), g["offset"]
+    tx = CircularLoop(x=[30.0], y=[0.0], z=[z], orientation=["z"], radius=[1.0])
+    rx = CircularLoop(x=[30.0 + off[0]], y=[off[1]], z=[z + off[2]], orientation=["x"], radius=[1.0])
+    dp = TempestDataPoint(x=30.0, y=0.0, z=float(g["z"]), elevation=0.0, system=[os.path.join(GOLDEN, "tempest.stm")], transmitter_loop=tx,
+                          receiver_loop=rx, secondary_field=g["secondary_field"], primary_field=g["primary_field"],
+                          channel_additive_error=g["additive_error"], lineNumber=0.0, fiducial=meta["fiducials"][1])
+    base = loop_pair_values(tx, rx)
+    dp.engine = OracleTempestEngine([to.parse_stm(os.path.join(GOLDEN, "tempest.stm"))], gaaem_tuple(base), base)
+    o = dict(meta["options"], initial_additive_error=[1.0, 1.0], save_hdf5=True)       # (the sampled levels are the multipliers)
+    inf = Inference1D(prng=generator_at(g["rng_state"]), world=None, **o)
+    inf.initialize(dp)
+    root = hdf.NpzGroup("/")
+    hdf.create_inference1d(root, inf, add_axis=meta["fiducials"])
+    for _ in range(meta["iterations"]):
+        inf.accept_reject()
+        inf.update()
+    inf.writeHdf(root)
+    _compare_tree(root.walk(), root.arrays(), ref, rtol=2e-6)
     assert meta["iteration"] == inf.iteration and meta["k"] == inf.state.k
 
 
