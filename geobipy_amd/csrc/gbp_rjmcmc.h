@@ -2018,7 +2018,8 @@ gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options* o, const gbp_rj_ch
     return GBP_OK;
 }
 
-gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
+// which: 1 = the packed launch (models of <= 8 layers), 2 = the one-wave-per-chain launch of deeper models, 3 = both
+static gbp_status rj_newton_part(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int which, void* stream)
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
@@ -2028,26 +2029,38 @@ gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_
     // owns the chain in the stage-1 physics launch -- five launches per iteration instead of seven: k_rj_physics goes from 104 to
     // 288 B of scratch per lane and the iteration is no faster, 39.7 vs 40.5 M chain-iterations/s at 8 192 ten-frequency chains,
     // 48.2 vs 51.5 M at 16 384: with two sub-blocks in flight the empty launches of one hide behind the other's kernels.)
-    hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                       rj::extend(*o), *c, (uint32_t)iteration);
-    if (o->max_layers > 8)
+    if (which & 1)
+        hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                           rj::extend(*o), *c, (uint32_t)iteration);
+    if ((which & 2) && o->max_layers > 8)
         hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
                            *c, (uint32_t)iteration, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
 
-gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, void* stream)
+gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
+{
+    return rj_newton_part(o, c, iteration, 3, stream);
+}
+
+static gbp_status rj_accept_part(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, int which, void* stream)
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    hipLaunchKernelGGL(rj::k_rj_accept8, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                       rj::extend(*o), *c, (uint32_t)iteration, accumulate);
-    if (o->max_layers > 8)
+    if (which & 1)
+        hipLaunchKernelGGL(rj::k_rj_accept8, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                           rj::extend(*o), *c, (uint32_t)iteration, accumulate);
+    if ((which & 2) && o->max_layers > 8)
         hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
                            *c, (uint32_t)iteration, accumulate, 8);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
+}
+
+gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, void* stream)
+{
+    return rj_accept_part(o, c, iteration, accumulate, 3, stream);
 }
 
 static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
@@ -2418,7 +2431,20 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         }
         // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
         if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->height, c->pred_r, c->J_r, main_q, 0)) != GBP_OK) return st;
-        if ((st = gbp_rj_newton(o, c, iter, stream)) != GBP_OK) return st;
+        // (the one-wave-per-chain launches of the deep models touch other chains than the packed ones: beside them, on the deep stream)
+        auto beside = [&](int slot, auto packed, auto deep) -> gbp_status {
+            if (ds == nullptr || K <= 8) { gbp_status a_ = packed(main_q); return a_ != GBP_OK ? a_ : deep(main_q); }
+            GBP_HIP(hipEventRecord(ds->fork[slot], main_q));
+            GBP_HIP(hipStreamWaitEvent(ds->q[slot], ds->fork[slot], 0));
+            gbp_status a_ = deep(ds->q[slot]);
+            if (a_ != GBP_OK) return a_;
+            GBP_HIP(hipEventRecord(ds->join[slot], ds->q[slot]));
+            if ((a_ = packed(main_q)) != GBP_OK) return a_;
+            GBP_HIP(hipStreamWaitEvent(main_q, ds->join[slot], 0));
+            return GBP_OK;
+        };
+        if ((st = beside(0, [&](hipStream_t q) { return rj_newton_part(o, c, iter, 1, q); },
+                         [&](hipStream_t q) { return rj_newton_part(o, c, iter, 2, q); })) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->fork, main_q));
             GBP_HIP(hipStreamWaitEvent(ss->q, ss->fork, 0));
@@ -2441,7 +2467,8 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipEventRecord(ss->join, ss->q));
             GBP_HIP(hipStreamWaitEvent(main_q, ss->join, 0));
         }
-        if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
+        if ((st = beside(1, [&](hipStream_t q) { return rj_accept_part(o, c, iter, accumulate, 1, q); },
+                         [&](hipStream_t q) { return rj_accept_part(o, c, iter, accumulate, 2, q); })) != GBP_OK) return st;
         if (moving) {
             hipLaunchKernelGGL(rj::k_td_moves_accept, dim3((B + 63) / 64), dim3(64), 0, main_q, rj::extend(*o), *c, td->moves, td->mix.n_weights, N);
             GBP_HIP(hipGetLastError());
