@@ -313,8 +313,11 @@ def _grids(inf):
     p = inf.posteriors
     K = int(o["maximum_number_of_layers"])
     rel, add = level_axes(o, data_kind(inf.datapoint))
+    # a sampled height (solve_z): the cells of its uniform prior, stored relative to the measured height (Point.set_z_posterior)
+    height = np.linspace(-float(o["maximum_z_change"]), float(o["maximum_z_change"]), 100) if o.get("solve_z") else None
     return dict(K=K, rel_edges=rel[0][0], add_edges=add[0][0], rel_to=rel[0][1], add_to=add[0][1], rel_axes=rel, add_axes=add,
-                depth_edges=p.depth_edges, value_edges=p.value_edges, value_to=p.relative_to, layer_edges=np.arange(K + 2) - 0.5)
+                depth_edges=p.depth_edges, value_edges=p.value_edges, value_to=p.relative_to, layer_edges=np.arange(K + 2) - 0.5,
+                height_edges=height)
 
 
 def _create_fdem_data(parent, dp, g_, n, fid):
@@ -324,7 +327,12 @@ def _create_fdem_data(parent, dp, g_, n, fid):
     _attrs(d, repr="FdemData")
     for key, label, units in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
                               ("line_number", "Line number", None)):
-        _data_array(d, key, (n,), label=label, units=units)
+        if key == "z" and g_["height_edges"] is not None:      # the height is sampled: a StatArray with its posterior (tests/golden/
+            _stat_array(d, key, n, (), label, units, (99,),    #   hdf_schema_height.json: the reference's tree for solve_z = True)
+                        [("y", dict(edges=g_["height_edges"], dimension=1, label=label, units=units, relative_to_rows=n, rel_label=label,
+                                    rel_units=units))], "RectilinearMesh2D")
+        else:
+            _data_array(d, key, (n,), label=label, units=units)
     _data_array(d, "fiducial", None, data=fid, label="fiducial")
     _data_array(d, "data", (n, N), label="Frequency domain data", units="ppm")
     _data_array(d, "std", (n, N), label="Standard deviation", units="ppm")
@@ -468,6 +476,10 @@ def write_inference1d(parent, inf, index=None):
         d["relative_error/data"][i] = best.rel
         d["additive_error/data"][i] = best.add
         d["relative_error/posterior/values/data"][i, :] = p.relative_error
+        if g_["height_edges"] is not None:                     # the best data point's height, the height posterior about the measured one
+            d["z/data"][i] = best.z
+            d["z/posterior/values/data"][i, :] = p.height
+            d["z/posterior/mesh/y/relative_to/data"][i] = inf.z_move.z0
         d["additive_error/posterior/values/data"][i, :] = p.additive_error
         d["relative_error/posterior/mesh/y/relative_to/data"][i] = g_["rel_to"]
         d["additive_error/posterior/mesh/y/relative_to/data"][i] = g_["add_to"]
@@ -563,7 +575,7 @@ class LineSpec:
 
 
 # per-sounding fields of a finished block, as survey.infer ships them to the writing rank: (name, columns, kind)
-def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0):
+def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0, height=False):
     """``n_rel`` / ``n_add``: error levels per sounding (time-domain data: one relative level per system x component, one additive
     level -- or Tempest multiplier -- per system / component); ``time_domain``: the loop pair's offset and both loops' angles, the
     per-channel standard deviation and the (file, predicted) primary fields travel too."""
@@ -573,18 +585,21 @@ def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_
         f64 += [("std", N), ("offset", 3), ("loop_angles", 6), ("primary", n_primary), ("predicted_primary", n_primary)]
     i32 = [("status", 1), ("burned_in_iteration", 1), ("iterations", 1), ("best_k", 1), ("k_hist", K + 1), ("edge_hist", n_depth),
            ("rel_hist", n_rel * n_err), ("add_hist", n_add * n_err)] + ([("hitmap", n_value * n_depth)] if hitmap else [])
+    if height:                                       # a sampled height (solve_z): the best state's, the measured one, the posterior
+        f64 += [("best_height", 1), ("height0", 1)]
+        i32 += [("height_hist", n_err)]
     return f64, i32
 
 
 def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True, kind="fdem", n_rel=1, n_add=1, n_primary=0,
-                      loop_radius=0.0, channel_additive=None):
+                      loop_radius=0.0, channel_additive=None, height=False):
     """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
     LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  Not written: the
     per-iteration traces ``acceptance_rate`` / ``phids`` (the device sampler keeps no per-iteration history), ``best_iteration``,
     the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
     wants increasing indices).  ``channel_additive`` (Tempest): the per-channel additive errors of the options file."""
     td = kind != "fdem"
-    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary)
+    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary, height=height)
     order = np.argsort(np.asarray(index), kind="stable")
     idx = np.asarray(index)[order]
     assert idx.size == 0 or np.all(np.diff(idx) > 0), ValueError("a sounding may be written once per call")
@@ -617,6 +632,10 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
         d["additive_error/posterior/values/data"][idx, :] = I["add_hist"]
         d["relative_error/posterior/mesh/y/relative_to/data"][idx] = rel_axes[0][1]
         d["additive_error/posterior/mesh/y/relative_to/data"][idx] = add_axes[0][1]
+        if height:
+            d["z/data"][idx] = F["best_height"][:, 0]
+            d["z/posterior/values/data"][idx, :] = I["height_hist"]
+            d["z/posterior/mesh/y/relative_to/data"][idx] = F["height0"][:, 0]
     else:
         tempest = kind == "tempest"
         one = lambda a: a if a.shape[1] > 1 else a[:, 0]

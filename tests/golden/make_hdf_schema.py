@@ -150,6 +150,9 @@ def main():
     options = up.user_parameters.read(opt_file, data_directory=SUP)
     options["system_filename"] = SUP + "/resolve.stm"
     options.update(n_markov_chains=150, save_hdf5=True, interactive_plot=False, update_plot_every=5000)
+    variant = os.environ.get("GBP_SCHEMA_VARIANT", "")           # "height": the same run with the height sampled -> hdf_schema_height.json
+    if variant == "height":
+        options.update(solve_z=True, maximum_z_change=1.0, z_proposal_variance=0.01)
     ds = FdemData.read_csv(SUP + "/resolve_glacial.csv", system=options["system_filename"])
     dp = ds.datapoint(30)
     inf = Inference1D(prng=get_prng(seed=options["seed"]), world=None, **options)
@@ -168,7 +171,9 @@ def main():
     meta = {"sounding": "resolve_glacial.csv row 30", "iterations": 150, "index": 1, "n_points": 3, "fiducials": [float(x) for x in fid],
             "seed": str(options["seed"]), "iteration": int(inf.iteration), "k": int(inf.model.nCells.item()),
             "note": "tree recorded from the reference's own createHdf / writeHdf through an in-memory stand-in for h5py"}
-    json.dump({"meta": meta, "tree": tree}, open(HERE + "/hdf_schema.json", "w"), indent=0, sort_keys=True)
+    if variant:
+        meta["variant"] = variant
+    json.dump({"meta": meta, "tree": tree}, open(HERE + ("/hdf_schema_" + variant + ".json" if variant else "/hdf_schema.json"), "w"), indent=0, sort_keys=True)
     print(len(tree), "entries;", sum(1 for v in tree.values() if v["kind"] == "dataset"), "datasets")
     for k in sorted(tree):
         v = tree[k]

@@ -181,6 +181,50 @@ def _compare_tree(ours, arrays, ref, skip_values=TD_VALUE_SKIP, values=True, rto
                 assert hashlib.sha1(np.ascontiguousarray(arrays[path][1]).tobytes()).hexdigest() == r["sha1_of_index_1"], path
 
 
+def test_container_with_the_height_sampled_matches_the_reference():
+    """``solve_z``: the tree the reference builds when the height has a prior -- /data/z becomes a StatArray with a 99-cell
+    posterior about the measured height (tests/golden/hdf_schema_height.json, recorded like hdf_schema.json with the three keys
+    added) -- entry by entry, and the numbers of the seeded 150-iteration sounding (the best data point's height included)."""
+    from geobipy_amd import FdemDataPoint, FdemSystem, Inference1D, hdf
+    from test_rjmcmc import RESOLVE_OPTIONS, OracleEngine, generator_at
+    schema = json.load(open(os.path.join(GOLDEN, "hdf_schema_height.json")))
+    ref, meta = schema["tree"], schema["meta"]
+    g = np.load(os.path.join(GOLDEN, "mcmc_height.npz"))             # same sounding, seed and keys: its inputs and generator state
+    z0 = float(g["z0"])
+    dp = FdemDataPoint(x=30.0, y=0.0, z=z0, elevation=0.0, data=g["data"], system=FdemSystem.read(os.path.join(GOLDEN, "resolve.stm")),
+                       lineNumber=0.0, fiducial=meta["fiducials"][1])
+    dp.engine = OracleEngine("resolve", z0)
+    o = dict(RESOLVE_OPTIONS, n_markov_chains=150, solve_z=True, maximum_z_change=1.0, z_proposal_variance=float(g["z_proposal_variance"]),
+             save_hdf5=True, update_plot_every=5000, reciprocate_parameters=True)
+    inf = Inference1D(prng=generator_at(g["rng_state"]), world=None, **o)
+    inf.initialize(dp)
+    root = hdf.NpzGroup("/")
+    hdf.create_inference1d(root, inf, add_axis=meta["fiducials"])
+    for _ in range(meta["iterations"]):
+        inf.accept_reject()
+        inf.update()
+    inf.writeHdf(root)
+    _compare_tree(root.walk(), root.arrays(), ref, skip_values=("/invtime", "/savetime"))
+    assert meta["iteration"] == inf.iteration and meta["k"] == inf.state.k and meta["variant"] == "height"
+    # device rows fill the same tree (LineSpec from the options)
+    spec = hdf.LineSpec(dp.system[0], dp.nChannels, dict(o, minimum_thickness=1.0))
+    root2 = hdf.NpzGroup("/")
+    hdf.create_inference1d(root2, spec, add_axis=meta["fiducials"])
+    assert sorted(root2.walk()) == sorted(ref)
+    N, K, nd, nv = dp.nChannels, 30, spec.posteriors.depth_edges.size - 1, 250
+    ff, fi = hdf.device_row_fields(N, K, nd, nv, height=True)
+    rng = np.random.default_rng(1)
+    f = rng.uniform(0.1, 1.0, (2, sum(w for _, w in ff)))
+    i_ = rng.integers(0, 5, (2, sum(w for _, w in fi))).astype(np.int32)
+    hdf.write_device_rows(root2, np.array([2, 0]), f, i_, N, K, nd, nv, dict(o, minimum_thickness=1.0), height=True)
+    a = root2.arrays()
+    cf = np.cumsum([0] + [w for _, w in ff])
+    names = [n_ for n_, _ in ff]
+    assert np.array_equal(a["/data/z/data"][[2, 0]], f[:, cf[names.index("best_height")]])
+    assert np.array_equal(a["/data/z/posterior/mesh/y/relative_to/data"][[2, 0]], f[:, cf[names.index("height0")]])
+    assert np.array_equal(a["/data/z/posterior/values/data"][[2, 0]], i_[:, -99:]) and np.isnan(a["/data/z/data"][1])
+
+
 def test_time_domain_container_matches_the_reference_layout_and_values():
     """SkyTEM (two systems, Z): the tree entry by entry and -- with the host sampler walking the reference's own 300-iteration chain
     (tests/test_tdem_object_api.py) -- every number the reference wrote at index 1: counters, traces, best model, both error

@@ -403,7 +403,7 @@ def test_invert_the_wedge_survey(tmp_path):
 
 
 @pytest.mark.gpu
-def test_survey_with_the_height_move_recovers_a_wrong_altitude():
+def test_survey_with_the_height_move_recovers_a_wrong_altitude(tmp_path):
     """``solve_z`` end to end (the keys the reference's data point reads, added to the options): the wedge survey with every
     sounding's recorded altitude 0.8 m too high -- data of a conductive-over-resistive ground computed at 29.2 m, file says 30 m.  With the height fixed the chains
     cannot reach the noise level; with the height sampled (prior +- 1.5 m) they do, and the posterior height sits at the true
@@ -420,7 +420,12 @@ def test_survey_with_the_height_move_recovers_a_wrong_altitude():
     ds.data[:] = clean + rng.normal(size=clean.shape) * np.sqrt((0.03 * clean) ** 2 + 3.0 ** 2)
     kw = dict(data=ds, burn_in_min_iterations=800, check_every=400, exact_jacobian=True, n_markov_chains=4000)
     fixed = survey.infer(OPTIONS, **kw)
-    moved = survey.infer(OPTIONS, solve_z=True, maximum_z_change=1.5, z_proposal_variance=0.05, **kw)
+    moved = survey.infer(OPTIONS, solve_z=True, maximum_z_change=1.5, z_proposal_variance=0.05, results_directory=str(tmp_path), **kw)
+    from geobipy_amd import hdf                      # the per-line container: /data/z is a StatArray with the height posterior (hdf_schema_height.json)
+    zc_ = hdf.load_npz(str(tmp_path / "0.0.h5.npz"))
+    order = np.argsort(ds.fiducial)
+    assert np.array_equal(zc_["/data/z/posterior/values/data"], moved["height_posterior"][order]) and np.array_equal(zc_["/data/z/data"], moved["best_height"][order])
+    assert np.all(zc_["/data/z/posterior/mesh/y/relative_to/data"] == 30.0) and np.allclose(zc_["/data/z/posterior/mesh/y/edges/data"], np.linspace(-1.5, 1.5, 100))
     assert "height" not in fixed and moved["height_posterior"].shape == (S, 99)
     done = moved["status"] == 1
     zc = 30.0 - 1.5 + (np.arange(99) + 0.5) * (3.0 / 99)
