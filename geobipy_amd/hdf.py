@@ -257,13 +257,21 @@ def _stat_array_n(parent, name, n, n_levels, label, units, hist_axes_per_level):
     return g
 
 
-def _loop_rows(parent, name, n):
-    """CircularLoops.createHdf with an added axis (system/CircularLoop.py:95-110, EmLoop.py:421-431): one value per sounding."""
+def _loop_rows(parent, name, n, sampled=None):
+    """CircularLoops.createHdf with an added axis (system/CircularLoop.py:95-110, EmLoop.py:421-431): one value per sounding.
+    ``sampled``: {angle: edges relative to the measured value} for the attitude angles of this loop that are sampled -- those are
+    StatArrays with their posterior (EmLoop.set_pitch_posterior ...: tests/golden/hdf_schema_tempest_pitch.json)."""
     g = parent.create_group(name)
     _attrs(g, repr="CircularLoops")
     for key, label, units in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
                               ("pitch", "Pitch", "$^{o}$"), ("roll", "Roll", "$^{o}$"), ("yaw", "Yaw", "$^{o}$"), ("moment", "Moment", ""),
                               ("radius", "Radius", "m")):
+        if sampled and key in sampled:
+            e_ = np.asarray(sampled[key], dtype=np.float64)
+            _stat_array(g, key, n, (), label, units, (e_.size - 1,),
+                        [("y", dict(edges=e_, dimension=1, label=label, units=units, relative_to_rows=n, rel_label=label, rel_units=units))],
+                        "RectilinearMesh2D")
+            continue
         _data_array(g, key, (n,), label=label, units=units)
     _data_array(g, "orientation", (n,), dtype="i4", fill=None, label="Orientation")
     return g
@@ -315,9 +323,17 @@ def _grids(inf):
     rel, add = level_axes(o, data_kind(inf.datapoint))
     # a sampled height (solve_z): the cells of its uniform prior, stored relative to the measured height (Point.set_z_posterior)
     height = np.linspace(-float(o["maximum_z_change"]), float(o["maximum_z_change"]), 100) if o.get("solve_z") else None
+    # sampled attitude angles of a time-domain loop pair: the cells of their uniform priors, relative to the measured angle
+    angles = {}
+    if data_kind(inf.datapoint) != "fdem":
+        from .tdem_geometry import LOOP_PAIR_SCALARS
+        for name, stem, nb in LOOP_PAIR_SCALARS:
+            if name[3:] in ("pitch", "roll", "yaw") and o.get("solve_" + stem):
+                m_ = float(o["maximum_" + stem + "_change"])
+                angles[name] = np.linspace(-m_, m_, nb + 1)
     return dict(K=K, rel_edges=rel[0][0], add_edges=add[0][0], rel_to=rel[0][1], add_to=add[0][1], rel_axes=rel, add_axes=add,
                 depth_edges=p.depth_edges, value_edges=p.value_edges, value_to=p.relative_to, layer_edges=np.arange(K + 2) - 0.5,
-                height_edges=height)
+                height_edges=height, angle_edges=angles)
 
 
 def _create_fdem_data(parent, dp, g_, n, fid):
@@ -389,8 +405,9 @@ def _create_tdem_data(parent, dp, g_, n, fid, kind):
     _attrs(lp, repr="Loop_pair")
     for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m")):
         _data_array(lp, key, (n,), label=label, units=u)
-    _loop_rows(lp, "transmitter", n)
-    _loop_rows(lp, "receiver", n)
+    ang = g_.get("angle_edges") or {}
+    _loop_rows(lp, "transmitter", n, {k_[3:]: v_ for k_, v_ in ang.items() if k_.startswith("tx_")})
+    _loop_rows(lp, "receiver", n, {k_[3:]: v_ for k_, v_ in ang.items() if k_.startswith("rx_")})
     nc = dp.system[0].n_components
     wide = lambda m: (n, m) if m > 1 else (n,)
     _data_array(d, "primary_field", wide(n_sys * nc), label="Primary field", units=units)
@@ -519,7 +536,13 @@ def _write_tdem_point(d, i, dp, data, best, p, g_, error_model):
     tempest = data_kind(dp) == "tempest"
     off = dp.offset
     nc = dp.system[0].n_components
-    pf = np.concatenate([s_.primary_field(*off, attitude=dp.attitude) for s_ in dp.system])          # predicted primary field per component
+    best_geom = getattr(best, "geom", None) or {}
+    att = dp.attitude
+    if best_geom:                                             # a sampled geometry: the best data point's loop pair
+        from .tdem_geometry import gaaem_tuple, loop_pair_values
+        g10 = gaaem_tuple(dict(loop_pair_values(dp.transmitter, dp.receiver), **best_geom))
+        off, att = tuple(g10[4:7]), tuple(np.r_[g10[1:4], g10[7:10]])
+    pf = np.concatenate([s_.primary_field(*off, attitude=att) for s_ in dp.system])                  # predicted primary field per component
     per = [s_.nwindows for s_ in dp.system for _ in range(s_.n_components)]
     d["data/data"][i, :] = data
     d["std/data"][i, :] = error_model.std(data, rel, add)
@@ -543,7 +566,14 @@ def _write_tdem_point(d, i, dp, data, best, p, g_, error_model):
         d[add_name + "/posterior{}/values/data".format(g)][i, :] = np.atleast_2d(p.additive_error)[g]
         d[add_name + "/posterior{}/mesh/y/relative_to/data".format(g)][i] = g_["add_axes"][g][1]
     ang = [float(np.atleast_1d(getattr(lp_, k_))[0]) for lp_ in (dp.transmitter, dp.receiver) for k_ in ("pitch", "roll", "yaw")]
+    for j_, name in enumerate(("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw")):
+        if name in best_geom:                                   # a sampled angle: the best data point's (Inference1D.writeHdf :1076-1088)
+            ang[j_] = float(best_geom[name])
     _write_loop_pair(d, i, float(dp.x), float(dp.y), float(dp.z[0]), off, ang, dp.system[0].loopRadius())
+    for name in (g_.get("angle_edges") or {}):
+        grp = "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
+        d[grp + "/posterior/values/data"][i, :] = p.geometry[name]
+        d[grp + "/posterior/mesh/y/relative_to/data"][i] = p.geometry_edges[name][0] + 0.5 * (p.geometry_edges[name][-1] - p.geometry_edges[name][0])
     d["primary_field/data"][i] = getattr(dp, "primary_field", np.zeros(pf.size)) if pf.size > 1 else 0.0
     d["predicted_primary_field/data"][i] = pf[:nc] if nc > 1 else pf[0]
 
@@ -575,7 +605,8 @@ class LineSpec:
 
 
 # per-sounding fields of a finished block, as survey.infer ships them to the writing rank: (name, columns, kind)
-def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0, height=False):
+def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0, height=False,
+                      angles=()):
     """``n_rel`` / ``n_add``: error levels per sounding (time-domain data: one relative level per system x component, one additive
     level -- or Tempest multiplier -- per system / component); ``time_domain``: the loop pair's offset and both loops' angles, the
     per-channel standard deviation and the (file, predicted) primary fields travel too."""
@@ -588,18 +619,22 @@ def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_
     if height:                                       # a sampled height (solve_z): the best state's, the measured one, the posterior
         f64 += [("best_height", 1), ("height0", 1)]
         i32 += [("height_hist", n_err)]
+    for name, nb in angles:                          # sampled attitude angles [(name, cells)]: the same three per angle
+        f64 += [("best_" + name, 1), (name + "_centre", 1)]
+        i32 += [(name + "_hist", nb)]
     return f64, i32
 
 
 def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True, kind="fdem", n_rel=1, n_add=1, n_primary=0,
-                      loop_radius=0.0, channel_additive=None, height=False):
+                      loop_radius=0.0, channel_additive=None, height=False, angles=()):
     """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
     LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  Not written: the
     per-iteration traces ``acceptance_rate`` / ``phids`` (the device sampler keeps no per-iteration history), ``best_iteration``,
     the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
     wants increasing indices).  ``channel_additive`` (Tempest): the per-channel additive errors of the options file."""
     td = kind != "fdem"
-    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary, height=height)
+    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary, height=height,
+                               angles=angles)
     order = np.argsort(np.asarray(index), kind="stable")
     idx = np.asarray(index)[order]
     assert idx.size == 0 or np.all(np.diff(idx) > 0), ValueError("a sounding may be written once per call")
@@ -662,8 +697,16 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
         if n_primary and tempest:                # (SkyTEM files carry no primary-field columns; the reference leaves those rows at their fill)
             d["primary_field/data"][idx] = one(F["primary"])
             d["predicted_primary_field/data"][idx] = one(F["predicted_primary"])
+        la = np.array(F["loop_angles"], dtype=np.float64)
+        cols_ = {"tx_pitch": 0, "tx_roll": 1, "tx_yaw": 2, "rx_pitch": 3, "rx_roll": 4, "rx_yaw": 5}
+        for name, _ in angles:                                   # sampled angles: the best state's instead of the file's
+            la[:, cols_[name]] = F["best_" + name][:, 0]
         _write_loop_pair(d, idx, F["x"][:, 0], F["y"][:, 0], F["z"][:, 0], (F["offset"][:, 0], F["offset"][:, 1], F["offset"][:, 2]),
-                         F["loop_angles"], loop_radius)
+                         la, loop_radius)
+        for name, _ in angles:
+            grp = "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
+            d[grp + "/posterior/values/data"][idx, :] = I[name + "_hist"]
+            d[grp + "/posterior/mesh/y/relative_to/data"][idx] = F[name + "_centre"][:, 0]
     m = parent["model"]
     k = I["best_k"][:, 0]
     m["mesh/nCells/data"][idx] = k

@@ -330,7 +330,8 @@ def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
     td = kind != "fdem"
     n_primary = (ds.primary_field.shape[1] if getattr(ds, "primary_field", None) is not None else 0) if td else 0
     height = bool(getattr(dc, "solve_height", False))
-    fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height)
+    angles = tuple((m_[0], m_[5]) for m_ in (getattr(dc, "_moves", None) or ()))
+    fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles)
     ff, fi = hdf.device_row_fields(N, K, nd, nv, **fkw)
     wf, wi = sum(w for _, w in ff), sum(w for _, w in fi)
     line_col = [n_ for n_, _ in ff].index("line_number")
@@ -344,7 +345,7 @@ def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
     lines, paths = {}, []
     wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
                loop_radius=ds.system[0].loopRadius() if td else 0.0, channel_additive=o.get("initial_additive_error") if kind == "tempest" else None,
-               height=height)
+               height=height, angles=angles)
 
     def close(ln):
         root, fid, path, _ = lines.pop(ln)
@@ -544,6 +545,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 cols_f += [host(ds.primary_field), torch.as_tensor(dc.predicted_primary(), device=dev).reshape(idx.size, -1)]
         if getattr(dc, "solve_height", False):
             cols_f += [t["best_height"][:, None], t["height0"][:, None]]
+        if getattr(dc, "_moves", None):
+            bst, ctr = dc.sampled_angles("best_geom"), dc.sampled_angles("geom0")
+            for m_ in dc._moves:
+                cols_f += [bst[m_[0]][:, None], ctr[m_[0]][:, None]]
         f64_block = torch.cat(cols_f, dim=1).contiguous()
         st, bi = t["status"].to(torch.int32), t["burned_in_iteration"].to(torch.int32)
         ran = torch.where(st == 1, bi + n_mc + 1, torch.where(st == 2, torch.full_like(bi, n_mc), torch.full_like(bi, dc.iteration)))
@@ -553,6 +558,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
         if getattr(dc, "solve_height", False):
             cols.append(t["height_hist"])
+        for q_, m_ in enumerate(getattr(dc, "_moves", None) or ()):
+            cols.append(t["geom_hist"][:, q_, :m_[5]])
         to_host = lambda x: x.cpu()
         return (torch.as_tensor(np.asarray(idx), dtype=torch.int64), to_host(f64_block),
                 to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))

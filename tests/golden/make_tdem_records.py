@@ -51,6 +51,8 @@ def run(kind, n_it, trace):
         options["system_filename"] = SUP + "/tempest.stm"
         csv = SUP + "/tempest_glacial.csv"
     options.update(n_markov_chains=n_it, save_hdf5=True, interactive_plot=False, update_plot_every=5000)
+    if os.environ.get("GBP_SCHEMA_VARIANT") == "pitch":      # the same Tempest run with the receiver pitch sampled -> hdf_schema_tempest_pitch.json
+        options.update(solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.3)
     ds = Data.read_csv(csv, system=options["system_filename"]) if kind == "skytem" else Data.read_csv(csv, options["system_filename"])
     if kind == "tempest":        # (the dataset's error levels start at 0, which Tempest_datapoint refuses: the example scripts set them first)
         ds.relative_error = np.tile(np.atleast_1d(options["initial_relative_error"]).astype(float), (ds.nPoints, 1))
@@ -89,7 +91,8 @@ def run(kind, n_it, trace):
             d = inf.datapoint
             lev = np.asarray(d.additive_error_multiplier, dtype=np.float64) if kind == "tempest" else np.asarray(d.additive_error, dtype=np.float64)
             rows.append(np.r_[float(bool(inf.accepted)), float(inf.model.nCells.item()), float(inf.data_misfit),
-                              np.asarray(d.relative_error, dtype=np.float64), lev, float(inf.prior), float(inf.likelihood)])
+                              np.asarray(d.relative_error, dtype=np.float64), lev, float(inf.prior), float(inf.likelihood),
+                              float(np.squeeze(d.receiver.pitch))])
     inf.writeHdf(root, index=1)
     tree = {}
     root.walk(tree)
@@ -109,6 +112,12 @@ def main():
     import h5py
     h5py.Group, h5py.File, h5py.Dataset = Group, Group, Dataset
     out = {}
+    if os.environ.get("GBP_SCHEMA_VARIANT") == "pitch":
+        meta, tree, rec, rows = run("tempest", 60, True)
+        json.dump({"meta": dict(meta, variant="pitch"), "tree": tree}, open(HERE + "/hdf_schema_tempest_pitch.json", "w"), indent=0, sort_keys=True)
+        np.savez_compressed(HERE + "/mcmc_trace_tempest_pitch.npz", rows=rows, **{k: np.asarray(v) for k, v in rec.items()})
+        print("tempest + receiver pitch:", len(tree), "entries; accepted", int(rows[:, 0].sum()), "pitch", rows[-1, -1])
+        return
     # (the container trees come from the 300- / 60-iteration runs; the Tempest trace from a run of its own, 200 iterations)
     for kind, n_it, trace, schema in (("skytem", N_TRACE, True, True), ("tempest", 60, False, True), ("tempest", 200, True, False)):
         meta, tree, rec, rows = run(kind, n_it, trace)

@@ -440,7 +440,7 @@ def test_survey_with_the_height_move_recovers_a_wrong_altitude(tmp_path):
 
 
 @pytest.mark.gpu
-def test_tempest_survey_recovers_a_wrong_receiver_pitch():
+def test_tempest_survey_recovers_a_wrong_receiver_pitch(tmp_path):
     """``solve_receiver_pitch`` end to end on the device sampler (gbp_td_moves): Tempest soundings whose receiver was pitched by 1.5
     degrees -- secondary AND primary field computed with that attitude -- while the file records level flight.  With the geometry
     fixed the predicted primary field is off by ~ 35 fT x sin(1.5 deg) on channels known to ~ 0.04 fT and the chains cannot fit;
@@ -464,8 +464,15 @@ def test_tempest_survey_recovers_a_wrong_receiver_pitch():
     kw = dict(data=ds, burn_in_min_iterations=1500, check_every=500, n_markov_chains=2500)
     fixed = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), **kw)
     moved = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0,
-                         receiver_pitch_proposal_variance=0.2, **kw)
+                         receiver_pitch_proposal_variance=0.2, results_directory=str(tmp_path), **kw)
     assert "rx_pitch" not in fixed and moved["rx_pitch_posterior"].shape == (S, 199)
+    from geobipy_amd import hdf                 # the per-line container: the receiver's pitch is a StatArray with its posterior (hdf_schema_tempest_pitch.json)
+    zc_ = hdf.load_npz(str(tmp_path / "0.0.h5.npz"))
+    order = np.argsort(ds.fiducial)
+    assert np.array_equal(zc_["/data/loop_pair/receiver/pitch/posterior/values/data"], moved["rx_pitch_posterior"][order])
+    assert np.array_equal(zc_["/data/loop_pair/receiver/pitch/data"], moved["best_rx_pitch"][order])
+    assert np.all(zc_["/data/loop_pair/receiver/pitch/posterior/mesh/y/relative_to/data"] == 0.0)
+    assert np.allclose(zc_["/data/loop_pair/receiver/pitch/posterior/mesh/y/edges/data"], np.linspace(-5.0, 5.0, 200))
     print("receiver pitch: final", np.round(moved["rx_pitch"], 3), "median misfit fixed / moved", np.median(fixed["misfit"]), np.median(moved["misfit"]),
           "done", int((moved["status"] == 1).sum()), "of", S)
     assert np.mean(np.abs(moved["rx_pitch"] - 1.5) < 0.25) >= 0.8 and np.all(np.abs(moved["best_rx_pitch"]) <= 5.0)
