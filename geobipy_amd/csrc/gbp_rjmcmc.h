@@ -2253,6 +2253,14 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         const double want = 7500.0 / (0.4 * B) * (1.0 + std::min(B, 16384) / 16384.0);
         for (int d = 1; d <= F; ++d)                    // the largest divisor of nF not (much) above the target
             if (F % d == 0 && d <= 16 && (double)d <= 1.15 * want) sw = d;
+        // time-domain handles carry 22 ... 75 "frequencies" (spline nodes x basis integrals): at least four waves per chain, whether
+        // or not four divides their number -- measured (scripts/bench_tdem_sampler.py through -DGBP_RJ_SENS_WAVES builds; 22 nodes,
+        // M chain-iterations/s with 2 / 3 / 4 / 6 waves): 4 096 chains 7.0 7.4 7.7 7.4; 8 192: 10.4 10.9 11.1 10.9; 16 384: 13.6 13.9
+        // 14.1 12.9; 44 nodes, 8 192 chains: 5.4 - 5.8 5.5
+        if (td != nullptr) sw = std::max(sw, std::min(4, F));
+#ifdef GBP_RJ_SENS_WAVES
+        sw = GBP_RJ_SENS_WAVES;                              // (A/B builds under scripts/ab only)
+#endif
     }
     const int fw = o->forward_waves;   // 0: the forward kernels choose from the batch size
     const int N = o->n_channels;

@@ -4,6 +4,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import warnings; warnings.filterwarnings("ignore")
+from geobipy_amd import _lib
+if os.environ.get("GBP_AB_LIB"):                     # A/B builds of the library (scripts/ab/*.so): this script only, never the product
+    _lib.LIB_PATH = os.path.abspath(os.environ["GBP_AB_LIB"])
 from geobipy_amd.tdem import TdemDeviceChains
 from test_tdem_sampler import _survey, OFFSET
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192").split(",")]:
