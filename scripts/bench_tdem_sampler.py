@@ -11,7 +11,7 @@ from geobipy_amd.tdem import TdemDeviceChains
 from test_tdem_sampler import _survey, OFFSET
 for B in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1024,8192").split(",")]:
     s, h, data, scale, opts, _ = _survey(B, seed=2, stm=tuple(os.environ.get("TD_STM", "SkytemLM.stm").split(",")))
-    dc = TdemDeviceChains(s, h, data, OFFSET, seed=1, hankel_eps=(float(os.environ['TD_EPS']) if 'TD_EPS' in os.environ else None), **opts)
+    dc = TdemDeviceChains(s, h, data, OFFSET, seed=1, hankel_eps=(float(os.environ['TD_EPS']) if 'TD_EPS' in os.environ else None), **dict(opts, **({'forward_waves': int(os.environ['TD_FW'])} if 'TD_FW' in os.environ else {})))
     m0 = float(dc.misfit.median())
     dc.run(100); torch.cuda.synchronize()
     t0 = time.perf_counter(); dc.run(300); torch.cuda.synchronize(); dt = time.perf_counter() - t0
