@@ -2475,8 +2475,9 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipEventRecord(ss->join, ss->q));
             GBP_HIP(hipStreamWaitEvent(main_q, ss->join, 0));
         }
-        if ((st = beside(1, [&](hipStream_t q) { return rj_accept_part(o, c, iter, accumulate, 1, q); },
-                         [&](hipStream_t q) { return rj_accept_part(o, c, iter, accumulate, 2, q); })) != GBP_OK) return st;
+        // (NOT the accept stage: which launch owns a chain is decided from the chain's CURRENT layer count, which the other launch
+        //  may just have rewritten -- a 9 -> 8 layer death accepted by the deep launch would be taken again by the packed one)
+        if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
         if (moving) {
             hipLaunchKernelGGL(rj::k_td_moves_accept, dim3((B + 63) / 64), dim3(64), 0, main_q, rj::extend(*o), *c, td->moves, td->mix.n_weights, N);
             GBP_HIP(hipGetLastError());
