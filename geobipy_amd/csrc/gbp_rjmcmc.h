@@ -1871,68 +1871,81 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-// One helper stream (+ fork / join events) per device and host thread, created on first use and kept for the life of the process.
+// Helper streams of the drivers: ONE pool of three per device and host thread, created on first use and kept for the life of the
+// process.  The runtime maps streams onto a handful of hardware queues (four by default); streams that share a queue run one
+// after the other, so every driver draws from the same three -- with the caller's stream that makes four -- instead of each
+// creating its own (a process that had run the sub-block driver before the time-domain one lost 13 % in the latter: its side and
+// deep streams landed on the queues of the four sub-block streams created earlier).
+struct AuxStreams {
+    static const int N = 3;
+    hipStream_t q[N] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork[N] = {nullptr, nullptr, nullptr}, join[N] = {nullptr, nullptr, nullptr};
+    hipEvent_t start = nullptr;
+};
+AuxStreams* aux_streams()
+{
+    static thread_local AuxStreams table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    AuxStreams& s = table[dev];
+    if (s.start == nullptr) {
+        for (int i = 0; i < AuxStreams::N; ++i) {
+            if (hipStreamCreateWithFlags(&s.q[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&s.fork[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&s.start, hipEventDisableTiming) != hipSuccess) { s.start = nullptr; return nullptr; }
+    }
+    return &s;
+}
+
+// The side stream of the evaluations at the proposals (+ fork / join events): aux stream 0.
 struct SideStream {
     hipStream_t q = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
 SideStream* side_stream()
 {
-    static thread_local SideStream table[64];
+    static thread_local SideStream view[64];
+    AuxStreams* a = aux_streams();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SideStream& s = table[dev];
-    if (s.q == nullptr) {
-        if (hipStreamCreateWithFlags(&s.q, hipStreamNonBlocking) != hipSuccess) { s.q = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &s;
+    if (a == nullptr || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    view[dev].q = a->q[0]; view[dev].fork = a->fork[0]; view[dev].join = a->join[0];
+    return &view[dev];
 }
 
-// Two more streams (+ fork / join events) for the Jacobian launches of the models of more than 8 layers, see rj_run_lockstep.
+// The streams of the Jacobian launches of the models of more than 8 layers (see rj_run_lockstep): aux streams 1 and 2.
 struct DeepStreams {
     hipStream_t q[2] = {nullptr, nullptr};
     hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
 };
 DeepStreams* deep_streams()
 {
-    static thread_local DeepStreams table[64];
+    static thread_local DeepStreams view[64];
+    AuxStreams* a = aux_streams();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    DeepStreams& s = table[dev];
-    if (s.q[0] == nullptr) {
-        for (int i = 0; i < 2; ++i) {
-            if (hipStreamCreateWithFlags(&s.q[i], hipStreamNonBlocking) != hipSuccess) { s.q[0] = nullptr; return nullptr; }
-            if (hipEventCreateWithFlags(&s.fork[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) != hipSuccess) { s.q[0] = nullptr; return nullptr; }
-        }
-    }
-    return &s;
+    if (a == nullptr || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < 2; ++i) { view[dev].q[i] = a->q[1 + i]; view[dev].fork[i] = a->fork[1 + i]; view[dev].join[i] = a->join[1 + i]; }
+    return &view[dev];
 }
 
-// A pool of helper streams for the concurrent sub-blocks of a lock-step run (one set per device and host thread, kept for the
-// life of the process), each with a "done" event the caller's stream waits on.
+// The streams of the concurrent sub-blocks of a lock-step run, each with a "done" event the caller's stream waits on: the aux
+// streams again (the sub-block driver forks nothing else).
 struct BlockStreams {
-    static const int MAX = 4;
-    hipStream_t q[MAX] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t done[MAX] = {nullptr, nullptr, nullptr, nullptr};
+    static const int MAX = AuxStreams::N;
+    hipStream_t q[MAX] = {nullptr, nullptr, nullptr};
+    hipEvent_t done[MAX] = {nullptr, nullptr, nullptr};
     hipEvent_t start = nullptr;
 };
 BlockStreams* block_streams()
 {
-    static thread_local BlockStreams table[64];
+    static thread_local BlockStreams view[64];
+    AuxStreams* a = aux_streams();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    BlockStreams& s = table[dev];
-    if (s.start == nullptr) {
-        for (int i = 0; i < BlockStreams::MAX; ++i) {
-            if (hipStreamCreateWithFlags(&s.q[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&s.done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        }
-        if (hipEventCreateWithFlags(&s.start, hipEventDisableTiming) != hipSuccess) { s.start = nullptr; return nullptr; }
-    }
-    return &s;
+    if (a == nullptr || hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < BlockStreams::MAX; ++i) { view[dev].q[i] = a->q[i]; view[dev].done[i] = a->join[i]; }
+    view[dev].start = a->start;
+    return &view[dev];
 }
 
 // Rows b0 .. b0 + n - 1 of a block of chains as a block of its own.  Every per-chain array is offset by its row width; the two
