@@ -2167,16 +2167,19 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
     return GBP_OK;
 }
 
-// Concurrent sub-blocks of the fused lock-step driver by block size.  Measured (Resolve, reference Jacobian, scripts/bench_rj_parts.py;
-// M chain-iterations/s for 1 / 2 / 4 sub-blocks): 2 048 chains 18.1 / 19.6 / 10.6, 4 096: 28.1 / 31.8 / 19.3, 8 192: 38.0 / 45.2 / 31.3,
-// 16 384: 50.7 / 55.9 / 42.6.  Two always pay; four are bound by the host's launch rate (7 launches per iteration and sub-block at
-// ~8 us each, serialised inside the runtime whether one host thread issues them or four).
+// Concurrent sub-blocks of the fused lock-step driver by block size.  Each sub-block runs on one of the pool's three helper streams
+// (aux_streams(): as many as map onto hardware queues of their own beside torch's stream; a fourth shares a queue and serialises --
+// the first measurement of four, with the drivers' separate stream sets still in place, lost 30 %).  Measured (reference Jacobian,
+// scripts/bench_rj_parts.py, M chain-iterations/s for 2 / 3 sub-blocks; Resolve | 10-frequency system): 2 048 chains 19.6 / 19.9 |
+// 17.4 / 17.5, 3 072: 26.9 / 27.8 | 23.4 / 24.1, 4 096: 32.1 / 33.9 | 27.8 / 29.5, 8 192: 47.6 / 50.0 | 41.0 / 42.9, 16 384:
+// 62.0 / 63.4 | 52.1 / 53.1, 32 768: 62.8 / 62.8 | 50.5 / 50.6 (one sub-block, Resolve: 18.1 / 28.1 / 38.0 / 50.7 at 2 048 ... 16 384).
+// Three never lose: the host issues 7 launches per iteration and sub-block at ~8 us each, which the GPU side still hides at three.
 static int lockstep_parts(int B)
 {
 #ifdef GBP_RJ_LOCKSTEP_PARTS
     return B >= 2048 ? GBP_RJ_LOCKSTEP_PARTS : 1;              // (A/B builds under scripts/ab only)
 #endif
-    return B >= 2048 ? 2 : 1;
+    return B >= 2048 ? 3 : 1;
 }
 
 gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
