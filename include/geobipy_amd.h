@@ -409,9 +409,9 @@ gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, con
  * propose, the evaluations at the remapped models, Newton (2), the evaluations at the proposals, accept (2)),
  * 2 = persistent kernel (one workgroup owns a chain and loops over all n_iterations in ONE launch; frequency-domain data),
  * 3 = lock-step with one launch per kind of evaluation and layer-count bucket (ten per iteration; what time-domain blocks use),
- * 4 = lock-step as 1, the block cut into 2 contiguous sub-blocks that advance concurrently on streams of their own (a host thread
- * each for the duration of the call) -- the latency-bound per-chain stages of one overlap the physics of the other: +8 % at 2 048
- * chains, +13 % at 4 096, +19 % at 8 192, +10 % at 16 384.
+ * 4 = lock-step as 1, the block cut into 3 contiguous sub-blocks that advance concurrently on streams of their own (a host thread
+ * each for the duration of the call) -- the latency-bound per-chain stages of one overlap the physics of the others: +9 % at 2 048
+ * chains, +20 % at 4 096, +25 % at 8 192, +12 % at 16 384.
  * All drivers walk bit-identical chains; small blocks (config 5 split over 8 GPUs: 1 024 chains per GPU) are about twice as
  * fast in mode 2, medium ones (2 048 ... ~20 000 chains) fastest in mode 4, large ones in mode 1.  Mode 0 chooses.  In mode 4 the
  * launch masks nl_a / nl_c hold one [3, n] block per sub-block instead of one [3, B] array (scratch of an iteration). */
