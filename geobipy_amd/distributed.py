@@ -127,7 +127,8 @@ def gather_rows(rows, values, N, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev, C = values.device, values.shape[1]
     if world == 1:
-        assert int(rows.numel()) == N and int(torch.unique(rows).numel()) == N, ValueError("gather_rows: every row must arrive exactly once")
+        if int(rows.numel()) != N or int(torch.unique(rows).numel()) != N:
+            raise RuntimeError("gather_rows: every row must arrive exactly once")
         out = torch.full((N, C), float("nan"), dtype=torch.float64, device=dev)
         out[rows] = values
         return out
@@ -142,7 +143,8 @@ def gather_rows(rows, values, N, group=None):
     if rank != 0:
         return None
     # every row exactly once: a queue that handed out nothing (or a chunk twice) must not come back as uninitialised memory
-    assert int(counts.sum()) == N, RuntimeError("gather_rows: {} rows arrived for {} soundings".format(int(counts.sum()), N))
+    if int(counts.sum()) != N:
+        raise RuntimeError("gather_rows: {} rows arrived for {} soundings".format(int(counts.sum()), N))
     out = torch.full((N, C), float("nan"), dtype=torch.float64, device=dev)
     seen = torch.zeros(N, dtype=torch.bool, device=dev)
     for r in range(world):
@@ -151,7 +153,8 @@ def gather_rows(rows, values, N, group=None):
         idx = block[:, 0].to(torch.int64)
         out[idx] = block[:, 1:]
         seen[idx] = True
-    assert bool(seen.all()), RuntimeError("gather_rows: some soundings never arrived (and others twice)")
+    if not bool(seen.all()):
+        raise RuntimeError("gather_rows: some soundings never arrived (and others twice)")
     return out
 
 

@@ -58,9 +58,11 @@ class _Dataset:
     def _check(k):
         keys = k if isinstance(k, tuple) else (k,)
         lists = [np.asarray(q) for q in keys if isinstance(q, (list, np.ndarray)) and np.ndim(q) > 0 and np.asarray(q).dtype != bool]
-        assert len(lists) <= 1, TypeError("only one indexing vector or array is currently allowed for fancy indexing (h5py)")
+        if len(lists) > 1:                                   # h5py's rules (and its exception type), so that what passes here passes there
+            raise TypeError("only one indexing vector or array is currently allowed for fancy indexing (h5py)")
         for q in lists:
-            assert q.size < 2 or np.all(np.diff(q) > 0), TypeError("indexing elements must be in increasing order (h5py)")
+            if q.size >= 2 and not np.all(np.diff(q) > 0):
+                raise TypeError("indexing elements must be in increasing order (h5py)")
 
     def __getitem__(self, k):
         self._check(k)
@@ -637,7 +639,8 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
                                angles=angles)
     order = np.argsort(np.asarray(index), kind="stable")
     idx = np.asarray(index)[order]
-    assert idx.size == 0 or np.all(np.diff(idx) > 0), ValueError("a sounding may be written once per call")
+    if idx.size > 1 and not np.all(np.diff(idx) > 0):
+        raise ValueError("a sounding may be written once per call")
     f64, i32 = np.asarray(f64)[order], np.asarray(i32)[order]
     col, F, I = 0, {}, {}
     for name, w in ff:

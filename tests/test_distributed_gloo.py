@@ -130,7 +130,7 @@ def test_chunk_queue_without_a_process_group():
     rows = torch.tensor([2, 0, 1])
     out = gather_rows(rows, torch.tensor([[2.0], [0.0], [1.0]], dtype=torch.float64), 3)
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0]
-    with pytest.raises(AssertionError):                  # a row missing / twice is an error, never uninitialised memory
+    with pytest.raises(RuntimeError):                    # a row missing / twice is an error, never uninitialised memory
         gather_rows(torch.tensor([0, 0, 1]), torch.zeros((3, 1), dtype=torch.float64), 3)
 
 
