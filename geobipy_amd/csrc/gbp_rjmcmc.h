@@ -523,6 +523,110 @@ __device__ inline void data_weights(const gbp_rj_chains& c, const double* data, 
     }
 }
 
+// The packed (8 lanes per chain) stages are latency chains of one wave: what they cost is the number of DEPENDENT trips to memory,
+// not bytes or flops (profiles/r3/summary_rjmcmc_8192.json: 0.04 - 0.05 VALU issue utilisation, ~25 cycles per instruction).  A loop
+// `for n: x = row[n]; use(x)` is one trip per turn -- the compiler cannot hoist a load over the stores (or the branches) of the turn
+// before.  The helpers below issue the loads of several turns back to back and keep the arithmetic, and its order, as it was.
+//
+// TRIPS = true selects them (the lock-step launches of small and medium blocks, whose iteration is this latency chain); the
+// persistent kernel (rows in LDS: nothing to wait for, the extra selects only cost) and the large blocks (throughput bound: the extra
+// registers cost occupancy) take the plain loops -- measured in gbp_rj_newton below.
+//
+// f(n, M[n][col]) for the rows n = 0 .. N - 1 of a row-major [N][K] matrix in ascending order; `on` == false: f(n, 0.0), nothing read.
+template <bool TRIPS, class F>
+__device__ __forceinline__ void for_column(const double* M, int K, int N, int col, bool on, F f)
+{
+    if constexpr (!TRIPS) {
+        for (int n = 0; n < N; ++n) f(n, on ? M[(size_t)n * K + col] : 0.0);
+    } else {
+        const int cc = on ? col : 0;                         // (a column every lane may read: the loads are unconditional)
+        double cur[8], nxt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = M[(size_t)min(u, N - 1) * K + cc];
+        for (int n0 = 0; n0 < N; n0 += 8) {                  // the next eight rows are in flight while these are used
+            if (n0 + 8 < N) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nxt[u] = M[(size_t)min(n0 + 8 + u, N - 1) * K + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (n0 + u < N) f(n0 + u, on ? cur[u] : 0.0);   // (wave-uniform bound)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+        }
+    }
+}
+
+// f(n, data[n], pred[n], variance of channel n) for the channels n = i, i + 8, ... of one lane of a group of 8 (variance_at);
+// TRIPS: four channels per trip to memory.
+template <bool TRIPS, class F>
+__device__ __forceinline__ void for_channels8(const gbp_rj_chains& c, const double* data, const double* pred, const Levels& e, int N, int i, F f)
+{
+    if constexpr (!TRIPS) {
+        for (int n = i; n < N; n += 8) {
+            const double d = data[n];
+            f(n, d, d > 0.0 ? pred[n] : 0.0, d > 0.0 ? variance_at(c, e, d, n) : 1.0);
+        }
+    } else {
+        for (int n0 = i; n0 < N; n0 += 32) {
+            double d[4], p[4], as[4];
+            int rg[4], ag[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = min(n0 + 8 * u, N - 1);
+                d[u] = data[n]; p[u] = pred[n];
+                rg[u] = c.rel_group != nullptr ? c.rel_group[n] : 0;
+                ag[u] = c.add_group != nullptr ? c.add_group[n] : 0;
+                as[u] = c.add_scale != nullptr ? c.add_scale[n] : 1.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + 8 * u;
+                if (n < N) {
+                    const double rd = pick4(e.rel, rg[u]) * d[u];
+                    double an = pick4(e.add, ag[u]);
+                    if (c.add_scale != nullptr) an *= as[u];
+                    f(n, d[u], p[u], rd * rd + an * an);
+                }
+            }
+        }
+    }
+}
+
+// data_weights for a group of 8 lanes
+template <bool TRIPS>
+__device__ __forceinline__ void data_weights8(const gbp_rj_chains& c, const double* data, const double* pred, const Levels& e, int N, int i,
+                                              double* P, double* PR)
+{
+    for_channels8<TRIPS>(c, data, pred, e, N, i, [&](int n, double d, double p, double var) {
+        const bool act = d > 0.0;
+        const double w = act ? 1.0 / var : 0.0;
+        P[n] = w;
+        PR[n] = act ? w * (p - d) : 0.0;
+    });
+}
+
+// copy of the entries j = i, i + 8, ... < n of one or two rows (s2 == nullptr: one); TRIPS: the loads of four turns go out together,
+// then their stores (turn by turn the compiler may not move a load above a store that could alias it: one trip per turn)
+template <bool TRIPS>
+__device__ __forceinline__ void copy_strided8(double* d1, const double* s1, double* d2, const double* s2, int n, int i)
+{
+    if constexpr (!TRIPS) {
+        for (int j = i; j < n; j += 8) { d1[j] = s1[j]; if (s2 != nullptr) d2[j] = s2[j]; }
+    } else {
+        for (int j0 = i; j0 < n; j0 += 32) {
+            double v1[4], v2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int j = min(j0 + 8 * u, n - 1); v1[u] = s1[j]; v2[u] = s2 != nullptr ? s2[j] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 8 * u;
+                if (j < n) { d1[j] = v1[u]; if (s2 != nullptr) d2[j] = v2[u]; }
+            }
+        }
+    }
+}
+
 // solve C C' x = g in place (g -> x), C lower in A (row stride KS); lane-parallel column sweeps
 __device__ inline void chol_solve(const double* A, int KS, int k, int lane, double* g, bool forward, bool backward)
 {
@@ -688,7 +792,7 @@ __device__ __forceinline__ double lane_dn(double v) { return dpp_mov64<0x101>(v)
 // KM: the algebra runs on the leading KM x KM block -- every chain of the wave has at most KM layers.  Rows and columns >= k are
 // identity rows: their Cholesky column is a unit vector, they add 0 x (finite) to every substitution step, so leaving them out
 // changes no bit of rows < k; KM = 8 is the full group.
-template <int KM>
+template <int KM, bool TRIPS>
 __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle)
 {
@@ -697,14 +801,14 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
     int k = b < c.B ? c.k_r[b] : 0;
     const bool live = k >= 1 && k <= 8;              // deeper chains: k_rj_newton.  No early exit: idle groups still take
     if (!live) k = 0;                                //   part in the cross-lane reads
-    const size_t bb = live ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used)
-    const bool changed = c.action[bb] != NONE;
+    const size_t bb = b < c.B ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used); not a function of k:
+    const bool changed = c.action[bb] != NONE;                 //   the loads below do not wait for the one above
     const double* J = (changed ? c.J_r : c.J) + bb * N * K;
     const double* pred = (changed ? c.pred_r : c.pred) + bb * N;
     const double* e = c.edges_r + bb * K;
     double* P = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * 2 * N;
     double* PR = P + N;
-    data_weights(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, 8, P, PR);
+    data_weights8<TRIPS>(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, P, PR);
     double t2 = 0.0;
     if (i < k - 1 && o.solve_gradient) {
         const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
@@ -723,13 +827,12 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
     double g = 0.0;
 #pragma unroll
     for (int j = 0; j < KM; ++j) { arow[j] = 0.0; acol[j] = 0.0; }
-    for (int n = 0; n < N; ++n) {                    // J'PJ and J'P r
-        const double Ji = i < k ? J[(size_t)n * K + i] : 0.0;
+    for_column<TRIPS>(J, K, N, i, i < k && i < K, [&](int n, double Ji) {        // J'PJ and J'P r
         const double jp = Ji * P[n];
         g += Ji * PR[n];
 #pragma unroll
         for (int j = 0; j < KM; ++j) arow[j] += jp * group_bcast(Ji, base, j);
-    }
+    });
     {   // + Wm'Wm (tridiagonal), Wm'Wm (ln sigma - ln sigma_ref)
         const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
         const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
@@ -793,21 +896,23 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
 
 // The packed Newton stage, sized by the deepest chain of the wave (wave-uniform): 2, 4 or all 8 columns.  One chain per wave
 // (persistent kernel): the chain's own layer count -- a 2-layer model runs a quarter of the cross-lane algebra of the full group.
+template <bool TRIPS>
 __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle = 0)
 {
     const int kb = b < c.B ? c.k_r[b] : 0;
     const int mine = kb <= 8 ? kb : 0;                            // (deeper chains are not this stage's)
     const unsigned long long deep4 = __ballot(mine > 4), deep2 = __ballot(mine > 2);
-    if (deep4 != 0ull) newton8_core<8>(o, c, iter, lane, b, sh_dyn, b_idle);
-    else if (deep2 != 0ull) newton8_core<4>(o, c, iter, lane, b, sh_dyn, b_idle);
-    else newton8_core<2>(o, c, iter, lane, b, sh_dyn, b_idle);
+    if (deep4 != 0ull) newton8_core<8, TRIPS>(o, c, iter, lane, b, sh_dyn, b_idle);
+    else if (deep2 != 0ull) newton8_core<4, TRIPS>(o, c, iter, lane, b, sh_dyn, b_idle);
+    else newton8_core<2, TRIPS>(o, c, iter, lane, b, sh_dyn, b_idle);
 }
 
+template <bool TRIPS>
 __global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    newton8_body(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
+    newton8_body<TRIPS>(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
 __device__ inline double log_uniform_prior(double x, double llo, double lhi, double nlog_span)
@@ -1133,13 +1238,13 @@ __device__ inline void hitmap_add8(const RjOpt& o, int32_t* hm, const double* ec
         int b = bin[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) b = edge[j - 1] <= zc ? bin[j] : b;       // interfaces ascend (+inf beyond the last)
-        hm[(size_t)b * o.n_depth_bins + cell] += weight;
+        hm[(size_t)b * o.n_depth_bins + cell] += weight;         // (an atomic add, sent and forgotten, is no faster: measured)
     }
 }
 
 // Reverse-move proposal density of the packed accept stage (Model.proposal_probabilities :577-659) on the leading KM x KM block:
 // every dimension-changing proposal of the wave has at most KM layers (rows >= k are identity rows, as in newton8_core).
-template <int KM>
+template <int KM, bool TRIPS>
 __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_chains& c, int i, int base, int k, size_t bb, bool jump,
                                                   const double* e, double lpv, double lmp, const double* PR)
 {
@@ -1156,21 +1261,37 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
     double arow[KM], acol[KM];
     const bool row = jump && i < k;
+    const double sigma_rem = c.sigma_r[bb * K + (i < K ? i : 0)];
     {
         const double* C = c.chol + bb * K * K;
+        if constexpr (TRIPS) {                       // row i and column i of the factor, requested unconditionally (ic, jc: entries
+            const int ic = i < K ? i : 0;            //   every lane may read) and selected afterwards
+            double cr[KM], cc[KM];
 #pragma unroll
-        for (int j = 0; j < KM; ++j) {
-            arow[j] = (row && j <= i) ? C[(size_t)i * K + j] : (j == i ? 1.0 : 0.0);
-            acol[j] = (row && j >= i && j < k) ? C[(size_t)j * K + i] : (j == i ? 1.0 : 0.0);
+            for (int j = 0; j < KM; ++j) {
+                const int jc = j < K ? j : 0;
+                cr[j] = C[(size_t)ic * K + jc];
+                cc[j] = C[(size_t)jc * K + ic];
+            }
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                arow[j] = (row && j <= i) ? cr[j] : (j == i ? 1.0 : 0.0);
+                acol[j] = (row && j >= i && j < k) ? cc[j] : (j == i ? 1.0 : 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                arow[j] = (row && j <= i) ? C[(size_t)i * K + j] : (j == i ? 1.0 : 0.0);
+                acol[j] = (row && j >= i && j < k) ? C[(size_t)j * K + i] : (j == i ? 1.0 : 0.0);
+            }
         }
     }
     double grad = 0.0;
-    if (row) {
+    {
         const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
         const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
-        grad = diag * v - t2_up * v_up - t2 * v_dn;
-        const double* Jp = c.J_p + bb * N * K;
-        for (int n = 0; n < N; ++n) grad += Jp[(size_t)n * K + i] * PR[n];
+        if (row) grad = diag * v - t2_up * v_up - t2 * v_dn;
+        for_column<TRIPS>(c.J_p + bb * N * K, K, N, i, row, [&](int n, double Jn) { if (row) grad += Jn * PR[n]; });
     }
 #pragma unroll
     for (int j = 0; j < KM; ++j) {                   // C y = grad
@@ -1186,7 +1307,7 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
     }
     const double mean_r = lpv + o.alpha * grad;
     const bool bad = row && !(fabs(mean_r) < 11356.0);
-    const double lrem = row ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
+    const double lrem = row ? rj_log(sigma_rem) : 0.0;
     const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
     double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
 #pragma unroll
@@ -1202,6 +1323,7 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
 }
 
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: PR[8][N]
+template <bool TRIPS>
 __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
                                              unsigned char* sh_dyn, int b_idle = 0)
 {
@@ -1211,13 +1333,23 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const int k_prev = b < c.B ? c.k[b] : 0;
     const bool live = k >= 1 && max(k, k_prev) <= 8;         // no early exit: idle groups still take part in cross-lane reads
     if (!live) k = 0;
-    const size_t bb = live ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used)
-    const int action = live ? c.action[bb] : NONE;
+    const size_t bb = b < c.B ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used); not a function of k:
+    const int action_bb = c.action[bb];                        //   the loads below do not wait for the ones above
+    const int action = live ? action_bb : NONE;
     const bool jump = action == INSERT || action == DELETE;
     const bool frozen = o.schedule == 1 && c.status[bb] != 0;
     const double* e = c.edges_r + bb * K;
     const double lmp = c.log_mean_prior[bb];
-    const double lpv = i < k ? c.log_prop[bb * K + i] : 0.0;
+    // everything the decision reads from the chain's rows is requested here, unconditionally (column ic: one every lane may read),
+    // and selected where it is used: one trip to memory for all of it
+    const int ic = i < K ? i : 0;
+    const double lpv_ic = c.log_prop[bb * K + ic], thk_ic = c.thk_r[bb * K + ic], sp_ic = c.sigma_p[bb * K + ic];
+    const double misfit_p0 = c.misfit_p[bb], like_p0 = c.like_p[bb];
+    const double prior_c = c.prior[bb], like_c = c.like[bb], best_prev = c.best_posterior[bb], misfit_c = c.misfit[bb];
+    const Levels lev_c = load_levels(o, c.rel, c.add, bb);
+    const double height_c = o.solve_height ? c.height[bb] : 0.0, height_p = o.solve_height ? c.height_p[bb] : 0.0;
+    const int dwell0 = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
+    const double lpv = i < k ? lpv_ic : 0.0;
     const double lpv_dn = lane_dn(lpv);
     // priors of the proposal
     double prior_p = -o.log_layers_m1;
@@ -1228,13 +1360,13 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     if (o.solve_gradient) {
         double g = 0.0;
-        if (i < k - 1) g = (lpv_dn - lpv) / rj_log(c.thk_r[bb * K + i]);
+        if (i < k - 1) g = (lpv_dn - lpv) / rj_log(thk_ic);
         const double g2 = group_sum8(g * g);
         const double n = (double)max(1, k - 1);
         prior_p += -0.5 * n * LOG_2PI + 0.5 * n * o.log_gradient_precision - 0.5 * o.gradient_precision * g2;
     }
     if (o.value_max > 0.0) {                         // parameter_limits (Model.probability :555-558)
-        const double sp = i < k ? c.sigma_p[bb * K + i] : o.value_min;
+        const double sp = i < k ? sp_ic : o.value_min;
         const unsigned long long out = __ballot(!(sp >= o.value_min && sp <= o.value_max));
         if ((out >> base) & 0xFFull) prior_p = -INF;
     }
@@ -1250,17 +1382,15 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     if (jump) {
         const double* pp = c.pred_p + bb * N;
         const double* ob = c.data + bb * N;
-        for (int n = i; n < N; n += 8) {
-            const double ov = ob[n];
+        for_channels8<TRIPS>(c, ob, pp, lev_p, N, i, [&](int n, double ov, double pn, double var) {
             double pr = 0.0;
             if (ov > 0.0) {
-                const double var = variance_at(c, lev_p, ov, n);
-                const double r = (pp[n] - ov) * (1.0 / sqrt(var));
+                const double r = (pn - ov) * (1.0 / sqrt(var));
                 s2 += r * r; logdet += rj_log(var); na += 1.0;
-                pr = (1.0 / var) * (pp[n] - ov);
+                pr = (1.0 / var) * (pn - ov);
             }
             PR[n] = pr;
-        }
+        });
     }
     s2 = group_sum8(s2); logdet = group_sum8(logdet); na = group_sum8(na);
     wave_sync();
@@ -1269,42 +1399,35 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     double dq = 0.0;
     {   // (wave-uniform: the cross-lane reads inside are issued by all 64 lanes; sized by the deepest jump of the wave)
         const unsigned long long any = __ballot(jump), deep4 = __ballot(jump && k > 4), deep2 = __ballot(jump && k > 2);
-        if (deep4 != 0ull) dq = accept8_reverse<8>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
-        else if (deep2 != 0ull) dq = accept8_reverse<4>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
-        else if (any != 0ull) dq = accept8_reverse<2>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        if (deep4 != 0ull) dq = accept8_reverse<8, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        else if (deep2 != 0ull) dq = accept8_reverse<4, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        else if (any != 0ull) dq = accept8_reverse<2, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
     }
-    const double misfit_p = jump ? s2 : c.misfit_p[bb];
-    const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : c.like_p[bb];
-    const double prior_c = c.prior[bb], like_c = c.like[bb], best_prev = c.best_posterior[bb];
+    const double misfit_p = jump ? s2 : misfit_p0;
+    const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : like_p0;
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
     const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool accept = live && !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (live && frozen && i == 0 && c.step_flags != nullptr) c.step_flags[bb] = 0;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
-    const double misfit_c = c.misfit[bb];
-    const Levels lev_c = load_levels(o, c.rel, c.add, bb);       // (read before the state is overwritten)
-    const double height_now = o.solve_height ? (accept ? c.height_p[bb] : c.height[bb]) : 0.0;
+    const double height_now = accept ? height_p : height_c;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
-    int dwell = c.hitmap != nullptr ? c.hit_dwell[bb] : 0;
+    int dwell = dwell0;
     if (c.hitmap != nullptr) {                       // the model changes: settle the old one in the hit map first
         const bool on = accept && dwell > 0;
         hitmap_add8(o, c.hitmap + bb * nh, c.edges + bb * K, c.sigma + bb * K, k_prev, lmp, i, base, dwell, on);
         if (on) dwell = 0;
     }
     if (accept) {
-        for (int j = i; j < K; j += 8) {
-            c.edges[bb * K + j] = e[j];
-            c.sigma[bb * K + j] = c.sigma_p[bb * K + j];
-        }
-        for (int n = i; n < N; n += 8) c.pred[bb * N + n] = c.pred_p[bb * N + n];
+        copy_strided8<TRIPS>(c.edges + bb * K, e, c.sigma + bb * K, c.sigma_p + bb * K, K, i);
+        copy_strided8<TRIPS>(c.pred + bb * N, c.pred_p + bb * N, nullptr, nullptr, N, i);
         if (action != NONE) {
             // (columns 0..7 only: both models have at most 8 layers, the Jacobian pass wrote these 8 columns, and nothing reads
             //  a column at or beyond the layer count)
-            const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
             double* Jd = c.J + bb * N * K;
-            if (i < K)
-                for (int n = 0; n < N; ++n) Jd[(size_t)n * K + i] = Js[(size_t)n * K + i];
+            for_column<TRIPS>((action == PERTURB ? c.J_r : c.J_p) + bb * N * K, K, N, i, i < K,
+                              [&](int n, double v) { if (i < K) Jd[(size_t)n * K + i] = v; });
         }
         if (i == 0) {
             c.k[bb] = k;
@@ -1324,10 +1447,11 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     if (i == 0 && c.step_flags != nullptr) c.step_flags[bb] = (accept ? 1 : 0) | bk;
 }
 
+template <bool TRIPS>
 __global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    accept8_body(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
+    accept8_body<TRIPS>(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
@@ -1667,7 +1791,7 @@ __device__ GBP_STAGE_ATTR void stage_propose(const PersistentCtx* x, uint32_t it
 __device__ GBP_STAGE_ATTR void stage_newton(const PersistentCtx* x, uint32_t iter, int lane)
 {
     const gbp_rj_chains& c = *x->c;
-    if (c.k_r[x->b] <= 8) newton8_body(*x->o, c, iter, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
+    if (c.k_r[x->b] <= 8) newton8_body<false>(*x->o, c, iter, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
     else newton_body(*x->o, c, iter, 8, x->b, lane, x->sh_dyn);
 }
 
@@ -1675,7 +1799,7 @@ __device__ GBP_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t ite
 {
     const gbp_rj_chains& c = *x->c;
     const int kr = c.k_r[x->b], kp = c.k[x->b];
-    if ((kr > kp ? kr : kp) <= 8) accept8_body(*x->o, c, iter, accumulate, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
+    if ((kr > kp ? kr : kp) <= 8) accept8_body<false>(*x->o, c, iter, accumulate, lane, lane < 8 ? x->b : c.B, x->sh_dyn, x->b);
     else accept_body(*x->o, c, iter, accumulate, 8, x->b, lane, x->sh_dyn);
 }
 
@@ -2031,6 +2155,22 @@ gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options* o, const gbp_rj_ch
     return GBP_OK;
 }
 
+// The lock-step launches take the build of the packed stages that issues its memory trips in batches (for_column); the persistent
+// kernel, whose rows are in LDS, the plain loops.  Measured (scripts/bench_rj_parts.py, A/B builds interleaved on one box, M
+// chain-iterations/s plain / batched, ten frequencies | Resolve): 2 048 chains 17.4 / 18.8 | 19.9 / 21.0, 4 096: 29.5 / 30.5, 8 192:
+// 43.1 / 44.0 | 49.9 / 51.0 -- k_rj_newton8 24.9 -> 20.0 us, k_rj_accept8 34.0 -> 28.1 us per launch of 2 731 chains --, 65 536:
+// 56.1 / 56.2; the persistent kernel with the batched build 17.9 -> 17.2 | 20.1 -> 19.7.  (At 8 192 chains and beyond the iteration
+// is bound by the physics launches of the three sub-blocks, which fill the GPU: shorter per-chain stages change little there.  Atomic
+// adds -- sent and forgotten -- instead of `+=` in the hit map and the counters were measured with it: no difference.)
+static bool packed_trips(int B)
+{
+    (void)B;
+#ifdef GBP_RJ_AB_TRIPS
+    return GBP_RJ_AB_TRIPS != 0;                     // (A/B builds under scripts/ab only)
+#endif
+    return true;
+}
+
 // which: 1 = the packed launch (models of <= 8 layers), 2 = the one-wave-per-chain launch of deeper models, 3 = both
 static gbp_status rj_newton_part(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int which, void* stream)
 {
@@ -2042,8 +2182,11 @@ static gbp_status rj_newton_part(const gbp_rj_options* o, const gbp_rj_chains* c
     // owns the chain in the stage-1 physics launch -- five launches per iteration instead of seven: k_rj_physics goes from 104 to
     // 288 B of scratch per lane and the iteration is no faster, 39.7 vs 40.5 M chain-iterations/s at 8 192 ten-frequency chains,
     // 48.2 vs 51.5 M at 16 384: with two sub-blocks in flight the empty launches of one hide behind the other's kernels.)
-    if (which & 1)
-        hipLaunchKernelGGL(rj::k_rj_newton8, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
+    if ((which & 1) && packed_trips(c->B))
+        hipLaunchKernelGGL(rj::k_rj_newton8<true>, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                           rj::extend(*o), *c, (uint32_t)iteration);
+    else if (which & 1)
+        hipLaunchKernelGGL(rj::k_rj_newton8<false>, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
                            rj::extend(*o), *c, (uint32_t)iteration);
     if ((which & 2) && o->max_layers > 8)
         hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
@@ -2061,8 +2204,11 @@ static gbp_status rj_accept_part(const gbp_rj_options* o, const gbp_rj_chains* c
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    if (which & 1)
-        hipLaunchKernelGGL(rj::k_rj_accept8, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
+    if ((which & 1) && packed_trips(c->B))
+        hipLaunchKernelGGL(rj::k_rj_accept8<true>, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
+                           rj::extend(*o), *c, (uint32_t)iteration, accumulate);
+    else if (which & 1)
+        hipLaunchKernelGGL(rj::k_rj_accept8<false>, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
                            rj::extend(*o), *c, (uint32_t)iteration, accumulate);
     if ((which & 2) && o->max_layers > 8)
         hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
