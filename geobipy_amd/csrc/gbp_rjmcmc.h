@@ -8,6 +8,8 @@
 //                 error proposals
 //   k_rj_newton   one wave per chain:  Gauss-Newton precision, its Cholesky factor in LDS, mean and sample
 //   k_rj_accept   one wave per chain:  priors, reversible-jump proposal ratio, Metropolis test, state update, posteriors
+//   k_rj_newton8 / k_rj_accept8: the same for models of <= 8 layers, 8 lanes per chain; their launch may carry the deeper chains'
+//                 workgroups too (one launch per stage, one_stage_launch)
 #pragma once
 
 // Register budget of the two per-chain physics kernels (k_rj_physics, k_rj_persistent): they are launched with at most 4 waves
@@ -908,10 +910,15 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
     else newton8_core<2, TRIPS>(o, c, iter, lane, b, sh_dyn, b_idle);
 }
 
+// The stage's workgroups: 0 .. n_packed - 1 hold eight chains of at most 8 layers each, workgroup n_packed + b is chain b's own wave
+// if the chain is deeper (it exits at once otherwise).  A launch holds both kinds or the packed ones only (the deep chains then get
+// k_rj_newton: a launch of workgroups that mostly exit at once is faster with that kernel's 69 VGPRs than with the 125 of this one).
+// Which of the two owns a chain follows from what neither of them writes (k_r and the move), so they need no order between them.
 template <bool TRIPS>
-__global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter)
+__global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter, int n_packed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    if ((int)blockIdx.x >= n_packed) { newton_body(o, c, iter, 8, (int)blockIdx.x - n_packed, threadIdx.x, sh_dyn); return; }
     newton8_body<TRIPS>(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
@@ -1066,7 +1073,9 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
     const int k = c.k_r[b], action = c.action[b];
-    if (max(k, c.k[b]) <= min_k) return;
+    // the layer count before this proposal, from what no accept stage writes (c.k[b] is what the packed stage of the same launch may
+    // be updating -- for ITS chains: a 9 -> 8 layer death accepted here must not look like an 8 -> 8 move over there)
+    if (max(k, k - (action == INSERT) + (action == DELETE)) <= min_k) return;
     const double* e = c.edges_r + (size_t)b * K;
     const double* lpv = c.log_prop + (size_t)b * K;
     const double* tr = c.thk_r + (size_t)b * K;
@@ -1330,11 +1339,12 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
     const int K = o.max_layers, N = o.n_channels;
     int k = b < c.B ? c.k_r[b] : 0;
-    const int k_prev = b < c.B ? c.k[b] : 0;
-    const bool live = k >= 1 && max(k, k_prev) <= 8;         // no early exit: idle groups still take part in cross-lane reads
-    if (!live) k = 0;
     const size_t bb = b < c.B ? (size_t)b : (size_t)b_idle;   // idle groups read a valid row (never used); not a function of k:
     const int action_bb = c.action[bb];                        //   the loads below do not wait for the ones above
+    // the layer count before this proposal (= c.k[b] until an accept stage writes it; derived: accept_body)
+    const int k_prev = k - (action_bb == INSERT) + (action_bb == DELETE);
+    const bool live = k >= 1 && max(k, k_prev) <= 8;         // no early exit: idle groups still take part in cross-lane reads
+    if (!live) k = 0;
     const int action = live ? action_bb : NONE;
     const bool jump = action == INSERT || action == DELETE;
     const bool frozen = o.schedule == 1 && c.status[bb] != 0;
@@ -1448,9 +1458,10 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
 }
 
 template <bool TRIPS>
-__global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate)
-{
+__global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed)
+{   // (workgroups as in k_rj_newton8)
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    if ((int)blockIdx.x >= n_packed) { accept_body(o, c, iter, accumulate, 8, (int)blockIdx.x - n_packed, threadIdx.x, sh_dyn); return; }
     accept8_body<TRIPS>(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
@@ -2171,55 +2182,73 @@ static bool packed_trips(int B)
     return true;
 }
 
-// which: 1 = the packed launch (models of <= 8 layers), 2 = the one-wave-per-chain launch of deeper models, 3 = both
-static gbp_status rj_newton_part(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int which, void* stream)
+// The launches of a per-chain stage: ONE (packed workgroups, then a wave per chain for the models above 8 layers) or TWO (packed;
+// deep -- mostly workgroups that exit at once).  Measured (scripts/bench_rj_parts.py / bench_tdem_sampler.py, A/B builds interleaved
+// on one box, M chain-iterations/s two / one): the time-domain driver, 14 launches per iteration with a fork and a join around the
+// deep Newton launch, 3.35 / 3.70 at 1 024 chains and 11.2 / 11.8 at 8 192; frequency-domain sub-blocks (chains per launch =
+// block / 3): 2 048 chains 18.7 / 19.1, 4 096: 30.8 / 30.8, 8 192: 43.7 / 42.6, 16 384: 52.2 / 50.4 -- with three sub-blocks in flight
+// two short launches interleave better with the other sub-blocks' physics than one --; one block of 65 536: 56.4 / 57.1.
+// (Folding the deep body into the packed WAVES was tried first: inlined it takes the accept stage from 111 to 178 VGPRs, as a call it
+// adds 1.1 - 1.3 KB of scratch per lane; so was running the deep bodies as calls inside the stage-1 physics launch: 104 -> 288 B of
+// scratch there.)
+static bool one_stage_launch(int n, bool time_domain)
+{
+    return time_domain || n <= 1536 || n >= 32768;
+}
+
+static gbp_status rj_newton_launch(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, bool one, void* stream)
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    // chains with <= 8 layers: packed kernel (8 per wave); the others: one wave each.  (Folding the deep body into the packed kernel
-    // -- one launch per stage -- was tried: inlined it takes k_rj_accept8 from 111 to 178 VGPRs, as a call it adds 1.1 - 1.3 KB of
-    // scratch per lane to every launch; the second launch stays.  So was running the two deep bodies as calls in the workgroup that
-    // owns the chain in the stage-1 physics launch -- five launches per iteration instead of seven: k_rj_physics goes from 104 to
-    // 288 B of scratch per lane and the iteration is no faster, 39.7 vs 40.5 M chain-iterations/s at 8 192 ten-frequency chains,
-    // 48.2 vs 51.5 M at 16 384: with two sub-blocks in flight the empty launches of one hide behind the other's kernels.)
-    if ((which & 1) && packed_trips(c->B))
-        hipLaunchKernelGGL(rj::k_rj_newton8<true>, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                           rj::extend(*o), *c, (uint32_t)iteration);
-    else if (which & 1)
-        hipLaunchKernelGGL(rj::k_rj_newton8<false>, dim3((c->B + 7) / 8), dim3(64), (size_t)16 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                           rj::extend(*o), *c, (uint32_t)iteration);
-    if ((which & 2) && o->max_layers > 8)
-        hipLaunchKernelGGL(rj::k_rj_newton, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
-                           *c, (uint32_t)iteration, 8);
+    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? c->B : 0;
+    const size_t lds8 = (size_t)16 * o->n_channels * sizeof(double), lds_deep = rj::Lds::bytes(o->max_layers, o->n_channels);
+    auto launch = [&](int grid, size_t lds, int np) {
+        if (packed_trips(c->B))
+            hipLaunchKernelGGL(rj::k_rj_newton8<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration, np);
+        else
+            hipLaunchKernelGGL(rj::k_rj_newton8<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration, np);
+    };
+    if (one || n_deep == 0) launch(n_packed + n_deep, n_deep ? std::max(lds8, lds_deep) : lds8, n_packed);
+    else {
+        launch(n_packed, lds8, n_packed);
+        hipLaunchKernelGGL(rj::k_rj_newton, dim3(n_deep), dim3(64), lds_deep, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration, 8);
+    }
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+static gbp_status rj_accept_launch(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, bool one, void* stream)
+{
+    gbp_status st = rj_check(o, c);
+    if (st != GBP_OK || c->B == 0) return st;
+    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? c->B : 0;
+    const size_t lds8 = (size_t)8 * o->n_channels * sizeof(double), lds_deep = rj::Lds::bytes(o->max_layers, o->n_channels);
+    auto launch = [&](int grid, size_t lds, int np) {
+        if (packed_trips(c->B))
+            hipLaunchKernelGGL(rj::k_rj_accept8<true>, dim3(grid), dim3(64), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration,
+                               accumulate, np);
+        else
+            hipLaunchKernelGGL(rj::k_rj_accept8<false>, dim3(grid), dim3(64), lds, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration,
+                               accumulate, np);
+    };
+    if (one || n_deep == 0) launch(n_packed + n_deep, n_deep ? std::max(lds8, lds_deep) : lds8, n_packed);
+    else {
+        launch(n_packed, lds8, n_packed);
+        hipLaunchKernelGGL(rj::k_rj_accept, dim3(n_deep), dim3(64), lds_deep, (hipStream_t)stream, rj::extend(*o), *c, (uint32_t)iteration,
+                           accumulate, 8);
+    }
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
 
 gbp_status gbp_rj_newton(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, void* stream)
 {
-    return rj_newton_part(o, c, iteration, 3, stream);
-}
-
-static gbp_status rj_accept_part(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, int which, void* stream)
-{
-    gbp_status st = rj_check(o, c);
-    if (st != GBP_OK || c->B == 0) return st;
-    if ((which & 1) && packed_trips(c->B))
-        hipLaunchKernelGGL(rj::k_rj_accept8<true>, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                           rj::extend(*o), *c, (uint32_t)iteration, accumulate);
-    else if (which & 1)
-        hipLaunchKernelGGL(rj::k_rj_accept8<false>, dim3((c->B + 7) / 8), dim3(64), (size_t)8 * o->n_channels * sizeof(double), (hipStream_t)stream,
-                           rj::extend(*o), *c, (uint32_t)iteration, accumulate);
-    if ((which & 2) && o->max_layers > 8)
-        hipLaunchKernelGGL(rj::k_rj_accept, dim3(c->B), dim3(64), rj::Lds::bytes(o->max_layers, o->n_channels), (hipStream_t)stream, rj::extend(*o),
-                           *c, (uint32_t)iteration, accumulate, 8);
-    GBP_HIP(hipGetLastError());
-    return GBP_OK;
+    return rj_newton_launch(o, c, iteration, one_stage_launch(c ? c->B : 0, false), stream);
 }
 
 gbp_status gbp_rj_accept(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, int accumulate, void* stream)
 {
-    return rj_accept_part(o, c, iteration, accumulate, 3, stream);
+    return rj_accept_launch(o, c, iteration, accumulate, one_stage_launch(c ? c->B : 0, false), stream);
 }
 
 static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_operator* td, const gbp_rj_options* o, const gbp_rj_chains* c,
@@ -2601,20 +2630,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         }
         // fm_dlogc at the remapped models whose structure changed (Model.py:383-384): prediction and Jacobian in one pass
         if ((st = fm_dlogc(c->nl_a, c->sigma_r, c->height, c->pred_r, c->J_r, main_q, 0)) != GBP_OK) return st;
-        // (the one-wave-per-chain launches of the deep models touch other chains than the packed ones: beside them, on the deep stream)
-        auto beside = [&](int slot, auto packed, auto deep) -> gbp_status {
-            if (ds == nullptr || K <= 8) { gbp_status a_ = packed(main_q); return a_ != GBP_OK ? a_ : deep(main_q); }
-            GBP_HIP(hipEventRecord(ds->fork[slot], main_q));
-            GBP_HIP(hipStreamWaitEvent(ds->q[slot], ds->fork[slot], 0));
-            gbp_status a_ = deep(ds->q[slot]);
-            if (a_ != GBP_OK) return a_;
-            GBP_HIP(hipEventRecord(ds->join[slot], ds->q[slot]));
-            if ((a_ = packed(main_q)) != GBP_OK) return a_;
-            GBP_HIP(hipStreamWaitEvent(main_q, ds->join[slot], 0));
-            return GBP_OK;
-        };
-        if ((st = beside(0, [&](hipStream_t q) { return rj_newton_part(o, c, iter, 1, q); },
-                         [&](hipStream_t q) { return rj_newton_part(o, c, iter, 2, q); })) != GBP_OK) return st;
+        if ((st = rj_newton_launch(o, c, iter, one_stage_launch(B, td != nullptr), stream)) != GBP_OK) return st;
         if (fork) {
             GBP_HIP(hipEventRecord(ss->fork, main_q));
             GBP_HIP(hipStreamWaitEvent(ss->q, ss->fork, 0));
@@ -2637,9 +2653,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipEventRecord(ss->join, ss->q));
             GBP_HIP(hipStreamWaitEvent(main_q, ss->join, 0));
         }
-        // (NOT the accept stage: which launch owns a chain is decided from the chain's CURRENT layer count, which the other launch
-        //  may just have rewritten -- a 9 -> 8 layer death accepted by the deep launch would be taken again by the packed one)
-        if ((st = gbp_rj_accept(o, c, iter, accumulate, stream)) != GBP_OK) return st;
+        if ((st = rj_accept_launch(o, c, iter, accumulate, one_stage_launch(B, td != nullptr), stream)) != GBP_OK) return st;
         if (moving) {
             hipLaunchKernelGGL(rj::k_td_moves_accept, dim3((B + 63) / 64), dim3(64), 0, main_q, rj::extend(*o), *c, td->moves, td->mix.n_weights, N);
             GBP_HIP(hipGetLastError());
