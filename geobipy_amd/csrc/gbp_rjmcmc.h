@@ -2545,8 +2545,10 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             // frequencies | Resolve): n = 1 024: 11.9 15.3 16.5 17.1 | 14.6 17.5 18.5 19.6;  2 048: 20.4 25.9 27.0 27.5 | 25.7 30.1 31.0
             // 31.7;  4 096: 31.9 40.6 40.4 38.5 | 41.0 47.0 45.8 45.2;  8 192: 48.7 51.5 48.1 44.9 | 61.2 61.3 56.3 53.1 -- a
             // chain's frequencies spread over four waves while the launch would not fill the SIMDs otherwise (<= 8 192 waves), two
-            // beyond.  (More than four -- a 320- or 384-thread launch bound -- is 30 % slower at every size.)
-            t.nw = std::min(n <= 2048 ? 4 : 2, GBP_RJ_PHYSICS_MAX_WAVES);
+            // beyond.  (More than four -- a 320- or 384-thread launch bound -- is 30 % slower at every size.)  With three sub-blocks
+            // in flight (2 / 3 / 4 waves, block = 3 n): n = 1 707: - / 35.0 / 34.7 | - / 39.0 / 39.4;  2 048: 35.9 38.0 37.2 | 43.0 44.6
+            // 43.6;  2 731: 43.6 44.1 41.3 | 51.3 49.7 48.1;  3 413: 47.8 44.6 43.7 | 56.4 51.8 50.0.
+            t.nw = std::min(n <= 1792 ? 4 : (n <= 2400 ? 3 : 2), GBP_RJ_PHYSICS_MAX_WAVES);
 #ifdef GBP_RJ_PHYSICS_NW
             t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
 #endif
