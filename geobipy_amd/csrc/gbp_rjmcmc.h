@@ -1736,11 +1736,14 @@ struct PersistentCtx {
     MathLds* math;
     double* sh_out;
     unsigned char* sh_dyn;
-    const Channel* chan;
+    const Channel* chan;              // abscissa window of the chain's current height ...
     const double* pts;
+    const Channel* chan_p;            // ... and of the proposal's (the same with a fixed height; a sampled one: set_windows per iteration)
+    const double* pts_p;
     unsigned char* deep_scratch;      // global working set of this chain's Jacobian pass for models of > 8 layers, or NULL: LDS
-    int npts_total, F, nw_deep, b;
+    int npts_total, npts_total_p, F, nw_deep, b;
     double sigma_direct;
+    double alt, alt_p;                // height of the current state / of the proposal
 };
 
 // LDS block of one chain in the persistent kernel: the doubles of GBP_RJ_D + data[N], then the int32s of GBP_RJ_I
@@ -1775,9 +1778,13 @@ __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_pro
     double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
     double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
     const double* th = c.thk_r + (size_t)b * K;
-    const double alt = c.height[b];
-    if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6), min(K, 8));
-    else sens_body<EXACT, 8>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, K, L,
+    // (a sampled height: the remapped model is evaluated at the chain's current height, the proposal at the proposed one -- k_rj_physics)
+    const double alt = at_proposal ? x->alt_p : x->alt;
+    const Channel* chan = at_proposal ? x->chan_p : x->chan;
+    const double* pts = at_proposal ? x->pts_p : x->pts;
+    const int npts = at_proposal ? x->npts_total_p : x->npts_total;
+    if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, chan, pts, npts, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6), min(K, 8));
+    else sens_body<EXACT, 8>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, chan, pts, npts, x->F, K, K, L,
                              sig, th, alt, Jb, pr, x->nw_deep, min(K, (L + 7) & ~7));
 }
 
@@ -1787,8 +1794,8 @@ __device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
     const gbp_rj_chains& c = *x->c;
     const int b = x->b, K = o.max_layers, N = o.n_channels;
     const gbp::MathCtx M = math_ctx(x->math);
-    forward_body<true>(M, x->sh_out, x->sh_dyn, x->chan, x->pts, x->npts_total, x->F, K, c.k_r[b], c.sigma_p + (size_t)b * K,
-                       c.thk_r + (size_t)b * K, c.height[b], c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N,
+    forward_body<true>(M, x->sh_out, x->sh_dyn, x->chan_p, x->pts_p, x->npts_total_p, x->F, K, c.k_r[b], c.sigma_p + (size_t)b * K,
+                       c.thk_r + (size_t)b * K, x->alt_p, c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N,
                        c.misfit_p + b, c.like_p + b, x->sigma_direct, (int)(blockDim.x >> 6));
 }
 
@@ -1879,20 +1886,34 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
         for (size_t i = threadIdx.x; i < (size_t)N; i += blockDim.x) p[i] = c_arg.data[bb * N + i];
         if (threadIdx.x == 0) sh_c.data = p - bb * N;
     }
-    if (bins != nullptr) {                                        // the chain's abscissa window: the bin of its sounding's altitude
-        const double alt = c_arg.height[b];
-        if (alt >= (double)bin0) {
+    // the abscissa window of a height: the bin of the altitude (the system's full tables below the first bin / without bins)
+    auto window_of = [&](double alt, const Channel*& wc, const double*& wp, int& wn) {
+        wc = chan; wp = pts; wn = npts_total;
+        if (bins != nullptr && alt >= (double)bin0) {
             const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
-            chan = bin_chan + d.chan_off;
-            pts = bin_pts + d.pts_off;
-            npts_total = d.npts_total;
+            wc = bin_chan + d.chan_off;
+            wp = bin_pts + d.pts_off;
+            wn = d.npts_total;
         }
-    }
+    };
+    // (thread 0: the current height's window and -- a sampled height, after the proposal kernel's stage -- the proposal's)
+    auto set_windows = [&](bool proposal_too) {
+        sh_x.alt = c_arg.height[b];
+        window_of(sh_x.alt, sh_x.chan, sh_x.pts, sh_x.npts_total);
+        if (proposal_too) {
+            sh_x.alt_p = c_arg.height_p[b];
+            window_of(sh_x.alt_p, sh_x.chan_p, sh_x.pts_p, sh_x.npts_total_p);
+        } else {
+            sh_x.alt_p = sh_x.alt; sh_x.chan_p = sh_x.chan; sh_x.pts_p = sh_x.pts; sh_x.npts_total_p = sh_x.npts_total;
+        }
+    };
     if (threadIdx.x == 0) {
-        sh_x.o = &sh_o; sh_x.c = &sh_c; sh_x.math = &sh_math; sh_x.sh_out = sh_out; sh_x.sh_dyn = stage_scratch; sh_x.chan = chan;
-        sh_x.pts = pts; sh_x.deep_scratch = deep_scratch != nullptr ? deep_scratch + (size_t)b * deep_bytes : nullptr;
-        sh_x.npts_total = npts_total; sh_x.F = F; sh_x.nw_deep = nw_deep; sh_x.b = b; sh_x.sigma_direct = sigma_direct;
+        sh_x.o = &sh_o; sh_x.c = &sh_c; sh_x.math = &sh_math; sh_x.sh_out = sh_out; sh_x.sh_dyn = stage_scratch;
+        sh_x.deep_scratch = deep_scratch != nullptr ? deep_scratch + (size_t)b * deep_bytes : nullptr;
+        sh_x.F = F; sh_x.nw_deep = nw_deep; sh_x.b = b; sh_x.sigma_direct = sigma_direct;
+        set_windows(false);
     }
+    const bool moving_height = o_arg.solve_height != 0;
     (void)math_setup(sh_math);                                    // tables -> LDS once per chain; ends with __syncthreads()
     const int32_t* status = c_arg.status;
     const int32_t* action_p = sh_c.action;
@@ -1906,6 +1927,10 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
         const uint32_t iter = iter0 + (uint32_t)it;
         if (schedule == 1 && status[b] != 0) break;               // done / failed chains keep their final state (workgroup-uniform)
         if (wave == 0) stage_propose(&sh_x, iter, lane);
+        if (moving_height) {                                      // Point.perturb: this iteration's two heights and their windows
+            __syncthreads();                                      //   (height_p is lane 0's write of the stage above; height its
+            if (threadIdx.x == 0) set_windows(true);              //   write of the accept stage of the iteration before)
+        }
         __syncthreads();
         tick(0);
         const int action = action_p[b];
@@ -2375,12 +2400,10 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
         const int nw = persistent_waves(sys, o, c->B, false);
         bool small = false;
-        if (nw > 0 && n_iterations >= 4 && !o->solve_height) small = (long long)c->B <= persistent_capacity(sys, o, nw);
+        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
         if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
         mode = lockstep_parts(c->B) > 1 ? 4 : 1;
     }
-    if (mode == 2 && o->solve_height)
-        return fail(GBP_ERR_INVALID_ARG, "the persistent kernel fixes a chain's abscissa window at launch: a sampled height (solve_height) runs under the lock-step drivers%s");
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, true, stream);
     return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, mode == 4 ? std::max(2, lockstep_parts(c->B)) : 1, stream);
 }

@@ -581,13 +581,14 @@ def test_height_move_on_the_device_equals_cpu_chains_with_the_same_seeds():
     test_rjmcmc.py::test_height_move_reproduces_the_reference_chain): CPU chains with the same counter-based streams -- the stage
     emulation with the C oracle evaluating the remapped model at the current height and the proposal at the proposed one -- walk
     the same chains as the device: every move and decision, the heights to 1e-9 m, the height posterior, over 400 iterations,
-    under the fused lock-step driver, the ten-launch driver and concurrent sub-blocks; the persistent kernel refuses the option;
+    under the fused lock-step driver, the ten-launch driver, concurrent sub-blocks and the persistent kernel (which re-reads the two
+    heights and their abscissa windows every iteration);
     cached state equals a from-scratch evaluation at the final heights."""
     from test_rjmcmc import OracleEngine
     n_it, B = 400, 6
     hopt = dict(solve_z=True, maximum_z_change=1.5, z_proposal_variance=0.15)
     runs = {}
-    for mode in (1, 3):
+    for mode in (1, 3, 2):
         d, s, dc = _chains(B, 2025, options=hopt)
         dc.run_mode = mode
         rng = np.random.default_rng(6)
@@ -627,24 +628,23 @@ def test_height_move_on_the_device_equals_cpu_chains_with_the_same_seeds():
         runs[mode] = dc
     for n in ("k", "sigma", "edges", "height", "height_hist", "best_height", "rel", "add", "misfit", "k_hist", "n_accepted"):
         assert torch.equal(getattr(runs[1], n), getattr(runs[3], n)), n
-    # concurrent sub-blocks (a block large enough for them), against the one-block driver; the persistent kernel says no
+        assert torch.equal(getattr(runs[1], n), getattr(runs[2], n)), n
+    # concurrent sub-blocks (a block large enough for them) and the persistent kernel in two rounds, against the one-block driver
     big = {}
-    for mode in (1, 4):
+    for mode in (1, 4, 2):
         d, s, dc = _chains(2304, 11, options=hopt)
         dc.run_mode = mode
         dc.run(60)
         big[mode] = dc
     for n in ("k", "sigma", "height", "height_hist", "misfit", "n_accepted"):
         assert torch.equal(getattr(big[1], n), getattr(big[4], n)), n
+        assert torch.equal(getattr(big[1], n), getattr(big[2], n)), n
     dc = big[4]
     from geobipy_amd import FdemBatch
     thk = torch.zeros_like(dc.sigma)
     thk[:, :-1] = torch.diff(torch.cat([torch.zeros(dc.B, 1, dtype=torch.float64, device=dc.device), dc.edges], dim=1), dim=1)[:, :-1].nan_to_num(posinf=0.0)
     fb = FdemBatch(s, dc.k.cpu().numpy(), dc.sigma.cpu().numpy(), thk.cpu().numpy(), dc.height.cpu().numpy(), hankel_eps_ppm=dc.hankel_eps_ppm)
     assert torch.allclose(fb.forward(), dc.pred, rtol=1e-9, atol=1e-7)
-    dc.run_mode = 2
-    with pytest.raises(Exception, match="solve_height"):
-        dc.run(5)
 
 
 @pytest.mark.gpu
