@@ -56,6 +56,8 @@ class FdemDataPoint:
             value = [value]
         assert all(isinstance(s, (str, FdemSystem)) for s in value), TypeError(
             "System must have items of type str or geobipy.FdemSystem")
+        # (the reference's loop over systems writes every system's response to predictedData[:F_i] / [F_i:] -- FdemDataPoint.py:541-545,
+        #  Jacobian :555-557 -- so a second system overwrites the first: one system is what the reference itself can run)
         assert len(value) == 1, ValueError("one FdemSystem per datapoint is supported")
         self._system = [FdemSystem.read(s) if isinstance(s, str) else s for s in value]
 
