@@ -170,9 +170,13 @@ def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
     m = int(rows.numel())
     own = lambda x: (x.clone() if x.device.type == "cpu" else x.cpu()).numpy()        # (a receive buffer is reused: hand out copies)
     to_host = lambda r, bs, a, b: (own(r[a:b]), [own(x[a:b]) for x in bs])
+    # this rank's own rows are nobody's buffer: views of host tensors as they are (the hit maps are 440 KB per row -- a copy of every
+    # chunk was a fifth of a survey's wall time), one device -> host copy otherwise
+    mine = lambda x: (x if x.device.type == "cpu" else x.cpu()).numpy()
+    own_rows = lambda a, b: (mine(rows[a:b]), [mine(x[a:b]) for x in blocks])
     if world == 1:
         for a in range(0, m, chunk_rows):
-            yield to_host(rows, blocks, a, min(m, a + chunk_rows))
+            yield own_rows(a, min(m, a + chunk_rows))
         return
     counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([m], dtype=torch.int64, device=dev), group=group)
@@ -188,7 +192,7 @@ def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
     n_rounds = max((c_ + chunk_rows - 1) // chunk_rows for c_ in counts) if counts else 0
     if rank == 0:
         for a in range(0, m, chunk_rows):
-            yield to_host(rows, blocks, a, min(m, a + chunk_rows))
+            yield own_rows(a, min(m, a + chunk_rows))
         peers = [r for r in range(1, world) if counts[r] > 0]
         rbuf = {r: torch.empty(chunk_rows, dtype=torch.int64, device=dev) for r in peers}
         bufs = {r: [torch.empty((chunk_rows,) + tuple(b.shape[1:]), dtype=b.dtype, device=dev) for b in blocks] for r in peers}

@@ -156,7 +156,14 @@ class NpzGroup:
         "__unwritten__", shape / dtype / fill value of the datasets that never were (they are all fill value; ``load_npz``
         puts them back) -- so a container costs what was written to it, not what it pre-allocates."""
         lazy = self.unwritten()
-        np.savez_compressed(path, **self.arrays(materialised_only=True))
+        # the .npz format (a zip of .npy members: numpy.load reads it), deflate level 1: the hit maps are mostly zeros and shrink
+        # 100-fold at any level, and at numpy's default level 6 compressing a line took ten times as long as inverting it
+        import zipfile
+        file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
+        with zipfile.ZipFile(file, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=1, allowZip64=True) as zf:
+            for name, arr in self.arrays(materialised_only=True).items():
+                with zf.open(name + ".npy", "w", force_zip64=True) as member:
+                    np.lib.format.write_array(member, np.asanyarray(arr), allow_pickle=False)
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
         attrs["__unwritten__"] = lazy
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
@@ -641,7 +648,11 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
     idx = np.asarray(index)[order]
     if idx.size > 1 and not np.all(np.diff(idx) > 0):
         raise ValueError("a sounding may be written once per call")
-    f64, i32 = np.asarray(f64)[order], np.asarray(i32)[order]
+    f64, i32 = np.asarray(f64), np.asarray(i32)
+    if not np.array_equal(order, np.arange(idx.size)):           # (rows of a line arrive in order: no copy of the hit maps then)
+        f64, i32 = f64[order], i32[order]
+    # consecutive rows are written as a slice (a block copy; h5py likes it better, too), anything else as the sorted index vector
+    sel = slice(int(idx[0]), int(idx[-1]) + 1) if idx.size and int(idx[-1]) - int(idx[0]) + 1 == idx.size else idx
     col, F, I = 0, {}, {}
     for name, w in ff:
         F[name] = f64[:, col:col + w]
@@ -652,77 +663,77 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
         col += w
     o = options
     rel_axes, add_axes = level_axes(o, kind)
-    parent["iteration"][idx] = I["iterations"][:, 0]
-    parent["burned_in_iteration"][idx] = np.maximum(I["burned_in_iteration"][:, 0], 0)
-    parent["burned_in"][idx] = I["status"][:, 0] == 1
-    parent["multiplier"][idx] = 1.0
-    parent["halfspace/data"][idx] = np.exp(F["log_mean_prior"][:, 0])
+    parent["iteration"][sel] = I["iterations"][:, 0]
+    parent["burned_in_iteration"][sel] = np.maximum(I["burned_in_iteration"][:, 0], 0)
+    parent["burned_in"][sel] = I["status"][:, 0] == 1
+    parent["multiplier"][sel] = 1.0
+    parent["halfspace/data"][sel] = np.exp(F["log_mean_prior"][:, 0])
     d = parent["data"]
     for key in ("x", "y", "z", "elevation", "line_number"):
-        d[key + "/data"][idx] = F[key][:, 0]
-    d["data/data"][idx, :] = F["data"]
-    d["predicted_data/data"][idx, :] = F["predicted"]
+        d[key + "/data"][sel] = F[key][:, 0]
+    d["data/data"][sel, :] = F["data"]
+    d["predicted_data/data"][sel, :] = F["predicted"]
     if not td:
-        d["std/data"][idx, :] = np.sqrt((F["relative_error"] * F["data"]) ** 2.0 + F["additive_error"] ** 2.0)
-        d["relative_error/data"][idx] = F["relative_error"][:, 0]
-        d["additive_error/data"][idx] = F["additive_error"][:, 0]
-        d["relative_error/posterior/values/data"][idx, :] = I["rel_hist"]
-        d["additive_error/posterior/values/data"][idx, :] = I["add_hist"]
-        d["relative_error/posterior/mesh/y/relative_to/data"][idx] = rel_axes[0][1]
-        d["additive_error/posterior/mesh/y/relative_to/data"][idx] = add_axes[0][1]
+        d["std/data"][sel, :] = np.sqrt((F["relative_error"] * F["data"]) ** 2.0 + F["additive_error"] ** 2.0)
+        d["relative_error/data"][sel] = F["relative_error"][:, 0]
+        d["additive_error/data"][sel] = F["additive_error"][:, 0]
+        d["relative_error/posterior/values/data"][sel, :] = I["rel_hist"]
+        d["additive_error/posterior/values/data"][sel, :] = I["add_hist"]
+        d["relative_error/posterior/mesh/y/relative_to/data"][sel] = rel_axes[0][1]
+        d["additive_error/posterior/mesh/y/relative_to/data"][sel] = add_axes[0][1]
         if height:
-            d["z/data"][idx] = F["best_height"][:, 0]
-            d["z/posterior/values/data"][idx, :] = I["height_hist"]
-            d["z/posterior/mesh/y/relative_to/data"][idx] = F["height0"][:, 0]
+            d["z/data"][sel] = F["best_height"][:, 0]
+            d["z/posterior/values/data"][sel, :] = I["height_hist"]
+            d["z/posterior/mesh/y/relative_to/data"][sel] = F["height0"][:, 0]
     else:
         tempest = kind == "tempest"
         one = lambda a: a if a.shape[1] > 1 else a[:, 0]
-        d["std/data"][idx, :] = F["std"]
-        d["relative_error/data"][idx] = one(F["relative_error"])
+        d["std/data"][sel, :] = F["std"]
+        d["relative_error/data"][sel] = one(F["relative_error"])
         add_name = "additive_error_multiplier" if tempest else "additive_error"
-        d[add_name + "/data"][idx] = one(F["additive_error"])
+        d[add_name + "/data"][sel] = one(F["additive_error"])
         if tempest and channel_additive is not None:
-            d["additive_error/data"][idx, :] = np.broadcast_to(np.asarray(channel_additive, dtype=np.float64), (idx.size, N))
+            d["additive_error/data"][sel, :] = np.broadcast_to(np.asarray(channel_additive, dtype=np.float64), (idx.size, N))
         rh, ah = I["rel_hist"].reshape(idx.size, n_rel, -1), I["add_hist"].reshape(idx.size, n_add, -1)
         for g in range(n_rel):
-            d["relative_error/posterior{}/values/data".format(g)][idx, :] = rh[:, g]
-            d["relative_error/posterior{}/mesh/y/relative_to/data".format(g)][idx] = rel_axes[g][1]
+            d["relative_error/posterior{}/values/data".format(g)][sel, :] = rh[:, g]
+            d["relative_error/posterior{}/mesh/y/relative_to/data".format(g)][sel] = rel_axes[g][1]
         for g in range(n_add):
-            d[add_name + "/posterior{}/values/data".format(g)][idx, :] = ah[:, g]
-            d[add_name + "/posterior{}/mesh/y/relative_to/data".format(g)][idx] = add_axes[g][1]
+            d[add_name + "/posterior{}/values/data".format(g)][sel, :] = ah[:, g]
+            d[add_name + "/posterior{}/mesh/y/relative_to/data".format(g)][sel] = add_axes[g][1]
         # Tempest channels hold primary + secondary (Tempest_datapoint.py:106-123); the fields are stored apart as well
         nc = max(1, n_primary)
         per = N // nc
         prim = np.repeat(F["primary"], per, axis=1) if (tempest and n_primary) else 0.0
         ppri = np.repeat(F["predicted_primary"], per, axis=1) if (tempest and n_primary) else 0.0
-        d["secondary_field/data"][idx, :] = F["data"] - prim
-        d["predicted_secondary_field/data"][idx, :] = F["predicted"] - ppri
+        d["secondary_field/data"][sel, :] = F["data"] - prim
+        d["predicted_secondary_field/data"][sel, :] = F["predicted"] - ppri
         if n_primary and tempest:                # (SkyTEM files carry no primary-field columns; the reference leaves those rows at their fill)
-            d["primary_field/data"][idx] = one(F["primary"])
-            d["predicted_primary_field/data"][idx] = one(F["predicted_primary"])
+            d["primary_field/data"][sel] = one(F["primary"])
+            d["predicted_primary_field/data"][sel] = one(F["predicted_primary"])
         la = np.array(F["loop_angles"], dtype=np.float64)
         cols_ = {"tx_pitch": 0, "tx_roll": 1, "tx_yaw": 2, "rx_pitch": 3, "rx_roll": 4, "rx_yaw": 5}
         for name, _ in angles:                                   # sampled angles: the best state's instead of the file's
             la[:, cols_[name]] = F["best_" + name][:, 0]
-        _write_loop_pair(d, idx, F["x"][:, 0], F["y"][:, 0], F["z"][:, 0], (F["offset"][:, 0], F["offset"][:, 1], F["offset"][:, 2]),
+        _write_loop_pair(d, sel, F["x"][:, 0], F["y"][:, 0], F["z"][:, 0], (F["offset"][:, 0], F["offset"][:, 1], F["offset"][:, 2]),
                          la, loop_radius)
         for name, _ in angles:
             grp = "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
-            d[grp + "/posterior/values/data"][idx, :] = I[name + "_hist"]
-            d[grp + "/posterior/mesh/y/relative_to/data"][idx] = F[name + "_centre"][:, 0]
+            d[grp + "/posterior/values/data"][sel, :] = I[name + "_hist"]
+            d[grp + "/posterior/mesh/y/relative_to/data"][sel] = F[name + "_centre"][:, 0]
     m = parent["model"]
     k = I["best_k"][:, 0]
-    m["mesh/nCells/data"][idx] = k
-    m["mesh/nCells/posterior/values/data"][idx, :] = I["k_hist"]
+    m["mesh/nCells/data"][sel] = k
+    m["mesh/nCells/posterior/values/data"][sel, :] = I["k_hist"]
     rows = np.full((idx.size, K + 1), np.nan)
     vals = np.full((idx.size, K), np.nan)
     for j in range(idx.size):
         kj = int(k[j])
         rows[j, :kj + 1] = np.r_[0.0, F["best_edges"][j, :kj - 1], np.inf]
         vals[j, :kj] = F["best_sigma"][j, :kj]
-    m["mesh/y/edges/data"][idx, :] = rows
-    m["mesh/y/edges/posterior/values/data"][idx, :] = I["edge_hist"]
-    m["values/data"][idx, :] = vals
+    m["mesh/y/edges/data"][sel, :] = rows
+    m["mesh/y/edges/posterior/values/data"][sel, :] = I["edge_hist"]
+    m["values/data"][sel, :] = vals
     if hitmap:
-        m["values/posterior/values/data"][idx, :, :] = I["hitmap"].reshape(idx.size, n_value, n_depth)
-    m["values/posterior/mesh/y/relative_to/data"][idx] = F["log_mean_prior"][:, 0] / np.log(10.0)
+        m["values/posterior/values/data"][sel, :, :] = I["hitmap"].reshape(idx.size, n_value, n_depth)
+    m["values/posterior/mesh/y/relative_to/data"][sel] = F["log_mean_prior"][:, 0] / np.log(10.0)

@@ -337,26 +337,43 @@ def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
     line_col = [n_ for n_, _ in ff].index("line_number")
     fid_col = [n_ for n_, _ in ff].index("fiducial")
     # the blocks were moved to host memory when they finished (payload): concatenating them costs host memory only
-    cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt)
-    rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, wf, torch.float64), cat(2, wi, torch.int32)
-    assert f_t.shape[1] == wf and i_t.shape[1] == wi
-    if dc.device.type != "cpu" and torch.distributed.is_initialized() and torch.distributed.get_backend() != "gloo":
-        rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
+    def all_rows():
+        if not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+            for rows_b, f_b, i_b in shipped:       # one process: block by block, as views -- no second copy of the hit maps
+                assert f_b.shape[1] == wf and i_b.shape[1] == wi
+                yield from stream_rows_to_root(rows_b, [f_b, i_b], chunk_rows=64)
+            return
+        # several ranks: ONE exchange (every rank enters it once, whatever number of blocks the dynamic schedule gave it)
+        cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt)
+        rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, wf, torch.float64), cat(2, wi, torch.int32)
+        assert f_t.shape[1] == wf and i_t.shape[1] == wi
+        if dc.device.type != "cpu" and torch.distributed.get_backend() != "gloo":
+            rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
+        yield from stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64)
+
     lines, paths = {}, []
     wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
                loop_radius=ds.system[0].loopRadius() if td else 0.0, channel_additive=o.get("initial_additive_error") if kind == "tempest" else None,
                height=height, angles=angles)
 
+    # finished lines are compressed and written by a few host threads (zlib releases the interpreter lock) while the next rows
+    # arrive; at most `workers` lines wait for their turn, so rank 0 still holds a bounded number of lines
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+    pool, pending = ThreadPoolExecutor(max_workers=workers), []
+
     def close(ln):
         root, fid, path, _ = lines.pop(ln)
         if isinstance(root, hdf.NpzGroup):
-            root.save(path)                        # numpy appends .npz: <line>.h5.npz (+ <line>.h5.attrs.json)
+            while len(pending) >= 2 * workers:
+                pending.pop(0).result()
+            pending.append(pool.submit(root.save, path))   # <line>.h5.npz (+ <line>.h5.attrs.json)
             paths.append(path + ".npz")
         else:
             root.close()
             paths.append(path)
 
-    for rows_np, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
+    for rows_np, (f, i) in all_rows():
         for ln in np.unique(f[:, line_col]):
             if ln not in lines:
                 fid = np.sort(ds.fiducial[ds.lineNumber == ln])
@@ -372,6 +389,9 @@ def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
                 close(ln)
     for ln in list(lines):
         close(ln)
+    for job in pending:
+        job.result()                               # (re-raises what a writer thread raised)
+    pool.shutdown()
     return paths
 
 
