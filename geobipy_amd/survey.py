@@ -318,81 +318,97 @@ def _container_kind(ds):
     return "tempest" if isinstance(ds, TempestData) else ("tdem" if isinstance(ds, TdemData) else "fdem")
 
 
-def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
-    """Rank 0 receives every rank's rows chunk by chunk and fills one container per flight line (geobipy_amd.hdf); a line's
-    container is written out and dropped as soon as its last sounding has arrived, so rank 0 holds the open lines only."""
-    import torch
-    from . import hdf
-    from .distributed import stream_rows_to_root
-    os.makedirs(directory, exist_ok=True)
-    K, N, nd, nv = dc.K, dc.N, dc.n_depth_bins, dc.n_value_bins
-    kind = _container_kind(ds)
-    td = kind != "fdem"
-    n_primary = (ds.primary_field.shape[1] if getattr(ds, "primary_field", None) is not None else 0) if td else 0
-    height = bool(getattr(dc, "solve_height", False))
-    angles = tuple((m_[0], m_[5]) for m_ in (getattr(dc, "_moves", None) or ()))
-    fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles)
-    ff, fi = hdf.device_row_fields(N, K, nd, nv, **fkw)
-    wf, wi = sum(w for _, w in ff), sum(w for _, w in fi)
-    line_col = [n_ for n_, _ in ff].index("line_number")
-    fid_col = [n_ for n_, _ in ff].index("fiducial")
-    # the blocks were moved to host memory when they finished (payload): concatenating them costs host memory only
-    def all_rows():
-        if not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
-            for rows_b, f_b, i_b in shipped:       # one process: block by block, as views -- no second copy of the hit maps
-                assert f_b.shape[1] == wf and i_b.shape[1] == wi
-                yield from stream_rows_to_root(rows_b, [f_b, i_b], chunk_rows=64)
-            return
-        # several ranks: ONE exchange (every rank enters it once, whatever number of blocks the dynamic schedule gave it)
-        cat = lambda j, w, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, w) if w else (0,), dtype=dt)
-        rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, wf, torch.float64), cat(2, wi, torch.int32)
-        assert f_t.shape[1] == wf and i_t.shape[1] == wi
-        if dc.device.type != "cpu" and torch.distributed.get_backend() != "gloo":
-            rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
-        yield from stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64)
+class _LineWriter:
+    """Fills one results container per flight line (geobipy_amd.hdf) from chunks of device rows; a line's container is compressed and
+    written out by a writer thread, and dropped, as soon as its last sounding has arrived -- what is held is the open lines."""
 
-    lines, paths = {}, []
-    wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
-               loop_radius=ds.system[0].loopRadius() if td else 0.0, channel_additive=o.get("initial_additive_error") if kind == "tempest" else None,
-               height=height, angles=angles)
+    def __init__(self, directory, ds, o, dc, hitmap):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import hdf
+        os.makedirs(directory, exist_ok=True)
+        self.hdf, self.directory, self.ds, self.o, self.hitmap = hdf, directory, ds, o, hitmap
+        self.K, self.N, self.nd, self.nv = dc.K, dc.N, dc.n_depth_bins, dc.n_value_bins
+        kind = self.kind = _container_kind(ds)
+        td = kind != "fdem"
+        n_primary = (ds.primary_field.shape[1] if getattr(ds, "primary_field", None) is not None else 0) if td else 0
+        height = bool(getattr(dc, "solve_height", False))
+        angles = tuple((m_[0], m_[5]) for m_ in (getattr(dc, "_moves", None) or ()))
+        fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles)
+        ff, fi = hdf.device_row_fields(self.N, self.K, self.nd, self.nv, **fkw)
+        self.wf, self.wi = sum(w for _, w in ff), sum(w for _, w in fi)
+        self.line_col = [n_ for n_, _ in ff].index("line_number")
+        self.fid_col = [n_ for n_, _ in ff].index("fiducial")
+        self.wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
+                        loop_radius=ds.system[0].loopRadius() if td else 0.0,
+                        channel_additive=o.get("initial_additive_error") if kind == "tempest" else None, height=height, angles=angles)
+        self.lines, self.paths = {}, []
+        # finished lines are compressed and written by a few host threads (zlib releases the interpreter lock) while the next rows
+        # arrive; at most 2 x workers lines wait for their turn, so the process still holds a bounded number of lines
+        self.workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+        self.pool, self.pending = ThreadPoolExecutor(max_workers=self.workers), []
 
-    # finished lines are compressed and written by a few host threads (zlib releases the interpreter lock) while the next rows
-    # arrive; at most `workers` lines wait for their turn, so rank 0 still holds a bounded number of lines
-    from concurrent.futures import ThreadPoolExecutor
-    workers = max(1, min(8, (os.cpu_count() or 2) - 1))
-    pool, pending = ThreadPoolExecutor(max_workers=workers), []
-
-    def close(ln):
-        root, fid, path, _ = lines.pop(ln)
-        if isinstance(root, hdf.NpzGroup):
-            while len(pending) >= 2 * workers:
-                pending.pop(0).result()
-            pending.append(pool.submit(root.save, path))   # <line>.h5.npz (+ <line>.h5.attrs.json)
-            paths.append(path + ".npz")
+    def _close(self, ln):
+        root, fid, path, _ = self.lines.pop(ln)
+        if isinstance(root, self.hdf.NpzGroup):
+            while len(self.pending) >= 2 * self.workers:
+                self.pending.pop(0).result()
+            self.pending.append(self.pool.submit(root.save, path))   # <line>.h5.npz (+ <line>.h5.attrs.json)
+            self.paths.append(path + ".npz")
         else:
             root.close()
-            paths.append(path)
+            self.paths.append(path)
 
-    for rows_np, (f, i) in all_rows():
-        for ln in np.unique(f[:, line_col]):
-            if ln not in lines:
+    def add(self, f, i):
+        """Rows of hdf.device_row_fields (numpy [m, wf] float64, [m, wi] int32) of any lines."""
+        hdf, ds = self.hdf, self.ds
+        for ln in np.unique(f[:, self.line_col]):
+            if ln not in self.lines:
                 fid = np.sort(ds.fiducial[ds.lineNumber == ln])
-                path = os.path.join(directory, "{}.h5".format(ln))
+                path = os.path.join(self.directory, "{}.h5".format(ln))
                 root = hdf.open_results(path)
-                hdf.create_inference1d(root, hdf.LineSpec(ds.system, N, o, n_value_bins=nv, kind=kind), add_axis=fid)
-                lines[ln] = [root, fid, path, 0]
-            root, fid, _, _ = lines[ln]
-            m = f[:, line_col] == ln
-            hdf.write_device_rows(root, np.searchsorted(fid, f[m, fid_col]), f[m], i[m], N, K, nd, nv, o, **wkw)
-            lines[ln][3] += int(m.sum())
-            if lines[ln][3] >= fid.size:
-                close(ln)
-    for ln in list(lines):
-        close(ln)
-    for job in pending:
-        job.result()                               # (re-raises what a writer thread raised)
-    pool.shutdown()
-    return paths
+                hdf.create_inference1d(root, hdf.LineSpec(ds.system, self.N, self.o, n_value_bins=self.nv, kind=self.kind), add_axis=fid)
+                self.lines[ln] = [root, fid, path, 0]
+            root, fid, _, _ = self.lines[ln]
+            m = f[:, self.line_col] == ln
+            every = bool(m.all())                   # (a chunk of one line: the rows as they are, no masked copy of the hit maps)
+            fm, im = (f, i) if every else (f[m], i[m])
+            hdf.write_device_rows(root, np.searchsorted(fid, fm[:, self.fid_col]), fm, im, self.N, self.K, self.nd, self.nv, self.o, **self.wkw)
+            self.lines[ln][3] += int(m.sum())
+            if self.lines[ln][3] >= fid.size:
+                self._close(ln)
+
+    def add_block(self, block):
+        """One finished block of this process (payload(): rows, float64 rows, int32 rows on the host), 64 rows at a time."""
+        from .distributed import stream_rows_to_root
+        rows_b, f_b, i_b = block
+        assert f_b.shape[1] == self.wf and i_b.shape[1] == self.wi
+        for _, (f, i) in stream_rows_to_root(rows_b, [f_b, i_b], chunk_rows=64):
+            self.add(f, i)
+
+    def finish(self):
+        for ln in list(self.lines):
+            self._close(ln)
+        for job in self.pending:
+            job.result()                           # (re-raises what a writer thread raised)
+        self.pool.shutdown()
+        return self.paths
+
+
+def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
+    """Several ranks: rank 0 receives every rank's rows chunk by chunk (ONE exchange: every rank enters it once, whatever number of
+    blocks the dynamic schedule gave it) and fills the line containers (_LineWriter).  (One process writes its blocks as they
+    finish: infer.)"""
+    import torch
+    from .distributed import stream_rows_to_root
+    w = _LineWriter(directory, ds, o, dc, hitmap)
+    cat = lambda j, wd, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, wd) if wd else (0,), dtype=dt)
+    rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, w.wf, torch.float64), cat(2, w.wi, torch.int32)
+    assert f_t.shape[1] == w.wf and i_t.shape[1] == w.wi
+    if dc.device.type != "cpu" and torch.distributed.is_initialized() and torch.distributed.get_backend() != "gloo":
+        rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
+    for _, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
+        w.add(f, i)
+    return w.finish()
 
 
 def select_soundings(ds, index=None, fiducial=None, line_number=None):
@@ -601,7 +617,13 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         out = None
         for off, idx in blocks:
             dc, named = run_block(idx, off)
-            if results_directory is not None:
+            if results_directory is not None and world == 1:
+                # one process: the block's rows go to the line containers now and are dropped (host memory holds the open lines,
+                # not the survey's hit maps)
+                if state.get("writer") is None:
+                    state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
+                state["writer"].add_block(payload(dc, idx))
+            elif results_directory is not None:
                 shipped.append(payload(dc, idx))
             part = torch.cat([v for _, v in named], dim=1).contiguous()
             state.update(iterations=max(state["iterations"], dc.iteration), dc=dc, named=named)
@@ -638,7 +660,11 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         it = torch.tensor([iterations_run], dtype=torch.int64, device=dc.device)
         dist.all_reduce(it, op=dist.ReduceOp.MAX)
         iterations_run = int(it)
-    if results_directory is not None:
+    if results_directory is not None and world == 1:
+        if state.get("writer") is None:             # (no sounding at all: the empty set of containers)
+            state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
+        state["writer"].finish()
+    elif results_directory is not None:
         _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
     if rank != 0:
         return None

@@ -1,6 +1,6 @@
 """End-to-end time of a survey inversion (CSV -> chains on the device -> results containers): a synthetic Resolve survey of
 N soundings built from the reference's wedge file (rows repeated with 2 % noise), the options of tests/golden/resolve_options_small.
-python scripts/bench_survey.py [N] [n_markov_chains] [lines]"""
+python scripts/bench_survey.py [N] [n_markov_chains] [lines]     (SURVEY_CHUNK=n: the dynamic schedule in chunks of n soundings)"""
 import os, sys, time, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,8 @@ ds = survey.FdemData.read_csv(os.path.join(d, "survey.csv"), os.path.join(G, "re
 t1 = time.perf_counter()
 import torch
 res = survey.infer(os.path.join(G, "resolve_options_small"), data=ds, n_markov_chains=n_mc, burn_in_min_iterations=n_mc // 4,
-                   results_directory=os.path.join(d, "out"), output=os.path.join(d, "summary.npz"))
+                   results_directory=os.path.join(d, "out"), output=os.path.join(d, "summary.npz"),
+                   **(dict(schedule="dynamic", chunk=int(os.environ["SURVEY_CHUNK"])) if "SURVEY_CHUNK" in os.environ else {}))
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 size = sum(os.path.getsize(os.path.join(d, "out", f)) for f in os.listdir(os.path.join(d, "out")))
