@@ -241,7 +241,27 @@ class FdemDataPoint:
         if self.engine is not None:
             self._sensitivity_matrix = np.asarray(self.engine.sensitivity(*self._engine_model(mod), **self._engine_height()))
             return self._sensitivity_matrix
-        self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0][:, : int(mod.mesh.nCells)]
+        import torch
+        from . import _lib
+        from .system import DEFAULT_HANKEL_EPS_PPM
+        ws = self._workspace()
+        L = self._pack(ws, mod)
+        if L is None:                       # deeper than the packed workspace: generic path
+            self._sensitivity_matrix = self._batch(mod).sensitivity().cpu().numpy()[0][:, : int(mod.mesh.nCells)]
+            return self._sensitivity_matrix
+        # the entry, handle and arguments FdemBatch.sensitivity uses for this sounding (abscissa window of its altitude), on the packed
+        # workspace: one copy in, one launch, one copy out
+        N, Lc = self.nChannels, self._LCAP
+        if "J" not in ws:
+            ws["J"] = torch.empty((N, Lc), dtype=torch.float64, device="cuda")
+            ws["J_host"] = torch.empty((N, Lc), dtype=torch.float64).pin_memory()
+        handle = self._system[0].handle_binned(DEFAULT_HANKEL_EPS_PPM, float(self.z[0]), float(self.z[0]))
+        base, es = ws["dev"].data_ptr(), 8
+        _lib.check(_lib.load().gbp_fdem_sensitivity_ex(handle.ptr, 1, Lc, ws["nl"].data_ptr(), base, base + es * Lc, base + es * 2 * Lc,
+                                                       ws["J"].data_ptr(), L, 0, torch.cuda.current_stream().cuda_stream))
+        ws["J_host"].copy_(ws["J"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        self._sensitivity_matrix = ws["J_host"].numpy()[:, :L].copy()
         return self._sensitivity_matrix
 
     def fm_dlogc(self, mod):

@@ -44,11 +44,65 @@ class GpuEngine:
         J = b.sensitivity(max_layers=int(nl.max()), exact=self.exact).cpu().numpy()
         return [J[i][:, : nl[i]] for i in range(len(models))]
 
+    # One sounding at a time -- what the serial, reference-signature loop asks for thousands of times: a persistent B = 1 workspace
+    # (one pinned staging buffer -> ONE copy in, the same entries FdemBatch calls with the same arguments, one copy out) instead of
+    # a fresh FdemBatch with four small uploads per request.  Same kernels, same values.
+    def _single(self, edges, values, z):
+        import torch
+        from . import _lib
+        from .system import DEFAULT_HANKEL_EPS_PPM
+        L, Lc = int(np.size(values)), self.lmax
+        if L > Lc:
+            return None
+        ws = getattr(self, "_ws", None)
+        if ws is None:
+            if not torch.cuda.is_available():
+                raise _lib.NativeLibraryError("GpuEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+            _lib.load()
+            N = 2 * self.system.nFrequencies
+            ws = self._ws = dict(
+                host=torch.zeros(2 * Lc + 1, dtype=torch.float64).pin_memory(), dev=torch.zeros(2 * Lc + 1, dtype=torch.float64, device="cuda"),
+                nl_host=torch.ones(1, dtype=torch.int32).pin_memory(), nl=torch.ones(1, dtype=torch.int32, device="cuda"),
+                pred=torch.empty(N, dtype=torch.float64, device="cuda"), pred_host=torch.empty(N, dtype=torch.float64).pin_memory(),
+                J=torch.empty((N, Lc), dtype=torch.float64, device="cuda"), J_host=torch.empty((N, Lc), dtype=torch.float64).pin_memory(), N=N)
+        h = ws["host"].numpy()
+        h[:L] = values
+        h[Lc:Lc + L - 1] = np.diff(np.r_[0.0, edges])
+        h[Lc + L - 1:2 * Lc] = 0.0
+        h[2 * Lc] = self.z if z is None else float(z)
+        ws["nl_host"][0] = L
+        ws["nl"].copy_(ws["nl_host"], non_blocking=True)
+        ws["dev"].copy_(ws["host"], non_blocking=True)
+        ws["handle"] = self.system.handle_binned(DEFAULT_HANKEL_EPS_PPM, float(h[2 * Lc]), float(h[2 * Lc]))   # (cached by the system)
+        return ws, L
+
     def forward(self, edges, values, z=None):
-        return self.forward_many([(edges, values)], None if z is None else [z])[0]
+        one = self._single(edges, values, z)
+        if one is None:                      # deeper than the workspace: the batch path
+            return self.forward_many([(edges, values)], None if z is None else [z])[0]
+        import torch
+        from . import _lib
+        ws, L = one
+        base, Lc = ws["dev"].data_ptr(), self.lmax
+        _lib.check(_lib.load().gbp_fdem_forward_ex(ws["handle"].ptr, 1, Lc, ws["nl"].data_ptr(), base, base + 8 * Lc, base + 16 * Lc,
+                                                   ws["pred"].data_ptr(), 0, torch.cuda.current_stream().cuda_stream))
+        ws["pred_host"].copy_(ws["pred"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return ws["pred_host"].numpy().copy()
 
     def sensitivity(self, edges, values, z=None):
-        return self.sensitivity_many([(edges, values)], None if z is None else [z])[0]
+        one = self._single(edges, values, z)
+        if one is None:
+            return self.sensitivity_many([(edges, values)], None if z is None else [z])[0]
+        import torch
+        from . import _lib
+        ws, L = one
+        base, Lc = ws["dev"].data_ptr(), self.lmax
+        _lib.check(_lib.load().gbp_fdem_sensitivity_ex(ws["handle"].ptr, 1, Lc, ws["nl"].data_ptr(), base, base + 8 * Lc, base + 16 * Lc,
+                                                       ws["J"].data_ptr(), L, 1 if self.exact else 0, torch.cuda.current_stream().cuda_stream))
+        ws["J_host"].copy_(ws["J"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return ws["J_host"].numpy()[:, :L].copy()
 
 
 OPTION_DEFAULTS = dict(covariance_scaling=1.0, gradient_standard_deviation=1.5, factor=10.0, minimum_thickness=1.0,
