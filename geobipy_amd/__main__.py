@@ -32,9 +32,10 @@ def parse(argv=None):
     p.add_argument("--no-containers", action="store_true",
                    help="skip the reference-layout results containers (<line>.h5, or <line>.h5.npz without h5py); the per-line "
                         "summary files <line>.npz are always written")
-    p.add_argument("--schedule", choices=("static", "dynamic"), default="static",
+    p.add_argument("--schedule", choices=("static", "dynamic", "lines"), default="static",
                    help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
-                        "(the reference's master / worker scheduling)")
+                        "(the reference's master / worker scheduling); lines: whole flight lines per rank, each rank writes the "
+                        "results containers of its own lines")
     p.add_argument("--chunk", type=int, default=None, help="soundings per chunk of the dynamic schedule")
     a = p.parse_args(argv)
     if a.seed is not None:

@@ -158,6 +158,18 @@ def gather_rows(rows, values, N, group=None):
     return out
 
 
+def assign_lines(counts, world):
+    """Whole flight lines to ranks (the "lines" schedule: a rank that owns a line writes that line's results file itself, so no
+    posterior row travels): the longest line first, each to the rank with the fewest soundings so far (ties: the lowest rank).
+    ``counts``: soundings per line -> one ascending list of line indices per rank; deterministic, the same on every rank."""
+    load, out = [0] * world, [[] for _ in range(world)]
+    for i in sorted(range(len(counts)), key=lambda j: (-int(counts[j]), j)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        out[r].append(i)
+        load[r] += int(counts[i])
+    return [sorted(x) for x in out]
+
+
 def stream_rows_to_root(rows, blocks, chunk_rows=64, group=None):
     """Generator for rank 0: (rows int64[m] numpy, [block[m, W_i] numpy ...]) chunk by chunk, over every rank's rows -- the
     bounded-memory exchange for per-sounding payloads too large to gather at once (config 5's conductivity-depth hit maps are

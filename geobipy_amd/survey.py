@@ -379,11 +379,11 @@ class _LineWriter:
 
     def add_block(self, block):
         """One finished block of this process (payload(): rows, float64 rows, int32 rows on the host), 64 rows at a time."""
-        from .distributed import stream_rows_to_root
-        rows_b, f_b, i_b = block
+        _, f_b, i_b = block
         assert f_b.shape[1] == self.wf and i_b.shape[1] == self.wi
-        for _, (f, i) in stream_rows_to_root(rows_b, [f_b, i_b], chunk_rows=64):
-            self.add(f, i)
+        f_np, i_np = f_b.numpy(), i_b.numpy()      # (host tensors: views, no copy of the hit maps; nothing collective here -- ranks
+        for a in range(0, f_np.shape[0], 64):      #  that own whole lines call this as often as they have blocks)
+            self.add(f_np[a:a + 64], i_np[a:a + 64])
 
     def finish(self):
         for ln in list(self.lines):
@@ -436,7 +436,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
-    ``schedule``: "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
+    ``schedule``: "lines" -- whole flight lines per rank, longest first to the least loaded rank (``distributed.assign_lines``): every
+    rank writes the results containers of its own lines and no posterior row travels (the choice for many GPUs with containers);
+    "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
     of ``chunk`` soundings (default: a 16th of a rank's static share, at least 256) from a shared counter until none are left
     (``distributed.ChunkQueue``; the reference's master / worker loop, Inference3D.py:518-635, without a master), which evens
     out the different numbers of iterations soundings need.  Chains are keyed by the sounding's row in the data file, so the
@@ -617,7 +619,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         out = None
         for off, idx in blocks:
             dc, named = run_block(idx, off)
-            if results_directory is not None and world == 1:
+            if results_directory is not None and (world == 1 or schedule == "lines"):
                 # one process: the block's rows go to the line containers now and are dropped (host memory holds the open lines,
                 # not the survey's hit maps)
                 if state.get("writer") is None:
@@ -634,8 +636,29 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             out[torch.as_tensor(idx - first, device=part.device)] = part
         return out
 
-    assert schedule in ("static", "dynamic"), ValueError("schedule must be 'static' or 'dynamic'")
-    if schedule == "static":
+    assert schedule in ("static", "dynamic", "lines"), ValueError("schedule must be 'static', 'dynamic' or 'lines'")
+    if schedule == "lines":
+        # whole flight lines per rank: every rank fills and writes the results files of its own lines (as the reference's ranks write
+        # their own rows, Inference3D.py:586-635), only the one-row summaries are gathered
+        from .distributed import assign_lines, gather_rows
+        change = np.flatnonzero(np.diff(ds.lineNumber) != 0) + 1
+        firsts = np.r_[0, change] if ds.nPoints else np.zeros(0, dtype=np.int64)
+        counts = np.diff(np.r_[firsts, ds.nPoints])
+        if np.unique(ds.lineNumber[firsts]).size != firsts.size:
+            raise ValueError("schedule='lines' needs every flight line in one run of consecutive rows of the data file (use 'static' or 'dynamic')")
+        n = -1                                      # (every block is a selection: chains keyed by chain_id)
+        size = int(chunk) if chunk else 16384       # a long line goes through the device in pieces of this many soundings
+        done_rows, done_vals = [], []
+        for li in assign_lines(counts, world)[rank]:
+            for first in range(int(firsts[li]), int(firsts[li] + counts[li]), size):
+                count = min(size, int(firsts[li] + counts[li]) - first)
+                done_vals.append(process(first, count))
+                done_rows.append(torch.arange(first, first + count, dtype=torch.int64, device=done_vals[-1].device))
+        if not done_vals:                           # more ranks than lines: an empty block fixes the row width and the device
+            done_vals.append(process(0, 0))
+            done_rows.append(torch.zeros(0, dtype=torch.int64, device=done_vals[-1].device))
+        gathered = gather_rows(torch.cat(done_rows), torch.cat(done_vals), ds.nPoints)
+    elif schedule == "static":
         local = process(start, n)
         if world > 1:                               # the one exchange of the job: per-sounding result rows to rank 0
             from .distributed import SummaryGather
@@ -660,7 +683,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         it = torch.tensor([iterations_run], dtype=torch.int64, device=dc.device)
         dist.all_reduce(it, op=dist.ReduceOp.MAX)
         iterations_run = int(it)
-    if results_directory is not None and world == 1:
+    if results_directory is not None and (world == 1 or schedule == "lines"):
         if state.get("writer") is None:             # (no sounding at all: the empty set of containers)
             state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
         state["writer"].finish()

@@ -172,3 +172,13 @@ def test_stream_rows_to_root_gloo(world, N):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def test_whole_lines_go_to_the_least_loaded_rank():
+    from geobipy_amd.distributed import assign_lines
+    assert assign_lines([5, 9, 3, 9, 1], 2) == [[0, 1], [2, 3, 4]]          # 9 | 9, then 5 -> rank 0 (14), 3 and 1 -> rank 1 (13)
+    got = assign_lines([5, 9, 3, 9, 1], 2)
+    assert sorted(i for r in got for i in r) == [0, 1, 2, 3, 4]
+    assert abs(sum([5, 9, 3, 9, 1][i] for i in got[0]) - sum([5, 9, 3, 9, 1][i] for i in got[1])) <= 1
+    assert assign_lines([4], 3) == [[0], [], []] and assign_lines([], 2) == [[], []]
+    assert assign_lines([7, 7, 7], 3) == [[0], [1], [2]]

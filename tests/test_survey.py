@@ -330,7 +330,7 @@ def test_two_ranks_write_the_files_one_rank_writes(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), "-m", "geobipy_amd", OPTIONS, str(two), "--exact-jacobian", "--schedule", "dynamic",
-                        "--chunk", "9"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                        "--chunk", "9"], cwd=root, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-3000:]
     names = sorted(n for n in os.listdir(one) if n.endswith(".npz"))
     assert names == sorted(n for n in os.listdir(two) if n.endswith(".npz")) and any(n.endswith(".h5.npz") for n in names)
@@ -339,6 +339,47 @@ def test_two_ranks_write_the_files_one_rank_writes(tmp_path):
         assert sorted(a.files) == sorted(b.files)
         for k in a.files:
             assert np.array_equal(a[k], b[k], equal_nan=True), (n, k)
+
+
+@pytest.mark.gpu
+def test_ranks_that_own_whole_lines_write_their_own_files(tmp_path):
+    """--schedule lines: three flight lines over two processes (gloo, sharing this GPU) -- each rank inverts whole lines and writes
+    their results containers itself, only the summaries travel -- against the single-process run: every file the same, array for
+    array; and a line that comes back later in the file is refused."""
+    import socket
+    import subprocess
+    import sys
+    from geobipy_amd.__main__ import main
+    raw = open(os.path.join(GOLDEN, "resolve_glacial_clean.csv")).read().splitlines()
+    rows = [r.split(",") for r in raw[1:]]
+    for j, r in enumerate(rows):
+        r[0] = "10.0" if j < 30 else ("20.0" if j < 55 else "30.0")
+    (tmp_path / "lines.csv").write_text("\n".join([raw[0]] + [",".join(r) for r in rows]) + "\n")
+    (tmp_path / "resolve.stm").write_text(open(os.path.join(GOLDEN, "resolve.stm")).read())     # (system_filename is relative to data_directory)
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    common = ["--exact-jacobian", "--data_directory", str(tmp_path), "--data_filename", "lines.csv"]
+    assert main([OPTIONS, str(one)] + common) == 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GBP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "geobipy_amd", OPTIONS, str(two), "--schedule", "lines", "--chunk", "16"] + common,
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    names = sorted(n for n in os.listdir(one) if n.endswith(".npz"))
+    assert names == sorted(n for n in os.listdir(two) if n.endswith(".npz")) and sum(n.endswith(".h5.npz") for n in names) == 3
+    for n in names:
+        a, b = np.load(one / n), np.load(two / n)
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (n, k)
+    ds = survey.FdemData.read_csv(str(tmp_path / "lines.csv"), os.path.join(GOLDEN, "resolve.stm"))
+    ds.lineNumber[70:] = 10.0
+    with pytest.raises(ValueError, match="one run"):
+        survey.infer(OPTIONS, data=ds, schedule="lines")
 
 
 @pytest.mark.gpu
