@@ -264,6 +264,43 @@ def rjmcmc_extra(system, height, obs, device, Btot):
     return out
 
 
+def survey_extra(n_soundings=8192, n_lines=16, n_markov_chains=2000):
+    """The whole user flow around the hot path, timed end to end in this process: a data file read from CSV
+    (the reference's Resolve wedge file, rows repeated with 2 % noise), every sounding inverted under the reference's burn-in / stop
+    schedule, the per-line results containers written.  (scripts/bench_survey.py is the stand-alone form.)"""
+    import shutil, tempfile
+    import torch
+    from geobipy_amd import survey
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    src = os.path.join(golden, "resolve_glacial_clean.csv")
+    hdr = open(src).readline().strip()
+    raw = np.loadtxt(src, delimiter=",", skiprows=1)
+    rng = np.random.default_rng(1)
+    rows = raw[rng.integers(0, raw.shape[0], n_soundings)].copy()
+    rows[:, 6:] *= 1.0 + 0.02 * rng.standard_normal((n_soundings, raw.shape[1] - 6))
+    rows[:, 0] = np.repeat(np.arange(n_lines), -(-n_soundings // n_lines))[:n_soundings] + 100.0
+    rows[:, 1] = np.arange(n_soundings)
+    d = tempfile.mkdtemp()
+    try:
+        np.savetxt(os.path.join(d, "survey.csv"), rows, delimiter=",", header=hdr, comments="")
+        t0 = time.perf_counter()
+        ds = survey.FdemData.read_csv(os.path.join(d, "survey.csv"), os.path.join(golden, "resolve.stm"))
+        res = survey.infer(os.path.join(golden, "resolve_options_small"), data=ds, n_markov_chains=n_markov_chains,
+                           burn_in_min_iterations=n_markov_chains // 4, results_directory=os.path.join(d, "out"),
+                           output=os.path.join(d, "summary.npz"))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        size = sum(os.path.getsize(os.path.join(d, "out", f)) for f in os.listdir(os.path.join(d, "out")))
+        return {"value": n_soundings / dt, "unit": "soundings/s", "soundings": n_soundings, "lines": n_lines, "seconds": dt,
+                "n_markov_chains": n_markov_chains, "burned_in": int((res["status"] == 1).sum()),
+                "mean_iterations": float(np.mean(res["iterations"])), "container_megabytes": size / 1e6,
+                "note": "end to end in one process: CSV read, chains on the device under the reference's burn-in / stop schedule "
+                        "(resolve_options_small, n_markov_chains as stated), hit maps to the host, per-line results containers "
+                        "(reference layout; .npz stand-in, deflate level 1, writer threads) written to a temporary directory"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,6 +627,11 @@ def main():
                                                "22 spline nodes x 19 gates, mean ~4 layers; blocks of 8 192 and 1 024 chains")
             except Exception as e:                               # an extra, never the measurement
                 line["tdem"]["sampler"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras:
+            try:
+                line["survey"] = survey_extra()
+            except Exception as e:                               # an extra, never the measurement
+                line["survey"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))
