@@ -2543,7 +2543,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
     // (scripts/bench_rj_modes.py, mode 1 vs 3: +17 % at 1 024 chains, +4 % at 8 192, -8 % at 65 536, where the forward chains
     // would run at the Jacobian pass's occupancy).
     if (fused && td == nullptr && (long long)B * sys->t.nF < 196608) {
-        // One physics launch per stage (k_rj_physics): 7 launches per iteration and sub-block.  `parts` > 1: the block is cut into
+        // One physics launch per stage (k_rj_physics): 5 - 7 launches per iteration and sub-block (one_stage_launch).  `parts` > 1: the block is cut into
         // that many contiguous sub-blocks which advance CONCURRENTLY, each on a stream of its own, launches issued round-robin --
         // the latency-bound per-chain stages of one sub-block (propose / Newton / accept: 23 + 28 + 38 us at 8 192 chains, one
         // wave per SIMD) overlap the physics of another, and a physics launch of a quarter of the chains has a shorter tail.

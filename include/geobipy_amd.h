@@ -405,8 +405,8 @@ gbp_status gbp_rj_accept(const gbp_rj_options *opt, const gbp_rj_chains *c, int6
  * synchronisation.  `accumulate` != 0 adds every post-step state to the posterior histograms. */
 gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                       int64_t first_iteration, int n_iterations, int accumulate, void *stream);
-/* `mode`: 0 = gbp_rj_run's choice, 1 = lock-step driver (seven stream-ordered launches per iteration over the whole block:
- * propose, the evaluations at the remapped models, Newton (2), the evaluations at the proposals, accept (2)),
+/* `mode`: 0 = gbp_rj_run's choice, 1 = lock-step driver (five to seven stream-ordered launches per iteration over the whole block:
+ * propose, the evaluations at the remapped models, Newton (1 or 2), the evaluations at the proposals, accept (1 or 2)),
  * 2 = persistent kernel (one workgroup owns a chain and loops over all n_iterations in ONE launch; frequency-domain data),
  * 3 = lock-step with one launch per kind of evaluation and layer-count bucket (ten per iteration; what time-domain blocks use),
  * 4 = lock-step as 1, the block cut into 3 contiguous sub-blocks that advance concurrently on streams of their own (a host thread
