@@ -27,8 +27,9 @@ class GpuEngine:
     def _batch(self, models, heights=None):
         n = len(models)
         nl = np.array([v.size for _, v in models], dtype=np.int32)
-        sig = np.ones((n, self.lmax))
-        thk = np.zeros((n, self.lmax))
+        width = max(self.lmax, int(nl.max()) if n else 1)          # (a model deeper than lmax widens the batch instead of failing)
+        sig = np.ones((n, width))
+        thk = np.zeros((n, width))
         for i, (e, v) in enumerate(models):
             sig[i, : v.size] = v
             thk[i, : v.size - 1] = np.diff(np.r_[0.0, e])

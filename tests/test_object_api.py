@@ -164,3 +164,29 @@ def test_reference_accept_reject_body_on_the_gpu_objects():
     d, dp = _datapoint(engine=False)
     assert dp.engine is None
     _check_chain(_setup(dp, d), d, 300)
+
+
+@pytest.mark.gpu
+def test_single_sounding_workspace_equals_the_batch_path():
+    """GpuEngine.forward / sensitivity of one sounding (persistent packed workspace, one copy in and out) and FdemDataPoint.sensitivity
+    return the bits of the FdemBatch path they replace (same entries, same arguments), for shallow and deep models and a moved height;
+    a model deeper than the workspace falls back to the batch path."""
+    from geobipy_amd import FdemSystem, Model, RectilinearMesh1D
+    from geobipy_amd.inference import GpuEngine
+    system = FdemSystem.read(os.path.join(GOLDEN, "resolve.stm"))
+    eng = GpuEngine(system, 30.0, lmax=32)
+    rng = np.random.default_rng(5)
+    for L, z in ((1, None), (3, None), (9, 31.7), (30, None), (32, 28.2)):
+        edges = np.cumsum(rng.uniform(1.0, 8.0, L - 1))
+        values = 10.0 ** rng.uniform(-3.0, 0.0, L)
+        heights = None if z is None else [z]
+        assert np.array_equal(eng.forward(edges, values, z), eng.forward_many([(edges, values)], heights)[0]), L
+        assert np.array_equal(eng.sensitivity(edges, values, z), eng.sensitivity_many([(edges, values)], heights)[0]), L
+    small = GpuEngine(system, 30.0, lmax=4)                       # deeper than its workspace: the batch path, same numbers
+    edges, values = np.cumsum(rng.uniform(1.0, 8.0, 5)), 10.0 ** rng.uniform(-3.0, 0.0, 6)
+    assert small._single(edges, values, None) is None
+    assert np.allclose(small.forward_many([(edges, values)])[0], GpuEngine(system, 30.0, lmax=8).forward(edges, values), rtol=0, atol=1e-9)
+    d, dp = _datapoint(engine=False)
+    mod = Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, 6.0, 15.0, 40.0, np.inf]), values=np.array([0.02, 0.2, 0.004, 0.08]))
+    J = dp.sensitivity(mod).copy()
+    assert np.array_equal(J, dp._batch(mod).sensitivity().cpu().numpy()[0][:, :4]) and J.shape == (12, 4)
