@@ -423,3 +423,56 @@ def test_fallback_container_is_lazy_and_keeps_h5py_indexing_rules(tmp_path):
     assert np.load(str(tmp_path / "c.h5.npz")).files == ["/y"]
     back = hdf.load_npz(str(tmp_path / "c.h5.npz"))
     assert sorted(back) == ["/x", "/y"] and np.all(np.isnan(back["/x"])) and back["/y"].tolist() == [[0, 0], [3, 3]]
+
+
+def test_line_writer_fills_and_writes_one_container_per_line(tmp_path):
+    """survey._LineWriter (what a process feeds its finished blocks to): rows of two flight lines arriving in mixed chunks land in
+    one container per line -- each equal to a container filled by write_device_rows directly --, a line's file is written (by a
+    writer thread, deflate level 1) once its last row is in, and numpy.load / hdf.load_npz read it back."""
+    import types
+    from geobipy_amd import FdemSystem, hdf, survey
+    system = FdemSystem.read(os.path.join(GOLDEN, "resolve.stm"))
+    o = dict(RESOLVE_OPTIONS, n_markov_chains=200, update_plot_every=5000)
+    N, K = 12, int(o["maximum_number_of_layers"])
+    spec = hdf.LineSpec(system, N, o)
+    nd, nv = spec.posteriors.depth_edges.size - 1, spec.posteriors.value_edges.size - 1
+    n = 150
+    line = np.where(np.arange(n) < 90, 7.0, 9.0)
+    fid = np.arange(n, dtype=np.float64) * 2.0
+    ds = types.SimpleNamespace(system=system, lineNumber=line, fiducial=fid, primary_field=None)
+    dc = types.SimpleNamespace(K=K, N=N, n_depth_bins=nd, n_value_bins=nv, n_rel_groups=1, n_add_groups=1)
+    ff, fi = hdf.device_row_fields(N, K, nd, nv)
+    rng = np.random.default_rng(3)
+    f = np.zeros((n, sum(w for _, w in ff))); i = np.zeros((n, sum(w for _, w in fi)), dtype=np.int32)
+    col, c0 = {}, 0
+    for name, w in ff:
+        col[name] = slice(c0, c0 + w); c0 += w
+    c0 = 0
+    for name, w in fi:
+        col["i_" + name] = slice(c0, c0 + w); c0 += w
+    f[:, col["data"]] = rng.uniform(50, 500, (n, N)); f[:, col["predicted"]] = f[:, col["data"]] * 1.01
+    f[:, col["relative_error"]] = 0.05; f[:, col["additive_error"]] = 5.0; f[:, col["log_mean_prior"]] = np.log(0.02)
+    f[:, col["best_edges"]] = np.inf; f[:, col["best_sigma"]] = 1.0; f[:, col["best_sigma"].start] = rng.uniform(0.01, 0.1, n)
+    f[:, col["fiducial"]] = fid[:, None]; f[:, col["line_number"]] = line[:, None]
+    i[:, col["i_status"]] = 1; i[:, col["i_best_k"]] = 1; i[:, col["i_iterations"]] = rng.integers(100, 300, (n, 1))
+    i[:, col["i_hitmap"]] = rng.integers(0, 3, (n, nv * nd)) * (rng.random((n, nv * nd)) < 0.01)
+    w = survey._LineWriter(str(tmp_path), ds, o, dc, True)
+    import torch
+    order = np.r_[np.arange(90, 150), np.arange(0, 90)]                              # line 9 completes before line 7 does
+    for a in range(0, n, 75):
+        sel = order[a:a + 75]
+        w.add_block((torch.as_tensor(sel), torch.as_tensor(f[sel]), torch.as_tensor(i[sel])))
+        if a == 0:
+            assert 9.0 not in w.lines and 7.0 in w.lines                               # closed (and handed to a writer thread) / still open
+    paths = w.finish()
+    assert sorted(os.path.basename(q) for q in paths) == ["7.0.h5.npz", "9.0.h5.npz"]
+    for ln, rows in ((7.0, np.arange(0, 90)), (9.0, np.arange(90, 150))):
+        root = hdf.NpzGroup("/")
+        hdf.create_inference1d(root, hdf.LineSpec(system, N, o), add_axis=fid[rows])
+        hdf.write_device_rows(root, np.arange(rows.size), f[rows], i[rows], N, K, nd, nv, o)
+        want = root.arrays()
+        got = hdf.load_npz(os.path.join(str(tmp_path), "{}.h5".format(ln)))
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k]), equal_nan=True), (ln, k)
+        assert os.path.getsize(os.path.join(str(tmp_path), "{}.h5.npz".format(ln))) < 2_000_000          # (dense hit maps: 39 MB)
