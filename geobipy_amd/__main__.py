@@ -36,7 +36,7 @@ def parse(argv=None):
                    help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
                         "(the reference's master / worker scheduling); lines: whole flight lines per rank, each rank writes the "
                         "results containers of its own lines")
-    p.add_argument("--chunk", type=int, default=None, help="soundings per chunk of the dynamic schedule")
+    p.add_argument("--chunk", type=int, default=None, help="soundings per block on the device (default: 16384 for static and lines; a 16th of a rank's share for dynamic)")
     a = p.parse_args(argv)
     if a.seed is not None:
         a.seed = int(a.seed)

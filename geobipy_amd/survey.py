@@ -436,6 +436,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
+    ``chunk``: soundings per block on the device (default 16 384 for "static" and "lines"; see "dynamic").
     ``schedule``: "lines" -- whole flight lines per rank, longest first to the least loaded rank (``distributed.assign_lines``): every
     rank writes the results containers of its own lines and no posterior row travels (the choice for many GPUs with containers);
     "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
@@ -659,7 +660,14 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             done_rows.append(torch.zeros(0, dtype=torch.int64, device=done_vals[-1].device))
         gathered = gather_rows(torch.cat(done_rows), torch.cat(done_vals), ds.nPoints)
     elif schedule == "static":
-        local = process(start, n)
+        # a rank's block goes through the device in pieces of `chunk` soundings (default 16 384): the posteriors of a piece (440 KB of hit
+        # map per sounding) leave the GPU, and with one process the host, before the next piece runs -- 65 536 soundings: 19.6 s and 16 GB
+        # of host memory in pieces against 24.7 s and 38 GB in one block (scripts/bench_survey.py); the chains are keyed by row either way
+        piece = int(chunk) if chunk else 16384
+        if n > piece:
+            local = torch.cat([process(first, min(piece, start + n - first)) for first in range(start, start + n, piece)])
+        else:
+            local = process(start, n)
         if world > 1:                               # the one exchange of the job: per-sounding result rows to rank 0
             from .distributed import SummaryGather
             g = SummaryGather(ds.nPoints, local.shape[1], local.device)

@@ -34,6 +34,8 @@ res = survey.infer(os.path.join(G, KIND + "_options_small"), data=ds, n_markov_c
                    **(dict(schedule="dynamic", chunk=int(os.environ["SURVEY_CHUNK"])) if "SURVEY_CHUNK" in os.environ else {}))
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+import resource
+peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6                # GB (Linux: KiB)
 size = sum(os.path.getsize(os.path.join(d, "out", f)) for f in os.listdir(os.path.join(d, "out")))
 print(f"{KIND} N={N} n_markov_chains={n_mc} lines={n_lines}: read csv {t1 - t0:.2f} s, infer + containers {t2 - t1:.2f} s "
-      f"({N / (t2 - t1):.0f} soundings/s), containers {size / 1e6:.0f} MB in {len(os.listdir(os.path.join(d, 'out')))} files")
+      f"({N / (t2 - t1):.0f} soundings/s), containers {size / 1e6:.0f} MB in {len(os.listdir(os.path.join(d, 'out')))} files, peak host memory {peak:.1f} GB")

@@ -388,9 +388,11 @@ def test_dynamic_schedule_gives_the_static_result():
     row of the data file, so every number equals the static run's."""
     static = survey.infer(OPTIONS, exact_jacobian=True)
     dyn = survey.infer(OPTIONS, exact_jacobian=True, schedule="dynamic", chunk=5)
-    assert set(static) == set(dyn)
+    pieces = survey.infer(OPTIONS, exact_jacobian=True, chunk=32)          # the static block in pieces of 32 soundings
+    assert set(static) == set(dyn) == set(pieces)
     for k in static:
         assert np.array_equal(np.asarray(static[k]), np.asarray(dyn[k]), equal_nan=True), k
+        assert np.array_equal(np.asarray(static[k]), np.asarray(pieces[k]), equal_nan=True), k
 
 
 @pytest.mark.gpu
