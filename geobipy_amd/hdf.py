@@ -156,17 +156,22 @@ class NpzGroup:
         "__unwritten__", shape / dtype / fill value of the datasets that never were (they are all fill value; ``load_npz``
         puts them back) -- so a container costs what was written to it, not what it pre-allocates."""
         lazy = self.unwritten()
-        # the .npz format (a zip of .npy members: numpy.load reads it), deflate level 1: the hit maps are mostly zeros and shrink
-        # 100-fold at any level, and at numpy's default level 6 compressing a line took ten times as long as inverting it
-        import zipfile
-        file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
-        with zipfile.ZipFile(file, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=1, allowZip64=True) as zf:
-            for name, arr in self.arrays(materialised_only=True).items():
-                with zf.open(name + ".npy", "w", force_zip64=True) as member:
-                    np.lib.format.write_array(member, np.asanyarray(arr), allow_pickle=False)
+        save_npz(path, self.arrays(materialised_only=True))
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
         attrs["__unwritten__"] = lazy
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
+
+
+def save_npz(path, arrays, compresslevel=1):
+    """numpy.savez_compressed with a chosen deflate level: the .npz format (a zip of .npy members, read back by numpy.load).  Level 1:
+    posterior counts and hit maps are mostly zeros and shrink 100-fold at any level, and at numpy's level 6 compressing a flight
+    line's container took ten times as long as inverting the line."""
+    import zipfile
+    file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
+    with zipfile.ZipFile(file, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=compresslevel, allowZip64=True) as zf:
+        for name, arr in arrays.items():
+            with zf.open(name + ".npy", "w", force_zip64=True) as member:
+                np.lib.format.write_array(member, np.asanyarray(arr), allow_pickle=False)
 
 
 def load_npz(path):

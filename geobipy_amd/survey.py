@@ -264,7 +264,8 @@ class SurveyResult(dict):
     the 5 / 50 / 95 % conductivity percentiles per depth cell."""
 
     def save(self, filename):
-        np.savez_compressed(filename, **self)
+        from .hdf import save_npz
+        save_npz(filename, self)               # (.npz, deflate level 1: hdf.save_npz)
 
     @classmethod
     def load(cls, filename):
@@ -286,13 +287,14 @@ class SurveyResult(dict):
 
     def save_lines(self, directory):
         """One file per flight line, ``<line number>.npz`` (the reference writes ``<line number>.h5`` there)."""
+        from .hdf import save_npz
         S = self["line"].size
         paths = []
         for ln in np.unique(self["line"]):
             m = self["line"] == ln
             part = {k: (v[m] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == S else v) for k, v in self.items()}
             paths.append(os.path.join(directory, "{}.npz".format(ln)))
-            np.savez_compressed(paths[-1], **part)
+            save_npz(paths[-1], part)
         return paths
 
 
