@@ -2402,7 +2402,10 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         bool small = false;
         if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
         if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
-        mode = lockstep_parts(c->B) > 1 ? 4 : 1;
+        // (concurrent sub-blocks cost a host thread each and a fork / join of streams per call: they pay from about four iterations per
+        //  call -- 8 192 chains, M chain-iterations/s at 1 / 4 / 16 / 200 iterations per call: 28.5 37.2 40.9 43.1 against 33.3 - 33.7 for
+        //  the one-block driver; 2 048 chains: 11.2 16.0 17.9 19.0 against 15.4 - 15.8)
+        mode = (lockstep_parts(c->B) > 1 && n_iterations >= 4) ? 4 : 1;
     }
     if (mode == 2) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, true, stream);
     return rj_run_lockstep(sys, nullptr, o, c, first_iteration, n_iterations, accumulate, mode != 3, mode == 4 ? std::max(2, lockstep_parts(c->B)) : 1, stream);
