@@ -413,7 +413,8 @@ gbp_status gbp_rj_run(const gbp_fdem_system *sys, const gbp_rj_options *opt, con
  * each for the duration of the call) -- the latency-bound per-chain stages of one overlap the physics of the others: +9 % at 2 048
  * chains, +20 % at 4 096, +25 % at 8 192, +12 % at 16 384.
  * All drivers walk bit-identical chains; small blocks (config 5 split over 8 GPUs: 1 024 chains per GPU) are about twice as
- * fast in mode 2, medium ones (2 048 ... ~20 000 chains) fastest in mode 4, large ones in mode 1.  Mode 0 chooses.  In mode 4 the
+ * fast in mode 2, medium ones (2 048 ... ~20 000 chains) fastest in mode 4 (from about four iterations per call: the sub-blocks'
+ * host threads and stream joins are per call), large ones in mode 1.  Mode 0 chooses.  In mode 4 the
  * launch masks nl_a / nl_c hold one [3, n] block per sub-block instead of one [3, B] array (scratch of an iteration). */
 gbp_status gbp_rj_run_mode(const gbp_fdem_system *sys, const gbp_rj_options *opt, const gbp_rj_chains *c,
                            int64_t first_iteration, int n_iterations, int accumulate, int mode, void *stream);
