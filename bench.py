@@ -315,6 +315,9 @@ def main():
     ap.add_argument("--no-rjmcmc", action="store_true", help="skip the extra full-rjMCMC-step measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra Jacobian and time-domain measurements")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: initialise RCCL with ONE rank and run the N > 1 exchange anyway (side stream + all_gather_into_tensor "
+                         "per round) -- executes the multi-GPU code path on a single-GPU box; not the headline configuration")
     args = ap.parse_args()
 
     import torch
@@ -334,7 +337,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     backend = os.environ.get("GBP_BENCH_BACKEND", "nccl")
-    if world > 1:
+    exchange = world > 1 or args.force_collective          # does a round end with the gather of the summaries?
+    if exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -362,13 +369,13 @@ def main():
     sig_sets = [synthetic.redraw_sigma(Btot, L, seed=synthetic.SEED + 10 + i)[sl] for i in range(N_SIGMA_SETS)]
     batches = [FdemBatch(system, nl[sl], s, thk[sl], height[sl], data=obs, relative_error=rel, additive_error=add,
                          device=device) for s in sig_sets]
-    gather = SummaryGather(Btot, 2, device)
-    side = torch.cuda.Stream(device=device) if world > 1 else None
+    gather = SummaryGather(Btot, 2, device, force_collective=args.force_collective)
+    side = torch.cuda.Stream(device=device) if exchange else None
 
     def round_(i, pending):
         b = batches[i % N_SIGMA_SETS]
         chi2, logl = b.forward_loglike(want_pred=False)
-        if world == 1:
+        if not exchange:
             return None          # single rank: the summaries are already resident on "rank 0"
         # finish the previous round's gather, then start this one on the side stream behind the kernel
         if pending is not None:
@@ -382,7 +389,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if exchange:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -437,7 +444,7 @@ def main():
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
-    if world > 1:
+    if exchange:
         result = gather.finish()
     else:
         last = batches[(n_rounds - 1) % N_SIGMA_SETS]
@@ -485,6 +492,11 @@ def main():
             },
             "finite": bool(torch.isfinite(result).all()),
         }
+        if args.force_collective:
+            last = batches[(n_rounds - 1) % N_SIGMA_SETS]
+            line["forced_collective"] = {"backend": backend, "world": world, "rounds": n_rounds,
+                                         "gathered_equals_local": bool(torch.equal(result, torch.stack([last.chi2, last.logL], dim=1)[:result.shape[0]])),
+                                         "note": "one-rank process group: every round ends with all_gather_into_tensor on a side stream (the N > 1 path)"}
         if world == 1 and not args.no_windowed:
             # the same rounds with ALL 120 abscissae per frequency (FdemBatch(hankel_eps_ppm=0)): what the default's per-sounding
             # abscissa window leaves out is bounded by 1e-12 ppm per output (|rTE| <= 1); measured difference below
@@ -659,7 +671,7 @@ def main():
                                      "max_abs_chi2": float(np.max(np.abs(chi2[:sample].cpu().numpy() - c_ref))),
                                      "max_abs_logL": float(np.max(np.abs(logl[:sample].cpu().numpy() - l_ref)))}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -37,17 +37,21 @@ class SummaryGather:
     without synchronising.
     """
 
-    def __init__(self, N, C, device, group=None):
+    def __init__(self, N, C, device, group=None, force_collective=False):
+        """``force_collective``: issue the collective even in a one-rank group (a one-rank job needs none and skips it by
+        default) -- how the RCCL path (communicator set-up, stream semantics, ``all_gather_into_tensor`` on device buffers) is
+        exercised on a box with ONE GPU (tests/test_rccl_single_gpu.py)."""
         self.N, self.C, self.group = N, C, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collective = self.world > 1 or (bool(force_collective) and dist.is_initialized())
         self.starts, self.sizes = partition(N, self.world)
         self.pad = int(self.sizes.max())
         self.send = torch.zeros((self.pad, C), dtype=torch.float64, device=device)
         # all_gather_into_tensor is the one collective every backend implements natively (RCCL ring /
         # direct all-gather over xGMI); the 16 B/sounding payload makes the extra copies on ranks != 0 free
         self.recv = torch.empty((self.world * self.pad, C), dtype=torch.float64, device=device) \
-            if self.world > 1 else None
+            if self.collective else None
         self.out = torch.empty((N, C), dtype=torch.float64, device=device) if self.rank == 0 else None
 
     def launch(self, *columns):
@@ -55,7 +59,7 @@ class SummaryGather:
         n = int(self.sizes[self.rank])
         for c, col in enumerate(columns):
             self.send[:n, c].copy_(col[:n])
-        if self.world == 1:
+        if not self.collective:
             self.out[:n].copy_(self.send[:n])
             return None
         return dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
@@ -66,7 +70,7 @@ class SummaryGather:
             work.wait()
         if self.rank != 0:
             return None
-        if self.world > 1:
+        if self.collective:
             for r in range(self.world):
                 s, n = int(self.starts[r]), int(self.sizes[r])
                 self.out[s:s + n].copy_(self.recv[r * self.pad: r * self.pad + n])
@@ -119,14 +123,14 @@ class ChunkQueue:
             yield s, min(self.chunk, self.n_items - s)
 
 
-def gather_rows(rows, values, N, group=None):
+def gather_rows(rows, values, N, group=None, force_collective=False):
     """[N, C] on rank 0 (None elsewhere) from every rank's (rows[m] int64, values[m, C] float64): the exchange at the end of a
     dynamically scheduled job, where a rank's rows are not a contiguous block.  Two collectives: the row counts, then one
     ``all_gather_into_tensor`` of blocks padded to the largest count, the row index travelling as an extra column."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev, C = values.device, values.shape[1]
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):      # (force_collective: see SummaryGather)
         if int(rows.numel()) != N or int(torch.unique(rows).numel()) != N:
             raise RuntimeError("gather_rows: every row must arrive exactly once")
         out = torch.full((N, C), float("nan"), dtype=torch.float64, device=dev)

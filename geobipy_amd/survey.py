@@ -572,10 +572,18 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         badd = torch.where(none[:, None], t["add"], t["best_add"]).contiguous()
         pred = torch.empty_like(t["data"])
         chi2, logl = torch.empty_like(t["misfit"]), torch.empty_like(t["misfit"])
+        # sampled attitude angles: the best data point's OWN geometry -- the prediction and the predicted primary field of the
+        # highest-posterior angles, not of the chain's last state / the measured geometry (Inference1D.writeHdf :1076-1088 writes
+        # the best data point: predicted_secondary_field = predictedData - predicted_primary_field there)
+        best_mix = {}
+        best_primary = None
+        if getattr(dc, "_moves", None):
+            bw, boff, best_primary = dc.mix_for_geometry(torch.where(none[:, None], t["geom"], t["best_geom"]))
+            best_mix = dict(weights=bw, offset=boff)
         with torch.cuda.device(dev):                # one batched forward at the best models, through the sampler's own entry
             dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(),
                              t["best_height"] if t.get("best_height") is not None else t["height"], t["data"],
-                             brel, badd, pred, chi2, logl)
+                             brel, badd, pred, chi2, logl, **best_mix)
         host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
         cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
                   brel, badd, t["log_mean_prior"][:, None], be, bs]
@@ -583,7 +591,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             n_pf = ds.primary_field.shape[1] if ds.primary_field is not None else 0
             cols_f += [dc.channel_std(t["data"], brel, badd), host(ds.offsets), host(ds.loop_angles)]
             if n_pf:
-                cols_f += [host(ds.primary_field), torch.as_tensor(dc.predicted_primary(), device=dev).reshape(idx.size, -1)]
+                cols_f += [host(ds.primary_field),
+                           torch.as_tensor(dc.predicted_primary() if best_primary is None else best_primary, device=dev).reshape(idx.size, -1)]
         if getattr(dc, "solve_height", False):
             cols_f += [t["best_height"][:, None], t["height0"][:, None]]
         if getattr(dc, "_moves", None):

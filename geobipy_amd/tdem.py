@@ -808,15 +808,36 @@ class TdemDeviceChains(DeviceChains):
         g = self.t[which]
         return {name: (sg * g[:, e]).clone() for name, e, sg, _, _, _ in self._moves}
 
-    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl):
+    def mix_for_geometry(self, geom_rows):
+        """(mixing weights [B, n_w] on the device, predicted-primary offset [B, N] on the device or None, primary field [B, components]
+        numpy or None) of the GA-AEM tuples ``geom_rows`` [B, 10] in THIS block's basis layout -- e.g. of the highest-posterior
+        attitudes (``t["best_geom"]``) when the results containers are filled: rotations change neither the table sets nor the
+        layout (the layout keeps every basis integral a sampled rotation can switch on), only the weights and the primary field."""
+        g = geom_rows.detach().cpu().numpy() if torch.is_tensor(geom_rows) else np.asarray(geom_rows, dtype=np.float64)
+        gm = GeometryMix(self.td_systems, g, force_basis=tuple(self._gm.basis))
+        assert gm.basis == self._gm.basis and gm.weights.shape[1] == self._mix.weights.shape[1], "a rotation cannot change the basis layout"
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device).contiguous()
+        if self._pred_offset0 is None:
+            return dev(gm.weights), None, None
+        pp = gm.primary_field()
+        reps = np.concatenate([[s_.nwindows] * s_.n_components for s_ in self.td_systems])
+        return dev(gm.weights), dev(np.repeat(pp, reps, axis=1)), pp
+
+    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl, weights=None, offset=None):
+        """``weights`` / ``offset``: per-row mixing weights and predicted-primary offsets to evaluate with instead of the chains'
+        current ones (mix_for_geometry)."""
         td = self._td()
         lib, n = _lib.load(), k.numel()
         nodal = torch.empty((n, self._mix.n_in), dtype=torch.float64, device=self.device)
         _lib.check(lib.gbp_fdem_forward_rows_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
                                                 nodal.data_ptr(), td.table_set, self.forward_waves, self._stream()))
         p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
+        mix = td.mix
+        if weights is not None or offset is not None:
+            mix = self._mix.struct(self._w_rows if weights is None else weights)
+            mix.offset = td.mix.offset if offset is None else offset.data_ptr()
         _lib.check(lib.gbp_td_apply_mix(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(), nodal.data_ptr(),
-                                        None, p.data_ptr(), None, ctypes.byref(td.mix), self._stream()))
+                                        None, p.data_ptr(), None, ctypes.byref(mix), self._stream()))
         rg = self.t["rel_group"].long() if self.t["rel_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         ag = self.t["add_group"].long() if self.t["add_group"] is not None else torch.zeros(data.shape[1], dtype=torch.long, device=self.device)
         sd = torch.sqrt((rel[:, rg] * data) ** 2 + (add[:, ag] * self.t["add_scale"][None, :]) ** 2).contiguous()
@@ -899,7 +920,10 @@ class TdemEngine:
     def fm_dlogc(self, edges, values, geometry=None):
         b, nl = self._batch([(np.asarray(edges, dtype=np.float64), np.asarray(values, dtype=np.float64))], geometry)
         p, J = b.fm_dlogc()
-        return p.cpu().numpy()[0], J.cpu().numpy()[0][:, : nl[0]]
+        p = p.cpu().numpy()[0]
+        if self.total_field:                 # like forward_many: Tempest predictions carry the primary field (which no layer moves)
+            p = p + np.repeat(b.primary_field(), [s_.nwindows for s_ in self.systems for _ in range(s_.n_components)], axis=1)[0]
+        return p, J.cpu().numpy()[0][:, : nl[0]]
 
 
 class TdemDataPoint:
@@ -990,13 +1014,13 @@ class TdemDataPoint:
 
     @property
     def active(self):
-        d = self._data.copy()
+        d = np.array(self.data, dtype=np.float64)              # (Tempest: the TOTAL field, EmDataPoint.active :45-56)
         d[d <= 0.0] = np.nan
         return ~np.isnan(d)
 
     @property
     def deltaD(self):
-        return self._predictedData - self._data
+        return self._predictedData - self.data
 
     # -- engine -------------------------------------------------------------------------------------------------------
     def make_engine(self, lmax=32, hankel_eps=None):
@@ -1073,10 +1097,10 @@ class TdemDataPoint:
     def _loglike(self):
         if self.engine is not None:                      # CPU test tier
             from . import rjmcmc
-            return rjmcmc.gauss_loglike(self._predictedData, self._data, self.std)
+            return rjmcmc.gauss_loglike(self._predictedData, self.data, self.std)
         dev = torch.device("cuda", torch.cuda.current_device())
         t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)[None, :]).to(dev)
-        p, d, sd = t(self._predictedData), t(self._data), t(self.std)
+        p, d, sd = t(self._predictedData), t(self.data), t(self.std)      # (self.data: Tempest's channels hold the total field)
         out = torch.empty(2, dtype=torch.float64, device=dev)
         _lib.check(_lib.load().gbp_gauss_loglike_std(1, self.nChannels, p.data_ptr(), d.data_ptr(), sd.data_ptr(), out.data_ptr(),
                                                      out.data_ptr() + 8, torch.cuda.current_stream(dev).cuda_stream))
@@ -1089,6 +1113,25 @@ class TdemDataPoint:
     def likelihood(self, log):
         ll = self._loglike()[1]
         return np.float64(ll) if log else np.float64(np.exp(ll))
+
+    def find_best_halfspace(self, minConductivity=1e-4, maxConductivity=1e4, nSamples=100):
+        """Half-space Model that best fits the data: brute-force search over ``nSamples`` log-spaced conductivities
+        (EmDataPoint.find_best_halfspace, data/datapoint/EmDataPoint.py:148-186) -- ONE launch over the trial half-spaces here.
+        Like the reference's loop, the search leaves ``predictedData`` at the LAST trial (maxConductivity), not at the best one
+        (EmDataPoint.py:176-183: ``data_misfit()`` right after it is the misfit of that last half-space -- the number the
+        reference's gallery prints, tests/golden/make_tdem_doc_pins.py)."""
+        from . import rjmcmc
+        from .model import Model, RectilinearMesh1D
+        assert maxConductivity > minConductivity, ValueError("Maximum conductivity must be greater than the minimum")
+        c = np.logspace(np.log10(minConductivity), np.log10(maxConductivity), nSamples)
+        none = np.zeros(0)
+        eng = self._eng(1)
+        models = [(none, np.array([ci])) for ci in c]
+        preds = eng.forward_many(models) if hasattr(eng, "forward_many") else np.stack([eng.forward(e, v) for e, v in models])
+        data, std = np.asarray(self.data), self.std
+        phi = [rjmcmc.gauss_loglike(p_, data, std)[0] for p_ in preds]
+        self._predictedData[:] = preds[-1]
+        return Model(mesh=RectilinearMesh1D(edges=np.r_[0.0, np.inf]), values=np.array([c[int(np.argmin(phi))]]))
 
     # -- rjMCMC members (DataPoint.py:454-489, 531-644; TdemDataPoint.py:681, 950-985): error-level priors, proposals, moves -----
     def set_priors(self, relative_error_prior=None, additive_error_prior=None, data_prior=None, **kwargs):

@@ -520,6 +520,21 @@ def test_tempest_survey_recovers_a_wrong_receiver_pitch(tmp_path):
           "done", int((moved["status"] == 1).sum()), "of", S)
     assert np.mean(np.abs(moved["rx_pitch"] - 1.5) < 0.25) >= 0.8 and np.all(np.abs(moved["best_rx_pitch"]) <= 5.0)
     assert np.median(moved["misfit"]) < 0.05 * np.median(fixed["misfit"])
+    # the container describes ONE geometry -- the best data point's own: its predicted primary field and its predicted
+    # secondary field are those of the best model at the best PITCH, recomputed here from scratch
+    bk = moved["best_n_layers"].astype(np.int32)
+    be, bs = moved["best_edges"], moved["best_conductivity"]
+    bthk = np.zeros_like(bs)
+    for i_ in range(S):
+        bthk[i_, : bk[i_] - 1] = np.diff(np.r_[0.0, be[i_, : bk[i_] - 1]])
+    ds.loop_angles[:, 3] = moved["best_rx_pitch"]
+    tb = TdemBatch(ds.system, bk, bs, bthk, ds.z, ds.offsets, attitude=ds.attitude)
+    sec_b, prim_b = tb.forward().cpu().numpy(), tb.primary_field()
+    ds.loop_angles[:, 3] = 0.0
+    assert np.abs(zc_["/data/predicted_primary_field/data"] - prim_b[order]).max() <= 1e-9 * np.abs(prim_b).max()
+    assert np.abs(zc_["/data/predicted_secondary_field/data"] - sec_b[order]).max() <= 1e-8 * np.abs(sec_b).max()
+    level = np.array(ds.system[0].primary_field(*ds.offsets[0]))                    # what the measured (level-flight) geometry would give
+    assert np.abs(zc_["/data/predicted_primary_field/data"] - level[None, :]).max() > 0.1     # ~ 35 fT x sin(1.4 degrees)
     with pytest.raises(NotImplementedError, match="position move"):
         survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_x=True, maximum_receiver_x_change=5.0, receiver_x_proposal_variance=0.01, **kw)
 
