@@ -74,7 +74,12 @@ def measured_traffic(Btot, L, world):
         return None
     path = found[-1]                                   # the latest round's PMC passes
     d = json.load(open(path))["derived"]
+    TRAFFIC_SOURCES["headline"] = os.path.relpath(path, ROOT)
     return d["hbm_fetch_bytes_x2_gfx950_correction"] + d["hbm_write_bytes_raw"]
+
+
+TRAFFIC_SOURCES = {}     # which committed profile each ``traffic`` figure of the line was read from (they are NOT measured in this run:
+                         # PMC counters need rocprofv3 passes of their own -- profiles/run_profile_r4.sh regenerates them)
 
 
 def usable_cores():
@@ -97,6 +102,7 @@ def rjmcmc_traffic(n_chains):
     if not found:
         return None
     d = json.load(open(found[-1]))
+    TRAFFIC_SOURCES[f"rjmcmc_{n_chains}"] = os.path.relpath(found[-1], ROOT)
     return d.get("derived", {}).get("hbm_bytes_per_iteration")
 
 
@@ -105,6 +111,7 @@ def tdem_traffic():
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary_tdem_config4.json")))
     if not found:
         return None
+    TRAFFIC_SOURCES["tdem"] = os.path.relpath(found[-1], ROOT)
     return json.load(open(found[-1])).get("derived", {}).get("hbm_bytes_per_launch")
 
 
@@ -244,6 +251,7 @@ def rjmcmc_extra(system, height, obs, device, Btot):
             q = os.path.join(ROOT, "profiles", "r3", path)
             if os.path.exists(q):
                 d = json.load(open(q))
+                full[name + "__read_from"] = "profiles/r3/" + path + " (committed result of an earlier build, not measured by this run)"
                 full[name] = ([{k: a[k] for k in ("exact_jacobian", "hankel_eps_ppm", "exact_matches", "chains", "drift_median_final")} for a in d]
                               if isinstance(d, list) else d["summary"])
         out["cpu_replay"] = {"chains": n_rep, "iterations": it_rep, "exact_matches": arms["reference_jacobian"]["exact_matches"],
@@ -283,17 +291,26 @@ def survey_extra(n_soundings=8192, n_lines=16, n_markov_chains=2000):
     d = tempfile.mkdtemp()
     try:
         np.savetxt(os.path.join(d, "survey.csv"), rows, delimiter=",", header=hdr, comments="")
-        t0 = time.perf_counter()
-        ds = survey.FdemData.read_csv(os.path.join(d, "survey.csv"), os.path.join(golden, "resolve.stm"))
-        res = survey.infer(os.path.join(golden, "resolve_options_small"), data=ds, n_markov_chains=n_markov_chains,
-                           burn_in_min_iterations=n_markov_chains // 4, results_directory=os.path.join(d, "out"),
-                           output=os.path.join(d, "summary.npz"))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        def once(timings):
+            t0 = time.perf_counter()
+            ds = survey.FdemData.read_csv(os.path.join(d, "survey.csv"), os.path.join(golden, "resolve.stm"))
+            t_csv = time.perf_counter() - t0
+            shutil.rmtree(os.path.join(d, "out"), ignore_errors=True)
+            res = survey.infer(os.path.join(golden, "resolve_options_small"), data=ds, n_markov_chains=n_markov_chains,
+                               burn_in_min_iterations=n_markov_chains // 4, results_directory=os.path.join(d, "out"),
+                               output=os.path.join(d, "summary.npz"), timings=timings)
+            torch.cuda.synchronize()
+            return res, time.perf_counter() - t0, t_csv
+        res, dt, _ = once(None)                    # the number of record: no phase clocks, nothing synchronised for them
+        phases = {}
+        _, dt_p, t_csv = once(phases)              # the same run again with device-synchronised phase clocks
+        phases = dict({"csv_read": t_csv}, **phases)
+        phases["other"] = dt_p - sum(phases.values())
         size = sum(os.path.getsize(os.path.join(d, "out", f)) for f in os.listdir(os.path.join(d, "out")))
         return {"value": n_soundings / dt, "unit": "soundings/s", "soundings": n_soundings, "lines": n_lines, "seconds": dt,
                 "n_markov_chains": n_markov_chains, "burned_in": int((res["status"] == 1).sum()),
                 "mean_iterations": float(np.mean(res["iterations"])), "container_megabytes": size / 1e6,
+                "phases_seconds": {k_: round(v_, 4) for k_, v_ in phases.items()}, "phases_run_seconds": dt_p,
                 "note": "end to end in one process: CSV read, chains on the device under the reference's burn-in / stop schedule "
                         "(resolve_options_small, n_markov_chains as stated), hit maps to the host, per-line results containers "
                         "(reference layout; .npz stand-in, deflate level 1, writer threads) written to a temporary directory"}
@@ -576,8 +593,18 @@ def main():
                              "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true>"), "note": note}
                 del bk
             Jbuf = batches[0].sensitivity()
-            ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 10)
+            ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 100)
+            fpj = flop_per_jacobian_point(L, exact=False) * F * 120
+            achj = Btot * fpj / (ms * 1e-3) / 1e12
+            ptsj = batches[0]._h.bin_points(35.0) if hasattr(batches[0]._h, "bin_points") else batches[0]._h.npoints
             line["jacobian"] = {"value": Btot / ms * 1e3, "unit": "Jacobians/s", "ms_per_launch": ms, "soundings": Btot,
+                                "roofline": {"bound": "fp64_valu", "achieved": achj, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": achj / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": fpj,
+                                             "flop_per_abscissa_point": flop_per_jacobian_point(L, exact=False),
+                                             "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, 8>",
+                                             "frac_of_evaluated_flops": achj / FP64_VECTOR_PEAK_TFLOPS * ptsj / batches[0]._h.npoints,
+                                             "count": "builder's extension of SURVEY 8(d) to the prediction + Jacobian pass (flop_per_jacobian_point: "
+                                                      "same per-operation weights, all 120 abscissae per frequency); 100 timed launches after a 50 ms warm-up"},
                                 "note": "d pred / d ln sigma [2F x L] of the same batch (gbp_fdem_sensitivity, reference expression)"}
             del Jbuf
             golden = os.path.join(ROOT, "tests", "golden")
@@ -594,7 +621,7 @@ def main():
                                    ("skytem_all", ["SkytemHM.stm", "SkytemLM.stm"], dict(hankel_eps=0.0))):
                 systems = [TdemSystem(os.path.join(golden, f)) for f in files]
                 tb = TdemBatch(systems, nlt, sgt, tht, ht, (-13.0, 0.0, 2.0), device=device, **kw)
-                ms = per_call(tb.forward, 10)
+                ms = per_call(tb.forward, 100)
                 nodes = sum(sy.node_frequencies().size * sy.n_components for sy in systems)
                 td[key] = dict(ms=ms, nodes=nodes, gates=tb.nChannels, points=sum(h.npoints for h in tb._h),
                                points_at_35_m=sum(h.bin_points(35.0) for h in tb._h), pred=tb.predicted.clone() if key.startswith("config4") else None)
@@ -610,7 +637,10 @@ def main():
                                          "evals_per_launch": Bt, "kernel_ms": c4["ms"],
                                          "evaluated_flop_per_eval_at_35_m": (72 * Lt + 33) * c4["points_at_35_m"],
                                          "frac_of_evaluated_flops": ach_eval / FP64_VECTOR_PEAK_TFLOPS,
-                                         "kernel": "k_fdem_forward<false> on the spline nodes + k_td_apply (window operator)"},
+                                         "kernel": "k_fdem_forward<false> on the spline nodes + k_td_apply (window operator)",
+                                         "count": "builder's extension of SURVEY 8(d) (which defines the FDEM count only): (72 L + 33) flop per "
+                                                  "(spline node, abscissa) point x 120 abscissae x the system's spline nodes; 100 timed launches "
+                                                  "after a 50 ms warm-up"},
                             "abscissa_window": {"eps_relative": 1e-12, "points_all_abscissae": c4["points"], "points_at_35_m": c4["points_at_35_m"],
                                                 "all_abscissae_value": Bt / td["config4_all"]["ms"] * 1e3,
                                                 "max_rel_diff_to_all_abscissae": d4},
@@ -621,6 +651,31 @@ def main():
                                     "counts the algorithmic flops of all 120 abscissae, as the headline's does; parity against the reference's CSV known "
                                     "answers: every gate within 1e-3 |ref| + 7e-5 peak (Tempest) / 1e-2 |ref| + 4e-5 peak, median 6e-4 (SkyTEM), "
                                     "tests/test_tdem.py, scripts/tdem_study/README.md"}
+            # parity of the time-domain half against REAL gatdaem1d numbers (the reference's rendered gallery:
+            # tests/golden/make_tdem_doc_pins.py, tests/test_tdem_doc_pins.py), per quantity, from this GPU in this run
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import test_tdem_doc_pins as tp
+                pins = np.load(os.path.join(golden, "tdem_doc_pins.npz"))
+                gr = tp.gpu_report(pins)
+                rel = lambda a, b: float(abs(a / float(b) - 1.0))
+                line["tdem"]["parity"] = {
+                    "source": "gatdaem1d outputs printed in /root/reference/docs/_sources/examples/Datapoints/plot_{tempest,skytem}_datapoint.rst.txt "
+                              "(tests/golden/tdem_doc_pins.npz); bars in tests/test_tdem_doc_pins.py",
+                    "tempest_jacobian_30x30": dict(tp.jacobian_report(gr["J_batch"], pins["tempest_J"]),
+                                                   bars={"max_abs_over_max": tp.J_ATOL_ALL, "max_abs_over_row_max": tp.J_ATOL_ROW, "median_rel": tp.J_MEDIAN_REL}),
+                    "tempest_chi2_rel": rel(gr["tempest_chi2"], pins["tempest_chi2"]), "tempest_logl_rel": rel(gr["tempest_logl"], pins["tempest_logl"]),
+                    "tempest_like_bar": tp.TEMPEST_LIKE_RTOL,
+                    "tempest_best_halfspace_same_cell": bool(rel(gr["tempest_best_halfspace"], pins["tempest_best_halfspace"]) < 1e-6),
+                    "skytem_chi2_rel": rel(gr["skytem_chi2"], pins["skytem_chi2"]), "skytem_logl_rel": rel(gr["skytem_logl"], pins["skytem_logl"]),
+                    "skytem_like_bar": tp.SKYTEM_LIKE_RTOL,
+                    "skytem_best_halfspace_same_cell": bool(rel(gr["skytem_best_halfspace"], pins["skytem_best_halfspace"]) < 1e-6),
+                    "skytem_chi2_last_trial_rel": rel(gr["skytem_chi2_after_search"], pins["skytem_chi2_best_halfspace"]),
+                    "skytem_last_trial_bar": tp.SKYTEM_LAST_TRIAL_RTOL,
+                    "forward_csv_bars": "tests/test_tdem.py: every gate of 474 soundings within 1e-3 |ref| + 7e-5 peak (Tempest) / 1e-2 |ref| + 4e-5 peak (SkyTEM)",
+                    "reference_allclose_criterion": "met for FDEM; vacuous for SkyTEM (atol 1e-8 >> 1e-11 data); NOT met for Tempest (rtol 1e-5)"}
+            except Exception as e:                               # an extra, never the measurement
+                line["tdem"]["parity"] = {"error": repr(e)}
             # the device sampler on time-domain data (gbp_rj_run_td): SkyTEM low moment (22 spline nodes, 19 gates), 3-layer synthetic
             # soundings of tests/test_tdem_sampler.py, blocks of 8 192 and 1 024 chains
             try:
@@ -670,6 +725,9 @@ def main():
             line["parity_vs_cpu"] = {"max_abs_pred_ppm": float(np.max(np.abs(p - p_ref))),
                                      "max_abs_chi2": float(np.max(np.abs(chi2[:sample].cpu().numpy() - c_ref))),
                                      "max_abs_logL": float(np.max(np.abs(logl[:sample].cpu().numpy() - l_ref)))}
+        if TRAFFIC_SOURCES:
+            line["traffic_sources"] = dict(TRAFFIC_SOURCES, note="every 'traffic' figure is read from the committed rocprofv3 PMC summary named "
+                                           "here (separate --pmc passes, gfx950 x2 fetch correction), not measured by this run")
         print(json.dumps(line), flush=True)
     if exchange:
         dist.destroy_process_group()

@@ -30,7 +30,8 @@ def parse(argv=None):
                    help="accuracy budget of the Hankel-filter abscissa window: ppm for frequency-domain data (default 1e-10, 0 = all "
                         "abscissae), relative to the inductive-limit value for time-domain data (default 1e-12)")
     p.add_argument("--no-containers", action="store_true",
-                   help="skip the reference-layout results containers (<line>.h5, or <line>.h5.npz without h5py); the per-line "
+                   help="skip the reference-layout results containers (<line>.h5 -- real HDF5 -- when h5py is installed, else the stand-in <line>.results.npz + "
+                        "<line>.results.attrs.json with the same dataset paths); the per-line "
                         "summary files <line>.npz are always written")
     p.add_argument("--schedule", choices=("static", "dynamic", "lines"), default="static",
                    help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
@@ -73,6 +74,13 @@ def main(argv=None):
         done, failed = int((res["status"] == 1).sum()), int((res["status"] == 2).sum())
         print("{} soundings: {} done, {} failed to burn in; {:.1f} s; wrote {}".format(
             res["status"].size, done, failed, time.perf_counter() - t0, ", ".join(os.path.basename(q) for q in paths)))
+        if containers is not None:
+            from . import hdf
+            kind = hdf.container_type()
+            print("results containers (the reference's Inference2D / Inference1D layout): " +
+                  ("HDF5 files <line>.h5" if kind == "hdf5" else
+                   "h5py is not installed -- written as the stand-in <line>.results.npz + <line>.results.attrs.json (same dataset paths, "
+                   "geobipy_amd.hdf.load_npz reads them; NOT HDF5 files)"))
     if world > 1:
         dist.destroy_process_group()
     return 0

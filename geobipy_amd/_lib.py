@@ -28,14 +28,16 @@ class RjOptions(ctypes.Structure):
                 + [("depth_bin_width", ctypes.c_double), ("value_half_width", ctypes.c_double)]
                 + [("seed", ctypes.c_uint64), ("first_chain", ctypes.c_uint64)]
                 + [("solve_height", ctypes.c_int32), ("height_half_width", ctypes.c_double), ("height_scale", ctypes.c_double),
-                   ("additive_independent", ctypes.c_int32), ("add_centre", ctypes.c_double * 4), ("extra_log_prior", ctypes.c_double)])
+                   ("additive_independent", ctypes.c_int32), ("add_centre", ctypes.c_double * 4), ("extra_log_prior", ctypes.c_double),
+                   ("trace_every", ctypes.c_int32), ("trace_length", ctypes.c_int32)])
 
 
 RJ_CHAIN_FIELDS = ("rel_group", "add_group", "add_scale", "chain_id", "data", "height", "log_mean_prior", "k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit",
                    "action", "k_r", "nl_a", "nl_c", "nl_b", "edges_r", "sigma_r", "thk_r", "rel_p", "add_p", "pred_r", "J_r", "chol",
                    "log_prop", "sigma_p", "pred_p", "misfit_p", "like_p", "J_p", "log_ratio", "n_accepted", "k_hist", "edge_hist",
                    "rel_hist", "add_hist", "hitmap", "hit_dwell", "burned_in_iteration", "status", "best_posterior", "best_k", "best_edges", "best_sigma",
-                   "best_rel", "best_add", "iteration0", "height_p", "height0", "height_hist", "best_height", "step_flags")
+                   "best_rel", "best_add", "iteration0", "height_p", "height0", "height_hist", "best_height", "step_flags", "trace_misfit", "trace_accept",
+                   "best_iteration")
 
 
 class RjChains(ctypes.Structure):

@@ -990,12 +990,18 @@ __device__ inline double group_sum8(double v)
 template <int W>
 __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
                                    int kc, const double* ec, const double* sc, double post, double best_prev, double misfit_now,
-                                   const Levels& lev, double lmp, int dwell, double height_now)
+                                   const Levels& lev, double lmp, int dwell, double height_now, bool accepted)
 {
     const int K = o.max_layers, N = o.n_channels;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     bool reset_best = false;
     int finished = 0;
+    const int upd = (int)iter + 1 - (c.iteration0 != nullptr ? c.iteration0[b] : 0);   // this update, 1-based from the chain's (re)start
+    if (c.trace_misfit != nullptr && i == 0) {                  // Inference1D.update :713, :749 -- every trace_every-th entry of the two arrays
+        const int e = o.trace_every;
+        if ((upd - 1) % e == 0 && (upd - 1) / e < o.trace_length) c.trace_misfit[b * o.trace_length + (upd - 1) / e] = misfit_now;
+        if (upd % e == 0 && upd / e < o.trace_length) c.trace_accept[b * o.trace_length + upd / e] = accepted ? 1 : 0;
+    }
     if (o.schedule == 1) {                                       // the reference's per-sounding schedule
         const int it1 = (int)iter + 1 - (c.iteration0 != nullptr ? c.iteration0[b] : 0);   // counted from the chain's (re)start
         int bi = c.burned_in_iteration[b];
@@ -1037,6 +1043,7 @@ __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32
             if (c.best_add != nullptr)
                 for (int g = 0; g < o.n_add_groups; ++g) c.best_add[b * o.n_add_groups + g] = lev.add[g];
             if (c.best_height != nullptr) c.best_height[b] = height_now;
+            if (c.best_iteration != nullptr) c.best_iteration[b] = upd;
         }
     }
     if (accumulate) {
@@ -1210,7 +1217,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     }
     const int bk = bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
                                    accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c,
-                                   best_prev, accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now);
+                                   best_prev, accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept);
     if (lane == 0 && c.step_flags != nullptr) c.step_flags[b] = (accept ? 1 : 0) | bk;
 }
 
@@ -1453,7 +1460,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     const int bk = bookkeeping<8>(o, c, iter, accumulate, bb, i, accept ? k : k_prev, accept ? e : c.edges + bb * K,
                                   accept ? c.sigma_p + bb * K : c.sigma + bb * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
-                                  accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now);
+                                  accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept);
     if (i == 0 && c.step_flags != nullptr) c.step_flags[bb] = (accept ? 1 : 0) | bk;
 }
 
@@ -2037,7 +2044,10 @@ namespace {
 // creating its own (a process that had run the sub-block driver before the time-domain one lost 13 % in the latter: its side and
 // deep streams landed on the queues of the four sub-block streams created earlier).
 struct AuxStreams {
-    static const int N = 3;
+#ifndef GBP_AUX_STREAMS
+#define GBP_AUX_STREAMS 3
+#endif
+    static const int N = GBP_AUX_STREAMS;
     hipStream_t q[N] = {nullptr, nullptr, nullptr};
     hipEvent_t fork[N] = {nullptr, nullptr, nullptr}, join[N] = {nullptr, nullptr, nullptr};
     hipEvent_t start = nullptr;
@@ -2093,8 +2103,8 @@ DeepStreams* deep_streams()
 // streams again (the sub-block driver forks nothing else).
 struct BlockStreams {
     static const int MAX = AuxStreams::N;
-    hipStream_t q[MAX] = {nullptr, nullptr, nullptr};
-    hipEvent_t done[MAX] = {nullptr, nullptr, nullptr};
+    hipStream_t q[MAX] = {};
+    hipEvent_t done[MAX] = {};
     hipEvent_t start = nullptr;
 };
 BlockStreams* block_streams()
@@ -2127,6 +2137,7 @@ gbp_rj_chains slice_chains(const gbp_rj_options& o, const gbp_rj_chains& c, int 
     GBP_OFF(burned_in_iteration, 1) GBP_OFF(status, 1) GBP_OFF(best_posterior, 1) GBP_OFF(best_k, 1) GBP_OFF(best_edges, K) GBP_OFF(best_sigma, K)
     GBP_OFF(best_rel, Gr) GBP_OFF(best_add, Ga) GBP_OFF(iteration0, 1)
     GBP_OFF(height_p, 1) GBP_OFF(height0, 1) GBP_OFF(height_hist, nb) GBP_OFF(best_height, 1) GBP_OFF(step_flags, 1)
+    GBP_OFF(trace_misfit, (size_t)o.trace_length) GBP_OFF(trace_accept, (size_t)o.trace_length) GBP_OFF(best_iteration, 1)
 #undef GBP_OFF
     return s;
 }
@@ -2150,6 +2161,8 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
     if (o->solve_height && (!c->height_p || !c->height0 || !(o->height_half_width > 0.0) || !(o->height_scale >= 0.0)))
         return fail(GBP_ERR_INVALID_ARG, "solve_height needs height_p, height0, height_half_width > 0 and height_scale >= 0%s");
     if (c->height_hist && (!o->solve_height || o->n_error_bins < 1)) return fail(GBP_ERR_INVALID_ARG, "height_hist needs solve_height and n_error_bins >= 1%s");
+    if ((c->trace_misfit != nullptr) != (c->trace_accept != nullptr) || (c->trace_misfit && (o->trace_every < 1 || o->trace_length < 1)))
+        return fail(GBP_ERR_INVALID_ARG, "trace_misfit and trace_accept come together, with trace_every >= 1 and trace_length >= 1%s");
     if ((c->rel_hist != nullptr) != (c->add_hist != nullptr) || (c->rel_hist && o->n_error_bins < 1))
         return fail(GBP_ERR_INVALID_ARG, "rel_hist and add_hist come together, with n_error_bins >= 1%s");
     const void* need[] = {c->data, c->height, c->log_mean_prior, c->k, c->edges, c->sigma, c->rel, c->add, c->pred, c->J, c->prior,

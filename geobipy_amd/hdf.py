@@ -190,14 +190,34 @@ def load_npz(path):
     return out
 
 
-def open_results(path, mode="w"):
-    """An ``h5py.File`` when h5py is importable, otherwise an ``NpzGroup`` (call ``.save(path)`` when done)."""
+def _h5py():
+    """The h5py module when a usable one is importable (``h5py.File`` a class), else None."""
     try:
         import h5py
         if hasattr(h5py, "File") and isinstance(h5py.File, type):
-            return h5py.File(path, mode)
+            return h5py
     except ImportError:
         pass
+    return None
+
+
+def container_type():
+    """"hdf5" when the results containers are real HDF5 files (h5py importable), else "npz": the stand-in with the same dataset paths."""
+    return "hdf5" if _h5py() is not None else "npz"
+
+
+def results_path(directory, line):
+    """Path ``open_results`` / ``NpzGroup.save`` take for a flight line's container: ``<line>.h5`` with h5py -- the reference's file --,
+    ``<line>.results`` without it (saved as ``<line>.results.npz`` + ``<line>.results.attrs.json``: a stand-in is not named .h5)."""
+    import os
+    return os.path.join(str(directory), "{}.{}".format(line, "h5" if _h5py() is not None else "results"))
+
+
+def open_results(path, mode="w"):
+    """An ``h5py.File`` when h5py is importable, otherwise an ``NpzGroup`` (call ``.save(path)`` when done)."""
+    h5py = _h5py()
+    if h5py is not None:
+        return h5py.File(path, mode)
     return NpzGroup("/")
 
 
@@ -453,8 +473,16 @@ def create_inference1d(parent, inf, add_axis):
     for key, dt, fill in (("iteration", "i8", 0), ("burned_in_iteration", "i8", 0), ("best_iteration", "i8", 0), ("burned_in", "?", 0),
                           ("multiplier", "f8", np.nan), ("invtime", "f8", np.nan), ("savetime", "f8", np.nan)):
         parent.create_dataset(key, shape=(n,), dtype=dt, fillvalue=fill)
-    _data_array(parent, "acceptance_rate", (n, 2 * inf.n_markov_chains), dtype="u1", fill=None, label="% Acceptance")
-    _data_array(parent, "phids", (n, 2 * inf.n_markov_chains), label="Data Misfit")
+    # per-iteration traces (Inference1D.acceptance_v / data_misfit_v :408, 414): 2 n_markov_chains entries per sounding.  A device
+    # block may keep every `trace_every`-th entry only (LineSpec.trace_every > 1): the datasets then hold those entries side by
+    # side -- ceil(2 n_markov_chains / trace_every) columns -- and carry the stride as their attribute `trace_every`
+    every = int(getattr(inf, "trace_every", 1) or 1)
+    n_tr = -(-2 * inf.n_markov_chains // every)
+    ga = _data_array(parent, "acceptance_rate", (n, n_tr), dtype="u1", fill=None, label="% Acceptance")
+    gp = _data_array(parent, "phids", (n, n_tr), label="Data Misfit")
+    if every > 1:
+        _attrs(ga, trace_every=every)
+        _attrs(gp, trace_every=every)
     _data_array(parent, "halfspace", (n,), label="halfspace", units=CONDUCTIVITY_UNITS)
 
     m = parent.create_group("model")
@@ -601,7 +629,7 @@ class LineSpec:
     acquisition system(s), the options, the kind of data point ('fdem' | 'tdem' | 'tempest') and the posterior grids (the device
     accumulators bin on the reference's grids: RectilinearMesh1D.set_posteriors :1438-1455, Model.set_posteriors)."""
 
-    def __init__(self, system, n_channels, options, n_value_bins=250, kind="fdem"):
+    def __init__(self, system, n_channels, options, n_value_bins=250, kind="fdem", trace_every=1):
         from types import SimpleNamespace
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
@@ -616,11 +644,12 @@ class LineSpec:
         self.interactive_plot = False
         self.reciprocate_parameter = bool(o.get("reciprocate_parameters", True))
         self.n_markov_chains = int(o["n_markov_chains"])
+        self.trace_every = int(trace_every or 1)       # stride of the per-iteration traces the device block kept (1: the reference's arrays)
 
 
 # per-sounding fields of a finished block, as survey.infer ships them to the writing rank: (name, columns, kind)
 def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_add=1, time_domain=False, n_primary=0, height=False,
-                      angles=()):
+                      angles=(), trace_length=0):
     """``n_rel`` / ``n_add``: error levels per sounding (time-domain data: one relative level per system x component, one additive
     level -- or Tempest multiplier -- per system / component); ``time_domain``: the loop pair's offset and both loops' angles, the
     per-channel standard deviation and the (file, predicted) primary fields travel too."""
@@ -628,7 +657,7 @@ def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_
            ("relative_error", n_rel), ("additive_error", n_add), ("log_mean_prior", 1), ("best_edges", K), ("best_sigma", K)]
     if time_domain:
         f64 += [("std", N), ("offset", 3), ("loop_angles", 6), ("primary", n_primary), ("predicted_primary", n_primary)]
-    i32 = [("status", 1), ("burned_in_iteration", 1), ("iterations", 1), ("best_k", 1), ("k_hist", K + 1), ("edge_hist", n_depth),
+    i32 = [("status", 1), ("burned_in_iteration", 1), ("iterations", 1), ("best_k", 1), ("best_iteration", 1), ("k_hist", K + 1), ("edge_hist", n_depth),
            ("rel_hist", n_rel * n_err), ("add_hist", n_add * n_err)] + ([("hitmap", n_value * n_depth)] if hitmap else [])
     if height:                                       # a sampled height (solve_z): the best state's, the measured one, the posterior
         f64 += [("best_height", 1), ("height0", 1)]
@@ -636,19 +665,22 @@ def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_
     for name, nb in angles:                          # sampled attitude angles [(name, cells)]: the same three per angle
         f64 += [("best_" + name, 1), (name + "_centre", 1)]
         i32 += [(name + "_hist", nb)]
+    if trace_length:                                 # the (decimated) per-iteration traces: misfit, accept / reject decisions
+        f64 += [("trace_misfit", trace_length)]
+        i32 += [("trace_accept", trace_length)]
     return f64, i32
 
 
 def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True, kind="fdem", n_rel=1, n_add=1, n_primary=0,
-                      loop_radius=0.0, channel_additive=None, height=False, angles=()):
+                      loop_radius=0.0, channel_additive=None, height=False, angles=(), trace_length=0):
     """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
-    LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  Not written: the
-    per-iteration traces ``acceptance_rate`` / ``phids`` (the device sampler keeps no per-iteration history), ``best_iteration``,
-    the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
+    LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  The per-iteration
+    traces ``acceptance_rate`` / ``phids`` come from the device block's (decimated) traces when it kept them (``trace_length`` > 0;
+    DeviceChains(trace_every=...)).  Not written: the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
     wants increasing indices).  ``channel_additive`` (Tempest): the per-channel additive errors of the options file."""
     td = kind != "fdem"
     ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary, height=height,
-                               angles=angles)
+                               angles=angles, trace_length=trace_length)
     order = np.argsort(np.asarray(index), kind="stable")
     idx = np.asarray(index)[order]
     if idx.size > 1 and not np.all(np.diff(idx) > 0):
@@ -671,6 +703,12 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
     parent["iteration"][sel] = I["iterations"][:, 0]
     parent["burned_in_iteration"][sel] = np.maximum(I["burned_in_iteration"][:, 0], 0)
     parent["burned_in"][sel] = I["status"][:, 0] == 1
+    parent["best_iteration"][sel] = I["best_iteration"][:, 0]
+    if trace_length:
+        n_tr = parent["phids/data"].shape[1]
+        w = min(n_tr, trace_length)
+        parent["phids/data"][sel, :w] = F["trace_misfit"][:, :w]
+        parent["acceptance_rate/data"][sel, :w] = I["trace_accept"][:, :w].astype(np.uint8)
     parent["multiplier"][sel] = 1.0
     parent["halfspace/data"][sel] = np.exp(F["log_mean_prior"][:, 0])
     d = parent["data"]

@@ -86,7 +86,11 @@ class DeviceChains:
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
                  min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, extra_log_prior=0.0,
-                 additive_independent=False, **options):
+                 additive_independent=False, trace_every=0, trace_length=None, **options):
+        """``trace_every`` > 0: keep every ``trace_every``-th entry of the reference's per-iteration arrays ``data_misfit_v`` /
+        ``acceptance_v`` (Inference1D.py:408, 414) on the device -- ``trace_misfit`` [B, trace_length] (NaN = not reached),
+        ``trace_accept`` uint8 [B, trace_length]; ``trace_length`` defaults to the reference's 2 n_markov_chains / trace_every (needs
+        n_markov_chains).  1 = the reference's arrays in full."""
         from .inference import OPTION_DEFAULTS
         o = dict(OPTION_DEFAULTS)
         o.update({k: v for k, v in options.items() if v is not None})
@@ -175,6 +179,13 @@ class DeviceChains:
         # Tempest's additive-error multipliers as the reference samples them (gbp_rj_options.additive_independent)
         ro.additive_independent = int(bool(additive_independent))
         ro.add_centre = (ctypes.c_double * 4)(*(list(self._add0) + [1.0] * (4 - Ga)))
+        self.trace_every = int(trace_every or 0)
+        if self.trace_every > 0:
+            if trace_length is None:
+                assert ro.n_markov_chains > 0, ValueError("trace_every needs trace_length or n_markov_chains (the reference's arrays hold 2 n_markov_chains entries)")
+                trace_length = -(-2 * ro.n_markov_chains // self.trace_every)
+            ro.trace_every, ro.trace_length = self.trace_every, int(trace_length)
+        self.trace_length = int(ro.trace_length)
         self._o = ro
         B, N, dev = self.B, self.N, self.device
         z = lambda *shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
@@ -197,7 +208,10 @@ class DeviceChains:
             iteration0=z(B, dt=i32),
             height_p=heights.clone() if self.solve_height else None, height0=heights if self.solve_height else None,
             height_hist=z(B, 99, dt=i32) if self.solve_height else None, best_height=heights.clone() if self.solve_height else None,
-            step_flags=z(B, dt=i32))
+            step_flags=z(B, dt=i32),
+            trace_misfit=torch.full((B, self.trace_length), float("nan"), dtype=torch.float64, device=dev) if self.trace_every > 0 else None,
+            trace_accept=z(B, self.trace_length, dt=torch.uint8) if self.trace_every > 0 else None,
+            best_iteration=z(B, dt=i32))
         self._bind()
         self.iteration = 0
         self.forward_waves = int(forward_waves)      # also passed explicitly to the forward calls of the initialisation
@@ -423,6 +437,10 @@ class DeviceChains:
         t["best_add"][r] = add0
         t["best_sigma"][r] = t["sigma"][r]
         t["best_edges"][r] = float("inf")
+        t["best_iteration"][r] = 0
+        if t.get("trace_misfit") is not None:                    # (Inference1D.reset :984-999 starts the two arrays over)
+            t["trace_misfit"][r] = float("nan")
+            t["trace_accept"][r] = 0
         t["status"].copy_(torch.where(give_up, torch.full_like(t["status"], 2), torch.where(reset, torch.zeros_like(t["status"]), t["status"])))
 
     def _restart_more(self, r):

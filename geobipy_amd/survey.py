@@ -335,14 +335,17 @@ class _LineWriter:
         n_primary = (ds.primary_field.shape[1] if getattr(ds, "primary_field", None) is not None else 0) if td else 0
         height = bool(getattr(dc, "solve_height", False))
         angles = tuple((m_[0], m_[5]) for m_ in (getattr(dc, "_moves", None) or ()))
-        fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles)
+        self.trace_every, self.trace_length = int(getattr(dc, "trace_every", 0) or 0), int(getattr(dc, "trace_length", 0) or 0)
+        fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles,
+                   trace_length=self.trace_length)
         ff, fi = hdf.device_row_fields(self.N, self.K, self.nd, self.nv, **fkw)
         self.wf, self.wi = sum(w for _, w in ff), sum(w for _, w in fi)
         self.line_col = [n_ for n_, _ in ff].index("line_number")
         self.fid_col = [n_ for n_, _ in ff].index("fiducial")
         self.wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
                         loop_radius=ds.system[0].loopRadius() if td else 0.0,
-                        channel_additive=o.get("initial_additive_error") if kind == "tempest" else None, height=height, angles=angles)
+                        channel_additive=o.get("initial_additive_error") if kind == "tempest" else None, height=height, angles=angles,
+                        trace_length=self.trace_length)
         self.lines, self.paths = {}, []
         # finished lines are compressed and written by a few host threads (zlib releases the interpreter lock) while the next rows
         # arrive; at most 2 x workers lines wait for their turn, so the process still holds a bounded number of lines
@@ -354,7 +357,7 @@ class _LineWriter:
         if isinstance(root, self.hdf.NpzGroup):
             while len(self.pending) >= 2 * self.workers:
                 self.pending.pop(0).result()
-            self.pending.append(self.pool.submit(root.save, path))   # <line>.h5.npz (+ <line>.h5.attrs.json)
+            self.pending.append(self.pool.submit(root.save, path))   # <line>.results.npz (+ <line>.results.attrs.json)
             self.paths.append(path + ".npz")
         else:
             root.close()
@@ -366,9 +369,10 @@ class _LineWriter:
         for ln in np.unique(f[:, self.line_col]):
             if ln not in self.lines:
                 fid = np.sort(ds.fiducial[ds.lineNumber == ln])
-                path = os.path.join(self.directory, "{}.h5".format(ln))
+                path = hdf.results_path(self.directory, ln)     # <line>.h5 with h5py, <line>.results(.npz) without
                 root = hdf.open_results(path)
-                hdf.create_inference1d(root, hdf.LineSpec(ds.system, self.N, self.o, n_value_bins=self.nv, kind=self.kind), add_axis=fid)
+                hdf.create_inference1d(root, hdf.LineSpec(ds.system, self.N, self.o, n_value_bins=self.nv, kind=self.kind,
+                                                          trace_every=max(1, self.trace_every)), add_axis=fid)
                 self.lines[ln] = [root, fid, path, 0]
             root, fid, _, _ = self.lines[ln]
             m = f[:, self.line_col] == ln
@@ -433,7 +437,7 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
 
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
           exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
-          chunk=None, results_directory=None, **overrides):
+          chunk=None, results_directory=None, timings=None, traces="auto", **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
@@ -447,8 +451,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     out the different numbers of iterations soundings need.  Chains are keyed by the sounding's row in the data file, so the
     results do not depend on the schedule.
     ``results_directory``: also write the reference's per-line results containers there (``<line number>.h5``: the layout of
-    Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf``; ``<line number>.h5.npz`` with the same dataset paths when
-    h5py is not installed) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
+    Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf``; ``<line number>.results.npz`` with the same dataset paths when
+    h5py is not installed -- ``hdf.container_type()`` says which) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
     map), best model and its predicted data.  The rows travel to rank 0 in bounded chunks (``distributed.stream_rows_to_root``).
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
@@ -460,6 +464,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     from .distributed import shard
     from .rjmcmc_gpu import DeviceChains
 
+    overrides_timings = timings
     o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
     tempest = o["data_type"] in ("TempestData", "Tempest_datapoint")
     time_domain = tempest or o["data_type"] in ("TdemData", "TdemDataPoint")
@@ -510,12 +515,37 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     assert rows.size == 1 or np.all(np.diff(rows) == 1), "selected soundings must be contiguous rows"
     common = dict(seed=int(seed) % (1 << 64), device=device, hitmap=hitmap, first_chain=int(rows[0]) + start, reference_schedule=True,
                   burn_in_min_iterations=burn_in_min_iterations, **{k: o[k] for k in keys if o.get(k) is not None})
+    # per-iteration traces for the containers' `phids` / `acceptance_rate` (Inference1D.data_misfit_v / acceptance_v): kept on the
+    # device at a stride -- "auto": the smallest stride with at most 4 096 entries per sounding (32 + 4 KB per sounding beside a
+    # 440 KB hit map; the reference's full arrays are 2 n_markov_chains x 9 bytes = 1.8 MB at its default 100 000); an int: that
+    # stride (1 = the reference's arrays in full); None / 0: no traces (the two datasets stay at their fill values)
+    if results_directory is not None and traces:
+        n_mc2 = 2 * int(o["n_markov_chains"])
+        common.update(trace_every=max(1, -(-n_mc2 // 4096)) if traces == "auto" else int(traces))
     if time_domain and hankel_eps is not None:
         common.update(hankel_eps=float(hankel_eps))
     elif not time_domain and hankel_eps is not None:
         common.update(hankel_eps_ppm=float(hankel_eps))
     f64 = lambda x: x.to(torch.float64)
     col = lambda x: f64(x)[:, None]
+    # wall time by phase (device-synchronised at the phase borders only when a caller asks for it with timings={}: bench.py's
+    # ``survey`` object; a normal run never synchronises for this)
+    timings = overrides_timings
+    import time as _time
+
+    class _Phase:
+        def __init__(self, name):
+            self.name = name
+        def __enter__(self):
+            if timings is not None:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                self.t0 = _time.perf_counter()
+        def __exit__(self, *a):
+            if timings is not None:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                timings[self.name] = timings.get(self.name, 0.0) + _time.perf_counter() - self.t0
 
     def run_block(idx, offset=None):
         """Chains of the soundings ``idx`` (rows of ds, ascending) to completion -> (sampler, [(name, [len(idx), w])])."""
@@ -534,8 +564,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             dc = TdemDeviceChains(ds.system, ds.z[idx], ds.total_field(idx) if isinstance(ds, TempestData) else ds.data[idx], offset,
                                   attitude=ds.attitude[idx] if idx.size else None, **kw)
         else:
-            dc = DeviceChains(ds.system, ds.z[idx], ds.data[idx], exact_jacobian=exact_jacobian, **kw)
-        dc.infer(check_every=check_every)
+            with _Phase("upload_and_initialise"):
+                dc = DeviceChains(ds.system, ds.z[idx], ds.data[idx], exact_jacobian=exact_jacobian, **kw)
+        with _Phase("chains"):
+            dc.infer(check_every=check_every)
         t = dc.t
         named = [("status", col(t["status"])), ("burned_in_iteration", col(t["burned_in_iteration"])), ("n_accepted", col(t["n_accepted"])),
                  ("misfit", col(t["misfit"])), ("relative_error", t["rel"]), ("additive_error", t["add"]), ("n_layers", col(t["k"])),
@@ -550,7 +582,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         if getattr(dc, "solve_height", False):     # the sampled height: final and highest-posterior values, posterior on the prior's 99 cells
             named += [("height", col(t["height"])), ("best_height", col(t["best_height"])), ("height_posterior", f64(t["height_hist"]))]
         if hitmap:
-            mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
+            with _Phase("hitmap_statistics"):
+                mean, pct = _hitmap_statistics(dc.hitmap, t["log_mean_prior"], dc.value_half_width)     # (attribute access settles dwell times)
             named += [("mean_log10_conductivity", mean)] + [("log10_conductivity_" + q, p) for q, p in zip(("p05", "p50", "p95"), pct)]
         return dc, named
 
@@ -599,10 +632,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             bst, ctr = dc.sampled_angles("best_geom"), dc.sampled_angles("geom0")
             for m_ in dc._moves:
                 cols_f += [bst[m_[0]][:, None], ctr[m_[0]][:, None]]
+        if getattr(dc, "trace_every", 0):
+            cols_f.append(t["trace_misfit"])
         f64_block = torch.cat(cols_f, dim=1).contiguous()
         st, bi = t["status"].to(torch.int32), t["burned_in_iteration"].to(torch.int32)
         ran = torch.where(st == 1, bi + n_mc + 1, torch.where(st == 2, torch.full_like(bi, n_mc), torch.full_like(bi, dc.iteration)))
-        cols = [st[:, None], bi[:, None], ran[:, None], bk.to(torch.int32)[:, None], t["k_hist"], t["edge_hist"], t["rel_hist"].flatten(1),
+        cols = [st[:, None], bi[:, None], ran[:, None], bk.to(torch.int32)[:, None], t["best_iteration"][:, None], t["k_hist"], t["edge_hist"], t["rel_hist"].flatten(1),
                 t["add_hist"].flatten(1)]
         if hitmap:
             cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
@@ -610,6 +645,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             cols.append(t["height_hist"])
         for q_, m_ in enumerate(getattr(dc, "_moves", None) or ()):
             cols.append(t["geom_hist"][:, q_, :m_[5]])
+        if getattr(dc, "trace_every", 0):
+            cols.append(t["trace_accept"])
         to_host = lambda x: x.cpu()
         return (torch.as_tensor(np.asarray(idx), dtype=torch.int64), to_host(f64_block),
                 to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
@@ -636,7 +673,11 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 # not the survey's hit maps)
                 if state.get("writer") is None:
                     state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
-                state["writer"].add_block(payload(dc, idx))
+                with _Phase("rows_to_host"):
+                    pl = payload(dc, idx)
+                with _Phase("container_fill"):
+                    state["writer"].add_block(pl)
+                del pl
             elif results_directory is not None:
                 shipped.append(payload(dc, idx))
             part = torch.cat([v for _, v in named], dim=1).contiguous()
@@ -705,7 +746,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     if results_directory is not None and (world == 1 or schedule == "lines"):
         if state.get("writer") is None:             # (no sounding at all: the empty set of containers)
             state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
-        state["writer"].finish()
+        with _Phase("compress_and_write_tail"):
+            state["writer"].finish()
     elif results_directory is not None:
         _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
     if rank != 0:

@@ -335,6 +335,12 @@ typedef struct gbp_rj_options {
     double extra_log_prior;      /* constant added to every proposal's log prior: the densities of the uniform priors of sampled
                                     scalars that live outside the chains struct, in gbp_td_moves; cancels in the acceptance ratio, keeps
                                     the stored prior / posterior values those of the full model                              */
+    int32_t trace_every, trace_length; /* per-iteration traces (chains->trace_misfit / trace_accept; Inference1D.data_misfit_v / acceptance_v,
+                                    inversion/Inference1D.py:408, 414, 713, 749): every `trace_every`-th entry of the reference's two
+                                    arrays is kept, `trace_length` slots per chain -- slot j holds data_misfit_v[j * trace_every] (the misfit
+                                    after update j * trace_every + 1) and acceptance_v[j * trace_every] (the decision of update j *
+                                    trace_every), updates counted from the chain's (re)start.  trace_every = 1, trace_length = 2 *
+                                    n_markov_chains: the reference's arrays in full.  0: no traces                                  */
 } gbp_rj_options;
 
 typedef struct gbp_rj_chains {
@@ -393,6 +399,10 @@ typedef struct gbp_rj_chains {
                                       bit 1 the highest-posterior state was replaced, bit 2 the posteriors were reset (burn-in),
                                       bit 3 the post-step state was added to the posteriors; 0 for a frozen chain.  Read by the
                                       stages that carry further per-chain state (gbp_td_moves)                             */
+    double *trace_misfit;          /* [B, trace_length] or NULL  decimated misfit trace (opt->trace_every; NaN = not reached)      */
+    uint8_t *trace_accept;         /* [B, trace_length] or NULL  decimated accept / reject decisions (both traces or neither)      */
+    int32_t *best_iteration;       /* [B] or NULL  the update (1-based, from the chain's (re)start) that produced the highest-posterior
+                                      state (Inference1D.best_iteration :733, 743)                                                */
 } gbp_rj_chains;
 
 /* The three host-logic stages of one iteration, exposed separately for the tests ... */

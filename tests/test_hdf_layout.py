@@ -465,14 +465,167 @@ def test_line_writer_fills_and_writes_one_container_per_line(tmp_path):
         if a == 0:
             assert 9.0 not in w.lines and 7.0 in w.lines                               # closed (and handed to a writer thread) / still open
     paths = w.finish()
-    assert sorted(os.path.basename(q) for q in paths) == ["7.0.h5.npz", "9.0.h5.npz"]
+    assert sorted(os.path.basename(q) for q in paths) == ["7.0.results.npz", "9.0.results.npz"]
     for ln, rows in ((7.0, np.arange(0, 90)), (9.0, np.arange(90, 150))):
         root = hdf.NpzGroup("/")
         hdf.create_inference1d(root, hdf.LineSpec(system, N, o), add_axis=fid[rows])
         hdf.write_device_rows(root, np.arange(rows.size), f[rows], i[rows], N, K, nd, nv, o)
         want = root.arrays()
-        got = hdf.load_npz(os.path.join(str(tmp_path), "{}.h5".format(ln)))
+        got = hdf.load_npz(os.path.join(str(tmp_path), "{}.results".format(ln)))
         assert sorted(got) == sorted(want)
         for k in want:
             assert np.array_equal(np.asarray(got[k]), np.asarray(want[k]), equal_nan=True), (ln, k)
-        assert os.path.getsize(os.path.join(str(tmp_path), "{}.h5.npz".format(ln))) < 2_000_000          # (dense hit maps: 39 MB)
+        assert os.path.getsize(os.path.join(str(tmp_path), "{}.results.npz".format(ln))) < 2_000_000          # (dense hit maps: 39 MB)
+
+
+def test_h5py_branch_of_the_writer_makes_the_same_calls_as_the_fallback(tmp_path, monkeypatch):
+    """h5py is not installed in this image, so ``hdf.open_results``' h5py branch can only be driven by a stand-in: a fake ``h5py``
+    module whose ``File`` RECORDS what the writer asks of it (groups, datasets with shape / dtype / fill value, attributes, every
+    slice or index-vector assignment with a digest of the values) -- the same surface tests/golden/make_hdf_schema.py records the
+    reference's own createHdf / writeHdf with.  A two-line survey (traces kept at a stride) goes through survey._LineWriter twice,
+    once per branch: the two call logs are equal, the h5py branch names its files <line>.h5 and never touches the .npz writer, the
+    fallback names them <line>.results.npz.  What this cannot show is a real HDF5 library accepting the calls (README says so)."""
+    import sys
+    import types
+    import torch
+    from geobipy_amd import FdemSystem, hdf, survey
+
+    class Recorder:
+        log = None
+
+        def __init__(self, name="/"):
+            self.name, self.items_, self.attrs = name, {}, _Attrs(self, name)
+
+        def _split(self, path):
+            parts = [q for q in path.split("/") if q]
+            g = self
+            for q in parts[:-1]:
+                g = g.items_[q]
+            return g, parts[-1]
+
+        def create_group(self, name):
+            g, last = self._split(name)
+            full = g.name.rstrip("/") + "/" + last
+            Recorder.log.append(("group", full))
+            g.items_[last] = Recorder(full)
+            return g.items_[last]
+
+        def create_dataset(self, name, shape=None, dtype=None, data=None, fillvalue=None, **kw):
+            g, last = self._split(name)
+            full = g.name.rstrip("/") + "/" + last
+            if data is not None:
+                a = np.asarray(data)
+                Recorder.log.append(("dataset", full, a.shape, str(a.dtype if dtype is None else np.dtype(dtype)), digest(a)))
+            else:
+                shp = (int(shape),) if np.isscalar(shape) else tuple(int(q) for q in shape)
+                Recorder.log.append(("dataset", full, shp, str(np.dtype(dtype if dtype is not None else "f8")), repr(fillvalue)))
+            g.items_[last] = _Data(full, np.asarray(data).shape if data is not None else shp)
+            return g.items_[last]
+
+        def __getitem__(self, path):
+            g = self
+            for q in [q for q in path.split("/") if q]:
+                g = g.items_[q]
+            return g
+
+        def __contains__(self, path):
+            try:
+                self[path]
+                return True
+            except KeyError:
+                return False
+
+        def close(self):
+            Recorder.log.append(("close", self.name))
+
+    class _Attrs(dict):
+        def __init__(self, owner, name):
+            super().__init__()
+            self.owner_name = name
+
+        def __setitem__(self, k, v):
+            Recorder.log.append(("attr", self.owner_name, k, repr(v)))
+            super().__setitem__(k, v)
+
+    class _Data:
+        def __init__(self, name, shape):
+            self.name, self.attrs = name, _Attrs(self, name)
+            self.shape = tuple(shape)
+
+        def __setitem__(self, key, value):
+            keys = key if isinstance(key, tuple) else (key,)
+            desc = tuple(("slice", q.start, q.stop, q.step) if isinstance(q, slice) else (("index", digest(np.asarray(q))) if np.ndim(q) > 0 else ("int", int(q)))
+                         for q in keys)
+            Recorder.log.append(("write", self.name, desc, digest(np.asarray(value))))
+
+    def digest(a):
+        a = np.ascontiguousarray(a)
+        return (a.shape, str(a.dtype), hashlib.sha1(a.tobytes()).hexdigest())
+
+    class File(Recorder):
+        def __init__(self, path, mode="w"):
+            super().__init__("/")
+            Recorder.log.append(("open", os.path.basename(path), mode))
+
+    system = FdemSystem.read(os.path.join(GOLDEN, "resolve.stm"))
+    o = dict(RESOLVE_OPTIONS, n_markov_chains=200, update_plot_every=5000)
+    N, K, T, every = 12, int(o["maximum_number_of_layers"]), 100, 4
+    spec = hdf.LineSpec(system, N, o, trace_every=every)
+    nd, nv = spec.posteriors.depth_edges.size - 1, spec.posteriors.value_edges.size - 1
+    n = 40
+    line = np.where(np.arange(n) < 25, 7.0, 9.0)
+    fid = np.arange(n, dtype=np.float64) * 2.0
+    ds = types.SimpleNamespace(system=system, lineNumber=line, fiducial=fid, primary_field=None)
+    dc = types.SimpleNamespace(K=K, N=N, n_depth_bins=nd, n_value_bins=nv, n_rel_groups=1, n_add_groups=1, trace_every=every, trace_length=T)
+    ff, fi = hdf.device_row_fields(N, K, nd, nv, trace_length=T)
+    rng = np.random.default_rng(5)
+    f = rng.uniform(0.5, 2.0, (n, sum(w for _, w in ff)))
+    i = rng.integers(0, 3, (n, sum(w for _, w in fi))).astype(np.int32)
+    col, c0 = {}, 0
+    for name, w in ff:
+        col[name] = slice(c0, c0 + w); c0 += w
+    c0 = 0
+    for name, w in fi:
+        col["i_" + name] = slice(c0, c0 + w); c0 += w
+    f[:, col["fiducial"]] = fid[:, None]; f[:, col["line_number"]] = line[:, None]
+    f[:, col["best_edges"]] = np.inf
+    i[:, col["i_best_k"]] = 1; i[:, col["i_status"]] = 1
+
+    def run(directory):
+        w = survey._LineWriter(str(directory), ds, o, dc, True)
+        for a in range(0, n, 16):
+            w.add_block((torch.arange(a, min(n, a + 16)), torch.as_tensor(f[a:a + 16]), torch.as_tensor(i[a:a + 16])))
+        return w.finish()
+
+    # (1) the fallback, recorded through the same recorder wrapped around nothing: its files and its values
+    d_npz = tmp_path / "npz"
+    paths = run(d_npz)
+    assert hdf.container_type() == "npz" and sorted(os.path.basename(q) for q in paths) == ["7.0.results.npz", "9.0.results.npz"]
+    got = hdf.load_npz(str(d_npz / "7.0.results"))
+    assert got["/phids/data"].shape == (25, T) and np.array_equal(got["/phids/data"], f[:25, col["trace_misfit"]])
+    assert got["/acceptance_rate/data"].dtype == np.uint8 and np.array_equal(got["/acceptance_rate/data"], i[:25, col["i_trace_accept"]])
+    assert np.array_equal(got["/best_iteration"], i[:25, col["i_best_iteration"]][:, 0])
+    attrs = json.load(open(d_npz / "7.0.results.attrs.json"))
+    assert attrs["/phids"]["trace_every"] == every and attrs["/acceptance_rate"]["trace_every"] == every
+    # (2) the same calls against an NpzGroup-shaped recorder, and (3) against the fake h5py.File from open_results' h5py branch
+    logs = {}
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    for which in ("recorded_fallback", "h5py"):
+        Recorder.log = []
+        if which == "h5py":
+            monkeypatch.setitem(sys.modules, "h5py", fake)
+            assert hdf.container_type() == "hdf5"
+            saved = []
+            monkeypatch.setattr(hdf, "save_npz", lambda *a_, **k_: saved.append(a_))
+            paths = run(tmp_path / "h5")
+            assert sorted(os.path.basename(q) for q in paths) == ["7.0.h5", "9.0.h5"] and not saved
+            assert [e for e in Recorder.log if e[0] == "open"] == [("open", "7.0.h5", "w"), ("open", "9.0.h5", "w")]
+        else:
+            monkeypatch.setattr(hdf, "open_results", lambda path, mode="w": File(path, mode))
+            monkeypatch.setattr(hdf, "results_path", lambda d_, ln: os.path.join(str(d_), "{}.h5".format(ln)))
+            run(tmp_path / "rec")
+            monkeypatch.undo()
+        logs[which] = list(Recorder.log)
+    assert len(logs["h5py"]) > 200 and logs["h5py"] == logs["recorded_fallback"]
+    assert sum(e[0] == "close" for e in logs["h5py"]) == 2 and any(e[0] == "write" and e[1] == "/phids/data" for e in logs["h5py"])

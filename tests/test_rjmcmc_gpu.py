@@ -797,3 +797,50 @@ def test_concurrent_sub_blocks_walk_the_same_chains_at_size():
             for n in names + (["hitmap"] if (mode != 0 and B < 3000) else []):
                 a, b = getattr(runs[1], n), getattr(runs[mode], n)
                 assert torch.equal(torch.nan_to_num(a.double(), nan=-1.25), torch.nan_to_num(b.double(), nan=-1.25)), (B, mode, n)
+
+
+@pytest.mark.gpu
+def test_per_iteration_traces_on_the_device():
+    """gbp_rj_options.trace_every / gbp_rj_chains.trace_misfit, trace_accept, best_iteration: the reference's per-iteration arrays
+    (Inference1D.data_misfit_v[update - 1] = misfit, acceptance_v[update] = accepted, best_iteration; inversion/Inference1D.py:408,
+    414, 713, 743, 749) kept on the device at a stride.  Stride 1 = the arrays in full: they add up to the counters the sampler keeps
+    anyway and follow the chain step by step; a stride of 3 is exactly every third entry; all drivers write the same traces."""
+    B, n_it = 96, 240
+    runs = {}
+    for key, every, mode in (("full", 1, 1), ("third", 3, 1), ("persistent", 1, 2), ("sub_blocks", 1, 4)):
+        d, s, dc = _chains(B if mode != 4 else 2304, 77, trace_every=every, trace_length=-(-(n_it + 10) // every))
+        rng = np.random.default_rng(2)
+        dc.data.copy_(torch.as_tensor(np.tile(d["data"], (dc.B, 1)) * rng.uniform(0.8, 1.25, (dc.B, 1))))
+        dc._initialize()
+        dc.run_mode = mode
+        if key == "full":                                       # step by step: the trace follows the chain
+            mis, acc = [], []
+            prev = dc.n_accepted.clone()
+            for _ in range(n_it):
+                dc.run(1)
+                mis.append(dc.misfit.clone()); acc.append((dc.n_accepted - prev).clone()); prev = dc.n_accepted.clone()
+            mis, acc = torch.stack(mis, dim=1), torch.stack(acc, dim=1)
+            assert torch.equal(dc.trace_misfit[:, :n_it], mis) and torch.isnan(dc.trace_misfit[:, n_it:]).all()
+            assert torch.equal(dc.trace_accept[:, 1:n_it + 1].long(), acc) and int(dc.trace_accept[:, 0].sum()) == 0
+        else:
+            dc.run(n_it)
+        torch.cuda.synchronize()
+        runs[key] = dc
+    full = runs["full"]
+    assert torch.equal(full.trace_accept.long().sum(dim=1), full.n_accepted) and int(full.n_accepted.sum()) > 0.05 * B * n_it
+    assert bool(((full.best_iteration >= 1) & (full.best_iteration <= n_it)).all())
+    third = runs["third"]
+    T3 = third.trace_length
+    assert torch.equal(torch.nan_to_num(third.trace_misfit, nan=-1.0), torch.nan_to_num(full.trace_misfit[:, ::3][:, :T3], nan=-1.0))
+    assert torch.equal(third.trace_accept, full.trace_accept[:, ::3][:, :T3]) and torch.equal(third.best_iteration, full.best_iteration)
+    for n in ("trace_misfit", "trace_accept", "best_iteration", "misfit", "k"):
+        assert torch.equal(torch.nan_to_num(getattr(runs["persistent"], n).double(), nan=-1.0), torch.nan_to_num(getattr(full, n).double(), nan=-1.0)), n
+    # sub-blocks (2 304 chains: three concurrent sub-blocks, every array sliced by rows) against a one-block run of the same chains
+    d, s, one = _chains(2304, 77, trace_every=1, trace_length=n_it + 10)
+    rng = np.random.default_rng(2)
+    one.data.copy_(torch.as_tensor(np.tile(d["data"], (one.B, 1)) * rng.uniform(0.8, 1.25, (one.B, 1))))
+    one._initialize()
+    one.run_mode = 1
+    one.run(n_it)
+    for n in ("trace_misfit", "trace_accept", "best_iteration", "n_accepted"):
+        assert torch.equal(torch.nan_to_num(getattr(runs["sub_blocks"], n).double(), nan=-1.0), torch.nan_to_num(getattr(one, n).double(), nan=-1.0)), n
