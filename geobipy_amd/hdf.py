@@ -45,6 +45,7 @@ class _Dataset:
     shape = property(lambda s: s._shape)
     dtype = property(lambda s: s._dtype)
     materialised = property(lambda s: s._arr is not None)
+    sparse = property(lambda s: s._arr is None and bool(getattr(s, "_rle", None)))
 
     @property
     def arr(self):
@@ -52,7 +53,46 @@ class _Dataset:
             self._arr = np.zeros(self._shape, dtype=self._dtype)
             if self._fill is not None:
                 self._arr[...] = self._fill
+            for rows, ptr, start, val in getattr(self, "_rle", None) or ():     # rows written as runs: densify on first dense access
+                self._arr.reshape(self._shape[0], -1)[rows] = self._expand(rows.size, ptr, start, val)
+            self._rle = None
         return self._arr
+
+    def _expand(self, n_rows, ptr, start, val):
+        """[n_rows, M] dense rows from their runs (row j owns runs ptr[j]:ptr[j + 1]; a run lasts to the next run's start / the row's end)."""
+        M = int(np.prod(self._shape[1:]))
+        g = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(ptr)) * M + start
+        return np.repeat(val, np.diff(np.r_[g, n_rows * M])).reshape(n_rows, M)
+
+    def write_run_rows(self, rows, ptr, start, val):
+        """Rows ``rows`` (first axis) := their run-length form over the flattened remaining axes: row j owns runs ptr[j]:ptr[j + 1], run
+        r holds ``val[r]`` from flat position ``start[r]`` (the first run of a row starts at 0) to the next run's start.  Kept in that
+        form while nothing reads or writes the dataset densely: a conductivity-depth hit map is 440 KB per sounding but a few
+        thousand runs (depth is the fast axis and a layer fills a run of depth cells of ONE value bin with the same count) --
+        survey._LineWriter; ``NpzGroup.save`` writes the runs, ``load_npz`` puts the dense array back."""
+        rows, ptr = np.asarray(rows, dtype=np.int64), np.asarray(ptr, dtype=np.int64)
+        part = (rows, ptr - ptr[0], np.asarray(start, dtype=np.int32), np.asarray(val).astype(self._dtype, copy=False))
+        if self._arr is not None:
+            self._arr.reshape(self._shape[0], -1)[rows] = self._expand(rows.size, *part[1:])
+            return
+        if getattr(self, "_rle", None) is None:
+            self._rle = []
+        self._rle.append(part)
+
+    def runs(self):
+        """(rows, ptr, start, value) of a dataset held in run-length form, rows ascending (rows never written are absent: fill value)."""
+        parts = self._rle
+        rows = np.concatenate([p_[0] for p_ in parts]) if parts else np.zeros(0, np.int64)
+        cnt = np.concatenate([np.diff(p_[1]) for p_ in parts]) if parts else np.zeros(0, np.int64)
+        order = np.argsort(rows, kind="stable")
+        if parts and not np.array_equal(order, np.arange(rows.size)):
+            first = np.concatenate([p_[1][:-1] + off for p_, off in zip(parts, np.r_[0, np.cumsum([p_[2].size for p_ in parts])[:-1]])])
+            take = np.concatenate([np.arange(first[j_], first[j_] + cnt[j_]) for j_ in order])
+        else:
+            take = slice(None)
+        start = np.concatenate([p_[2] for p_ in parts]) if parts else np.zeros(0, np.int32)
+        val = np.concatenate([p_[3] for p_ in parts]) if parts else np.zeros(0, self._dtype)
+        return rows[order].astype(np.int32), np.r_[0, np.cumsum(cnt[order])].astype(np.int64), start[take], val[take]
 
     @staticmethod
     def _check(k):
@@ -137,8 +177,18 @@ class NpzGroup:
         for v in self._items.values():
             if isinstance(v, NpzGroup):
                 v.arrays(out, materialised_only)
-            elif v.materialised or not materialised_only:
+            elif v.materialised or not materialised_only:          # (a dataset held in sparse form is densified by the access)
                 out[v.name] = v.arr
+        return out
+
+    def sparse_datasets(self, out=None):
+        """{path: dataset} of the datasets held in sparse form (written with ``write_sparse_rows`` only)."""
+        out = {} if out is None else out
+        for v in self._items.values():
+            if isinstance(v, NpzGroup):
+                v.sparse_datasets(out)
+            elif v.sparse:
+                out[v.name] = v
         return out
 
     def unwritten(self, out=None):
@@ -147,7 +197,7 @@ class NpzGroup:
         for v in self._items.values():
             if isinstance(v, NpzGroup):
                 v.unwritten(out)
-            elif not v.materialised:
+            elif not v.materialised and not v.sparse:
                 out[v.name] = dict(shape=list(v.shape), dtype=str(v.dtype), fill=None if v._fill is None else (float(v._fill) if np.isfinite(v._fill) else "nan"))
         return out
 
@@ -156,32 +206,52 @@ class NpzGroup:
         "__unwritten__", shape / dtype / fill value of the datasets that never were (they are all fill value; ``load_npz``
         puts them back) -- so a container costs what was written to it, not what it pre-allocates."""
         lazy = self.unwritten()
-        save_npz(path, self.arrays(materialised_only=True))
+        sparse = self.sparse_datasets()          # (before arrays(): a dense access would densify them)
+        members = {}
+        for name, ds_ in sparse.items():         # "<path>#row" / "#ptr" / "#start" / "#value": the rows' runs; shape in the side file
+            members[name + "#row"], members[name + "#ptr"], members[name + "#start"], members[name + "#value"] = ds_.runs()
+        dense = self.arrays(materialised_only=True)
+        save_npz(path, dict(dense, **members))
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
         attrs["__unwritten__"] = lazy
+        attrs["__sparse__"] = {name: dict(shape=list(ds_.shape), dtype=str(ds_.dtype)) for name, ds_ in sparse.items()}
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
 
 
 def save_npz(path, arrays, compresslevel=1):
     """numpy.savez_compressed with a chosen deflate level: the .npz format (a zip of .npy members, read back by numpy.load).  Level 1:
     posterior counts and hit maps are mostly zeros and shrink 100-fold at any level, and at numpy's level 6 compressing a flight
-    line's container took ten times as long as inverting the line."""
+    line's container took ten times as long as inverting the line.  Large floating-point members (percentile / mean maps, misfit
+    traces: measured values, which deflate shrinks by a few % at 150 MB/s) are STORED: a survey's summary file went from 0.39 s to
+    0.1 s for 8 192 soundings."""
     import zipfile
     file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
     with zipfile.ZipFile(file, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=compresslevel, allowZip64=True) as zf:
         for name, arr in arrays.items():
-            with zf.open(name + ".npy", "w", force_zip64=True) as member:
-                np.lib.format.write_array(member, np.asanyarray(arr), allow_pickle=False)
+            a = np.asanyarray(arr)
+            info = zipfile.ZipInfo(name + ".npy")
+            info.compress_type = zipfile.ZIP_STORED if (a.dtype.kind == "f" and a.nbytes >= (1 << 20)) else zipfile.ZIP_DEFLATED
+            if info.compress_type == zipfile.ZIP_DEFLATED:
+                info._compresslevel = compresslevel
+            with zf.open(info, "w", force_zip64=True) as member:
+                np.lib.format.write_array(member, a, allow_pickle=False)
 
 
 def load_npz(path):
     """{hdf path: array} of a container written by ``NpzGroup.save``, unwritten datasets expanded to their fill value."""
     out = {}
+    side = str(path)[:-4] if str(path).endswith(".npz") else str(path)
+    side_file = json.load(open(side + ".attrs.json"))
+    sparse = side_file.get("__sparse__", {})
     with np.load(path if str(path).endswith(".npz") else str(path) + ".npz") as z:
         for k in z.files:
-            out[k] = z[k]
-    side = str(path)[:-4] if str(path).endswith(".npz") else str(path)
-    meta = json.load(open(side + ".attrs.json")).get("__unwritten__", {})
+            if "#" not in k:
+                out[k] = z[k]
+        for k, m in sparse.items():              # datasets stored as runs (NpzGroup.save): back to dense
+            d_ = _Dataset(k, m["shape"], m["dtype"], fillvalue=0)
+            d_.write_run_rows(z[k + "#row"], z[k + "#ptr"], z[k + "#start"], z[k + "#value"])
+            out[k] = d_.arr
+    meta = side_file.get("__unwritten__", {})
     for k, m in meta.items():
         a = np.zeros(m["shape"], dtype=np.dtype(m["dtype"]))
         if m["fill"] is not None:
@@ -672,15 +742,18 @@ def device_row_fields(N, K, n_depth, n_value, n_err=99, hitmap=True, n_rel=1, n_
 
 
 def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, hitmap=True, kind="fdem", n_rel=1, n_add=1, n_primary=0,
-                      loop_radius=0.0, channel_additive=None, height=False, angles=(), trace_length=0):
+                      loop_radius=0.0, channel_additive=None, height=False, angles=(), trace_length=0, hitmap_csr=None):
     """Rows ``index`` (positions along the line's sorted fiducials) of a container made by ``create_inference1d(parent,
     LineSpec(...), fiducials)``, from the two blocks of ``device_row_fields`` (numpy, one row per sounding).  The per-iteration
+    ``hitmap_csr`` = (ptr [m + 1], start, value): the rows' hit maps in run-length form (flat position value_bin * n_depth + depth cell;
+    _Dataset.write_run_rows) instead of dense ``hitmap`` columns in ``i32`` (device_row_fields(hitmap=False) then); the fallback
+    container keeps the runs, a real HDF5 dataset gets the dense rows.  The per-iteration
     traces ``acceptance_rate`` / ``phids`` come from the device block's (decimated) traces when it kept them (``trace_length`` > 0;
     DeviceChains(trace_every=...)).  Not written: the wall-clock fields.  ``index`` may be in any order and hold a row once (written with one sorted fancy assignment: h5py
     wants increasing indices).  ``channel_additive`` (Tempest): the per-channel additive errors of the options file."""
     td = kind != "fdem"
-    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap, n_rel=n_rel, n_add=n_add, time_domain=td, n_primary=n_primary, height=height,
-                               angles=angles, trace_length=trace_length)
+    ff, fi = device_row_fields(N, K, n_depth, n_value, hitmap=hitmap and hitmap_csr is None, n_rel=n_rel, n_add=n_add, time_domain=td,
+                               n_primary=n_primary, height=height, angles=angles, trace_length=trace_length)
     order = np.argsort(np.asarray(index), kind="stable")
     idx = np.asarray(index)[order]
     if idx.size > 1 and not np.all(np.diff(idx) > 0):
@@ -688,6 +761,11 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
     f64, i32 = np.asarray(f64), np.asarray(i32)
     if not np.array_equal(order, np.arange(idx.size)):           # (rows of a line arrive in order: no copy of the hit maps then)
         f64, i32 = f64[order], i32[order]
+        if hitmap_csr is not None:
+            ptr0, ind0, val0 = (np.asarray(a_) for a_ in hitmap_csr)
+            cnt = np.diff(ptr0)[order]
+            take = np.concatenate([np.arange(ptr0[j_], ptr0[j_ + 1]) for j_ in order]) if order.size else np.zeros(0, np.int64)
+            hitmap_csr = (np.r_[0, np.cumsum(cnt)], ind0[take], val0[take])
     # consecutive rows are written as a slice (a block copy; h5py likes it better, too), anything else as the sorted index vector
     sel = slice(int(idx[0]), int(idx[-1]) + 1) if idx.size and int(idx[-1]) - int(idx[0]) + 1 == idx.size else idx
     col, F, I = 0, {}, {}
@@ -777,6 +855,15 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
     m["mesh/y/edges/data"][sel, :] = rows
     m["mesh/y/edges/posterior/values/data"][sel, :] = I["edge_hist"]
     m["values/data"][sel, :] = vals
-    if hitmap:
+    if hitmap and hitmap_csr is not None:
+        ptr_, ind_, val_ = hitmap_csr
+        target = m["values/posterior/values/data"]
+        if hasattr(target, "write_run_rows"):
+            target.write_run_rows(idx, ptr_, ind_, val_)
+        else:                                    # a real HDF5 dataset: the dense rows
+            tmp = _Dataset("tmp", (idx.size, n_value * n_depth), "i4", fillvalue=0)
+            ptr0 = np.asarray(ptr_, dtype=np.int64)
+            target[sel, :, :] = tmp._expand(idx.size, ptr0 - ptr0[0], np.asarray(ind_), np.asarray(val_).astype(np.int32)).reshape(idx.size, n_value, n_depth)
+    elif hitmap:
         m["values/posterior/values/data"][sel, :, :] = I["hitmap"].reshape(idx.size, n_value, n_depth)
     m["values/posterior/mesh/y/relative_to/data"][sel] = F["log_mean_prior"][:, 0] / np.log(10.0)

@@ -316,6 +316,19 @@ def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     return mean, pct
 
 
+def _usable_cores():
+    """Host cores this process may really use: the scheduler affinity capped by the cgroup CPU quota (a 16-CPU quota on a 256-thread
+    host: more writer threads than that only contend)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _container_kind(ds):
     return "tempest" if isinstance(ds, TempestData) else ("tdem" if isinstance(ds, TdemData) else "fdem")
 
@@ -339,7 +352,12 @@ class _LineWriter:
         fkw = dict(hitmap=hitmap, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, time_domain=td, n_primary=n_primary, height=height, angles=angles,
                    trace_length=self.trace_length)
         ff, fi = hdf.device_row_fields(self.N, self.K, self.nd, self.nv, **fkw)
-        self.wf, self.wi = sum(w for _, w in ff), sum(w for _, w in fi)
+        # int32 rows come with dense hit-map columns (wi_dense: rows streamed from other ranks) or without (wi: the hit maps travel as
+        # their non-zero entries); hm_tail = the columns after the hit map's
+        self.wf, self.wi_dense = sum(w for _, w in ff), sum(w for _, w in fi)
+        names_i = [n_ for n_, _ in fi]
+        self.hm_tail = sum(w for _, w in fi[names_i.index("hitmap") + 1:]) if hitmap else 0
+        self.wi = self.wi_dense - (self.nv * self.nd if hitmap else 0)
         self.line_col = [n_ for n_, _ in ff].index("line_number")
         self.fid_col = [n_ for n_, _ in ff].index("fiducial")
         self.wkw = dict(hitmap=hitmap, kind=kind, n_rel=dc.n_rel_groups, n_add=dc.n_add_groups, n_primary=n_primary,
@@ -349,7 +367,7 @@ class _LineWriter:
         self.lines, self.paths = {}, []
         # finished lines are compressed and written by a few host threads (zlib releases the interpreter lock) while the next rows
         # arrive; at most 2 x workers lines wait for their turn, so the process still holds a bounded number of lines
-        self.workers = max(1, min(8, (os.cpu_count() or 2) - 1))
+        self.workers = max(1, min(16, _usable_cores() - 1))
         self.pool, self.pending = ThreadPoolExecutor(max_workers=self.workers), []
 
     def _close(self, ln):
@@ -363,9 +381,18 @@ class _LineWriter:
             root.close()
             self.paths.append(path)
 
-    def add(self, f, i):
-        """Rows of hdf.device_row_fields (numpy [m, wf] float64, [m, wi] int32) of any lines."""
+    def add(self, f, i, csr=None):
+        """Rows of hdf.device_row_fields (numpy [m, wf] float64, [m, wi] int32) of any lines; ``csr`` = (ptr, index, value): the
+        rows' hit maps in run-length form (hdf._Dataset.write_run_rows; the int32 rows then carry no hit-map columns)."""
         hdf, ds = self.hdf, self.ds
+        if csr is None and self.hitmap:               # dense hit-map columns (rows streamed from other ranks): the same run-length form
+            c0 = self.wi_dense - self.hm_tail - self.nv * self.nd
+            hm = i[:, c0:c0 + self.nv * self.nd]
+            edge = np.ones(hm.shape, dtype=bool)     # run starts: a row's first cell and every change of value
+            edge[:, 1:] = hm[:, 1:] != hm[:, :-1]
+            r_, j_ = np.nonzero(edge)
+            csr = (np.r_[0, np.cumsum(np.bincount(r_, minlength=hm.shape[0]))], j_.astype(np.int32), hm[r_, j_])
+            i = np.concatenate([i[:, :c0], i[:, c0 + self.nv * self.nd:]], axis=1)
         for ln in np.unique(f[:, self.line_col]):
             if ln not in self.lines:
                 fid = np.sort(ds.fiducial[ds.lineNumber == ln])
@@ -376,19 +403,39 @@ class _LineWriter:
                 self.lines[ln] = [root, fid, path, 0]
             root, fid, _, _ = self.lines[ln]
             m = f[:, self.line_col] == ln
-            every = bool(m.all())                   # (a chunk of one line: the rows as they are, no masked copy of the hit maps)
+            every = bool(m.all())                   # (a chunk of one line: the rows as they are, no masked copy)
             fm, im = (f, i) if every else (f[m], i[m])
-            hdf.write_device_rows(root, np.searchsorted(fid, fm[:, self.fid_col]), fm, im, self.N, self.K, self.nd, self.nv, self.o, **self.wkw)
+            sub = csr
+            if csr is not None and not every:       # the line's rows of the chunk's CSR block (a run of consecutive rows, usually)
+                rows_ = np.flatnonzero(m)
+                ptr_, ind_, val_ = csr
+                if rows_[-1] - rows_[0] + 1 == rows_.size:
+                    a_, b_ = int(ptr_[rows_[0]]), int(ptr_[rows_[-1] + 1])
+                    sub = (ptr_[rows_[0]:rows_[-1] + 2] - a_, ind_[a_:b_], val_[a_:b_])
+                else:
+                    take = np.concatenate([np.arange(ptr_[q_], ptr_[q_ + 1]) for q_ in rows_])
+                    sub = (np.r_[0, np.cumsum(np.diff(ptr_)[rows_])], ind_[take], val_[take])
+            hdf.write_device_rows(root, np.searchsorted(fid, fm[:, self.fid_col]), fm, im, self.N, self.K, self.nd, self.nv, self.o,
+                                  hitmap_csr=sub, **self.wkw)
             self.lines[ln][3] += int(m.sum())
             if self.lines[ln][3] >= fid.size:
                 self._close(ln)
 
     def add_block(self, block):
-        """One finished block of this process (payload(): rows, float64 rows, int32 rows on the host), 64 rows at a time."""
-        _, f_b, i_b = block
-        assert f_b.shape[1] == self.wf and i_b.shape[1] == self.wi
-        f_np, i_np = f_b.numpy(), i_b.numpy()      # (host tensors: views, no copy of the hit maps; nothing collective here -- ranks
-        for a in range(0, f_np.shape[0], 64):      #  that own whole lines call this as often as they have blocks)
+        """One finished block of this process: payload() -- (rows, float64 rows, int32 rows) on the host with dense hit-map columns,
+        taken 64 rows at a time, or (rows, float64 rows, int32 rows, (ptr, index, value)) with the hit maps as their non-zero
+        entries, taken whole (the rows of a line are then one slice of each array)."""
+        f_b, i_b = block[1], block[2]
+        csr = block[3] if len(block) > 3 else None
+        f_np, i_np = f_b.numpy(), i_b.numpy()      # (host tensors: views; nothing collective here -- ranks that own whole lines call
+        assert f_b.shape[1] == self.wf             #  this as often as they have blocks)
+        if csr is not None:
+            assert i_b.shape[1] == self.wi
+            if f_np.shape[0]:
+                self.add(f_np, i_np, csr)
+            return
+        assert i_b.shape[1] == self.wi_dense
+        for a in range(0, f_np.shape[0], 64):
             self.add(f_np[a:a + 64], i_np[a:a + 64])
 
     def finish(self):
@@ -408,8 +455,8 @@ def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
     from .distributed import stream_rows_to_root
     w = _LineWriter(directory, ds, o, dc, hitmap)
     cat = lambda j, wd, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, wd) if wd else (0,), dtype=dt)
-    rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, w.wf, torch.float64), cat(2, w.wi, torch.int32)
-    assert f_t.shape[1] == w.wf and i_t.shape[1] == w.wi
+    rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, w.wf, torch.float64), cat(2, w.wi_dense, torch.int32)
+    assert f_t.shape[1] == w.wf and i_t.shape[1] == w.wi_dense
     if dc.device.type != "cpu" and torch.distributed.is_initialized() and torch.distributed.get_backend() != "gloo":
         rows_t, f_t, i_t = rows_t.to(dc.device), f_t.to(dc.device), i_t.to(dc.device)     # RCCL sends device memory, 64 rows at a time
     for _, (f, i) in stream_rows_to_root(rows_t, [f_t, i_t], chunk_rows=64):
@@ -590,9 +637,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     state = dict(iterations=0, dc=None, named=None)
     shipped = []                                   # per block: (rows, float64 block, int32 block) of hdf.device_row_fields, on the HOST
 
-    def payload(dc, idx):
+    def payload(dc, idx, sparse=False):
         """The rows of hdf.device_row_fields for a finished block, moved to host memory at once (the hit maps are 440 KB per
-        sounding: what stays on the GPU is the running block, not every block a rank has finished)."""
+        sounding: what stays on the GPU is the running block, not every block a rank has finished).  ``sparse``: the hit maps leave
+        the device in run-length form (per row: the flat positions value_bin * n_depth + depth cell at which the count changes, and
+        the counts; hdf._Dataset.write_run_rows) instead of dense int32 columns -- depth is the fast axis and a layer fills a run of
+        cells with one count: a few thousand runs against 110 000 cells -- for a process that fills its own containers."""
         from .rjmcmc_gpu import layer_widths
         t, dev = dc.t, dc.device
         n_mc = int(o["n_markov_chains"])
@@ -639,7 +689,18 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         ran = torch.where(st == 1, bi + n_mc + 1, torch.where(st == 2, torch.full_like(bi, n_mc), torch.full_like(bi, dc.iteration)))
         cols = [st[:, None], bi[:, None], ran[:, None], bk.to(torch.int32)[:, None], t["best_iteration"][:, None], t["k_hist"], t["edge_hist"], t["rel_hist"].flatten(1),
                 t["add_hist"].flatten(1)]
-        if hitmap:
+        csr = None
+        if hitmap and sparse:
+            hm = dc.hitmap.flatten(1)               # (attribute access settles the dwell times)
+            edge = torch.ones_like(hm, dtype=torch.bool)      # run starts: the row's first cell and every change of value
+            edge[:, 1:] = hm[:, 1:] != hm[:, :-1]
+            nz = torch.nonzero(edge)                # [runs, 2] row-major: sorted by row, then by flat position
+            cnt = torch.bincount(nz[:, 0], minlength=hm.shape[0])
+            ptr = torch.zeros(hm.shape[0] + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(cnt, 0)
+            csr = (ptr.cpu().numpy(), nz[:, 1].to(torch.int32).cpu().numpy(), hm[nz[:, 0], nz[:, 1]].cpu().numpy())
+            del nz, edge
+        elif hitmap:
             cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
         if getattr(dc, "solve_height", False):
             cols.append(t["height_hist"])
@@ -648,8 +709,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         if getattr(dc, "trace_every", 0):
             cols.append(t["trace_accept"])
         to_host = lambda x: x.cpu()
-        return (torch.as_tensor(np.asarray(idx), dtype=torch.int64), to_host(f64_block),
-                to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
+        out = (torch.as_tensor(np.asarray(idx), dtype=torch.int64), to_host(f64_block),
+               to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
+        return out + (csr,) if sparse else out
 
     def process(first, count):
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
@@ -674,7 +736,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 if state.get("writer") is None:
                     state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
                 with _Phase("rows_to_host"):
-                    pl = payload(dc, idx)
+                    pl = payload(dc, idx, sparse=True)
                 with _Phase("container_fill"):
                     state["writer"].add_block(pl)
                 del pl
@@ -743,16 +805,19 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         it = torch.tensor([iterations_run], dtype=torch.int64, device=dc.device)
         dist.all_reduce(it, op=dist.ReduceOp.MAX)
         iterations_run = int(it)
-    if results_directory is not None and (world == 1 or schedule == "lines"):
-        if state.get("writer") is None:             # (no sounding at all: the empty set of containers)
-            state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
-        with _Phase("compress_and_write_tail"):
-            state["writer"].finish()
-    elif results_directory is not None:
-        _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
+    def finish_containers():
+        if results_directory is not None and (world == 1 or schedule == "lines"):
+            if state.get("writer") is None:         # (no sounding at all: the empty set of containers)
+                state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
+            with _Phase("compress_and_write_tail"):
+                state["writer"].finish()
+        elif results_directory is not None:
+            _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
     if rank != 0:
+        finish_containers()
         return None
-    r = gathered.cpu().numpy()
+    with _Phase("summaries_to_host"):
+        r = gathered.cpu().numpy()
     res = SurveyResult(line=ds.lineNumber, fiducial=ds.fiducial, x=ds.x, y=ds.y, z=ds.z, elevation=ds.elevation,
                        depth_bin_width=np.float64(dc.depth_bin_width))
     c0 = 0
@@ -775,6 +840,23 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     res["acceptance"] = res.pop("n_accepted") / np.maximum(1, ran)
     for k_ in ("status", "burned_in_iteration", "n_layers", "best_n_layers"):
         res[k_] = res[k_].astype(np.int32)
+    # the summary file is compressed on a thread of its own while the containers' writer threads finish (zlib releases the lock)
+    saver = None
     if output is not None:
-        res.save(output)
+        import threading
+        failed = []
+
+        def save_summary():
+            try:
+                res.save(output)
+            except BaseException as e:               # (handed to the caller's thread below)
+                failed.append(e)
+        saver = threading.Thread(target=save_summary)
+        saver.start()
+    finish_containers()
+    if saver is not None:
+        with _Phase("summary_file_tail"):
+            saver.join()
+        if failed:
+            raise failed[0]
     return res
