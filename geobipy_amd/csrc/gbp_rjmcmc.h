@@ -29,6 +29,7 @@
 #ifndef GBP_RJ_PERSISTENT_WAVES_PER_EU
 #define GBP_RJ_PERSISTENT_WAVES_PER_EU 2
 #endif
+#include <exception>
 #include <string>
 #include <thread>
 
@@ -2598,9 +2599,21 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipEventRecord(bs->start, main_q));
             for (int p = 0; p < P; ++p) GBP_HIP(hipStreamWaitEvent(part[p].q, bs->start, 0));
         }
-        for (int p = 0; p < P; ++p) {
+        bool alloc_failed = false;
+        for (int p = 0; p < P && !alloc_failed; ++p) {
             const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(part[p].nw, K) + 255) & ~(size_t)255) : 0;
-            if (deep_bytes > 0) GBP_HIP(hipMallocAsync((void**)&part[p].deep, deep_bytes * (size_t)part[p].c.B, part[p].q));
+            if (deep_bytes > 0 && hipMallocAsync((void**)&part[p].deep, deep_bytes * (size_t)part[p].c.B, part[p].q) != hipSuccess) {
+                part[p].deep = nullptr;
+                alloc_failed = true;
+            }
+        }
+        if (alloc_failed) {          // give back what was allocated and join the sub-block streams the caller's stream was forked into
+            const hipError_t e = hipGetLastError();
+            for (int p = 0; p < P; ++p) {
+                if (part[p].deep != nullptr) (void)hipFreeAsync(part[p].deep, part[p].q);
+                if (P > 1) { (void)hipEventRecord(bs->done[p], part[p].q); (void)hipStreamWaitEvent(main_q, bs->done[p], 0); }
+            }
+            return fail(GBP_ERR_HIP, "sampler sub-blocks: working set of the deep models: %s", hipGetErrorString(e));
         }
         auto physics = [&](const Part& t, int stage) {
             const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(t.nw, K) + 255) & ~(size_t)255) : 0;
@@ -2638,9 +2651,16 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if (s2 != GBP_OK) perr[p] = gbp_last_error();      // (the message is per host thread: hand it to the caller's)
         };
         {
+            // (std::thread's constructor throws std::system_error when the process is out of threads: nothing may leave an
+            //  extern "C" entry -- the sub-blocks that got no thread run on the caller's, after its own)
             std::vector<std::thread> workers;
-            for (int p = 1; p < P; ++p) workers.emplace_back(run_part, p);
+            std::vector<int> inline_parts;
+            for (int p = 1; p < P; ++p) {
+                try { workers.emplace_back(run_part, p); }
+                catch (const std::exception&) { inline_parts.push_back(p); }
+            }
             run_part(0);
+            for (int p : inline_parts) run_part(p);
             for (auto& w : workers) w.join();
         }
         for (int p = 0; p < P; ++p)

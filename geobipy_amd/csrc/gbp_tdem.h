@@ -7,6 +7,7 @@
 // of Re / Im in log10 f, periodic bipolar waveform by FFT over one period, first-order low-pass sections, area-under-curve
 // or boxcar (+- 1e-7 s) windows, all folded into one matrix W[2 * n_nodes, n_windows] per system.
 #pragma once
+#include <mutex>
 
 #include <map>
 #include <memory>
@@ -188,12 +189,26 @@ struct gbp_tdem_system {
         int32_t *d_src = nullptr, *d_col = nullptr;      // index maps of gbp_td_mix for this layout
     };
     std::map<int, Layout> layouts;               // key: basis mask | on-axis << 8
-    // staging + device scratch, grown as needed and kept (no allocation per call once warm)
-    std::vector<int32_t> h_set;
-    std::vector<double> h_height, h_weights;
-    double *d_height = nullptr, *d_nodal = nullptr, *d_weights = nullptr, *d_jnodal = nullptr;
-    int32_t* d_set = nullptr;
-    size_t cap_rows = 0, cap_set = 0, cap_nodal = 0, cap_weights = 0, cap_jnodal = 0;
+    // Staging + device scratch of ONE call in flight (the entries are re-entrant -- any number of host threads may call
+    // gbp_tdem_forward / gbp_tdem_fm_dlogc on one handle, each on a stream of its own): grown as needed and kept, so a warm handle
+    // allocates nothing per call.  A call leases a workspace: the one it used last on the same stream (stream order makes the reuse
+    // safe), else one whose last call has completed (`done`), else a new one.
+    struct Work {
+        hipStream_t q = nullptr;
+        bool busy = false;
+        hipEvent_t done = nullptr;
+        std::vector<int32_t> h_set;
+        std::vector<double> h_height, h_weights;
+        double *d_height = nullptr, *d_nodal = nullptr, *d_weights = nullptr, *d_jnodal = nullptr;
+        int32_t* d_set = nullptr;
+        size_t cap_rows = 0, cap_set = 0, cap_nodal = 0, cap_weights = 0, cap_jnodal = 0;
+    };
+    std::vector<std::unique_ptr<Work>> works;
+    // `mu` guards what calls share: the workspace pool, the lazily uploaded operator, and the layouts -- a call looks its table sets
+    // up, grows them if its geometry is new (device tables are re-allocated then: hipFree waits for the kernels that still read the
+    // old ones, all of which were enqueued under this lock) and enqueues its launches with the pointers it read, all under the lock;
+    // the GPU work of concurrent callers overlaps, their host-side enqueue (tens of microseconds per call) takes turns.
+    std::mutex mu;
     double hankel_eps = 1.0e-12;                 // per-sounding abscissa windows (gbp_tdem_system_set_hankel_eps); 0: all abscissae
 };
 
@@ -454,19 +469,47 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
     const hipStream_t q = (hipStream_t)stream;
     const bool loop = s->loop_radius > 0.0;
     const int nc = s->n_components, n = s->n_nodes, N = nc * s->n_windows, n_out = 2 * nc * n;
-    try {
-        if (s->d_Wb == nullptr) {
-            hipError_t e = hipMalloc((void**)&s->d_Wb, sizeof(double) * s->Wb.size());
-            if (e == hipSuccess) e = hipMemcpy(s->d_Wb, s->Wb.data(), sizeof(double) * s->Wb.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { if (s->d_Wb) (void)hipFree(s->d_Wb); s->d_Wb = nullptr; return fail(GBP_ERR_HIP, "window operator upload failed: %s", hipGetErrorString(e)); }
+    // this call's workspace (see gbp_tdem_system::Work); given back -- with an event on the caller's stream -- on every way out
+    struct Lease {
+        gbp_tdem_system* s; gbp_tdem_system::Work* w; hipStream_t q;
+        ~Lease()
+        {
+            if (!w) return;
+            if (w->done) (void)hipEventRecord(w->done, q);
+            std::lock_guard<std::mutex> lk(s->mu);
+            w->busy = false;
         }
-        s->h_height.resize(B);
-        s->h_set.resize(B);
-        for (int b = 0; b < B; ++b) s->h_height[b] = geometry[(size_t)b * 10];
+    } lease{s, nullptr, q};
+    try {
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (s->d_Wb == nullptr) {
+                hipError_t e = hipMalloc((void**)&s->d_Wb, sizeof(double) * s->Wb.size());
+                if (e == hipSuccess) e = hipMemcpy(s->d_Wb, s->Wb.data(), sizeof(double) * s->Wb.size(), hipMemcpyHostToDevice);
+                if (e != hipSuccess) { if (s->d_Wb) (void)hipFree(s->d_Wb); s->d_Wb = nullptr; return fail(GBP_ERR_HIP, "window operator upload failed: %s", hipGetErrorString(e)); }
+            }
+            for (auto& w : s->works)
+                if (!w->busy && w->q == q) { lease.w = w.get(); break; }
+            if (!lease.w)
+                for (auto& w : s->works)
+                    if (!w->busy && (w->done == nullptr || hipEventQuery(w->done) == hipSuccess)) { lease.w = w.get(); break; }
+            (void)hipGetLastError();                          // (hipEventQuery's hipErrorNotReady is not an error of this call)
+            if (!lease.w) {
+                s->works.emplace_back(new gbp_tdem_system::Work());
+                lease.w = s->works.back().get();
+                if (hipEventCreateWithFlags(&lease.w->done, hipEventDisableTiming) != hipSuccess) lease.w->done = nullptr;
+            }
+            lease.w->busy = true;
+            lease.w->q = q;
+        }
+        gbp_tdem_system::Work* const ws = lease.w;
+        ws->h_height.resize(B);
+        ws->h_set.resize(B);
+        for (int b = 0; b < B; ++b) ws->h_height[b] = geometry[(size_t)b * 10];
         gbp_status st;
-        if ((st = grow(&s->d_height, &s->cap_rows, (size_t)B)) != GBP_OK) return st;
-        if ((st = grow(&s->d_set, &s->cap_set, (size_t)B)) != GBP_OK) return st;
-        GBP_HIP(hipMemcpyAsync(s->d_height, s->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
+        if ((st = grow(&ws->d_height, &ws->cap_rows, (size_t)B)) != GBP_OK) return st;
+        if ((st = grow(&ws->d_set, &ws->cap_set, (size_t)B)) != GBP_OK) return st;
+        GBP_HIP(hipMemcpyAsync(ws->d_height, ws->h_height.data(), sizeof(double) * (size_t)B, hipMemcpyHostToDevice, q));
         auto on_axis = [&](int b) { return geometry[(size_t)b * 10 + 4] == 0.0 && geometry[(size_t)b * 10 + 5] == 0.0; };
         // Jacobians go through the window stage in chunks of rows so that the nodal Jacobian scratch stays bounded
         const int chunk_rows = J != nullptr ? 2048 : B;
@@ -493,6 +536,7 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
             }
             int mask = 0;
             for (int i = 0; i < GBP_TD_NBASIS; ++i) if (used[i]) mask |= 1 << i;
+            std::unique_lock<std::mutex> shared(s->mu);       // layouts, their table sets and this run's launches (released at the end of the turn)
             gbp_tdem_system::Layout& ly = s->layouts[mask | ((int)ax << 8)];
             if (ly.n_basis == 0)
                 for (int i = 0; i < GBP_TD_NBASIS; ++i) if (used[i]) ly.basis[ly.n_basis++] = i;
@@ -500,11 +544,11 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
             if (nF_in > GBP_MAX_FREQ) return fail(GBP_ERR_INVALID_ARG, "spline nodes x basis integrals of this geometry exceed the limit of 128 frequencies%s");
             // table sets: one per distinct (rho, dz); consecutive rows with the same key share one look-up
             bool grown = false;
-            double lo = s->h_height[b0], hi = lo, last_rho = -1.0, last_dz = 0.0;
+            double lo = ws->h_height[b0], hi = lo, last_rho = -1.0, last_dz = 0.0;
             int last_set = -1;
             for (int b = b0; b < b1; ++b) {
                 const double* gm = geometry + (size_t)b * 10;
-                lo = std::min(lo, s->h_height[b]); hi = std::max(hi, s->h_height[b]);
+                lo = std::min(lo, ws->h_height[b]); hi = std::max(hi, ws->h_height[b]);
                 const double rho = std::hypot(gm[4], gm[5]);
                 if (last_set < 0 || rho != last_rho || gm[6] != last_dz) {
                     const auto key = std::make_pair(rho, gm[6]);
@@ -525,7 +569,7 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
                     }
                     last_rho = rho; last_dz = gm[6]; last_set = it->second;
                 }
-                s->h_set[b] = last_set;
+                ws->h_set[b] = last_set;
             }
             gbp_fdem_system* h = ly.h;
             const bool sets = ly.set_of.size() > 1;
@@ -562,32 +606,34 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
                 }
             }
             // this run's weights (the layout's basis integrals only), set indices, scratch
-            s->h_weights.resize((size_t)nr * n_w);
+            ws->h_weights.resize((size_t)nr * n_w);
             for (int r = 0; r < nr; ++r)
                 for (int c = 0; c < nc; ++c)
                     for (int t = 0; t < nb; ++t)
-                        s->h_weights[((size_t)r * nc + c) * nb + t] = wall[((size_t)r * nc + c) * GBP_TD_NBASIS + ly.basis[t]];
-            if ((st = grow(&s->d_weights, &s->cap_weights, (size_t)nr * n_w)) != GBP_OK) return st;
-            if ((st = grow(&s->d_nodal, &s->cap_nodal, (size_t)nr * n_in)) != GBP_OK) return st;
-            if (J != nullptr && (st = grow(&s->d_jnodal, &s->cap_jnodal, (size_t)nr * n_in * Lmax)) != GBP_OK) return st;
+                        ws->h_weights[((size_t)r * nc + c) * nb + t] = wall[((size_t)r * nc + c) * GBP_TD_NBASIS + ly.basis[t]];
+            if ((st = grow(&ws->d_weights, &ws->cap_weights, (size_t)nr * n_w)) != GBP_OK) return st;
+            if ((st = grow(&ws->d_nodal, &ws->cap_nodal, (size_t)nr * n_in)) != GBP_OK) return st;
+            if (J != nullptr && (st = grow(&ws->d_jnodal, &ws->cap_jnodal, (size_t)nr * n_in * Lmax)) != GBP_OK) return st;
             // (the staging vector is reused by the next run: the copy must have left the host before that)
-            GBP_HIP(hipMemcpyAsync(s->d_weights, s->h_weights.data(), sizeof(double) * (size_t)nr * n_w, hipMemcpyHostToDevice, q));
-            if (b1 < B) GBP_HIP(hipStreamSynchronize(q));
-            if (sets) GBP_HIP(hipMemcpyAsync(s->d_set + b0, s->h_set.data() + b0, sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, q));
-            const int32_t* rows = sets ? s->d_set + b0 : nullptr;
+            GBP_HIP(hipMemcpyAsync(ws->d_weights, ws->h_weights.data(), sizeof(double) * (size_t)nr * n_w, hipMemcpyHostToDevice, q));
+            if (sets) GBP_HIP(hipMemcpyAsync(ws->d_set + b0, ws->h_set.data() + b0, sizeof(int32_t) * (size_t)nr, hipMemcpyHostToDevice, q));
+            const int32_t* rows = sets ? ws->d_set + b0 : nullptr;
             const size_t ro = (size_t)b0 * Lmax;
             if (J == nullptr)
-                st = gbp_fdem_forward_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, s->d_height + b0, s->d_nodal, rows, 0, stream);
+                st = gbp_fdem_forward_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, ws->d_height + b0, ws->d_nodal, rows, 0, stream);
             else
-                st = gbp_fdem_fm_dlogc_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, s->d_height + b0, s->d_nodal, s->d_jnodal, Lmax, 1,
+                st = gbp_fdem_fm_dlogc_rows_ex(h, nr, Lmax, nlayers + b0, sigma + ro, thk + ro, ws->d_height + b0, ws->d_nodal, ws->d_jnodal, Lmax, 1,
                                                rows, 0, stream);
             if (st != GBP_OK) return st;
             gbp_td_mix mix;
-            mix.n_in = n_in; mix.terms = nb; mix.n_weights = n_w; mix.src = ly.d_src; mix.col = ly.d_col; mix.weights = s->d_weights;
+            mix.n_in = n_in; mix.terms = nb; mix.n_weights = n_w; mix.src = ly.d_src; mix.col = ly.d_col; mix.weights = ws->d_weights;
             mix.offset = nullptr;
-            st = gbp_td_apply_mix(nr, Lmax, n_out, N, nlayers + b0, s->d_Wb, s->d_nodal, J ? s->d_jnodal : nullptr, out + (size_t)b0 * N,
+            st = gbp_td_apply_mix(nr, Lmax, n_out, N, nlayers + b0, s->d_Wb, ws->d_nodal, J ? ws->d_jnodal : nullptr, out + (size_t)b0 * N,
                                   J ? J + (size_t)b0 * N * Lmax : nullptr, &mix, stream);
             if (st != GBP_OK) return st;
+            shared.unlock();
+            // (the weight staging vector and the nodal scratch are reused by the next run of this call: this run must have left them)
+            if (b1 < B) GBP_HIP(hipStreamSynchronize(q));
             b0 = b1;
         }
     } catch (const std::bad_alloc&) {
@@ -625,8 +671,12 @@ void gbp_tdem_system_destroy(gbp_tdem_system* s)
         if (kv.second.d_src) (void)hipFree(kv.second.d_src);
         if (kv.second.d_col) (void)hipFree(kv.second.d_col);
     }
-    for (void* p : {(void*)s->d_Wb, (void*)s->d_height, (void*)s->d_nodal, (void*)s->d_weights, (void*)s->d_jnodal, (void*)s->d_set})
-        if (p) (void)hipFree(p);
+    if (s->d_Wb) (void)hipFree(s->d_Wb);
+    for (auto& w : s->works) {
+        for (void* p : {(void*)w->d_height, (void*)w->d_nodal, (void*)w->d_weights, (void*)w->d_jnodal, (void*)w->d_set})
+            if (p) (void)hipFree(p);
+        if (w->done) (void)hipEventDestroy(w->done);
+    }
     delete s;
 }
 
@@ -634,6 +684,7 @@ gbp_status gbp_tdem_system_set_hankel_eps(gbp_tdem_system* s, double eps)
 {
     if (!s) return fail(GBP_ERR_INVALID_ARG, "system handle is NULL%s");
     if (!(eps >= 0.0)) return fail(GBP_ERR_INVALID_ARG, "eps must be >= 0%s");
+    std::lock_guard<std::mutex> lk(s->mu);
     if (eps != s->hankel_eps)                 // the cached tables were windowed for the old budget
         for (auto& kv : s->layouts)
             if (kv.second.h) gbp_hankel_system_clear_bins(kv.second.h);

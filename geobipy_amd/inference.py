@@ -428,6 +428,16 @@ class BatchedInference:
     def __init__(self, system, heights, data, prngs, **options):
         self.options = dict(OPTION_DEFAULTS)
         self.options.update({k: v for k, v in options.items() if v is not None})
+        # what Inference1D takes and this batched twin does not: refused, not silently ignored
+        if self.options.get("solve_z", False):
+            raise NotImplementedError("BatchedInference: solve_z (the height move) -- use Inference1D or the device sampler (DeviceChains)")
+        for key in ("initial_relative_error", "initial_additive_error", "minimum_relative_error", "maximum_relative_error",
+                    "minimum_additive_error", "maximum_additive_error", "relative_error_proposal_variance", "additive_error_proposal_variance"):
+            if np.ndim(self.options.get(key)) > 0:
+                raise NotImplementedError("BatchedInference: per-level error options (" + key + " is a list: time-domain data) -- use Inference1D "
+                                          "or the device sampler (TdemDeviceChains)")
+        if any((k_.startswith("solve_transmitter_") or k_.startswith("solve_receiver_")) and v_ for k_, v_ in self.options.items()):
+            raise NotImplementedError("BatchedInference: loop-pair moves -- use Inference1D or the device sampler")
         self.data = np.asarray(data, dtype=np.float64)
         self.heights = np.asarray(heights, dtype=np.float64)
         self.prngs = list(prngs)

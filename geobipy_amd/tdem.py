@@ -660,7 +660,11 @@ class TdemDeviceChains(DeviceChains):
         geom_rows = gaaem_geometry(heights, offset, attitude)
         force = ()
         if self._moves:
-            on_axis = bool(geom_rows.shape[0] > 0 and np.hypot(geom_rows[0, 4], geom_rows[0, 5]) == 0.0)
+            on = np.hypot(geom_rows[:, 4], geom_rows[:, 5]) == 0.0      # (one basis layout and one gbp_td_moves.on_axis per block)
+            if on.any() and not on.all():
+                raise NotImplementedError("sampled attitude angles: a block holds receivers ON the transmitter's axis and off it -- other filters "
+                                          "and another basis layout; invert the two groups as blocks of their own")
+            on_axis = bool(on.size > 0 and on.all())
             loop = float(systems[0].loopRadius()) > 0.0
             tx_moves = any(m_[0].startswith("tx_") for m_ in self._moves)
             force = ((0, 2) if tx_moves else (0,)) if on_axis else (((0, 1, 2, 3, 4) if loop else (0, 1, 4)) if tx_moves else (0, 1))

@@ -526,7 +526,14 @@ gbp_status gbp_rj_flush_posteriors(const gbp_rj_options *opt, const gbp_rj_chain
  * gbp_tdem_fm_dlogc: the same plus J [dev] f64[B, n_components * n_windows, Lmax] = d out / d ln sigma (columns >= nlayers[b]
  * are 0) -- what the reference gets from gatdaem1d's fm_dlogc / derivative(CONDUCTIVITYDERIVATIVE, layer) x sigma
  * (TD/tdem1d.py:98-154), here the exact derivative through the same kernels.
- * Stream-ordered; the handle caches tables and scratch, so use it from one thread and one stream at a time.
+ * Stream-ordered and RE-ENTRANT (SURVEY 8b "Threading"; round 4): host threads may share one handle, each calling on a stream of its
+ * own.  A call leases its staging vectors and device scratch from a pool in the handle (the workspace it used last on the same stream,
+ * else one whose last call has completed, else a new one); the table sets the calls share are looked up -- and, for a geometry the
+ * handle has not met, grown: the device tables are re-allocated then, which waits for the launches that still read the old ones --
+ * under the handle's lock, together with the enqueue of the call's launches, so the GPU work of concurrent callers overlaps and only
+ * their host-side enqueue takes turns.  Results do not depend on what else the handle has seen or is doing
+ * (tests/c_abi/two_threads_tdem.cpp: bit-equal to a fresh handle's single-threaded results while another thread grows the table sets).
+ * (The geometry rows and per-sounding heights are HOST arrays read during the call; gbp_tdem_system_set_hankel_eps takes the same lock.)
  */
 typedef struct gbp_tdem_system gbp_tdem_system;
 gbp_status gbp_tdem_system_create(const char *stm_text, const double *w0, const double *w1, gbp_tdem_system **out);

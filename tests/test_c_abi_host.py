@@ -97,3 +97,25 @@ def test_two_host_threads_share_one_system_handle(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 mismatching results" in out.stdout
+
+
+@pytest.mark.gpu
+def test_two_host_threads_share_one_time_domain_handle(tmp_path):
+    """The same for the time-domain boundary: gbp_tdem_forward / gbp_tdem_fm_dlogc are re-entrant -- a call leases
+    its staging and device scratch from a pool in the handle (by stream), the shared table sets are looked up, grown and handed to the
+    launches under the handle's lock.  tests/c_abi/two_threads_tdem.cpp: two threads, own streams, per-row offsets and attitudes,
+    one of them meeting new offsets (table growth) while the other's launches are in flight; every result bit-equal to a fresh
+    handle's single-threaded one."""
+    import numpy as np
+    from geobipy_amd import _lib
+    from geobipy_amd.filters import W0_J0_120, W1_J1_140
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "two_threads_tdem")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", os.path.join(HERE, "c_abi", "two_threads_tdem.cpp"), "-o", exe,
+                           "-L" + os.path.dirname(_lib.LIB_PATH), "-lgeobipy_amd", "-lpthread", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH)])
+    wfile = str(tmp_path / "weights.bin")
+    np.r_[np.asarray(W0_J0_120, dtype=np.float64), np.asarray(W1_J1_140, dtype=np.float64)].tofile(wfile)
+    for stm in ("SkytemLM.stm", "tempest.stm"):
+        out = subprocess.run([exe, os.path.join(HERE, "golden", stm), wfile], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "0 mismatching results" in out.stdout and "x 60 calls" in out.stdout
