@@ -42,7 +42,7 @@ struct Batch {
     double *sigma, *thk, *out, *J;
     hipStream_t q;
     std::vector<std::vector<double>> geom;        // one geometry block per variant (variant v: offsets seen from round v * 10 on)
-    std::vector<std::vector<double>> ref_out, ref_J;
+    std::vector<std::vector<double>> ref_out, ref_fwd, ref_J;   // windows from fm_dlogc / from forward (other kernels: other last bits), Jacobian
 };
 
 static std::vector<double> geometry(int B, int t, int variant)
@@ -100,6 +100,10 @@ int main(int argc, char** argv)
             b.ref_out.emplace_back((size_t)b.B * b.N); b.ref_J.emplace_back((size_t)b.B * b.N * b.L);
             HIP(hipMemcpy(b.ref_out[v].data(), b.out, sizeof(double) * b.ref_out[v].size(), hipMemcpyDeviceToHost));
             HIP(hipMemcpy(b.ref_J[v].data(), b.J, sizeof(double) * b.ref_J[v].size(), hipMemcpyDeviceToHost));
+            CHECK(gbp_tdem_forward(fresh, b.B, b.geom[v].data(), b.L, b.nl, b.sigma, b.thk, b.out, b.q));
+            HIP(hipStreamSynchronize(b.q));
+            b.ref_fwd.emplace_back((size_t)b.B * b.N);
+            HIP(hipMemcpy(b.ref_fwd[v].data(), b.out, sizeof(double) * b.ref_fwd[v].size(), hipMemcpyDeviceToHost));
             gbp_tdem_system_destroy(fresh);
         }
     }
@@ -116,7 +120,7 @@ int main(int argc, char** argv)
             else CHECK(gbp_tdem_forward(shared, b.B, b.geom[v].data(), b.L, b.nl, b.sigma, b.thk, b.out, b.q));
             HIP(hipStreamSynchronize(b.q));
             HIP(hipMemcpy(o.data(), b.out, sizeof(double) * o.size(), hipMemcpyDeviceToHost));
-            if (std::memcmp(o.data(), b.ref_out[v].data(), sizeof(double) * o.size()) != 0) ++bad;
+            if (std::memcmp(o.data(), (with_j ? b.ref_out[v] : b.ref_fwd[v]).data(), sizeof(double) * o.size()) != 0) ++bad;
             if (with_j) {
                 HIP(hipMemcpy(J.data(), b.J, sizeof(double) * J.size(), hipMemcpyDeviceToHost));
                 if (std::memcmp(J.data(), b.ref_J[v].data(), sizeof(double) * J.size()) != 0) ++bad;
