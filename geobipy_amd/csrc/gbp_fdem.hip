@@ -202,7 +202,7 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
                                                const double* __restrict__ pts, int P, int F, int L,
                                                const double* __restrict__ sig, const double* sh_t2,
                                                gbp::LayerK* sh_lay /* [2][Lmax] */, int Lmax, double alt, int p0,
-                                               int p1, int lane, cplx* sh_part /* [npass][2] of the sounding */)
+                                               int p1, int lane, cplx* sh_part /* [npass][2] of the sounding */, double row_scale)
 {
     if (p0 >= p1) return;
     int cur = 0;
@@ -239,6 +239,7 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
         } else {
             pt = gbp::load_point(pts, P, j);
         }
+        if (row_scale != 1.0) gbp::scale_point(pt, row_scale);     // (wave-uniform: a receiver moved off its table set's distance)
         cplx num, den;
         gbp::rte_num_den<DIRECT>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
         const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
@@ -299,7 +300,7 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
                                              int F, int Lmax, int L, const double* __restrict__ sig,
                                              const double* __restrict__ th, double alt, const double* __restrict__ obs_row,
                                              double rel_b, double add_b, double* __restrict__ pred_row, double* chi2_b,
-                                             double* logL_b, double sigma_direct, int nw_use)
+                                             double* logL_b, double sigma_direct, int nw_use, double row_scale = 1.0)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,9 +319,9 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
         const int p0 = wave * per;
         const int p1 = min(npass, p0 + per);
         if (direct)
-            forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part);
+            forward_passes<true>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part, row_scale);
         else
-            forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part);
+            forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part, row_scale);
     }
     __syncthreads();
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
                                                        double* __restrict__ chi2, double* __restrict__ logL,
                                                        double sigma_direct, const BinDesc* __restrict__ bins, int bin0, int n_bins,
                                                        const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts,
-                                                       const int* __restrict__ row_set)
+                                                       const int* __restrict__ row_set, const double* __restrict__ row_scale)
 {
     __shared__ double sh_out[2 * GBP_MAX_FREQ];
     __shared__ MathLds sh_math;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     forward_body<LIKE>(M, sh_out, sh_dyn, chan, pts, npts_total, F, Lmax, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
                        height[b], LIKE ? obs + (size_t)b * 2 * F : nullptr, LIKE ? rel[b] : 0.0, LIKE ? add[b] : 0.0,
                        pred != nullptr ? pred + (size_t)b * 2 * F : nullptr, LIKE ? chi2 + b : nullptr, LIKE ? logL + b : nullptr,
-                       sigma_direct, (int)(blockDim.x >> 6));
+                       sigma_direct, (int)(blockDim.x >> 6), row_scale != nullptr ? row_scale[b] : 1.0);
 }
 
 // Jacobian (+ prediction) of ONE sounding by the first `nw_use` waves of the calling workgroup: the body of k_fdem_sens, also
@@ -398,7 +399,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                                           const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
                                           const double* __restrict__ sig, const double* __restrict__ th, double alt,
                                           double* __restrict__ Jb /* [2F, Lmax] of this sounding */,
-                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to)
+                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0)
 {   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
     // sampler, whose consumers never read a column >= L, passes L rounded up to 8 and leaves the rest of the row alone)
     const int lane = threadIdx.x & 63;
@@ -431,6 +432,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                     const bool valid = j < ch.npts;
                     gbp::Point pt = gbp::load_point(pts, npts_total, ch.off + (valid ? j : ch.npts - 1));
                     if (!valid) pt.coef = gbp::mk(0.0, 0.0);
+                    if (row_scale != 1.0) gbp::scale_point(pt, row_scale);     // (wave-uniform, see forward_passes)
                     const cplx E = gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD);
                     const cplx t = gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, E * pt.coef, sh_D + lane,
                                                           GBP_SENS_STRIDE);
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
                                                     const double* __restrict__ height, double* __restrict__ J,
                                                     double* __restrict__ pred, const BinDesc* __restrict__ bins, int bin0, int n_bins,
                                                     const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts,
-                                                    int compact_rows, const int* __restrict__ row_set)
+                                                    int compact_rows, const int* __restrict__ row_set, const double* __restrict__ row_scale)
 {
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(1024) void k_fdem_sens(const Channel* __restrict__ 
     const gbp::MathCtx M = math_setup(sh_math);
     sens_body<EXACT, NG>(M, sh_dyn, chan, pts, npts_total, F, Lmax, Lalloc, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
                          height[b], J + (size_t)b * 2 * F * Lmax, pred != nullptr ? pred + (size_t)b * 2 * F : nullptr,
-                         (int)(blockDim.x >> 6), compact_rows ? min(Lmax, (L + 7) & ~7) : Lmax);
+                         (int)(blockDim.x >> 6), compact_rows ? min(Lmax, (L + 7) & ~7) : Lmax, row_scale != nullptr ? row_scale[b] : 1.0);
 }
 
 // chi^2 / logL with an explicit per-channel standard deviation (TdemDataPoint.std is time dependent)
@@ -668,7 +670,7 @@ gbp_status check_row_sets(const gbp_fdem_system* sys, const int32_t* set_of_row)
 
 static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
                                   const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
-                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream);
+                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream, const double* row_scale = nullptr);
 
 extern "C" {
 
@@ -945,6 +947,13 @@ gbp_status gbp_fdem_forward_rows_ex(const gbp_fdem_system* sys, int B, int Lmax,
                                     const double* sigma, const double* thk, const double* height, double* pred,
                                     const int32_t* set_of_row, int waves, void* stream)
 {
+    return gbp_fdem_forward_rows_scaled(sys, B, Lmax, nlayers, sigma, thk, height, pred, set_of_row, nullptr, waves, stream);
+}
+
+gbp_status gbp_fdem_forward_rows_scaled(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers,
+                                        const double* sigma, const double* thk, const double* height, double* pred,
+                                        const int32_t* set_of_row, const double* row_scale, int waves, void* stream)
+{
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
     if (waves < 0 || waves > 16) return fail(GBP_ERR_INVALID_ARG, "waves must be in [0, 16]%s");
@@ -955,7 +964,7 @@ gbp_status gbp_fdem_forward_rows_ex(const gbp_fdem_system* sys, int B, int Lmax,
     hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts,
-                       set_of_row);
+                       set_of_row, row_scale);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1007,7 +1016,7 @@ gbp_status gbp_fdem_forward_loglike_ex(const gbp_fdem_system* sys, int B, int Lm
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
     hipLaunchKernelGGL(k_fdem_forward<true>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, obs, rel, add, pred,
-                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts, nullptr);
+                       chi2, logL, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts, nullptr, nullptr);
     GBP_HIP(hipGetLastError());
     return GBP_OK;
 }
@@ -1093,12 +1102,19 @@ gbp_status gbp_fdem_fm_dlogc_rows_ex(const gbp_fdem_system* sys, int B, int Lmax
     return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, set_of_row, stream);
 }
 
+gbp_status gbp_fdem_fm_dlogc_rows_scaled(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
+                                         const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
+                                         const int32_t* set_of_row, const double* row_scale, int waves, void* stream)
+{
+    return fm_dlogc_launch(sys, B, Lmax, nlayers, sigma, thk, height, pred, J, max_layers, exact, waves, 0, set_of_row, stream, row_scale);
+}
+
 }  // extern "C"
 
 // compact_rows != 0 (the sampler's launches): only the columns up to the layer count rounded up to 8 are written
 static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, const int32_t* nlayers, const double* sigma,
                                   const double* thk, const double* height, double* pred, double* J, int max_layers, int exact,
-                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream)
+                                  int waves, int compact_rows, const int32_t* set_of_row, void* stream, const double* row_scale)
 {
     gbp_status st = check_batch(sys, B, Lmax, nlayers, sigma, thk, height);
     if (st != GBP_OK) return st;
@@ -1123,7 +1139,7 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
         if (lds > 48 * 1024) GBP_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), lds, (hipStream_t)stream, sys->d_chan, sys->d_pts, sys->t.npts, sys->t.nF,
                            Lmax, max_layers, nlayers, sigma, thk, height, J, pred, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                           sys->d_bin_pts, compact_rows, set_of_row);
+                           sys->d_bin_pts, compact_rows, set_of_row, row_scale);
         return GBP_OK;
     };
     // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs

@@ -55,6 +55,20 @@ GBP_HD Point load_point(const double* __restrict__ pts, int npts_total, int j)
     return p;
 }
 
+// The point of the same filter abscissa for a receiver at horizontal distance rho' = rho / s when the tables were built for rho (raw
+// Hankel handles of DIPOLE sources, csrc/gbp_tdem.h: lam = base / rho, coef = lam^2 w / (4 pi rho) or lam w / (4 pi rho^2)): lam -> s lam,
+// coef -> s^3 coef.  A sampled receiver position of the time-domain sampler is evaluated with its chain's table set and this scalar
+// instead of tables of its own (gbp_td_moves.scale; wave-uniform).
+GBP_HD void scale_point(Point& p, double s)
+{
+    const double s2 = s * s;
+    p.a *= s2;
+    p.u0.re *= s; p.u0.im *= s;
+    p.ue.re *= s; p.ue.im *= s;
+    const double s3 = s2 * s;
+    p.coef.re *= s3; p.coef.im *= s3;
+}
+
 // Per-layer, per-frequency constants of one sounding (wave-uniform; the kernel keeps them in LDS and
 // every lane reads them by broadcast, so no VALU issue is spent on uniform arithmetic in the layer loop).
 struct alignas(16) LayerK {

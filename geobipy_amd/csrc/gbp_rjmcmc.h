@@ -1664,6 +1664,10 @@ __global__ __launch_bounds__(64) void k_td_moves_propose(RjOpt o, gbp_rj_chains 
 #pragma unroll
     for (int j = 0; j < 10; ++j) mv.geom_p[(size_t)b * 10 + j] = g[j];
     td_weights_of(mv, g, mv.weights_p + (size_t)b * n_weights, mv.offset_p != nullptr ? mv.offset_p + (size_t)b * N : nullptr);
+    if (mv.rho_scale_p != nullptr) {                             // a moved position: the chain's table set at another distance / height
+        mv.rho_scale_p[b] = mv.rho_set[b] / hypot(g[4], g[5]);
+        c.height_p[b] = g[0] + 0.5 * (g[6] - mv.dz_set[b]);
+    }
 }
 
 // What the accept stage decided (chains->step_flags) carried over to the angles: state, posteriors, best state.
@@ -1677,6 +1681,10 @@ __global__ __launch_bounds__(64) void k_td_moves_accept(RjOpt o, gbp_rj_chains c
         for (int j = 0; j < n_weights; ++j) mv.weights[(size_t)b * n_weights + j] = mv.weights_p[(size_t)b * n_weights + j];
         if (mv.offset != nullptr)
             for (int j = 0; j < N; ++j) mv.offset[(size_t)b * N + j] = mv.offset_p[(size_t)b * N + j];
+        if (mv.rho_scale != nullptr) {
+            mv.rho_scale[b] = mv.rho_scale_p[b];
+            const_cast<double*>(c.height)[b] = c.height_p[b];
+        }
     }
     if (mv.hist != nullptr) {
         int32_t* h = mv.hist + (size_t)b * mv.n_moves * 199;
@@ -2503,9 +2511,12 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             mv.n_blocks * mv.n_basis != td->mix.n_weights || !mv.block_comp || !mv.block_scale || (mv.offset && (!mv.block_primary || !mv.block_windows)))
             return fail(GBP_ERR_INVALID_ARG, "incomplete gbp_td_moves (needs geometry mixing, chains->step_flags, weights = mix.weights, offset = mix.offset)%s");
         for (int q = 0; q < mv.n_moves; ++q)
-            if (!((mv.entry[q] >= 1 && mv.entry[q] <= 3) || (mv.entry[q] >= 7 && mv.entry[q] <= 9)) || !(mv.half_width[q] > 0.0) ||
+            if (!((mv.entry[q] >= 1 && mv.entry[q] <= 3) || (mv.entry[q] >= 7 && mv.entry[q] <= 9) ||
+                  (mv.rho_scale != nullptr && (mv.entry[q] == 0 || (mv.entry[q] >= 4 && mv.entry[q] <= 6)))) || !(mv.half_width[q] > 0.0) ||
                 !(mv.scale[q] >= 0.0) || mv.n_bins[q] < 1 || mv.n_bins[q] > 199)
-                return fail(GBP_ERR_INVALID_ARG, "gbp_td_moves: entries 1..3 / 7..9, half_width > 0, scale >= 0, 1 <= n_bins <= 199%s");
+                return fail(GBP_ERR_INVALID_ARG, "gbp_td_moves: entries 1..3 / 7..9 (angles) or, with the position arrays, 0 / 4..6; half_width > 0, scale >= 0, 1 <= n_bins <= 199%s");
+        if ((mv.rho_scale != nullptr) != (mv.rho_scale_p != nullptr) || (mv.rho_scale != nullptr && (!mv.rho_set || !mv.dz_set || !c->height_p)))
+            return fail(GBP_ERR_INVALID_ARG, "gbp_td_moves: position moves need rho_scale, rho_scale_p, rho_set, dz_set and chains->height_p%s");
     }
     auto td_apply = [&](const int32_t* nl, bool with_j, double* pred, double* J, hipStream_t q, bool proposed) -> gbp_status {   // nodal -> windows
         const size_t lds = ((size_t)td->n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
@@ -2525,7 +2536,12 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         return GBP_OK;
     };
     // prediction + Jacobian of the chains selected by nl (row 0: all of them, rows 1.. by layer bucket)
-    const double* height_prop = o->solve_height ? c->height_p : c->height;     // (a sampled height: proposals are evaluated at theirs)
+    // (a sampled height -- or, time-domain data, a sampled position of the loop pair: proposals are evaluated at theirs, and with the
+    //  proposal's distance scale of the chain's table set)
+    const bool moving_pos = moving && td->moves.rho_scale != nullptr;
+    const double* height_prop = (o->solve_height || moving_pos) ? c->height_p : c->height;
+    const double* scale_cur = moving_pos ? td->moves.rho_scale : nullptr;
+    const double* scale_prop = moving_pos ? td->moves.rho_scale_p : nullptr;
     // The launch of the models of more than 8 layers holds few chains, but with the working set of a K-layer model in LDS (32 KB per
     // wave at K = 30) each runs on ONE wave: all frequencies x up to 30 layers in sequence -- ~100 us for a 22-node time-domain system,
     // 21 % of an iteration at 8 192 chains when it follows the launch of the shallow models.  The two launches touch disjoint chains:
@@ -2543,7 +2559,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             }
             gbp_status s2 = fm_dlogc_launch(sys, B, K, nl + (size_t)(1 + i) * B, sigma, c->thk_r, height, td ? td->nodal : pred,
                                             td ? td->J_nodal : J, caps[i], o->exact_jacobian, sw, 1, td ? td->table_set : nullptr,
-                                            aside ? ds->q[slot] : q);
+                                            aside ? ds->q[slot] : q, proposed ? scale_prop : scale_cur);
             if (s2 != GBP_OK) return s2;
             if (aside) GBP_HIP(hipEventRecord(ds->join[slot], ds->q[slot]));
         }
@@ -2702,7 +2718,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if ((st = gbp_fdem_forward_loglike_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, height_prop, c->data, c->rel_p, c->add_p,
                                                   c->pred_p, c->misfit_p, c->like_p, fw, stream)) != GBP_OK) return st;
         } else {
-            if ((st = gbp_fdem_forward_rows_ex(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, height_prop, td->nodal, td->table_set, fw, stream)) != GBP_OK) return st;
+            if ((st = gbp_fdem_forward_rows_scaled(sys, B, K, c->nl_b, c->sigma_p, c->thk_r, height_prop, td->nodal, td->table_set, scale_prop, fw, stream)) != GBP_OK) return st;
             if ((st = td_apply(c->nl_b, false, c->pred_p, nullptr, main_q, true)) != GBP_OK) return st;
             hipLaunchKernelGGL(rj::k_td_loglike, dim3(B), dim3(64), 0, (hipStream_t)stream, rj::extend(*o), *c, c->nl_b, c->pred_p, c->rel_p, c->add_p,
                                c->misfit_p, c->like_p);

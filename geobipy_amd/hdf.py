@@ -221,8 +221,8 @@ class NpzGroup:
 def save_npz(path, arrays, compresslevel=1):
     """numpy.savez_compressed with a chosen deflate level: the .npz format (a zip of .npy members, read back by numpy.load).  Level 1:
     posterior counts and hit maps are mostly zeros and shrink 100-fold at any level, and at numpy's level 6 compressing a flight
-    line's container took ten times as long as inverting the line.  Large floating-point members (percentile / mean maps, misfit
-    traces: measured values, which deflate shrinks by a few % at 150 MB/s) are STORED: a survey's summary file went from 0.39 s to
+    line's container took ten times as long as inverting the line.  Large floating-point members that deflate would shrink by a few %
+    at 150 MB/s (percentile / mean maps: measured values; decided on a 64 KB probe) are STORED: a survey's summary file went from 0.39 s to
     0.1 s for 8 192 soundings."""
     import zipfile
     file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
@@ -230,7 +230,15 @@ def save_npz(path, arrays, compresslevel=1):
         for name, arr in arrays.items():
             a = np.asanyarray(arr)
             info = zipfile.ZipInfo(name + ".npy")
-            info.compress_type = zipfile.ZIP_STORED if (a.dtype.kind == "f" and a.nbytes >= (1 << 20)) else zipfile.ZIP_DEFLATED
+            # (stored when a probe says deflate would not pay: a 64 KB sample from the middle that shrinks by less than 10 %.  NaN-padded
+            #  traces and sparse maps are floating point too, and shrink 20-fold)
+            store = False
+            if a.dtype.kind == "f" and a.nbytes >= (1 << 20):
+                import zlib
+                flat = np.ascontiguousarray(a).reshape(-1)
+                mid = flat[flat.size // 2: flat.size // 2 + 8192].tobytes()
+                store = len(zlib.compress(mid, 1)) > 0.9 * len(mid)
+            info.compress_type = zipfile.ZIP_STORED if store else zipfile.ZIP_DEFLATED
             if info.compress_type == zipfile.ZIP_DEFLATED:
                 info._compresslevel = compresslevel
             with zf.open(info, "w", force_zip64=True) as member:

@@ -254,6 +254,20 @@ gbp_status gbp_fdem_fm_dlogc_rows_ex(const gbp_fdem_system *sys, int B, int Lmax
                                      double *pred, double *J, int max_layers, int exact, const int32_t *set_of_row,
                                      int waves, void *stream);
 
+/* The two row entries with one more per-row argument (round 4): row_scale [dev] f64[B] or NULL.  Row b is evaluated with the points of
+ * its table set taken to the horizontal distance rho_set / row_scale[b] -- abscissae x s, coefficients x s^3 (csrc/gbp_fdem_point.h
+ * scale_point): exact for raw Hankel handles of DIPOLE sources (time-domain systems without ModellingLoopRadius), whose tables depend on
+ * the distance through lam = base / rho only.  How the time-domain sampler evaluates a SAMPLED receiver position (gbp_td_moves) with the
+ * chain's own table set instead of building tables per proposal; a changed dz or transmitter height enters through `height`
+ * (2 h + dz = 2 (h + (dz - dz_set) / 2) + dz_set).  NULL: the `_ex` entries. */
+gbp_status gbp_fdem_forward_rows_scaled(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                        const double *sigma, const double *thk, const double *height, double *pred,
+                                        const int32_t *set_of_row, const double *row_scale, int waves, void *stream);
+gbp_status gbp_fdem_fm_dlogc_rows_scaled(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
+                                         const double *sigma, const double *thk, const double *height,
+                                         double *pred, double *J, int max_layers, int exact, const int32_t *set_of_row,
+                                         const double *row_scale, int waves, void *stream);
+
 /* NOT part of the product interface -- timing helper for bench.py: average kernel time (ms) of `reps` launches of the
  * fused kernel, measured with hipEvents recorded on `stream` around the launches. */
 gbp_status gbp_bench_time_forward_loglike(const gbp_fdem_system *sys, int B, int Lmax, const int32_t *nlayers,
@@ -461,7 +475,8 @@ typedef struct gbp_td_mix {
  * (chains->step_flags) moves them into the state.  Needs mix.n_in > 0 and chains->step_flags.  n_moves = 0: fixed geometry. */
 typedef struct gbp_td_moves {
     int32_t n_moves;             /* 0 .. 6                                                                              */
-    int32_t entry[6];            /* entry of the GA-AEM tuple a move samples: 1..3 transmitter roll, pitch, yaw; 7..9 receiver   */
+    int32_t entry[6];            /* entry of the GA-AEM tuple a move samples: 1..3 transmitter roll, pitch, yaw; 7..9 receiver;
+                                    with `rho_scale` (position moves): 0 transmitter height, 4..6 receiver offset dx, dy, dz           */
     double sign[6];              /* tuple entry = sign * sampled value (Loop_pair.Geometry negates pitch and yaw)        */
     double half_width[6];        /* maximum_<..>_change                                                                  */
     double scale[6];             /* <..>_proposal_variance, used as the standard deviation like the reference does       */
@@ -481,6 +496,13 @@ typedef struct gbp_td_moves {
     const double *block_scale;   /* [dev] f64[n_blocks]    output sign * output scaling                                   */
     const double *block_primary; /* [dev] f64[n_blocks]    factor of the free-space field in output units (with offset)   */
     const int32_t *block_windows;/* [dev] int32[n_blocks]  windows of the block (with offset)                             */
+    /* Position moves (the reference's solve_receiver_x / _y / _z = the pair's offset, solve_transmitter_z; Loop_pair.perturb :161-164,
+     * Point.perturb): a moved receiver keeps its chain's TABLE SET -- built for the measured (rho_set, dz_set) -- and is evaluated with
+     * the per-chain scalars  rho_scale = rho_set / rho  (gbp_fdem_*_rows_scaled; dipole sources only when dx / dy move) and the effective
+     * height  h + (dz - dz_set) / 2  written to chains->height_p (proposal) / chains->height (state; the const is dropped).  All NULL:
+     * angles only.  Needs chains->height_p. */
+    double *rho_scale, *rho_scale_p;  /* [dev] f64[B] rho_set / rho of the state / of the proposal (scratch)              */
+    const double *rho_set, *dz_set;  /* [dev] f64[B] horizontal distance and dz the chain's table set was built for       */
 } gbp_td_moves;
 typedef struct gbp_td_operator {
     int32_t n_nodal;        /* rows of W (= 2 * nF of `sys` without mixing)                                   */
