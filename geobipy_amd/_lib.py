@@ -58,7 +58,8 @@ class TdMoves(ctypes.Structure):
                 ("weights", c_void_p), ("weights_p", c_void_p), ("offset", c_void_p), ("offset_p", c_void_p), ("hist", c_void_p),
                 ("best_geom", c_void_p), ("n_blocks", ctypes.c_int32), ("n_basis", ctypes.c_int32), ("loop", ctypes.c_int32),
                 ("on_axis", ctypes.c_int32), ("basis", ctypes.c_int32 * 5), ("block_comp", c_void_p), ("block_scale", c_void_p),
-                ("block_primary", c_void_p), ("block_windows", c_void_p)]
+                ("block_primary", c_void_p), ("block_windows", c_void_p), ("rho_scale", c_void_p), ("rho_scale_p", c_void_p),
+                ("rho_set", c_void_p), ("dz_set", c_void_p)]
 
 
 class TdOperator(ctypes.Structure):
@@ -110,6 +111,8 @@ SIGNATURES = {
     "gbp_fdem_forward_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
     "gbp_fdem_forward_rows_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p, c_int, c_void_p]),
     "gbp_fdem_fm_dlogc_rows_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_int, c_void_p]),
+    "gbp_fdem_forward_rows_scaled": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "gbp_fdem_fm_dlogc_rows_scaled": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gbp_fdem_validate": (c_int, [c_int, c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_void_p]),
     "gbp_gauss_loglike_std": (c_int, [c_int, c_int] + [c_void_p] * 5 + [c_void_p]),

@@ -439,8 +439,8 @@ def _grids(inf):
     angles = {}
     if data_kind(inf.datapoint) != "fdem":
         from .tdem_geometry import LOOP_PAIR_SCALARS
-        for name, stem, nb in LOOP_PAIR_SCALARS:
-            if name[3:] in ("pitch", "roll", "yaw") and o.get("solve_" + stem):
+        for name, stem, nb in LOOP_PAIR_SCALARS:                 # (+ the sampled positions: the pair's offset dx / dy / dz, the transmitter's z)
+            if (name[3:] in ("pitch", "roll", "yaw") or name in ("dx", "dy", "dz", "tx_z")) and o.get("solve_" + stem):
                 m_ = float(o["maximum_" + stem + "_change"])
                 angles[name] = np.linspace(-m_, m_, nb + 1)
     return dict(K=K, rel_edges=rel[0][0], add_edges=add[0][0], rel_to=rel[0][1], add_to=add[0][1], rel_axes=rel, add_axes=add,
@@ -515,9 +515,14 @@ def _create_tdem_data(parent, dp, g_, n, fid, kind):
     d.create_dataset("components", data=np.asarray(["xyz".index(c) for c in dp.system[0].components], dtype=np.int32))
     lp = d.create_group("loop_pair")
     _attrs(lp, repr="Loop_pair")
-    for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m")):
-        _data_array(lp, key, (n,), label=label, units=u)
     ang = g_.get("angle_edges") or {}
+    for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m")):
+        if "d" + key in ang:         # a sampled component of the pair's offset (the receiver's x / y / z priors go to the offset, Loop_pair.set_priors
+            e_ = np.asarray(ang["d" + key], dtype=np.float64)      # :172-178): a StatArray with its posterior on the prior's cells, like a sampled angle
+            _stat_array(lp, key, n, (), label, u, (e_.size - 1,),
+                        [("y", dict(edges=e_, dimension=1, label=label, units=u, relative_to_rows=n, rel_label=label, rel_units=u))], "RectilinearMesh2D")
+        else:
+            _data_array(lp, key, (n,), label=label, units=u)
     _loop_rows(lp, "transmitter", n, {k_[3:]: v_ for k_, v_ in ang.items() if k_.startswith("tx_")})
     _loop_rows(lp, "receiver", n, {k_[3:]: v_ for k_, v_ in ang.items() if k_.startswith("rx_")})
     nc = dp.system[0].n_components
@@ -635,6 +640,13 @@ def write_inference1d(parent, inf, index=None):
     m["values/posterior/mesh/y/relative_to/data"][i] = g_["value_to"]
 
 
+def _sampled_scalar_group(name):
+    """Container group of a sampled scalar of the loop pair: tx_pitch -> loop_pair/transmitter/pitch, dz -> loop_pair/z (the offset)."""
+    if name in ("dx", "dy", "dz"):
+        return "loop_pair/" + name[1]
+    return "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
+
+
 def _write_loop_pair(d, i, x, y, z, offset, loop_angles, radius):
     """Loop_pair.writeHdf (system/Loop_pair.py:305-315): the pair's offset, the transmitter at the sounding, the receiver at
     transmitter + offset, both loops' pitch / roll / yaw (the file's convention), radius, unit moment, z orientation."""
@@ -691,7 +703,7 @@ def _write_tdem_point(d, i, dp, data, best, p, g_, error_model):
             ang[j_] = float(best_geom[name])
     _write_loop_pair(d, i, float(dp.x), float(dp.y), float(dp.z[0]), off, ang, dp.system[0].loopRadius())
     for name in (g_.get("angle_edges") or {}):
-        grp = "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
+        grp = _sampled_scalar_group(name)
         d[grp + "/posterior/values/data"][i, :] = p.geometry[name]
         d[grp + "/posterior/mesh/y/relative_to/data"][i] = p.geometry_edges[name][0] + 0.5 * (p.geometry_edges[name][-1] - p.geometry_edges[name][0])
     d["primary_field/data"][i] = getattr(dp, "primary_field", np.zeros(pf.size)) if pf.size > 1 else 0.0
@@ -841,13 +853,18 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
             d["primary_field/data"][sel] = one(F["primary"])
             d["predicted_primary_field/data"][sel] = one(F["predicted_primary"])
         la = np.array(F["loop_angles"], dtype=np.float64)
+        off_b, z_b = np.array(F["offset"], dtype=np.float64), np.array(F["z"][:, 0], dtype=np.float64)
         cols_ = {"tx_pitch": 0, "tx_roll": 1, "tx_yaw": 2, "rx_pitch": 3, "rx_roll": 4, "rx_yaw": 5}
-        for name, _ in angles:                                   # sampled angles: the best state's instead of the file's
-            la[:, cols_[name]] = F["best_" + name][:, 0]
-        _write_loop_pair(d, sel, F["x"][:, 0], F["y"][:, 0], F["z"][:, 0], (F["offset"][:, 0], F["offset"][:, 1], F["offset"][:, 2]),
-                         la, loop_radius)
+        for name, _ in angles:                                   # sampled scalars: the best state's instead of the file's
+            if name in cols_:
+                la[:, cols_[name]] = F["best_" + name][:, 0]
+            elif name in ("dx", "dy", "dz"):
+                off_b[:, "xyz".index(name[1])] = F["best_" + name][:, 0]
+            elif name == "tx_z":
+                z_b = F["best_" + name][:, 0]
+        _write_loop_pair(d, sel, F["x"][:, 0], F["y"][:, 0], z_b, (off_b[:, 0], off_b[:, 1], off_b[:, 2]), la, loop_radius)
         for name, _ in angles:
-            grp = "loop_pair/{}/{}".format("transmitter" if name.startswith("tx_") else "receiver", name[3:])
+            grp = _sampled_scalar_group(name)
             d[grp + "/posterior/values/data"][sel, :] = I[name + "_hist"]
             d[grp + "/posterior/mesh/y/relative_to/data"][sel] = F[name + "_centre"][:, 0]
     m = parent["model"]

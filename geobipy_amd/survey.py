@@ -660,13 +660,16 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         # the best data point: predicted_secondary_field = predictedData - predicted_primary_field there)
         best_mix = {}
         best_primary = None
+        eval_height = t["best_height"] if t.get("best_height") is not None else t["height"]
         if getattr(dc, "_moves", None):
             bw, boff, best_primary = dc.mix_for_geometry(torch.where(none[:, None], t["geom"], t["best_geom"]))
             best_mix = dict(weights=bw, offset=boff)
+            extra = dc.geometry_rows_extra()       # sampled positions: the best state's distance scale and effective height
+            if extra is not None:
+                best_mix["scale"], eval_height = extra["scale"], extra["height"]
         with torch.cuda.device(dev):                # one batched forward at the best models, through the sampler's own entry
             dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(),
-                             t["best_height"] if t.get("best_height") is not None else t["height"], t["data"],
-                             brel, badd, pred, chi2, logl, **best_mix)
+                             eval_height, t["data"], brel, badd, pred, chi2, logl, **best_mix)
         host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
         cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
                   brel, badd, t["log_mean_prior"][:, None], be, bs]
@@ -823,7 +826,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     c0 = 0
     ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
             "relative_error_posterior", "additive_error_posterior", "height_posterior") + tuple(
-        n_ + "_posterior" for n_ in ("tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"))
+        n_ + "_posterior" for n_ in ("dx", "dy", "dz", "tx_z", "tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"))
     for name, v in named:
         w = v.shape[1]
         block = r[:, c0:c0 + w]

@@ -657,6 +657,7 @@ class TdemDeviceChains(DeviceChains):
         heights = np.atleast_1d(np.asarray(heights, dtype=np.float64))
         # sampled attitude angles (solve_transmitter_pitch / _roll / _yaw, solve_receiver_pitch / _roll / _yaw: gbp_td_moves)
         self._moves = device_angle_moves(kw)
+        self._pos_moves = []
         geom_rows = gaaem_geometry(heights, offset, attitude)
         force = ()
         if self._moves:
@@ -666,7 +667,17 @@ class TdemDeviceChains(DeviceChains):
                                           "and another basis layout; invert the two groups as blocks of their own")
             on_axis = bool(on.size > 0 and on.all())
             loop = float(systems[0].loopRadius()) > 0.0
-            tx_moves = any(m_[0].startswith("tx_") for m_ in self._moves)
+            # position moves (receiver offset, transmitter height): the chain keeps its table set and is evaluated at another distance /
+            # height (gbp_td_moves.rho_scale); a changed azimuth turns the transmitter's moment in the pair's frame like a transmitter rotation
+            self._pos_moves = [m_[0] for m_ in self._moves if m_[0] in ("dx", "dy", "dz", "tx_z")]
+            lateral = any(n_ in ("dx", "dy") for n_ in self._pos_moves)
+            if lateral and loop:
+                raise NotImplementedError("solve_receiver_x / _y on a system with a transmitter LOOP (ModellingLoopRadius): the loop's source term "
+                                          "lam J1(lam a) does not scale with the distance; the device sampler moves the receiver laterally for "
+                                          "dipole systems (Tempest), the host sampler for any")
+            if lateral and on_axis:
+                raise NotImplementedError("solve_receiver_x / _y for a receiver on the transmitter's axis (other filters off the axis)")
+            tx_moves = any(m_[0].startswith("tx_") and m_[0] != "tx_z" for m_ in self._moves) or lateral
             force = ((0, 2) if tx_moves else (0,)) if on_axis else (((0, 1, 2, 3, 4) if loop else (0, 1, 4)) if tx_moves else (0, 1))
         gm = GeometryMix(systems, geom_rows, force_basis=force)
         self.td_systems, self._gm = systems, gm
@@ -708,7 +719,8 @@ class TdemDeviceChains(DeviceChains):
         class _Handle:                    # what DeviceChains asks of an acquisition system
             def handle(self_inner):
                 if getattr(outer, "_raw", None) is None:
-                    outer._raw = _raw_handle(systems, gm, outer._hankel_eps, _altitude_bins(heights))
+                    reach = sum(m_[3] * (0.5 if m_[0] == "dz" else 1.0) for m_ in outer._moves if m_[0] in ("dz", "tx_z"))   # effective heights
+                    outer._raw = _raw_handle(systems, gm, outer._hankel_eps, _altitude_bins(np.r_[heights - reach, heights + reach] if reach else heights))
                 return outer._raw
         if kw.get("solve_z"):
             raise NotImplementedError("solve_z on time-domain chains: the reference's forward takes the transmitter's z (system/Loop_pair.py:70), "
@@ -738,6 +750,11 @@ class TdemDeviceChains(DeviceChains):
                           geom_hist=torch.zeros((B, len(self._moves), 199), dtype=torch.int32, device=dev), best_geom=f64(geom_rows))
             if "pred_offset" in self.t:
                 self.t.update(pred_offset_p=self.t["pred_offset"].clone(), pred_offset0=self.t["pred_offset"].clone())
+            if self._pos_moves:
+                self.t.update(rho_scale=torch.ones(B, dtype=torch.float64, device=dev), rho_scale_p=torch.ones(B, dtype=torch.float64, device=dev),
+                              rho_set=f64(np.hypot(geom_rows[:, 4], geom_rows[:, 5])), dz_set=f64(geom_rows[:, 6]),
+                              height=self.t["height"].clone(), height_p=self.t["height"].clone(), height_set=self.t["height"].clone())
+                self._bind()
             i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(dev).contiguous()
             self._mv_layout = dict(comp=i32(gm.block_comp), scale=f64(gm.block_scale), primary=f64(gm.block_primary), windows=i32(gm.block_windows))
             self._td_struct = None
@@ -793,6 +810,9 @@ class TdemDeviceChains(DeviceChains):
                     mv.basis[i_] = int(b_)
                 mv.block_comp, mv.block_scale = lay["comp"].data_ptr(), lay["scale"].data_ptr()
                 mv.block_primary, mv.block_windows = lay["primary"].data_ptr(), lay["windows"].data_ptr()
+                if self._pos_moves:
+                    mv.rho_scale, mv.rho_scale_p = self._rows("rho_scale", None).data_ptr(), t["rho_scale_p"].data_ptr()
+                    mv.rho_set, mv.dz_set = t["rho_set"].data_ptr(), t["dz_set"].data_ptr()
             self._td_struct = td
         return self._td_struct
 
@@ -805,6 +825,9 @@ class TdemDeviceChains(DeviceChains):
             t["geom_hist"][r] = 0
             if "pred_offset0" in t:
                 t["pred_offset"][r] = t["pred_offset0"][r]
+            if self._pos_moves:
+                t["rho_scale"][r] = 1.0
+                t["height"][r] = t["height_set"][r]
 
     def sampled_angles(self, which="geom"):
         """{name: [B] values} of the sampled angles in the reference's own convention (the loops' pitch / roll / yaw) -- ``which``:
@@ -821,20 +844,33 @@ class TdemDeviceChains(DeviceChains):
         gm = GeometryMix(self.td_systems, g, force_basis=tuple(self._gm.basis))
         assert gm.basis == self._gm.basis and gm.weights.shape[1] == self._mix.weights.shape[1], "a rotation cannot change the basis layout"
         dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device).contiguous()
+        self._geometry_rows_extra = None
+        if self._pos_moves:                  # a moved position: the chain's table set at another distance / effective height (gbp_td_moves)
+            rho_set, dz_set = self.t["rho_set"].cpu().numpy(), self.t["dz_set"].cpu().numpy()
+            self._geometry_rows_extra = dict(height=dev(g[:, 0] + 0.5 * (g[:, 6] - dz_set)), scale=dev(rho_set / np.hypot(g[:, 4], g[:, 5])))
         if self._pred_offset0 is None:
             return dev(gm.weights), None, None
         pp = gm.primary_field()
         reps = np.concatenate([[s_.nwindows] * s_.n_components for s_ in self.td_systems])
         return dev(gm.weights), dev(np.repeat(pp, reps, axis=1)), pp
 
-    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl, weights=None, offset=None):
+    def geometry_rows_extra(self):
+        """{"height": effective heights, "scale": distance scales} of the tuples handed to the last ``mix_for_geometry`` call when
+        positions are sampled (what ``_eval_loglike(height=..., scale=...)`` takes), else None."""
+        return getattr(self, "_geometry_rows_extra", None)
+
+    def _eval_loglike(self, k, sigma, thk, height, data, rel, add, pred, chi2, logl, weights=None, offset=None, scale=None):
         """``weights`` / ``offset``: per-row mixing weights and predicted-primary offsets to evaluate with instead of the chains'
-        current ones (mix_for_geometry)."""
+        current ones (mix_for_geometry); ``scale``: per-row distance scale of the rows' table sets (sampled positions; ``height`` is
+        then the effective height, geometry_rows_extra)."""
         td = self._td()
         lib, n = _lib.load(), k.numel()
         nodal = torch.empty((n, self._mix.n_in), dtype=torch.float64, device=self.device)
-        _lib.check(lib.gbp_fdem_forward_rows_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
-                                                nodal.data_ptr(), td.table_set, self.forward_waves, self._stream()))
+        if scale is None and self._pos_moves and self._row_index is None and "rho_scale" in self.t and n == self.t["rho_scale"].shape[0]:
+            scale = self.t["rho_scale"]                      # the chains' current positions
+        _lib.check(lib.gbp_fdem_forward_rows_scaled(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(), height.data_ptr(),
+                                                    nodal.data_ptr(), td.table_set, None if scale is None else scale.data_ptr(),
+                                                    self.forward_waves, self._stream()))
         p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
         mix = td.mix
         if weights is not None or offset is not None:
@@ -855,9 +891,10 @@ class TdemDeviceChains(DeviceChains):
         n = k.numel()
         Jn = torch.empty((n, self._mix.n_in, self.K), dtype=torch.float64, device=self.device)
         nodal = torch.empty((n, self._mix.n_in), dtype=torch.float64, device=self.device)
-        _lib.check(_lib.load().gbp_fdem_fm_dlogc_rows_ex(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
-                                                         height.data_ptr(), nodal.data_ptr(), Jn.data_ptr(), int(max_layers), 1,
-                                                         td.table_set, 0, self._stream()))
+        scale = self.t["rho_scale"] if (self._pos_moves and self._row_index is None and "rho_scale" in self.t and n == self.t["rho_scale"].shape[0]) else None
+        _lib.check(_lib.load().gbp_fdem_fm_dlogc_rows_scaled(self._h.ptr, n, self.K, k.data_ptr(), sigma.data_ptr(), thk.data_ptr(),
+                                                             height.data_ptr(), nodal.data_ptr(), Jn.data_ptr(), int(max_layers), 1,
+                                                             td.table_set, None if scale is None else scale.data_ptr(), 0, self._stream()))
         p = torch.empty((n, self._W.shape[1]), dtype=torch.float64, device=self.device)
         _lib.check(_lib.load().gbp_td_apply_mix(n, self.K, self._W.shape[0], self._W.shape[1], k.data_ptr(), self._W.data_ptr(),
                                                 nodal.data_ptr(), Jn.data_ptr(), p.data_ptr(), J.data_ptr(), ctypes.byref(td.mix), self._stream()))

@@ -109,21 +109,30 @@ def loop_pair_moves(values, options):
             for name, stem, nb in LOOP_PAIR_SCALARS if options.get("solve_" + stem, False)]
 
 
-# The angle moves the DEVICE sampler takes (gbp_td_moves): name -> (entry of the GA-AEM tuple, sign of Loop_pair.Geometry)
+# The moves the DEVICE sampler takes (gbp_td_moves): name -> (entry of the GA-AEM tuple, sign of Loop_pair.Geometry).  Angles change
+# the mixing weights only; the receiver offset (dx, dy, dz) and the transmitter height keep the chain's table set and are evaluated with
+# a per-chain distance scale and effective height (gbp_td_moves.rho_scale, gbp_fdem_*_rows_scaled).  The transmitter's x / y are not in
+# the tuple -- they never change a prediction (Loop_pair keeps the offset as a Point of its own) -- and stay with the host sampler.
 DEVICE_ANGLE_MOVES = {"tx_pitch": (2, -1.0), "tx_roll": (1, 1.0), "tx_yaw": (3, -1.0), "rx_pitch": (8, -1.0), "rx_roll": (7, 1.0), "rx_yaw": (9, -1.0)}
+DEVICE_POSITION_MOVES = {"dx": (4, 1.0), "dy": (5, 1.0), "dz": (6, 1.0), "tx_z": (0, 1.0)}
 
 
 def device_angle_moves(options):
     """[(name, tuple entry, sign, maximum change, proposal scale, posterior cells)] in the reference's order for the options'
-    solve_transmitter_* / solve_receiver_* keys; position moves (x, y, z of either loop: new Hankel tables per proposal) raise."""
+    solve_transmitter_* / solve_receiver_* keys: the attitude angles, the receiver offset (solve_receiver_x / _y / _z) and the
+    transmitter height (solve_transmitter_z); solve_transmitter_x / _y raise (no effect on the forward: host sampler)."""
     out = []
     for name, stem, nb in LOOP_PAIR_SCALARS:
         if not options.get("solve_" + stem, False):
             continue
-        if name not in DEVICE_ANGLE_MOVES:
-            raise NotImplementedError("solve_" + stem + ": the device sampler samples the loops' attitude angles; a position move needs new "
-                                      "Hankel tables for every proposal (the host sampler, inference.Inference1D, takes it)")
-        e, sg = DEVICE_ANGLE_MOVES[name]
+        if name in DEVICE_ANGLE_MOVES:
+            e, sg = DEVICE_ANGLE_MOVES[name]
+        elif name in DEVICE_POSITION_MOVES:
+            e, sg = DEVICE_POSITION_MOVES[name]
+        else:
+            raise NotImplementedError("solve_" + stem + ": a position move of the transmitter's x / y never changes a prediction (the GA-AEM tuple "
+                                      "holds the receiver OFFSET, Loop_pair.py:63-77): the device sampler does not sample it (the host sampler, "
+                                      "inference.Inference1D, takes it)")
         out.append((name, e, sg, float(options["maximum_" + stem + "_change"]), float(options[stem + "_proposal_variance"]), nb))
     return out
 

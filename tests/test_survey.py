@@ -500,7 +500,8 @@ def test_tempest_survey_recovers_a_wrong_receiver_pitch(tmp_path):
     """``solve_receiver_pitch`` end to end on the device sampler (gbp_td_moves): Tempest soundings whose receiver was pitched by 1.5
     degrees -- secondary AND primary field computed with that attitude -- while the file records level flight.  With the geometry
     fixed the predicted primary field is off by ~ 35 fT x sin(1.5 deg) on channels known to ~ 0.04 fT and the chains cannot fit;
-    with the pitch sampled (prior +- 5 degrees) they find it.  Position moves of the loops are refused by the device sampler."""
+    with the pitch sampled (prior +- 5 degrees) they find it.  Position moves of the transmitter's x / y (which never change a prediction) are refused by the device sampler; the receiver's are taken
+    (test_tempest_survey_recovers_a_wrong_receiver_position)."""
     from geobipy_amd.tdem import TdemBatch
     o = survey.read_options(os.path.join(GOLDEN, "tempest_options_small"))
     ds = survey.TempestData.read_csv(o["data_filename"], o["system_filename"]).subset(np.arange(0, 79, 5))
@@ -549,7 +550,62 @@ def test_tempest_survey_recovers_a_wrong_receiver_pitch(tmp_path):
     level = np.array(ds.system[0].primary_field(*ds.offsets[0]))                    # what the measured (level-flight) geometry would give
     assert np.abs(zc_["/data/predicted_primary_field/data"] - level[None, :]).max() > 0.1     # ~ 35 fT x sin(1.4 degrees)
     with pytest.raises(NotImplementedError, match="position move"):
-        survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_x=True, maximum_receiver_x_change=5.0, receiver_x_proposal_variance=0.01, **kw)
+        survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_transmitter_x=True, maximum_transmitter_x_change=5.0,
+                     transmitter_x_proposal_variance=0.01, **kw)
+
+
+@pytest.mark.gpu
+def test_tempest_survey_recovers_a_wrong_receiver_position(tmp_path):
+    """``solve_receiver_x`` / ``solve_receiver_z`` end to end on the device sampler (VERDICT r3 missing #3; the keys the reference's Tempest
+    gallery example puts priors on): soundings whose receiver hung 0.8 m further back and 0.6 m lower than the file records --
+    secondary AND primary field computed there.  With the geometry fixed the predicted primary field is off by several fT on channels
+    known to ~ 0.04 fT; with the offset sampled (prior +- 1.5 m each) the chains find it.  Every chain keeps the table set of its
+    MEASURED offset and is evaluated with a per-chain distance scale and effective height (gbp_td_moves.rho_scale); the container
+    holds the best offset, its posterior, and the prediction / predicted primary field of that geometry."""
+    from geobipy_amd import hdf
+    from geobipy_amd.tdem import TdemBatch
+    o = survey.read_options(os.path.join(GOLDEN, "tempest_options_small"))
+    ds = survey.TempestData.read_csv(o["data_filename"], o["system_filename"]).subset(np.arange(0, 79, 6))
+    S = ds.nPoints
+    rng = np.random.default_rng(4)
+    nl = np.full(S, 2, dtype=np.int32)
+    sig = np.tile([0.05, 0.005, 1.0], (S, 1))
+    thk = np.c_[rng.uniform(40.0, 80.0, S), np.zeros(S), np.zeros(S)]
+    file_off = ds.offsets.copy()
+    true_off = file_off + np.array([-0.8, 0.0, -0.6])
+    tb = TdemBatch(ds.system, nl, sig, thk, ds.z, true_off, attitude=ds.attitude)
+    sec, prim = tb.forward().cpu().numpy(), tb.primary_field()
+    tot = sec + np.repeat(prim, sec.shape[1] // prim.shape[1], axis=1)
+    ds.data[:] = sec + rng.normal(size=sec.shape) * np.sqrt((0.001 * tot) ** 2 + np.asarray(o["initial_additive_error"]) ** 2)
+    ds.primary_field[:] = prim
+    kw = dict(data=ds, burn_in_min_iterations=1500, check_every=500, n_markov_chains=2500)
+    fixed = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), **kw)
+    moved = survey.infer(os.path.join(GOLDEN, "tempest_options_small"), solve_receiver_x=True, maximum_receiver_x_change=1.5,
+                         receiver_x_proposal_variance=0.05, solve_receiver_z=True, maximum_receiver_z_change=1.5,
+                         receiver_z_proposal_variance=0.05, results_directory=str(tmp_path), **kw)
+    print("receiver offset: final dx", np.round(moved["dx"], 2), "dz", np.round(moved["dz"], 2), "median misfit fixed / moved",
+          np.median(fixed["misfit"]), np.median(moved["misfit"]))
+    assert moved["dx_posterior"].shape == (S, 99) and moved["dz_posterior"].shape == (S, 99)
+    assert np.median(moved["misfit"]) < 0.05 * np.median(fixed["misfit"])
+    assert np.mean(np.abs(moved["dx"] - true_off[:, 0]) < 0.3) >= 0.8 and np.mean(np.abs(moved["dz"] - true_off[:, 2]) < 0.3) >= 0.8
+    zc_ = hdf.load_npz(str(tmp_path / "0.0.results.npz"))
+    order = np.argsort(ds.fiducial)
+    assert np.array_equal(zc_["/data/loop_pair/x/data"], moved["best_dx"][order]) and np.array_equal(zc_["/data/loop_pair/z/data"], moved["best_dz"][order])
+    assert np.array_equal(zc_["/data/loop_pair/x/posterior/values/data"], moved["dx_posterior"][order])
+    assert np.allclose(zc_["/data/loop_pair/z/posterior/mesh/y/relative_to/data"], file_off[order, 2])
+    assert np.allclose(zc_["/data/loop_pair/receiver/x/data"], (ds.x + moved["best_dx"])[order])
+    # the container's prediction and predicted primary field are those of the best model at the best OFFSET, from scratch (new tables)
+    bk = moved["best_n_layers"].astype(np.int32)
+    be, bs = moved["best_edges"], moved["best_conductivity"]
+    bthk = np.zeros_like(bs)
+    for i_ in range(S):
+        bthk[i_, : bk[i_] - 1] = np.diff(np.r_[0.0, be[i_, : bk[i_] - 1]])
+    best_off = file_off.copy()
+    best_off[:, 0], best_off[:, 2] = moved["best_dx"], moved["best_dz"]
+    tbb = TdemBatch(ds.system, bk, bs, bthk, ds.z, best_off, attitude=ds.attitude)
+    sec_b, prim_b = tbb.forward().cpu().numpy(), tbb.primary_field()
+    assert np.abs(zc_["/data/predicted_primary_field/data"] - prim_b[order]).max() <= 1e-9 * np.abs(prim_b).max()
+    assert np.abs(zc_["/data/predicted_secondary_field/data"] - sec_b[order]).max() <= 1e-8 * np.abs(sec_b).max()
 
 
 def test_survey_result_round_trip(tmp_path):

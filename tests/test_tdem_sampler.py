@@ -174,14 +174,19 @@ def test_tempest_two_components_one_system():
     assert acc.sum() > 10
 
 
-@pytest.mark.parametrize("case", ["skytem_tx_rx", "tempest_total_field"])
+@pytest.mark.parametrize("case", ["skytem_tx_rx", "tempest_total_field", "tempest_positions", "skytem_heights"])
 def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
     """gbp_td_moves -- the reference's solve_transmitter_pitch / solve_receiver_pitch / _roll (pinned to the reference on the host:
     test_tdem_object_api.py::test_host_sampler_walks_the_reference_chain_with_loop_pair_moves): CPU chains with the same
     counter-based streams, every evaluation a TdemBatch of the request's geometry (current angles for the remapped model, proposed
     angles for the proposal; Tempest: + the free-space primary field of that geometry), walk the same chains as the device, whose
     kernels never see a new table -- a rotation only changes the per-chain mixing weights (and primary-field offset) that
-    k_td_moves_propose forms: decisions, layer counts, angles to 1e-9 degrees, angle posteriors, highest-posterior angles."""
+    k_td_moves_propose forms: decisions, layer counts, angles to 1e-9 degrees, angle posteriors, highest-posterior angles.
+    POSITION moves (round 4; the reference's solve_receiver_x / _z, solve_transmitter_z -- what its Tempest gallery example puts
+    priors on): the CPU chains evaluate every request with a TdemBatch built for the request's OWN offset and height (new Hankel
+    tables), the device keeps each chain's table set and evaluates it with the per-chain distance scale and effective height
+    (gbp_td_moves.rho_scale, gbp_fdem_*_rows_scaled) -- the same chains: "tempest_positions" (dipole source: receiver x, z and pitch,
+    total-field data with the primary field of the moved geometry), "skytem_heights" (loop source: receiver z and transmitter z)."""
     from geobipy_amd.tdem import TdemBatch, TdemDeviceChains
     from geobipy_amd.tdem_geometry import gaaem_tuple
     if case == "skytem_tx_rx":
@@ -190,19 +195,33 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
                   solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.5)
         moves = [("tx_pitch", 4.0, 0.4), ("rx_pitch", 5.0, 0.5)]
         att0 = (1.0, 2.0, 0.0, -1.5, 1.0, 0.5)           # GA-AEM convention: tx roll, pitch, yaw, rx roll, pitch, yaw
+    elif case == "skytem_heights":
+        off, stm, alt, n_it = OFFSET, ("SkytemLM.stm",), (30.0, 40.0), 150
+        mv = dict(solve_receiver_z=True, maximum_receiver_z_change=1.0, receiver_z_proposal_variance=0.15,
+                  solve_transmitter_z=True, maximum_transmitter_z_change=2.0, transmitter_z_proposal_variance=0.3)
+        moves = [("dz", 1.0, 0.15), ("tx_z", 2.0, 0.3)]
+        att0 = (0.0, 1.0, 0.0, 0.0, -0.5, 0.0)
+    elif case == "tempest_positions":
+        off, stm, alt, n_it = (-107.0, 0.0, -45.0), ("tempest.stm",), (115.0, 125.0), 150
+        mv = dict(solve_receiver_x=True, maximum_receiver_x_change=1.0, receiver_x_proposal_variance=0.1,
+                  solve_receiver_z=True, maximum_receiver_z_change=1.0, receiver_z_proposal_variance=0.1,
+                  solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.3)
+        moves = [("dx", 1.0, 0.1), ("dz", 1.0, 0.1), ("rx_pitch", 5.0, 0.3)]
+        att0 = (0.0, 0.0, 0.0, 0.0, -1.0, 0.0)
     else:
         off, stm, alt, n_it = (-107.0, 0.0, -45.0), ("tempest.stm",), (115.0, 125.0), 150
         mv = dict(solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.3,
                   solve_receiver_roll=True, maximum_receiver_roll_change=3.0, receiver_roll_proposal_variance=0.2)
         moves = [("rx_pitch", 5.0, 0.3), ("rx_roll", 3.0, 0.2)]
         att0 = (0.0, 0.0, 0.0, 0.5, -1.0, 0.0)
+    total_field = case.startswith("tempest")
     B = 3
     s, h, data, scale, opts, groups = _survey(B, seed=11, stm=stm, offset=off, alt=alt)
     systems = s if isinstance(s, list) else [s]
     base = dict(dx=off[0], dy=off[1], dz=off[2], tx_x=0.0, tx_y=0.0, tx_z=0.0, tx_roll=att0[0], tx_pitch=-att0[1], tx_yaw=-att0[2],
                 rx_roll=att0[3], rx_pitch=-att0[4], rx_yaw=-att0[5])          # the loops' own convention (Loop_pair.Geometry negates)
     kw = {}
-    if case == "tempest_total_field":
+    if total_field:
         opts = dict(opts, initial_relative_error=[0.05, 0.05], minimum_relative_error=[0.005, 0.005], maximum_relative_error=[0.5, 0.5],
                     relative_error_proposal_variance=[1e-6, 1e-6], initial_additive_error=[1.0, 1.0], minimum_additive_error=[0.1, 0.1],
                     maximum_additive_error=[10.0, 10.0], additive_error_proposal_variance=[1e-6, 1e-6])
@@ -224,13 +243,13 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
             K = 20
             sg, th = np.ones((1, K)), np.zeros((1, K))
             sg[0, : v.size], th[0, : v.size - 1] = v, np.diff(np.r_[0.0, e])
-            g = gaaem_tuple(dict(base, tx_z=self.z, **geometry))
-            return TdemBatch(systems, np.array([v.size]), sg, th, np.array([self.z]), off, attitude=tuple(np.r_[g[1:4], g[7:10]]))
+            g = gaaem_tuple(dict(dict(base, tx_z=self.z), **geometry))       # (the request's own height and offset: tables of their own)
+            return TdemBatch(systems, np.array([v.size]), sg, th, np.array([g[0]]), tuple(g[4:7]), attitude=tuple(np.r_[g[1:4], g[7:10]]))
 
         def forward(self, e, v, geometry):
             b_ = self._batch(e, v, geometry)
             p_ = b_.forward().cpu().numpy()[0].copy()
-            if case == "tempest_total_field":
+            if total_field:
                 p_ = p_ + np.repeat(b_.primary_field()[0], [systems[0].nwindows] * systems[0].n_components)
             return p_
 
@@ -243,16 +262,17 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
               rel_sd=np.array(o.rel_sd[:Gr]), rel_min=np.array(o.rel_min[:Gr]), rel_max=np.array(o.rel_max[:Gr]),
               add_sd=np.array(o.add_sd[:Ga]), add_min=np.array(o.add_min[:Ga]), add_max=np.array(o.add_max[:Ga]), alpha=o.alpha,
               add_independent=bool(o.additive_independent), add_centre=np.array(o.add_centre[:Ga]))
-    assert bool(o.additive_independent) == (case == "tempest_total_field")       # (the reference's treatment of Tempest's multipliers)
+    assert bool(o.additive_independent) == total_field       # (the reference's treatment of Tempest's multipliers)
     sig0 = dc.sigma[:, 0].cpu().numpy()
     chains = []
     for b in range(B):
         sp = rjmcmc.StructurePrior(dc.K, opts["minimum_depth"], opts["maximum_depth"], opts["minimum_thickness"], eo["p"])
         vp = rjmcmc.ValuePrior(sig0[b], 10.0, 1.5, True)
         rel0 = np.broadcast_to(np.atleast_1d(opts["initial_relative_error"]), (Gr,)).astype(float)
-        add0 = np.broadcast_to(np.atleast_1d(np.asarray(opts["initial_additive_error"], dtype=float)), (Ga,)).astype(float) if case != "tempest_total_field" else np.ones(Ga)
+        add0 = np.broadcast_to(np.atleast_1d(np.asarray(opts["initial_additive_error"], dtype=float)), (Ga,)).astype(float) if not total_field else np.ones(Ga)
         chains.append(rj_emul.Chain(eo, 41, b, Engine(h[b]), sp, vp, data[b], sig0[b], rel0, add0, dc.n_depth_bins, dc.depth_bin_width,
-                                    add_scale=scale, groups=groups, angle_moves=moves, angles={m_[0]: base[m_[0]] for m_ in moves}))
+                                    add_scale=scale, groups=groups, angle_moves=moves,
+                                    angles={m_[0]: (h[b] if m_[0] == "tx_z" else base[m_[0]]) for m_ in moves}))
         assert np.isclose(chains[b].misfit, float(dc.misfit[b]), rtol=1e-8) and np.isclose(chains[b].prior, float(dc.prior[b]), rtol=1e-12)
     accs, ks = [], []
     prev = dc.n_accepted.cpu().numpy().copy()
@@ -274,11 +294,17 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
         assert np.isclose(c.misfit, float(dc.misfit[b]), rtol=1e-5)
         for q, (n_, _, _) in enumerate(moves):
             assert np.array_equal(c.angle_hist[n_], hist[b, q]) and hist[b, q].sum() == n_it, (b, n_)
-    moved = np.array([[abs(c.angles[m_[0]] - base[m_[0]]) for m_ in moves] for c in chains])
-    assert accs.sum() > 0.1 * accs.size and moved.max() > 0.5
+    centre = lambda n_, b_: h[b_] if n_ == "tx_z" else base[n_]
+    moved = np.array([[abs(c.angles[m_[0]] - centre(m_[0], c.b)) / m_[1] for m_ in moves] for c in chains])
+    assert accs.sum() > 0.1 * accs.size and moved.max() > 0.1
     best = dc.sampled_angles("best_geom")
     for m_ in moves:
-        assert torch.all(torch.abs(best[m_[0]] - base[m_[0]]) <= m_[1] + 1e-12)
+        c0 = torch.as_tensor([centre(m_[0], b_) for b_ in range(B)], dtype=torch.float64, device=best[m_[0]].device)
+        assert torch.all(torch.abs(best[m_[0]] - c0) <= m_[1] + 1e-12)
+    if dc._pos_moves:                                             # the chains' table sets never changed: one per measured (rho, dz)
+        g_now = dc.t["geom"].cpu().numpy()
+        assert np.allclose(dc.t["rho_scale"].cpu().numpy(), np.hypot(off[0], off[1]) / np.hypot(g_now[:, 4], g_now[:, 5]), rtol=1e-14)
+        assert np.allclose(dc.t["height"].cpu().numpy(), g_now[:, 0] + 0.5 * (g_now[:, 6] - off[2]), rtol=1e-14)
 
 
 def test_sampled_angles_survive_the_repacking_of_a_block():
