@@ -110,7 +110,22 @@ class _Dataset:
 
     def __setitem__(self, k, v):
         self._check(k)
+        if self._arr is None and not getattr(self, "_rle", None) and self._covers_all(k):
+            # the first write covers the whole dataset (a line's rows arriving in one block): one copy instead of allocate + fill + copy
+            a = np.empty(self._shape, dtype=self._dtype)
+            a[...] = v
+            self._arr = a
+            return
         self.arr[k] = v
+
+    def _covers_all(self, k):
+        keys = k if isinstance(k, tuple) else (k,)
+        if len(keys) > len(self._shape):
+            return False
+        for q, n_ in zip(keys, self._shape):
+            if not (isinstance(q, slice) and q.indices(n_) == (0, n_, 1)):
+                return False
+        return True
 
 
 class NpzGroup:
@@ -871,12 +886,14 @@ def write_device_rows(parent, index, f64, i32, N, K, n_depth, n_value, options, 
     k = I["best_k"][:, 0]
     m["mesh/nCells/data"][sel] = k
     m["mesh/nCells/posterior/values/data"][sel, :] = I["k_hist"]
+    # padded rows of the best model: edges 0, e_1 .. e_{k-1}, inf then NaN; values sigma_1 .. sigma_k then NaN
+    jj = np.arange(K + 1)[None, :]
+    kk = k.astype(np.int64)[:, None]
     rows = np.full((idx.size, K + 1), np.nan)
-    vals = np.full((idx.size, K), np.nan)
-    for j in range(idx.size):
-        kj = int(k[j])
-        rows[j, :kj + 1] = np.r_[0.0, F["best_edges"][j, :kj - 1], np.inf]
-        vals[j, :kj] = F["best_sigma"][j, :kj]
+    rows[:, 1:K] = F["best_edges"][:, :K - 1]
+    rows[:, 0] = 0.0
+    rows = np.where(jj < kk, rows, np.where(jj == kk, np.inf, np.nan))
+    vals = np.where(jj[:, :K] < kk, F["best_sigma"], np.nan)
     m["mesh/y/edges/data"][sel, :] = rows
     m["mesh/y/edges/posterior/values/data"][sel, :] = I["edge_hist"]
     m["values/data"][sel, :] = vals

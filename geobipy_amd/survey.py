@@ -403,13 +403,13 @@ class _LineWriter:
                 self.lines[ln] = [root, fid, path, 0]
             root, fid, _, _ = self.lines[ln]
             m = f[:, self.line_col] == ln
-            every = bool(m.all())                   # (a chunk of one line: the rows as they are, no masked copy)
-            fm, im = (f, i) if every else (f[m], i[m])
+            rows_ = np.flatnonzero(m)
+            run = rows_[-1] - rows_[0] + 1 == rows_.size       # the line's rows are one run of the chunk (the usual case): views, no copies
+            fm, im = (f[rows_[0]:rows_[-1] + 1], i[rows_[0]:rows_[-1] + 1]) if run else (f[m], i[m])
             sub = csr
-            if csr is not None and not every:       # the line's rows of the chunk's CSR block (a run of consecutive rows, usually)
-                rows_ = np.flatnonzero(m)
+            if csr is not None and rows_.size != f.shape[0]:       # the line's rows of the chunk's run-length block
                 ptr_, ind_, val_ = csr
-                if rows_[-1] - rows_[0] + 1 == rows_.size:
+                if run:
                     a_, b_ = int(ptr_[rows_[0]]), int(ptr_[rows_[-1] + 1])
                     sub = (ptr_[rows_[0]:rows_[-1] + 2] - a_, ind_[a_:b_], val_[a_:b_])
                 else:
@@ -417,7 +417,7 @@ class _LineWriter:
                     sub = (np.r_[0, np.cumsum(np.diff(ptr_)[rows_])], ind_[take], val_[take])
             hdf.write_device_rows(root, np.searchsorted(fid, fm[:, self.fid_col]), fm, im, self.N, self.K, self.nd, self.nv, self.o,
                                   hitmap_csr=sub, **self.wkw)
-            self.lines[ln][3] += int(m.sum())
+            self.lines[ln][3] += int(rows_.size)
             if self.lines[ln][3] >= fid.size:
                 self._close(ln)
 
