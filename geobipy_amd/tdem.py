@@ -677,6 +677,12 @@ class TdemDeviceChains(DeviceChains):
                                           "dipole systems (Tempest), the host sampler for any")
             if lateral and on_axis:
                 raise NotImplementedError("solve_receiver_x / _y for a receiver on the transmitter's axis (other filters off the axis)")
+            if lateral:                                        # the prior must keep the receiver off the axis (the distance scale is rho_set / rho)
+                reach = float(np.sqrt(sum(m_[3] ** 2 for m_ in self._moves if m_[0] in ("dx", "dy"))))
+                rho_min = float(np.hypot(geom_rows[:, 4], geom_rows[:, 5]).min())
+                if not reach < 0.5 * rho_min:
+                    raise ValueError("maximum_receiver_x / _y_change ({:.3g} m) must stay below half the smallest horizontal transmitter-receiver "
+                                     "distance of the block ({:.3g} m)".format(reach, rho_min))
             tx_moves = any(m_[0].startswith("tx_") and m_[0] != "tx_z" for m_ in self._moves) or lateral
             force = ((0, 2) if tx_moves else (0,)) if on_axis else (((0, 1, 2, 3, 4) if loop else (0, 1, 4)) if tx_moves else (0, 1))
         gm = GeometryMix(systems, geom_rows, force_basis=force)
