@@ -501,6 +501,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf``; ``<line number>.results.npz`` with the same dataset paths when
     h5py is not installed -- ``hdf.container_type()`` says which) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
     map), best model and its predicted data.  The rows travel to rank 0 in bounded chunks (``distributed.stream_rows_to_root``).
+    ``traces``: per-iteration misfit / acceptance traces for the containers' ``phids`` / ``acceptance_rate``, kept on the device at a stride --
+    "auto": at most 4 096 entries per sounding; an int: that stride (1 = the reference's arrays in full); None: none.
+    ``timings``: a dict that receives the wall time by phase (the device is synchronised at the phase borders then; bench.py).
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
     expression.  ``hankel_eps``: accuracy-budgeted window of the Hankel filter abscissae.  Frequency domain: ppm, per
@@ -511,7 +514,6 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     from .distributed import shard
     from .rjmcmc_gpu import DeviceChains
 
-    overrides_timings = timings
     o = read_options(options, **overrides) if isinstance(options, str) else dict(options)
     tempest = o["data_type"] in ("TempestData", "Tempest_datapoint")
     time_domain = tempest or o["data_type"] in ("TdemData", "TdemDataPoint")
@@ -577,7 +579,6 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     col = lambda x: f64(x)[:, None]
     # wall time by phase (device-synchronised at the phase borders only when a caller asks for it with timings={}: bench.py's
     # ``survey`` object; a normal run never synchronises for this)
-    timings = overrides_timings
     import time as _time
 
     class _Phase:
