@@ -242,7 +242,8 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
         if (row_scale != 1.0) gbp::scale_point(pt, row_scale);     // (wave-uniform: a receiver moved off its table set's distance)
         cplx num, den;
         gbp::rte_num_den<DIRECT>(M, pt.a, L, lay, sh_t2, pt.u0, num, den);
-        const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef);
+        const bool real_ue = __ballot(pt.ue.im != 0.0) == 0ull;            // (wave-uniform: see hankel_term)
+        const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef, real_ue);
         if (has_next) {
             const double sr = wave_sum(in_next ? 0.0 : t.re), si = wave_sum(in_next ? 0.0 : t.im);
             const double nr = wave_sum(in_next ? t.re : 0.0), ni = wave_sum(in_next ? t.im : 0.0);
@@ -433,8 +434,10 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                     gbp::Point pt = gbp::load_point(pts, npts_total, ch.off + (valid ? j : ch.npts - 1));
                     if (!valid) pt.coef = gbp::mk(0.0, 0.0);
                     if (row_scale != 1.0) gbp::scale_point(pt, row_scale);     // (wave-uniform, see forward_passes)
-                    const cplx E = gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD);
-                    const cplx t = gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, E * pt.coef, sh_D + lane,
+                    // (real exponents for every lane of the pass: exp only, same bits -- see gbp::hankel_term)
+                    const cplx Q = __ballot(pt.ue.im != 0.0) == 0ull ? pt.coef * gbp::exp_neg(M, pt.ue.re * hD)
+                                                                     : gbp::cexp_neg(M, pt.ue.re * hD, pt.ue.im * hD) * pt.coef;
+                    const cplx t = gbp::sens_point<EXACT>(M, pt.a, L, sh_lay, sh_t2, pt.u0, Q, sh_D + lane,
                                                           GBP_SENS_STRIDE);
                     fw_re += t.re;
                     fw_im += t.im;

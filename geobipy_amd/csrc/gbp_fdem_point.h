@@ -106,11 +106,16 @@ GBP_HD void rte_num_den(const MathCtx& M, double a, int L, const LayerK* __restr
 }
 
 // One term of H - H0: rTE * exp(ue * hD) * coef
-GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD, cplx coef)
+// `real_ue` (wave-uniform, decided by the caller): ue.im == 0 for every lane of the pass -- the abscissae above the free-space wavenumber,
+// i.e. every point of an abscissa window at survey altitudes, and every point of a raw (time-domain) handle.  cexp_neg(x, 0) is
+// (exp(x), +0) exactly (sincos_tab(0) = (0, 1) with no rounding) and a complex product with (e, +0) rounds like the two real products,
+// so the short path returns the same bits for 25 VALU issues less per pass.
+GBP_HD cplx hankel_term(const MathCtx& M, cplx num, cplx den, cplx ue, double hD, cplx coef, bool real_ue = false)
 {
-    const cplx E = cexp_neg(M, ue.re * hD, ue.im * hD);  // ue.im == 0 for the real-exponent kernels
     // |den| is at most 8 layers of growth away from the last renormalisation (<= ~1e30, >= ~1e-50),
     // so |den|^2 is safely inside the fp64 range
+    if (real_ue) return cdiv(num * (coef * exp_neg(M, ue.re * hD)), den);
+    const cplx E = cexp_neg(M, ue.re * hD, ue.im * hD);
     return cdiv(num * (E * coef), den);
 }
 
