@@ -30,9 +30,11 @@ def parse(argv=None):
                    help="accuracy budget of the Hankel-filter abscissa window: ppm for frequency-domain data (default 1e-10, 0 = all "
                         "abscissae), relative to the inductive-limit value for time-domain data (default 1e-12)")
     p.add_argument("--no-containers", action="store_true",
-                   help="skip the reference-layout results containers (<line>.h5 -- real HDF5 -- when h5py is installed, else the stand-in <line>.results.npz + "
-                        "<line>.results.attrs.json with the same dataset paths); the per-line "
+                   help="skip the reference-layout results containers (<line>.h5 -- real HDF5, through h5py or the HDF5 C library -- or, where neither "
+                        "exists, the stand-in <line>.results.npz + <line>.results.attrs.json with the same dataset paths); the per-line "
                         "summary files <line>.npz are always written")
+    p.add_argument("--container", choices=("auto", "hdf5", "npz"), default="auto",
+                   help="file type of the results containers: hdf5 (<line>.h5), npz (the stand-in), auto = hdf5 when it can be written")
     p.add_argument("--schedule", choices=("static", "dynamic", "lines"), default="static",
                    help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
                         "(the reference's master / worker scheduling); lines: whole flight lines per rank, each rank writes the "
@@ -67,7 +69,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
                        exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=containers,
-                       data_directory=a.data_directory,
+                       container=None if a.container == "auto" else a.container, data_directory=a.data_directory,
                        data_filename=a.data_filename)
     if rank == 0:
         paths = res.save_lines(a.output_directory)
@@ -76,11 +78,11 @@ def main(argv=None):
             res["status"].size, done, failed, time.perf_counter() - t0, ", ".join(os.path.basename(q) for q in paths)))
         if containers is not None:
             from . import hdf
-            kind = hdf.container_type()
+            kind = hdf.container_type(None if a.container == "auto" else a.container)
             print("results containers (the reference's Inference2D / Inference1D layout): " +
-                  ("HDF5 files <line>.h5" if kind == "hdf5" else
-                   "h5py is not installed -- written as the stand-in <line>.results.npz + <line>.results.attrs.json (same dataset paths, "
-                   "geobipy_amd.hdf.load_npz reads them; NOT HDF5 files)"))
+                  ("HDF5 files <line>.h5, written by " + str(hdf.hdf5_writer()) if kind == "hdf5" else
+                   "written as the stand-in <line>.results.npz + <line>.results.attrs.json (same dataset paths, "
+                   "geobipy_amd.hdf.load_npz reads them; NOT HDF5 files -- neither h5py nor a loadable HDF5 library here, or --container npz)"))
     if world > 1:
         dist.destroy_process_group()
     return 0

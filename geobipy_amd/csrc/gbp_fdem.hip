@@ -345,7 +345,7 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
     if (LIKE && wave == 0) loglike_wave(N, sh_out, obs_row, rel_b, add_b, lane, chi2_b, logL_b);
 }
 
-template <bool LIKE>
+template <bool LIKE, bool SCALED = false>   // SCALED: the rows carry a distance scale (gbp_fdem_forward_rows_scaled); the plain kernels do not pay for it (4 VGPRs, 36 B of scratch)
 __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict__ chan,
                                                        const double* __restrict__ pts, int npts_total, int F,
                                                        int Lmax, const int* __restrict__ nlayers,
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
     forward_body<LIKE>(M, sh_out, sh_dyn, chan, pts, npts_total, F, Lmax, L, sigma + (size_t)b * Lmax, thk + (size_t)b * Lmax,
                        height[b], LIKE ? obs + (size_t)b * 2 * F : nullptr, LIKE ? rel[b] : 0.0, LIKE ? add[b] : 0.0,
                        pred != nullptr ? pred + (size_t)b * 2 * F : nullptr, LIKE ? chi2 + b : nullptr, LIKE ? logL + b : nullptr,
-                       sigma_direct, (int)(blockDim.x >> 6), row_scale != nullptr ? row_scale[b] : 1.0);
+                       sigma_direct, (int)(blockDim.x >> 6), (SCALED && row_scale != nullptr) ? row_scale[b] : 1.0);
 }
 
 // Jacobian (+ prediction) of ONE sounding by the first `nw_use` waves of the calling workgroup: the body of k_fdem_sens, also
@@ -964,7 +964,8 @@ gbp_status gbp_fdem_forward_rows_scaled(const gbp_fdem_system* sys, int B, int L
     if (!pred) return fail(GBP_ERR_INVALID_ARG, "pred is NULL%s");
     if ((st = check_row_sets(sys, set_of_row)) != GBP_OK) return st;
     const int nw = pick_waves(B, sys->t.nF, Lmax, (sys->t.npts + 63) / 64, waves);
-    hipLaunchKernelGGL(k_fdem_forward<false>, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
+    auto kernel = row_scale != nullptr ? k_fdem_forward<false, true> : k_fdem_forward<false, false>;
+    hipLaunchKernelGGL(kernel, dim3(B), dim3(64 * nw), dyn_lds_bytes(nw, Lmax, (sys->t.npts + 63) / 64), (hipStream_t)stream, sys->d_chan,
                        sys->d_pts, sys->t.npts, sys->t.nF, Lmax, nlayers, sigma, thk, height, nullptr, nullptr,
                        nullptr, pred, nullptr, nullptr, sys->sigma_direct, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan, sys->d_bin_pts,
                        set_of_row, row_scale);
@@ -1156,3 +1157,25 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
 
 #include "gbp_rjmcmc.h"
 #include "gbp_tdem.h"
+#include "gbp_hostpack.h"
+
+// [host] rows of a hit map held as runs -> one zlib stream per row (see gbp_hostpack.h); no device work
+extern "C" gbp_status gbp_runs_to_zlib(int n_rows, int64_t cells_per_row, const int64_t* ptr, const int32_t* start, const int32_t* value,
+                                       uint8_t* out, int64_t out_capacity, int64_t* out_ptr)
+{
+    if (n_rows < 0 || cells_per_row < 1 || !ptr || !out || !out_ptr || out_capacity < 0 || (n_rows > 0 && (!start || !value)))
+        return fail(GBP_ERR_INVALID_ARG, "gbp_runs_to_zlib: NULL pointer or non-positive size%s");
+    int64_t pos = 0;
+    out_ptr[0] = 0;
+    for (int r = 0; r < n_rows; ++r) {
+        const int64_t a = ptr[r], b = ptr[r + 1];
+        if (b <= a || start[a] != 0) return fail(GBP_ERR_INVALID_ARG, "gbp_runs_to_zlib: every row needs a first run starting at cell 0%s");
+        for (int64_t q = a + 1; q < b; ++q)
+            if (start[q] <= start[q - 1] || start[q] >= cells_per_row) return fail(GBP_ERR_INVALID_ARG, "gbp_runs_to_zlib: run starts must increase within the row%s");
+        const size_t n = hostpack::row_to_zlib(cells_per_row, b - a, start + a, value + a, out + pos, (size_t)(out_capacity - pos));
+        if (n == 0) return fail(GBP_ERR_INVALID_ARG, "gbp_runs_to_zlib: output buffer too small%s");
+        pos += (int64_t)n;
+        out_ptr[r + 1] = pos;
+    }
+    return GBP_OK;
+}

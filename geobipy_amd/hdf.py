@@ -10,10 +10,12 @@ entry -- names, shapes, dtypes, attributes, and the values of a seeded sounding 
 
 ``parent`` is anything with the small h5py.Group surface used here (``create_group``, ``create_dataset(name, shape=, dtype=,
 data=, fillvalue=)``, ``attrs``, ``__getitem__``): an ``h5py.File`` / ``Group`` when h5py is installed (it is not in this
-image), or the bundled ``NpzGroup`` -- same tree, same names, saved as ``<path> -> array`` entries of a ``.npz`` plus a JSON
-sidecar of the attributes (``open_results`` picks whichever is available).
+image), or the bundled ``NpzGroup`` -- same tree, same names, held in memory and saved either as a REAL HDF5 file through the HDF5 C
+library (``geobipy_amd.h5lite``: ctypes on a libhdf5 of the image; the file the reference's ``h5py.File`` opens) or, where no such
+library exists, as ``<path> -> array`` entries of a ``.npz`` plus a JSON sidecar of the attributes.  ``container_type()`` says which.
 """
 import json
+import os
 
 import numpy as np
 
@@ -132,8 +134,9 @@ class NpzGroup:
     """In-memory group tree with h5py's create_group / create_dataset / attrs / [] surface; ``save(path)`` writes every
     dataset as the entry ``<hdf path>`` of ``path`` (.npz) and the attributes to ``path + '.attrs.json'``."""
 
-    def __init__(self, name="/"):
+    def __init__(self, name="/", container="npz"):
         self.name, self._items, self.attrs = name, {}, {}
+        self.container = container               # what save() writes: "npz" (+ .attrs.json) or "hdf5" (h5lite)
 
     def _child_name(self, last):
         return self.name.rstrip("/") + "/" + last
@@ -217,36 +220,113 @@ class NpzGroup:
         return out
 
     def save(self, path):
-        """``path`` (.npz): every dataset that was written; ``path + '.attrs.json'``: the attributes and, under the key
+        """container "hdf5": the HDF5 file ``path`` (h5lite.write_tree: groups, datasets, attributes as h5py would have written them; datasets
+        nothing was written to keep their fill value and take no space; datasets held as runs become chunked + deflated).
+        container "npz": ``path`` (.npz): every dataset that was written; ``path + '.attrs.json'``: the attributes and, under the key
         "__unwritten__", shape / dtype / fill value of the datasets that never were (they are all fill value; ``load_npz``
         puts them back) -- so a container costs what was written to it, not what it pre-allocates."""
+        if self.container == "hdf5":
+            from . import h5lite
+            return h5lite.write_tree(path, self)
         lazy = self.unwritten()
         sparse = self.sparse_datasets()          # (before arrays(): a dense access would densify them)
         members = {}
         for name, ds_ in sparse.items():         # "<path>#row" / "#ptr" / "#start" / "#value": the rows' runs; shape in the side file
             members[name + "#row"], members[name + "#ptr"], members[name + "#start"], members[name + "#value"] = ds_.runs()
         dense = self.arrays(materialised_only=True)
+        # per-iteration traces ([soundings, slots] float64, NaN beyond the iterations a chain ran): "<path>#len" / "#head" -- the rows'
+        # finite prefixes end to end -- when every row is a prefix followed by NaN only; measured misfits do not deflate, NaN padding is free
+        tails = {}
+        for name in [k for k, a in dense.items() if a.dtype.kind == "f" and a.ndim == 2 and a.nbytes >= (1 << 20)]:
+            a = dense[name]
+            nan = np.isnan(a)
+            ln = a.shape[1] - nan.sum(axis=1)
+            if ln.sum() <= 0.75 * a.size and np.array_equal(nan, np.arange(a.shape[1])[None, :] >= ln[:, None]):
+                members[name + "#len"], members[name + "#head"] = ln.astype(np.int32), a[~nan]
+                tails[name] = dict(shape=list(a.shape), dtype=str(a.dtype))
+                del dense[name]
         save_npz(path, dict(dense, **members))
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
         attrs["__unwritten__"] = lazy
+        attrs["__nantail__"] = tails
         attrs["__sparse__"] = {name: dict(shape=list(ds_.shape), dtype=str(ds_.dtype)) for name, ds_ in sparse.items()}
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
 
 
-def save_npz(path, arrays, compresslevel=1):
-    """numpy.savez_compressed with a chosen deflate level: the .npz format (a zip of .npy members, read back by numpy.load).  Level 1:
-    posterior counts and hit maps are mostly zeros and shrink 100-fold at any level, and at numpy's level 6 compressing a flight
-    line's container took ten times as long as inverting the line.  Large floating-point members that deflate would shrink by a few %
-    at 150 MB/s (percentile / mean maps: measured values; decided on a 64 KB probe) are STORED: a survey's summary file went from 0.39 s to
-    0.1 s for 8 192 soundings."""
-    import zipfile
+def _npy_member(name, arr, compresslevel):
+    """(member name, method, crc32, raw size, payload) of one array as a zip member holding a .npy file: deflated (raw stream) or STORED.
+    Large floating-point members that deflate would shrink by a few % at 150 MB/s (percentile / mean maps, misfit traces: measured values;
+    decided on a 64 KB probe from the middle that shrinks by less than 10 %) are stored.  Runs on any thread: zlib releases the lock."""
+    import io
+    import zlib
+    a = np.asanyarray(arr)
+    if a.dtype.hasobject:
+        raise ValueError("object arrays are not written")
+    if a.flags.f_contiguous and not a.flags.c_contiguous:      # written in Fortran order, like numpy.save does: no copy
+        flat = a.T
+    else:
+        a = flat = np.ascontiguousarray(a) if a.ndim else a
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(a))
+    head = head.getvalue()
+    body = memoryview(flat.reshape(-1).view(np.uint8)) if a.size else b""
+    store = False
+    if a.dtype.kind == "f" and a.nbytes >= (1 << 20):
+        mid = bytes(body[(a.nbytes // 2) & ~7: ((a.nbytes // 2) & ~7) + 65536])
+        store = len(zlib.compress(mid, 1)) > 0.9 * len(mid)
+    crc = zlib.crc32(body, zlib.crc32(head))
+    raw = len(head) + len(body)
+    if store:
+        return name + ".npy", 0, crc, raw, [head, body]
+    c = zlib.compressobj(compresslevel, zlib.DEFLATED, -15)
+    out = [c.compress(head), c.compress(body), c.flush()]
+    return name + ".npy", 8, crc, raw, out
+
+
+def save_npz(path, arrays, compresslevel=1, threads=1):
+    """numpy.savez_compressed with a chosen deflate level and the members compressed side by side: the .npz format (a zip of .npy members,
+    read back by numpy.load).  Level 1: posterior counts and hit maps are mostly zeros and shrink 100-fold at any level, and at numpy's
+    level 6 compressing a flight line's container took ten times as long as inverting the line.  ``threads`` > 1: that many members are
+    deflated at a time (a survey's summary file: five 29 MB maps; 0.41 s on one thread for 8 192 soundings), the zip is then put together
+    from the finished pieces.  Files beyond the 4 GB / 65 535-member limits of the plain zip records go through zipfile (ZIP64, one thread)."""
+    import struct
     file = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
+    items = list(arrays.items())
+    total = sum(np.asanyarray(v).nbytes + 128 for _, v in items)
+    if total >= 0xF0000000 or len(items) >= 0xFFFF:
+        return _save_npz_zipfile(file, arrays, compresslevel)
+    if threads > 1 and len(items) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        order = sorted(range(len(items)), key=lambda q: -np.asanyarray(items[q][1]).nbytes)       # the big ones first
+        done = [None] * len(items)
+        with ThreadPoolExecutor(max_workers=min(threads, len(items))) as pool:
+            for q, r in zip(order, pool.map(lambda q: _npy_member(items[q][0], items[q][1], compresslevel), order)):
+                done[q] = r
+    else:
+        done = [_npy_member(k, v, compresslevel) for k, v in items]
+    central, offset = [], 0
+    with open(file, "wb") as f:
+        for name, method, crc, raw, pieces in done:
+            nm = name.encode("utf-8")
+            size = sum(len(p_) for p_ in pieces)
+            flags = 0x800 if any(ord(ch) > 127 for ch in name) else 0
+            f.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 20, flags, method, 0, 0x21, crc, size, raw, len(nm), 0) + nm)
+            for p_ in pieces:
+                f.write(p_)
+            central.append(struct.pack("<IHHHHHHIIIHHHHHII", 0x02014B50, 20, 20, flags, method, 0, 0x21, crc, size, raw, len(nm), 0, 0, 0, 0, 0x01800000, offset) + nm)
+            offset += 30 + len(nm) + size
+        cd = b"".join(central)
+        f.write(cd)
+        f.write(struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, len(done), len(done), len(cd), offset, 0))
+
+
+def _save_npz_zipfile(file, arrays, compresslevel=1):
+    """The same members through zipfile (ZIP64 when needed), one after the other."""
+    import zipfile
     with zipfile.ZipFile(file, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=compresslevel, allowZip64=True) as zf:
         for name, arr in arrays.items():
             a = np.asanyarray(arr)
             info = zipfile.ZipInfo(name + ".npy")
-            # (stored when a probe says deflate would not pay: a 64 KB sample from the middle that shrinks by less than 10 %.  NaN-padded
-            #  traces and sparse maps are floating point too, and shrink 20-fold)
             store = False
             if a.dtype.kind == "f" and a.nbytes >= (1 << 20):
                 import zlib
@@ -274,6 +354,10 @@ def load_npz(path):
             d_ = _Dataset(k, m["shape"], m["dtype"], fillvalue=0)
             d_.write_run_rows(z[k + "#row"], z[k + "#ptr"], z[k + "#start"], z[k + "#value"])
             out[k] = d_.arr
+        for k, m in side_file.get("__nantail__", {}).items():     # traces stored as their finite prefixes: NaN put back behind them
+            a = np.full(m["shape"], np.nan, dtype=np.dtype(m["dtype"]))
+            a[np.arange(a.shape[1])[None, :] < z[k + "#len"][:, None]] = z[k + "#head"]
+            out[k] = a
     meta = side_file.get("__unwritten__", {})
     for k, m in meta.items():
         a = np.zeros(m["shape"], dtype=np.dtype(m["dtype"]))
@@ -294,24 +378,46 @@ def _h5py():
     return None
 
 
-def container_type():
-    """"hdf5" when the results containers are real HDF5 files (h5py importable), else "npz": the stand-in with the same dataset paths."""
-    return "hdf5" if _h5py() is not None else "npz"
+def hdf5_writer():
+    """What would write an HDF5 file here: "h5py", "libhdf5 <version> through ctypes (<path>)", or None."""
+    if _h5py() is not None:
+        return "h5py"
+    from . import h5lite
+    lib = h5lite.load()
+    return None if lib is None else "libhdf5 {}.{}.{} through ctypes ({})".format(*lib.version, lib.path)
 
 
-def results_path(directory, line):
-    """Path ``open_results`` / ``NpzGroup.save`` take for a flight line's container: ``<line>.h5`` with h5py -- the reference's file --,
-    ``<line>.results`` without it (saved as ``<line>.results.npz`` + ``<line>.results.attrs.json``: a stand-in is not named .h5)."""
-    import os
-    return os.path.join(str(directory), "{}.{}".format(line, "h5" if _h5py() is not None else "results"))
+def container_type(prefer=None):
+    """"hdf5" when the results containers are real HDF5 files -- h5py importable, or an HDF5 C library this process can load
+    (geobipy_amd.h5lite) --, else "npz": the stand-in with the same dataset paths.  ``prefer`` ("hdf5" | "npz" | "auto" / None), then the
+    environment variable GBP_CONTAINER, override the choice; asking for "hdf5" where nothing can write it raises."""
+    want = prefer or os.environ.get("GBP_CONTAINER") or "auto"
+    if want not in ("auto", "hdf5", "npz"):
+        raise ValueError("container must be 'auto', 'hdf5' or 'npz', not {!r}".format(want))
+    if want == "npz":
+        return "npz"
+    if hdf5_writer() is not None:
+        return "hdf5"
+    if want == "hdf5":
+        from . import h5lite
+        raise RuntimeError("HDF5 containers were asked for but neither h5py nor a loadable HDF5 library was found: " + str(h5lite.why_not()))
+    return "npz"
 
 
-def open_results(path, mode="w"):
-    """An ``h5py.File`` when h5py is importable, otherwise an ``NpzGroup`` (call ``.save(path)`` when done)."""
+def results_path(directory, line, container=None):
+    """Path ``open_results`` / ``NpzGroup.save`` take for a flight line's container: ``<line>.h5`` for HDF5 -- the reference's file --,
+    ``<line>.results`` for the stand-in (saved as ``<line>.results.npz`` + ``<line>.results.attrs.json``: a stand-in is not named .h5)."""
+    return os.path.join(str(directory), "{}.{}".format(line, "h5" if container_type(container) == "hdf5" else "results"))
+
+
+def open_results(path, mode="w", container=None):
+    """An ``h5py.File`` when h5py is importable; otherwise an ``NpzGroup`` whose ``.save(path)`` writes the HDF5 file through the HDF5 C
+    library (h5lite) or, without one, the .npz stand-in."""
+    kind = container_type(container)
     h5py = _h5py()
-    if h5py is not None:
+    if kind == "hdf5" and h5py is not None:
         return h5py.File(path, mode)
-    return NpzGroup("/")
+    return NpzGroup("/", container=kind)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -265,7 +265,7 @@ class SurveyResult(dict):
 
     def save(self, filename):
         from .hdf import save_npz
-        save_npz(filename, self)               # (.npz, deflate level 1: hdf.save_npz)
+        save_npz(filename, self, threads=max(1, min(8, _usable_cores())))     # (.npz, deflate level 1, members side by side: hdf.save_npz)
 
     @classmethod
     def load(cls, filename):
@@ -337,11 +337,12 @@ class _LineWriter:
     """Fills one results container per flight line (geobipy_amd.hdf) from chunks of device rows; a line's container is compressed and
     written out by a writer thread, and dropped, as soon as its last sounding has arrived -- what is held is the open lines."""
 
-    def __init__(self, directory, ds, o, dc, hitmap):
+    def __init__(self, directory, ds, o, dc, hitmap, container=None):
         from concurrent.futures import ThreadPoolExecutor
         from . import hdf
         os.makedirs(directory, exist_ok=True)
         self.hdf, self.directory, self.ds, self.o, self.hitmap = hdf, directory, ds, o, hitmap
+        self.container = hdf.container_type(container)        # "hdf5" (<line>.h5) | "npz" (<line>.results.npz + .attrs.json)
         self.K, self.N, self.nd, self.nv = dc.K, dc.N, dc.n_depth_bins, dc.n_value_bins
         kind = self.kind = _container_kind(ds)
         td = kind != "fdem"
@@ -375,8 +376,8 @@ class _LineWriter:
         if isinstance(root, self.hdf.NpzGroup):
             while len(self.pending) >= 2 * self.workers:
                 self.pending.pop(0).result()
-            self.pending.append(self.pool.submit(root.save, path))   # <line>.results.npz (+ <line>.results.attrs.json)
-            self.paths.append(path + ".npz")
+            self.pending.append(self.pool.submit(root.save, path))   # <line>.h5, or <line>.results.npz (+ <line>.results.attrs.json)
+            self.paths.append(path if root.container == "hdf5" else path + ".npz")
         else:
             root.close()
             self.paths.append(path)
@@ -396,8 +397,8 @@ class _LineWriter:
         for ln in np.unique(f[:, self.line_col]):
             if ln not in self.lines:
                 fid = np.sort(ds.fiducial[ds.lineNumber == ln])
-                path = hdf.results_path(self.directory, ln)     # <line>.h5 with h5py, <line>.results(.npz) without
-                root = hdf.open_results(path)
+                path = hdf.results_path(self.directory, ln, container=self.container)     # <line>.h5, or <line>.results(.npz) for the stand-in
+                root = hdf.open_results(path, container=self.container)
                 hdf.create_inference1d(root, hdf.LineSpec(ds.system, self.N, self.o, n_value_bins=self.nv, kind=self.kind,
                                                           trace_every=max(1, self.trace_every)), add_axis=fid)
                 self.lines[ln] = [root, fid, path, 0]
@@ -447,13 +448,13 @@ class _LineWriter:
         return self.paths
 
 
-def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank):
+def _write_line_containers(directory, ds, o, dc, shipped, hitmap, rank, container=None):
     """Several ranks: rank 0 receives every rank's rows chunk by chunk (ONE exchange: every rank enters it once, whatever number of
     blocks the dynamic schedule gave it) and fills the line containers (_LineWriter).  (One process writes its blocks as they
     finish: infer.)"""
     import torch
     from .distributed import stream_rows_to_root
-    w = _LineWriter(directory, ds, o, dc, hitmap)
+    w = _LineWriter(directory, ds, o, dc, hitmap, container)
     cat = lambda j, wd, dt: torch.cat([s_[j] for s_ in shipped]) if shipped else torch.zeros((0, wd) if wd else (0,), dtype=dt)
     rows_t, f_t, i_t = cat(0, 0, torch.int64), cat(1, w.wf, torch.float64), cat(2, w.wi_dense, torch.int32)
     assert f_t.shape[1] == w.wf and i_t.shape[1] == w.wi_dense
@@ -484,7 +485,7 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
 
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
           exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
-          chunk=None, results_directory=None, timings=None, traces="auto", **overrides):
+          chunk=None, results_directory=None, timings=None, traces="auto", container=None, **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
@@ -498,8 +499,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     out the different numbers of iterations soundings need.  Chains are keyed by the sounding's row in the data file, so the
     results do not depend on the schedule.
     ``results_directory``: also write the reference's per-line results containers there (``<line number>.h5``: the layout of
-    Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf``; ``<line number>.results.npz`` with the same dataset paths when
-    h5py is not installed -- ``hdf.container_type()`` says which) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
+    Inference2D.createHdf / Inference1D.writeHdf, ``geobipy_amd.hdf`` -- real HDF5 files, written by h5py when it is installed and through
+    the HDF5 C library otherwise (``geobipy_amd.h5lite``); ``<line number>.results.npz`` with the same dataset paths where neither exists.
+    ``container`` = "hdf5" | "npz" | None (the environment's GBP_CONTAINER, else whichever can be written; ``hdf.container_type()`` says
+    which) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
     map), best model and its predicted data.  The rows travel to rank 0 in bounded chunks (``distributed.stream_rows_to_root``).
     ``traces``: per-iteration misfit / acceptance traces for the containers' ``phids`` / ``acceptance_rate``, kept on the device at a stride --
     "auto": at most 4 096 entries per sounding; an int: that stride (1 = the reference's arrays in full); None: none.
@@ -526,7 +529,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
     if o.get("ignore_likelihood"):
-        # the reference then samples the prior alone (Inference1D.py:394, 519, 551, 596: no stochastic Newton step, no data term)
+        # the reference then samples the prior alone (Inference1D.py:394, 519, 551, 596: no stochastic Newton step, no data term) -- until the
+        # first birth or death, where its Model.proposal_probabilities dereferences the None observation (Model.py:619): nothing to reproduce
         raise NotImplementedError("ignore_likelihood (prior-only sampling) is not supported by the device sampler")
     # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
     # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- with the files as shipped the height
@@ -717,6 +721,17 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
         return out + (csr,) if sparse else out
 
+    def fill_containers():
+        if state.get("unfilled") is None:
+            return
+        dc_, idx_ = state.pop("unfilled")
+        if state.get("writer") is None:
+            state["writer"] = _LineWriter(results_directory, ds, o, dc_, hitmap, container)
+        with _Phase("rows_to_host"):
+            pl = payload(dc_, idx_, sparse=True)
+        with _Phase("container_fill"):
+            state["writer"].add_block(pl)
+
     def process(first, count):
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
         span = np.arange(first, first + count)
@@ -733,17 +748,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             blocks = [(None, span)]
         out = None
         for off, idx in blocks:
+            fill_containers()                       # (the block before this one, if any: before its sampler is dropped)
             dc, named = run_block(idx, off)
             if results_directory is not None and (world == 1 or schedule == "lines"):
-                # one process: the block's rows go to the line containers now and are dropped (host memory holds the open lines,
-                # not the survey's hit maps)
-                if state.get("writer") is None:
-                    state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
-                with _Phase("rows_to_host"):
-                    pl = payload(dc, idx, sparse=True)
-                with _Phase("container_fill"):
-                    state["writer"].add_block(pl)
-                del pl
+                # one process: the block's rows go to the line containers and are dropped (host memory holds the open lines, not the
+                # survey's hit maps) -- at the start of the next block, or, for the last one, once the summary file's thread is running
+                state["unfilled"] = (dc, idx)
             elif results_directory is not None:
                 shipped.append(payload(dc, idx))
             part = torch.cat([v for _, v in named], dim=1).contiguous()
@@ -811,12 +821,13 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         iterations_run = int(it)
     def finish_containers():
         if results_directory is not None and (world == 1 or schedule == "lines"):
+            fill_containers()
             if state.get("writer") is None:         # (no sounding at all: the empty set of containers)
-                state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap)
+                state["writer"] = _LineWriter(results_directory, ds, o, dc, hitmap, container)
             with _Phase("compress_and_write_tail"):
                 state["writer"].finish()
         elif results_directory is not None:
-            _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank)
+            _write_line_containers(results_directory, ds, o, dc, shipped, hitmap, rank, container)
     if rank != 0:
         finish_containers()
         return None

@@ -585,6 +585,13 @@ gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options *opt, const gbp_rj_
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);
 
+/* [host] Results containers (geobipy_amd/h5lite.py; no reference counterpart -- the reference stores its hit maps dense): the rows of
+ * a conductivity-depth hit map held as runs (row r owns runs ptr[r] .. ptr[r + 1] - 1; run q holds value[q] from cell start[q] of the row
+ * -- the first at 0 -- to the next run's start) -> one zlib stream of the row's dense int32 bytes per row, written from the runs
+ * (csrc/gbp_hostpack.h): out[out_ptr[r] .. out_ptr[r + 1]).  Capacity: 16 bytes per run + cells_per_row / 32 + 64 per row is enough. */
+gbp_status gbp_runs_to_zlib(int n_rows, int64_t cells_per_row, const int64_t *ptr, const int32_t *start, const int32_t *value,
+                            uint8_t *out, int64_t out_capacity, int64_t *out_ptr);
+
 #ifdef __cplusplus
 }
 #endif

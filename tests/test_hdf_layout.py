@@ -615,15 +615,16 @@ def test_h5py_branch_of_the_writer_makes_the_same_calls_as_the_fallback(tmp_path
         Recorder.log = []
         if which == "h5py":
             monkeypatch.setitem(sys.modules, "h5py", fake)
-            assert hdf.container_type() == "hdf5"
+            monkeypatch.setenv("GBP_CONTAINER", "auto")              # (the suite pins "npz", conftest.py)
+            assert hdf.container_type() == "hdf5" and hdf.hdf5_writer() == "h5py"
             saved = []
             monkeypatch.setattr(hdf, "save_npz", lambda *a_, **k_: saved.append(a_))
             paths = run(tmp_path / "h5")
             assert sorted(os.path.basename(q) for q in paths) == ["7.0.h5", "9.0.h5"] and not saved
             assert [e for e in Recorder.log if e[0] == "open"] == [("open", "7.0.h5", "w"), ("open", "9.0.h5", "w")]
         else:
-            monkeypatch.setattr(hdf, "open_results", lambda path, mode="w": File(path, mode))
-            monkeypatch.setattr(hdf, "results_path", lambda d_, ln: os.path.join(str(d_), "{}.h5".format(ln)))
+            monkeypatch.setattr(hdf, "open_results", lambda path, mode="w", container=None: File(path, mode))
+            monkeypatch.setattr(hdf, "results_path", lambda d_, ln, container=None: os.path.join(str(d_), "{}.h5".format(ln)))
             run(tmp_path / "rec")
             monkeypatch.undo()
         logs[which] = list(Recorder.log)
