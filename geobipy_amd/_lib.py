@@ -122,6 +122,8 @@ SIGNATURES = {
     "gbp_fdem_sensitivity_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "gbp_fdem_fm_dlogc": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "gbp_fdem_fm_dlogc_ex": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p]),
+    "gbp_hitmap_statistics": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_double] + [c_void_p] * 4 + [c_void_p]),
+    "gbp_hitmap_runs": (c_int, [c_int, ctypes.c_int64] + [c_void_p] * 5 + [c_void_p]),
     "gbp_runs_to_zlib": (c_int, [c_int, ctypes.c_int64] + [c_void_p] * 4 + [ctypes.c_int64, c_void_p]),
     "gbp_debug_math": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     "gbp_bench_time_forward_loglike": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 10 + [c_void_p, c_int,

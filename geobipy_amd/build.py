@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["gbp_fdem.hip"]
-HEADERS = ["gbp_math.h", "gbp_math_tables.h", "gbp_fdem_point.h", "gbp_fdem_tables.h", "gbp_rjmcmc.h", "gbp_tdem.h", "gbp_hostpack.h", "../../include/geobipy_amd.h"]
+HEADERS = ["gbp_math.h", "gbp_math_tables.h", "gbp_fdem_point.h", "gbp_fdem_tables.h", "gbp_rjmcmc.h", "gbp_tdem.h", "gbp_hostpack.h", "gbp_hitmap.h", "../../include/geobipy_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-pthread"]
 

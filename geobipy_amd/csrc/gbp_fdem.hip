@@ -1158,6 +1158,41 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
 #include "gbp_rjmcmc.h"
 #include "gbp_tdem.h"
 #include "gbp_hostpack.h"
+#include "gbp_hitmap.h"
+
+// Per-depth mean and 5 / 50 / 95 % points of log10 conductivity of B hit maps [B, nv, nz] (depth fastest) -> four [B, nz] arrays
+extern "C" gbp_status gbp_hitmap_statistics(int B, int nv, int nz, const int32_t* hitmap, const double* log_mean_prior, double half_width,
+                                            double* mean, double* p05, double* p50, double* p95, void* stream)
+{
+    if (B < 0 || nv < 1 || nz < 1 || !hitmap || !log_mean_prior || !mean || !p05 || !p50 || !p95)
+        return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_statistics: NULL pointer or non-positive size%s");
+    if (B == 0) return GBP_OK;
+    hipLaunchKernelGGL(hitmap::k_hitmap_stats, dim3(B, (nz + 255) / 256), dim3(256), 0, (hipStream_t)stream, nv, nz, hitmap, log_mean_prior, half_width,
+                       mean, p05, p50, p95);
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
+
+// The hit maps' rows (M = nv * nz cells each) as runs.  Call with start == NULL to COUNT (counts[B] <- runs per row), build the
+// exclusive prefix ptr[B + 1] of the counts, allocate ptr[B] entries, then call again with ptr / start / value to WRITE.
+extern "C" gbp_status gbp_hitmap_runs(int B, int64_t M, const int32_t* hitmap, int64_t* counts, const int64_t* ptr, int32_t* start,
+                                      int32_t* value, void* stream)
+{
+    if (B < 0 || M < 1 || M > 0x7fffffff || !hitmap) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: NULL pointer or size out of range%s");
+    if (B == 0) return GBP_OK;
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");
+    if (start == nullptr) {
+        if (!counts) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: counts is NULL%s");
+        hipLaunchKernelGGL(hitmap::k_hitmap_runs<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, (long long)M, hitmap, (long long*)counts,
+                           (const long long*)nullptr, (int*)nullptr, (int*)nullptr);
+    } else {
+        if (!ptr || !value) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: ptr / value is NULL%s");
+        hipLaunchKernelGGL(hitmap::k_hitmap_runs<true>, dim3(B), dim3(256), 0, (hipStream_t)stream, (long long)M, hitmap, (long long*)nullptr,
+                           (const long long*)ptr, start, value);
+    }
+    GBP_HIP(hipGetLastError());
+    return GBP_OK;
+}
 
 // [host] rows of a hit map held as runs -> one zlib stream per row (see gbp_hostpack.h); no device work
 extern "C" gbp_status gbp_runs_to_zlib(int n_rows, int64_t cells_per_row, const int64_t* ptr, const int32_t* start, const int32_t* value,

@@ -2401,7 +2401,7 @@ static int lockstep_parts(int B)
 #ifdef GBP_RJ_LOCKSTEP_PARTS
     return B >= 2048 ? GBP_RJ_LOCKSTEP_PARTS : 1;              // (A/B builds under scripts/ab only)
 #endif
-    return B >= 2048 ? 3 : 1;
+    return B >= 2048 ? 3 : (B >= 1600 ? 2 : 1);      // (1 600 ... 2 047 chains, two against one: 17.5 vs 15.4, 19.2 vs 15.8, 20.8 vs 17.1 M Resolve; 15.5 vs 13.6 ... 18.3 vs 15.1 M ten frequencies)
 }
 
 gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
@@ -2420,9 +2420,16 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // ~0.02 us per chain.  Measured (Resolve and the 10-frequency system, scripts/bench_rj_modes.py): the persistent kernel
         // wins while the whole block is resident at once (1 536 Resolve chains with one wave each: 20.2 vs 14.0 M
         // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
+        // A block up to a fifth beyond what is resident at once still runs faster persistently (the surplus workgroups start as the first
+        // finish) than as two lock-step sub-blocks: 1 600 / 1 802 chains 18.7 / 20.5 M against 17.5 / 19.2 M (Resolve, capacity 1 536; ten
+        // frequencies 16.6 / 18.3 against 15.5 / 17.1); at 2 000 the sub-blocks are level or ahead (20.8 = 20.9, 18.3 vs 16.9).  This is the
+        // size a survey block shrinks to when the chains that failed to burn in have stopped (survey.infer re-packs the running ones).
         const int nw = persistent_waves(sys, o, c->B, false);
         bool small = false;
-        if (nw > 0 && n_iterations >= 4) small = (long long)c->B <= persistent_capacity(sys, o, nw);
+        if (nw > 0 && n_iterations >= 4) {
+            const long long cap = persistent_capacity(sys, o, nw);
+            small = (long long)c->B <= cap + cap / 5;
+        }
         if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
         // (concurrent sub-blocks cost a host thread each and a fork / join of streams per call: they pay from about four iterations per
         //  call -- 8 192 chains, M chain-iterations/s at 1 / 4 / 16 / 200 iterations per call: 28.5 37.2 40.9 43.1 against 33.3 - 33.7 for

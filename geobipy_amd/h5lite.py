@@ -11,7 +11,8 @@ What is written, and how h5py would have done it (so that a reader cannot tell):
   * ``numpy.bool_`` as h5py's enum {FALSE = 0, TRUE = 1} over int8;
   * ``str`` attributes as variable-length UTF-8 strings on a scalar dataspace (``obj.attrs[k] = "text"`` in h5py);
   * a dataset nothing was written to: created with its fill value, no storage allocated -- reads return the fill value;
-  * dense datasets contiguous and uncompressed (h5py's default; the reference's own files are exactly that);
+  * dense datasets contiguous and uncompressed (h5py's default; the reference's own files are exactly that); the large ones (misfit
+    traces) are allocated early and their bytes written at the address ``H5Dget_offset`` reports once the file is closed, outside the lock;
   * a dataset held as runs (the conductivity-depth hit maps, hdf._Dataset.write_run_rows): chunked one sounding per chunk with the
     deflate filter; each chunk's zlib stream is made by the calling thread -- written straight from the runs by the package's native
     encoder (gbp_runs_to_zlib: O(runs), ~50 us per sounding against ~1 ms for zlib over the 440 KB dense row) -- and handed over with
@@ -40,6 +41,13 @@ H5S_SCALAR = 0
 H5T_VARIABLE = ctypes.c_size_t(-1).value
 H5T_CSET_UTF8 = 1
 H5Z_FILTER_DEFLATE = 1
+H5D_ALLOC_TIME_EARLY = 1
+H5D_FILL_TIME_NEVER = 1
+HADDR_UNDEF = ctypes.c_uint64(-1).value
+# Dense datasets of at least this many bytes are not copied by H5Dwrite under the library's lock: their contiguous storage is allocated
+# when the dataset is created, its address taken (H5Dget_offset), and the bytes are written into the closed file at that address by the
+# calling thread (os.pwrite) -- sixteen flight lines' 16 MB misfit traces then land side by side instead of one after the other.
+DIRECT_WRITE_BYTES = 1 << 20
 
 
 def _candidates():
@@ -117,6 +125,9 @@ def _bind(lib):
     _sig(lib, "H5Dwrite", herr_t, hid_t, hid_t, hid_t, hid_t, hid_t, c_void_p)
     _sig(lib, "H5Dwrite_chunk", herr_t, hid_t, hid_t, ctypes.c_uint32, P(hsize_t), c_size_t, c_void_p)
     _sig(lib, "H5Dclose", herr_t, hid_t)
+    _sig(lib, "H5Dget_offset", ctypes.c_uint64, hid_t)
+    _sig(lib, "H5Pset_alloc_time", herr_t, hid_t, c_int)
+    _sig(lib, "H5Pset_fill_time", herr_t, hid_t, c_int)
     _sig(lib, "H5Pcreate", hid_t, hid_t)
     _sig(lib, "H5Pset_chunk", herr_t, hid_t, c_int, P(hsize_t))
     _sig(lib, "H5Pset_deflate", herr_t, hid_t, c_uint)
@@ -251,6 +262,8 @@ def write_tree(path, root, compresslevel=1):
                 raise HDF5Error("dataset {}: dtype {} is not written".format(v.name, v.dtype))
     prepare(root)
 
+    direct = []                                   # (file address, array) of the large dense datasets, written after the file is closed
+
     # 2. the file, under the lock
     def emit(loc, g):
         _write_attrs(lib, loc, g.attrs)
@@ -267,10 +280,18 @@ def write_tree(path, root, compresslevel=1):
             space = _space(lib, v.shape)
             dcpl = _fill_plist(lib, v.dtype, v._fill)
             try:
+                a = None
                 if v.name in chunks:
                     cdims = (1,) + tuple(v.shape[1:])
                     _ok(lib.H5Pset_chunk(dcpl, len(cdims), _dims(cdims)), "H5Pset_chunk")
                     _ok(lib.H5Pset_deflate(dcpl, compresslevel), "H5Pset_deflate")
+                elif v.materialised:
+                    a = np.ascontiguousarray(v.arr)
+                    if a.dtype == np.bool_:
+                        a = a.view(np.int8)
+                    if a.nbytes >= DIRECT_WRITE_BYTES:
+                        _ok(lib.H5Pset_alloc_time(dcpl, H5D_ALLOC_TIME_EARLY), "H5Pset_alloc_time")
+                        _ok(lib.H5Pset_fill_time(dcpl, H5D_FILL_TIME_NEVER), "H5Pset_fill_time")
                 d = _ok(lib.H5Dcreate2(loc, name.encode(), ftype, space, 0, dcpl, 0), "H5Dcreate2 " + v.name)
                 try:
                     if v.name in chunks:
@@ -278,11 +299,11 @@ def write_tree(path, root, compresslevel=1):
                         for row, blob in chunks[v.name]:
                             off[0] = row
                             _ok(lib.H5Dwrite_chunk(d, 0, 0, off, len(blob), blob), "H5Dwrite_chunk " + v.name)
-                    elif v.materialised:
-                        a = np.ascontiguousarray(v.arr)
-                        if a.dtype == np.bool_:
-                            a = a.view(np.int8)
-                        if a.size:
+                    elif a is not None and a.size:
+                        addr = lib.H5Dget_offset(d) if a.nbytes >= DIRECT_WRITE_BYTES else HADDR_UNDEF
+                        if addr != HADDR_UNDEF:
+                            direct.append((int(addr), a))
+                        else:
                             _ok(lib.H5Dwrite(d, ftype, 0, 0, 0, a.ctypes.data_as(ctypes.c_void_p)), "H5Dwrite " + v.name)
                     _write_attrs(lib, d, v.attrs)
                 finally:
@@ -297,4 +318,13 @@ def write_tree(path, root, compresslevel=1):
             emit(f, root)
         finally:
             _ok(lib.H5Fclose(f), "H5Fclose")
+    if direct:                                    # outside the lock: the raw bytes of the large datasets, at the addresses the library gave
+        fd = os.open(str(path), os.O_WRONLY)
+        try:
+            for addr, a in direct:
+                view, done = memoryview(a.reshape(-1).view(np.uint8)), 0
+                while done < len(view):
+                    done += os.pwrite(fd, view[done:], addr + done)
+        finally:
+            os.close(fd)
     return str(path)

@@ -300,20 +300,9 @@ class SurveyResult(dict):
 
 def _hitmap_statistics(hitmap, log_mean_prior, half_width):
     """Mean and percentiles of log10 conductivity per depth cell from the hit map (the reference derives the same from
-    its Histogram2D posterior)."""
-    import torch
-    B, nv, nz = hitmap.shape                                      # stored value-major, depth fastest
-    centres = (torch.arange(nv, dtype=torch.float64, device=hitmap.device) + 0.5) / nv * (2.0 * half_width) - half_width
-    h = hitmap.transpose(1, 2).to(torch.float64)                  # [B, nz, nv]
-    tot = h.sum(dim=2).clamp(min=1.0)
-    shift = (log_mean_prior / np.log(10.0))[:, None]
-    mean = (h * centres).sum(dim=2) / tot + shift
-    cdf = torch.cumsum(h, dim=2) / tot[:, :, None]
-    pct = []
-    for q in (0.05, 0.5, 0.95):
-        idx = (cdf < q).sum(dim=2).clamp(max=nv - 1)
-        pct.append(centres[idx] + shift)
-    return mean, pct
+    its Histogram2D posterior): one kernel over the maps, geobipy_amd.hitmap."""
+    from .hitmap import statistics
+    return statistics(hitmap, log_mean_prior, half_width)
 
 
 def _usable_cores():
@@ -699,15 +688,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 t["add_hist"].flatten(1)]
         csr = None
         if hitmap and sparse:
-            hm = dc.hitmap.flatten(1)               # (attribute access settles the dwell times)
-            edge = torch.ones_like(hm, dtype=torch.bool)      # run starts: the row's first cell and every change of value
-            edge[:, 1:] = hm[:, 1:] != hm[:, :-1]
-            nz = torch.nonzero(edge)                # [runs, 2] row-major: sorted by row, then by flat position
-            cnt = torch.bincount(nz[:, 0], minlength=hm.shape[0])
-            ptr = torch.zeros(hm.shape[0] + 1, dtype=torch.int64, device=dev)
-            ptr[1:] = torch.cumsum(cnt, 0)
-            csr = (ptr.cpu().numpy(), nz[:, 1].to(torch.int32).cpu().numpy(), hm[nz[:, 0], nz[:, 1]].cpu().numpy())
-            del nz, edge
+            from .hitmap import runs                # run starts: a row's first cell and every change of value (csrc/gbp_hitmap.h)
+            ptr, start_, val_ = runs(dc.hitmap)     # (attribute access settles the dwell times)
+            csr = (ptr.cpu().numpy(), start_.cpu().numpy(), val_.cpu().numpy())
+            del start_, val_
         elif hitmap:
             cols.append(dc.hitmap.flatten(1))       # (attribute access settles the dwell times)
         if getattr(dc, "solve_height", False):
@@ -833,45 +817,47 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         return None
     with _Phase("summaries_to_host"):
         r = gathered.cpu().numpy()
-    res = SurveyResult(line=ds.lineNumber, fiducial=ds.fiducial, x=ds.x, y=ds.y, z=ds.z, elevation=ds.elevation,
-                       depth_bin_width=np.float64(dc.depth_bin_width))
-    c0 = 0
-    ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
-            "relative_error_posterior", "additive_error_posterior", "height_posterior") + tuple(
-        n_ + "_posterior" for n_ in ("dx", "dy", "dz", "tx_z", "tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"))
-    for name, v in named:
-        w = v.shape[1]
-        block = r[:, c0:c0 + w]
-        c0 += w
-        if name in ints:
-            block = block.astype(np.int64)
-        res[name] = block[:, 0] if w == 1 else block
-    for name, G in (("relative_error_posterior", dc.n_rel_groups), ("additive_error_posterior", dc.n_add_groups)):
-        if G > 1:                                   # [S, groups, cells]; ne cells, uniform in log10 between the prior bounds
-            res[name] = res[name].reshape(-1, G, dc.n_error_bins)
-    n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
-    ran = np.where(res["status"] == 1, res["burned_in_iteration"] + n_mc + 1, np.where(res["status"] == 2, n_mc, iterations_run))
-    res["iterations"] = ran.astype(np.int64)
-    res["acceptance"] = res.pop("n_accepted") / np.maximum(1, ran)
-    for k_ in ("status", "burned_in_iteration", "n_layers", "best_n_layers"):
-        res[k_] = res[k_].astype(np.int32)
-    # the summary file is compressed on a thread of its own while the containers' writer threads finish (zlib releases the lock)
-    saver = None
-    if output is not None:
-        import threading
-        failed = []
+    # the result is put together and the summary file compressed on a thread of its own while this one fills the line containers and
+    # their writer threads finish (numpy's conversions and zlib release the interpreter lock)
+    import threading
+    failed, made = [], []
 
-        def save_summary():
-            try:
+    def assemble_and_save():
+        try:
+            res = SurveyResult(line=ds.lineNumber, fiducial=ds.fiducial, x=ds.x, y=ds.y, z=ds.z, elevation=ds.elevation,
+                               depth_bin_width=np.float64(dc.depth_bin_width))
+            c0 = 0
+            ints = ("status", "burned_in_iteration", "n_layers", "best_n_layers", "layer_count_posterior", "interface_posterior",
+                    "relative_error_posterior", "additive_error_posterior", "height_posterior") + tuple(
+                n_ + "_posterior" for n_ in ("dx", "dy", "dz", "tx_z", "tx_pitch", "tx_roll", "tx_yaw", "rx_pitch", "rx_roll", "rx_yaw"))
+            for name, v in named:
+                w = v.shape[1]
+                block = r[:, c0:c0 + w]
+                c0 += w
+                if name in ints:
+                    block = block.astype(np.int64)
+                res[name] = block[:, 0] if w == 1 else block
+            for name, G in (("relative_error_posterior", dc.n_rel_groups), ("additive_error_posterior", dc.n_add_groups)):
+                if G > 1:                                   # [S, groups, cells]; ne cells, uniform in log10 between the prior bounds
+                    res[name] = res[name].reshape(-1, G, dc.n_error_bins)
+            n_mc = int(o["n_markov_chains"])             # iterations each chain ran before it froze (infer :641-688)
+            ran = np.where(res["status"] == 1, res["burned_in_iteration"] + n_mc + 1, np.where(res["status"] == 2, n_mc, iterations_run))
+            res["iterations"] = ran.astype(np.int64)
+            res["acceptance"] = res.pop("n_accepted") / np.maximum(1, ran)
+            for k_ in ("status", "burned_in_iteration", "n_layers", "best_n_layers"):
+                res[k_] = res[k_].astype(np.int32)
+            made.append(res)
+            if output is not None:
                 res.save(output)
-            except BaseException as e:               # (handed to the caller's thread below)
-                failed.append(e)
-        saver = threading.Thread(target=save_summary)
-        saver.start()
-    finish_containers()
-    if saver is not None:
+        except BaseException as e:                       # (handed to the caller's thread below)
+            failed.append(e)
+    saver = threading.Thread(target=assemble_and_save)
+    saver.start()
+    try:
+        finish_containers()
+    finally:
         with _Phase("summary_file_tail"):
             saver.join()
-        if failed:
-            raise failed[0]
-    return res
+    if failed:
+        raise failed[0]
+    return made[0]

@@ -585,6 +585,18 @@ gbp_status gbp_rj_debug_propose_variant(const gbp_rj_options *opt, const gbp_rj_
 gbp_status gbp_rj_debug_random(uint64_t seed, int64_t chain, int64_t iteration, int stream_id, int n,
                                double *uniforms, double *normals, void *stream);
 
+/* What leaves the device of a block's conductivity-depth hit maps (int32 [B, n_value, n_depth], depth fastest; csrc/gbp_hitmap.h; the
+ * reference derives the same on the host from its Histogram2D posterior, classes/statistics/Histogram.py mean / percentile):
+ * gbp_hitmap_statistics -- per depth cell the mean and the 5 / 50 / 95 % points of log10 conductivity [B, n_depth] (bin centres
+ * ((v + 0.5) / n_value) 2 half_width - half_width + log_mean_prior[b] / ln 10; the q-point is the first bin whose cumulative share is >= q);
+ * gbp_hitmap_runs -- the maps' rows (M = n_value * n_depth cells) in run-length form: first call with start == NULL writes the number
+ * of runs of every row to counts[B]; the caller forms ptr[B + 1] (exclusive prefix) and calls again with ptr, start[ptr[B]], value[ptr[B]]
+ * (run r of row b: value[ptr[b] + r] from cell start[ptr[b] + r] to the next run's start). */
+gbp_status gbp_hitmap_statistics(int B, int n_value, int n_depth, const int32_t *hitmap, const double *log_mean_prior, double half_width,
+                                 double *mean, double *p05, double *p50, double *p95, void *stream);
+gbp_status gbp_hitmap_runs(int B, int64_t M, const int32_t *hitmap, int64_t *counts, const int64_t *ptr, int32_t *start, int32_t *value,
+                           void *stream);
+
 /* [host] Results containers (geobipy_amd/h5lite.py; no reference counterpart -- the reference stores its hit maps dense): the rows of
  * a conductivity-depth hit map held as runs (row r owns runs ptr[r] .. ptr[r + 1] - 1; run q holds value[q] from cell start[q] of the row
  * -- the first at 0 -- to the next run's start) -> one zlib stream of the row's dense int32 bytes per row, written from the runs

@@ -162,7 +162,7 @@ def test_the_references_own_readers_open_our_file(tmp_path):
     assert got["h5py"] and got["hdf5"]
 
 
-def test_line_containers_with_run_length_hit_maps_as_hdf5(tmp_path):
+def test_line_containers_with_run_length_hit_maps_as_hdf5(tmp_path, monkeypatch):
     """survey._LineWriter(container="hdf5"): the device rows of two flight lines -> <line>.h5, hit maps handed over as runs and stored
     one deflated chunk per sounding; the real h5py reads back exactly what the .npz stand-in of the same rows holds."""
     _needs()
@@ -210,6 +210,8 @@ def test_line_containers_with_run_length_hit_maps_as_hdf5(tmp_path):
             w.add_block((torch.as_tensor(sel), torch.as_tensor(f[sel]), torch.as_tensor(i[sel])))
         return w.finish()
 
+    from geobipy_amd import h5lite
+    monkeypatch.setattr(h5lite, "DIRECT_WRITE_BYTES", 2048)          # (the large-dataset path -- bytes written at H5Dget_offset -- for these small lines too)
     paths = fill(tmp_path / "h5", "hdf5")
     assert sorted(os.path.basename(q) for q in paths) == ["7.0.h5", "9.0.h5"]
     assert sorted(os.listdir(tmp_path / "h5")) == ["7.0.h5", "9.0.h5"]                          # no side files

@@ -780,7 +780,9 @@ def test_concurrent_sub_blocks_walk_the_same_chains_at_size():
     o = {k: v for k, v in RESOLVE_OPTIONS.items() if k != "n_markov_chains"}
     names = ["k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit", "n_accepted", "k_hist", "edge_hist", "rel_hist",
              "add_hist", "best_posterior", "best_k", "best_edges", "best_sigma", "best_rel", "best_add"]
-    for B, ids in ((4099, False), (2500, True)):
+    # (1 802 and 1 950 chains: between the persistent kernel's resident capacity and the three-sub-block threshold -- the automatic choice
+    #  runs the first persistently with a short second round and the second as two sub-blocks; the size a survey block shrinks to)
+    for B, ids in ((4099, False), (2500, True), (1802, False), (1950, True)):
         nl, sig, thk, h = synthetic.draw_models(B, 4, seed=11)
         data = synthetic.noisy_observations(FdemBatch(system, nl, sig, thk, h, waves=2).forward().cpu().numpy(), seed=12)
         runs = {}
