@@ -177,33 +177,46 @@ def _dims(shape):
     return (hsize_t * len(shape))(*[int(s) for s in shape])
 
 
-def _write_attrs(lib, obj, attrs):
-    for k in sorted(attrs):
-        v = attrs[k]
-        space = _ok(lib.H5Screate(H5S_SCALAR), "H5Screate")
-        try:
-            if isinstance(v, (str, bytes)):
-                raw = v.encode("utf-8") if isinstance(v, str) else v
-                a = _ok(lib.H5Acreate2(obj, k.encode(), lib.vlen_str, space, 0, 0), "H5Acreate2 " + k)
-                buf = (ctypes.c_char_p * 1)(raw)
-                _ok(lib.H5Awrite(a, lib.vlen_str, buf), "H5Awrite " + k)
-                lib.H5Aclose(a)
-            else:
-                arr = np.asarray(v)
-                if arr.ndim != 0 or arr.dtype not in lib.t:
-                    raise HDF5Error("attribute {!r}: only strings and numeric scalars are written ({!r})".format(k, v))
-                a = _ok(lib.H5Acreate2(obj, k.encode(), lib.t[arr.dtype], space, 0, 0), "H5Acreate2 " + k)
-                tmp = np.ascontiguousarray(arr)
-                _ok(lib.H5Awrite(a, lib.t[arr.dtype], tmp.ctypes.data_as(ctypes.c_void_p)), "H5Awrite " + k)
-                lib.H5Aclose(a)
-        finally:
-            lib.H5Sclose(space)
-
-
 def _space(lib, shape):
     if len(shape) == 0:
         return _ok(lib.H5Screate(H5S_SCALAR), "H5Screate")
     return _ok(lib.H5Screate_simple(len(shape), _dims(shape), None), "H5Screate_simple")
+
+
+def _write_attrs(lib, obj, attrs):
+    """h5py's ``obj.attrs[k] = v`` for the values the containers carry: a str (scalar variable-length UTF-8 string), a list of str (1-D
+    array of such strings: a time-domain system's .stm lines, TdemSystem_GAAEM.py:118), numeric scalars and arrays."""
+    enc = lambda x: x.encode("utf-8") if isinstance(x, str) else bytes(x)
+    for k in sorted(attrs):
+        v = attrs[k]
+        strings = None
+        if isinstance(v, (str, bytes)):
+            strings, shape = [enc(v)], ()
+        elif isinstance(v, (list, tuple)) and len(v) > 0 and all(isinstance(x, (str, bytes)) for x in v):
+            strings, shape = [enc(x) for x in v], (len(v),)
+        if strings is not None:
+            space = _space(lib, shape)
+            try:
+                a = _ok(lib.H5Acreate2(obj, k.encode(), lib.vlen_str, space, 0, 0), "H5Acreate2 " + k)
+                buf = (ctypes.c_char_p * len(strings))(*strings)
+                _ok(lib.H5Awrite(a, lib.vlen_str, buf), "H5Awrite " + k)
+                lib.H5Aclose(a)
+            finally:
+                lib.H5Sclose(space)
+            continue
+        arr = np.asarray(v)
+        if arr.dtype not in lib.t:
+            raise HDF5Error("attribute {!r}: only strings, lists of strings and numeric values are written ({!r})".format(k, v))
+        space = _space(lib, arr.shape)
+        try:
+            a = _ok(lib.H5Acreate2(obj, k.encode(), lib.t[arr.dtype], space, 0, 0), "H5Acreate2 " + k)
+            tmp = np.ascontiguousarray(arr)
+            if tmp.dtype == np.bool_:
+                tmp = tmp.view(np.int8)
+            _ok(lib.H5Awrite(a, lib.t[arr.dtype], tmp.ctypes.data_as(ctypes.c_void_p)), "H5Awrite " + k)
+            lib.H5Aclose(a)
+        finally:
+            lib.H5Sclose(space)
 
 
 def _fill_plist(lib, dtype, fill):

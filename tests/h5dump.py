@@ -11,9 +11,11 @@ import numpy as np
 src, out = sys.argv[1], sys.argv[2]
 arrays, meta = {}, {}
 with h5py.File(src, "r") as f:
+    conv = lambda v: v.decode() if isinstance(v, bytes) else (v if isinstance(v, str) else np.asarray(v).tolist())
+
     def visit(name, obj):
         path = "/" + name
-        attrs = {k: (v.decode() if isinstance(v, bytes) else (v if isinstance(v, str) else np.asarray(v).tolist())) for k, v in obj.attrs.items()}
+        attrs = {k: conv(v) for k, v in obj.attrs.items()}
         types = {k: type(v).__name__ for k, v in obj.attrs.items()}
         if isinstance(obj, h5py.Dataset):
             arrays[path] = obj[()]
@@ -24,7 +26,7 @@ with h5py.File(src, "r") as f:
                               storage=int(obj.id.get_storage_size()))
         else:
             meta[path] = dict(kind="group", attrs=attrs, attr_types=types)
-    meta["/"] = dict(kind="group", attrs={k: v for k, v in f.attrs.items()}, attr_types={k: type(v).__name__ for k, v in f.attrs.items()})
+    meta["/"] = dict(kind="group", attrs={k: conv(v) for k, v in f.attrs.items()}, attr_types={k: type(v).__name__ for k, v in f.attrs.items()})
     f.visititems(visit)
     meta["__h5py__"] = dict(h5py=h5py.__version__, hdf5=h5py.version.hdf5_version, libver=list(f.libver))
 np.savez(out + ".npz", **arrays)

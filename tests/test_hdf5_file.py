@@ -292,23 +292,37 @@ def test_container_type_follows_what_can_be_written(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_survey_writes_hdf5_containers_the_real_h5py_reads(tmp_path):
-    """survey.infer(container="hdf5") on the GPU: the same seeded survey written as <line>.h5 and as the stand-in -- identical
-    datasets (the chains are reproducible), read back by the real h5py."""
+@pytest.mark.parametrize("kind", ["resolve", "skytem", "tempest"])
+def test_survey_writes_hdf5_containers_the_real_h5py_reads(tmp_path, kind):
+    """survey.infer(container="hdf5") on the GPU, for the three data types (FdemData; TdemData with two moments; TempestData with primary
+    fields and a sampled loop pair's groups): the same seeded survey written as <line>.h5 and as the stand-in -- identical datasets and
+    attributes (the chains are reproducible), read back by the real h5py."""
     _needs()
     from geobipy_amd import hdf, survey
-    kw = dict(n_markov_chains=300, burn_in_min_iterations=100, seed=5, index=None)
-    opts = os.path.join(GOLDEN, "resolve_options_small")
+    opts = os.path.join(GOLDEN, kind + "_options_small")
+    kw = dict(seed=5)
+    if kind == "resolve":
+        kw.update(n_markov_chains=300, burn_in_min_iterations=100)
+    else:
+        o = survey.read_options(opts)
+        cls = survey.TdemData if kind == "skytem" else survey.TempestData
+        kw.update(data=cls.read_csv(o["data_filename"], o["system_filename"]).subset(np.arange(0, 79, 6)), n_markov_chains=400,
+                  burn_in_min_iterations=200, check_every=200)
     survey.infer(opts, results_directory=str(tmp_path / "h5"), container="hdf5", **kw)
     survey.infer(opts, results_directory=str(tmp_path / "npz"), container="npz", **kw)
     h5 = sorted(n_ for n_ in os.listdir(tmp_path / "h5") if n_.endswith(".h5"))
     assert h5 and len(h5) == sum(n_.endswith(".results.npz") for n_ in os.listdir(tmp_path / "npz"))
     for name in h5:
         want = hdf.load_npz(str(tmp_path / "npz" / (name[:-3] + ".results")))
+        side = json.load(open(tmp_path / "npz" / (name[:-3] + ".results.attrs.json")))
         arrays, info = h5dump(tmp_path / "h5" / name, tmp_path)
         assert sorted(arrays) == sorted(want)
         for k in want:
             if k in ("/invtime", "/savetime"):
                 continue
-            assert np.array_equal(arrays[k], want[k], equal_nan=want[k].dtype.kind == "f"), (name, k)
+            assert arrays[k].dtype == want[k].dtype and np.array_equal(arrays[k], want[k], equal_nan=want[k].dtype.kind == "f"), (name, k)
+        for p_, a in side.items():
+            if not p_.startswith("__"):
+                assert info[p_]["attrs"] == a, (name, p_)
         assert info["/"]["kind"] == "group" and info["/model/values"]["attrs"]["repr"] == "StatArray"
+        assert info["/data"]["attrs"]["repr"] == {"resolve": "FdemData", "skytem": "TdemData", "tempest": "TempestData"}[kind]
