@@ -142,6 +142,31 @@ def _bind(lib):
     _sig(lib, "H5Tenum_create", hid_t, hid_t)
     _sig(lib, "H5Tenum_insert", herr_t, hid_t, c_char_p, c_void_p)
     _sig(lib, "H5Tclose", herr_t, hid_t)
+    # the reader's entry points
+    _sig(lib, "H5Fopen", hid_t, c_char_p, c_uint, hid_t)
+    _sig(lib, "H5Oopen", hid_t, hid_t, c_char_p, hid_t)
+    _sig(lib, "H5Oclose", herr_t, hid_t)
+    _sig(lib, "H5Iget_type", c_int, hid_t)
+    _sig(lib, "H5Dget_space", hid_t, hid_t)
+    _sig(lib, "H5Dget_type", hid_t, hid_t)
+    _sig(lib, "H5Dread", herr_t, hid_t, hid_t, hid_t, hid_t, hid_t, c_void_p)
+    _sig(lib, "H5Sget_simple_extent_ndims", c_int, hid_t)
+    _sig(lib, "H5Sget_simple_extent_dims", c_int, hid_t, P(hsize_t), P(hsize_t))
+    _sig(lib, "H5Sget_simple_extent_npoints", ctypes.c_int64, hid_t)
+    _sig(lib, "H5Tget_class", c_int, hid_t)
+    _sig(lib, "H5Tget_size", c_size_t, hid_t)
+    _sig(lib, "H5Tget_sign", c_int, hid_t)
+    _sig(lib, "H5Tis_variable_str", c_int, hid_t)
+    _sig(lib, "H5Tget_nmembers", c_int, hid_t)
+    _sig(lib, "H5Aget_num_attrs", c_int, hid_t)
+    _sig(lib, "H5Aopen_by_idx", hid_t, hid_t, c_char_p, c_int, c_int, hsize_t, hid_t, hid_t)
+    _sig(lib, "H5Aget_name", ctypes.c_ssize_t, hid_t, c_size_t, c_char_p)
+    _sig(lib, "H5Aget_type", hid_t, hid_t)
+    _sig(lib, "H5Aget_space", hid_t, hid_t)
+    _sig(lib, "H5Aread", herr_t, hid_t, hid_t, c_void_p)
+    _sig(lib, "H5Dvlen_reclaim", herr_t, hid_t, hid_t, hid_t, c_void_p)
+    lib.iter_cb = ctypes.CFUNCTYPE(herr_t, hid_t, c_char_p, c_void_p, c_void_p)
+    _sig(lib, "H5Literate", herr_t, hid_t, c_int, c_int, P(hsize_t), lib.iter_cb, c_void_p)
     g = lambda n: hid_t.in_dll(lib, n).value
     lib.t = {np.dtype(k): g(v) for k, v in {
         "f8": "H5T_NATIVE_DOUBLE_g", "f4": "H5T_NATIVE_FLOAT_g", "i1": "H5T_NATIVE_INT8_g", "i2": "H5T_NATIVE_INT16_g",
@@ -341,3 +366,127 @@ def write_tree(path, root, compresslevel=1):
         finally:
             os.close(fd)
     return str(path)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Reading: a results container -- this package's or the reference's own -- without h5py
+# ---------------------------------------------------------------------------------------------------------------------------------
+H5I_GROUP, H5I_DATASET = 2, 5
+H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_ENUM = 0, 1, 3, 8
+
+
+def _numpy_type(lib, tid):
+    """(numpy dtype, memory type id to read with, is variable-length string) of an HDF5 datatype; None for what is not handled."""
+    cls, size = lib.H5Tget_class(tid), int(lib.H5Tget_size(tid))
+    if cls == H5T_FLOAT and size in (4, 8):
+        dt = np.dtype("f%d" % size)
+        return dt, lib.t[dt], False
+    if cls == H5T_INTEGER and size in (1, 2, 4, 8):
+        dt = np.dtype(("i" if lib.H5Tget_sign(tid) == 1 else "u") + str(size))
+        return dt, lib.t[dt], False
+    if cls == H5T_ENUM and size == 1 and lib.H5Tget_nmembers(tid) == 2:       # h5py's boolean
+        return np.dtype("bool"), lib.t[np.dtype("bool")], False
+    if cls == H5T_STRING and lib.H5Tis_variable_str(tid) > 0:
+        return np.dtype("O"), lib.vlen_str, True
+    return None, None, False
+
+
+def _shape_of(lib, space):
+    nd = lib.H5Sget_simple_extent_ndims(space)
+    if nd <= 0:
+        return ()
+    dims = (hsize_t * nd)()
+    lib.H5Sget_simple_extent_dims(space, dims, None)
+    return tuple(int(d) for d in dims)
+
+
+def _read_attrs(lib, obj):
+    out = {}
+    for n in range(max(0, lib.H5Aget_num_attrs(obj))):
+        a = _ok(lib.H5Aopen_by_idx(obj, b".", 0, 0, n, 0, 0), "H5Aopen_by_idx")
+        try:
+            ln = lib.H5Aget_name(a, 0, None)
+            buf = ctypes.create_string_buffer(ln + 1)
+            lib.H5Aget_name(a, ln + 1, buf)
+            tid, space = lib.H5Aget_type(a), lib.H5Aget_space(a)
+            try:
+                dt, mem, vlen = _numpy_type(lib, tid)
+                shape = _shape_of(lib, space)
+                n_el = int(np.prod(shape)) if shape else 1
+                if dt is None:
+                    continue
+                if vlen:
+                    ptrs = (ctypes.c_char_p * n_el)()
+                    _ok(lib.H5Aread(a, mem, ptrs), "H5Aread")
+                    vals = [(p_ or b"").decode("utf-8") for p_ in ptrs]
+                    lib.H5Dvlen_reclaim(mem, space, 0, ptrs)
+                    out[buf.value.decode()] = vals[0] if shape == () else vals
+                else:
+                    arr = np.empty(shape, dtype=np.int8 if dt == np.bool_ else dt)
+                    _ok(lib.H5Aread(a, mem, arr.ctypes.data_as(ctypes.c_void_p)), "H5Aread")
+                    arr = arr.astype(bool) if dt == np.bool_ else arr
+                    out[buf.value.decode()] = arr.item() if shape == () else arr
+            finally:
+                lib.H5Tclose(tid)
+                lib.H5Sclose(space)
+        finally:
+            lib.H5Aclose(a)
+    return out
+
+
+def read_tree(path):
+    """({hdf path: array} of every dataset, {hdf path: attributes} of every group and dataset that has any) of an HDF5 file -- a results
+    container written by this package or by the reference (numeric, boolean and variable-length string data: what those files hold)."""
+    lib = load()
+    if lib is None:
+        raise HDF5Error("no usable HDF5 library: " + str(_err))
+    arrays, attrs = {}, {}
+
+    def children(gid):
+        names = []
+        cb = lib.iter_cb(lambda g_, name, info, data: names.append(name) or 0)
+        idx = hsize_t(0)
+        _ok(lib.H5Literate(gid, 0, 0, ctypes.byref(idx), cb, None), "H5Literate")
+        return names
+
+    def walk(gid, prefix):
+        a = _read_attrs(lib, gid)
+        if a:
+            attrs[prefix or "/"] = a
+        for name in children(gid):
+            obj = _ok(lib.H5Oopen(gid, name, 0), "H5Oopen")
+            try:
+                path_ = prefix + "/" + name.decode()
+                kind = lib.H5Iget_type(obj)
+                if kind == H5I_GROUP:
+                    walk(obj, path_)
+                elif kind == H5I_DATASET:
+                    tid, space = lib.H5Dget_type(obj), lib.H5Dget_space(obj)
+                    try:
+                        dt, mem, vlen = _numpy_type(lib, tid)
+                        shape = _shape_of(lib, space)
+                        if dt is not None and not vlen:
+                            arr = np.empty(shape, dtype=np.int8 if dt == np.bool_ else dt)
+                            if arr.size:
+                                _ok(lib.H5Dread(obj, mem, 0, 0, 0, arr.ctypes.data_as(ctypes.c_void_p)), "H5Dread " + path_)
+                            arrays[path_] = arr.astype(bool) if dt == np.bool_ else arr
+                    finally:
+                        lib.H5Tclose(tid)
+                        lib.H5Sclose(space)
+                    a2 = _read_attrs(lib, obj)
+                    if a2:
+                        attrs[path_] = a2
+            finally:
+                lib.H5Oclose(obj)
+
+    with _LOCK:
+        f = _ok(lib.H5Fopen(os.fsencode(str(path)), 0, 0), "H5Fopen " + str(path))
+        try:
+            root = _ok(lib.H5Oopen(f, b"/", 0), "H5Oopen /")
+            try:
+                walk(root, "")
+            finally:
+                lib.H5Oclose(root)
+        finally:
+            lib.H5Fclose(f)
+    return arrays, attrs

@@ -38,11 +38,22 @@ class _Dataset:
         if data is not None:
             a = np.array(data)
             self._arr = a.astype(dtype) if dtype is not None else a
-            self._shape, self._dtype, self._fill = self._arr.shape, self._arr.dtype, None
+            self._shape, self._dtype = self._arr.shape, self._arr.dtype
         else:
             self._shape = (int(shape),) if np.isscalar(shape) else tuple(int(s_) for s_ in shape)
             self._dtype = np.dtype(dtype if dtype is not None else "f8")
-            self._fill = fillvalue if (fillvalue is not None and (self._dtype.kind == "f" or np.isfinite(fillvalue))) else None
+        # The fill value as HDF5 holds it.  The reference creates its integer datasets (counters, posterior counts) with fillvalue = NaN
+        # like the floating-point ones (DataArray.createHdf, core/DataArray.py:1011-1100); h5py hands the library a double NaN, whose
+        # conversion to a signed integer is the most negative value (x86-64; seen in a file the reference wrote, tests/test_hdf5_file.py):
+        # rows nothing was written to read -2147483648 / -9223372036854775808 there, and here.  Unsigned and boolean: 0.
+        self._fill = None
+        if fillvalue is not None:
+            if self._dtype.kind == "f":
+                self._fill = fillvalue
+            elif np.isfinite(fillvalue):
+                self._fill = fillvalue
+            elif self._dtype.kind == "i":
+                self._fill = int(np.iinfo(self._dtype).min)
 
     shape = property(lambda s: s._shape)
     dtype = property(lambda s: s._dtype)
@@ -188,6 +199,8 @@ class NpzGroup:
                 v.walk(out)
             else:
                 out[v.name] = dict(kind="dataset", shape=list(v.shape), dtype=str(v.dtype), **({"attrs": dict(v.attrs)} if v.attrs else {}))
+                if v._fill is not None:            # as tests/golden/hdf_schema*.json record it: "nan" or the number the file holds
+                    out[v.name]["fill"] = "nan" if (v.dtype.kind == "f" and np.isnan(v._fill)) else (int(v._fill) if v.dtype.kind in "iub" else float(v._fill))
         return out
 
     def arrays(self, out=None, materialised_only=False):
@@ -216,7 +229,7 @@ class NpzGroup:
             if isinstance(v, NpzGroup):
                 v.unwritten(out)
             elif not v.materialised and not v.sparse:
-                out[v.name] = dict(shape=list(v.shape), dtype=str(v.dtype), fill=None if v._fill is None else (float(v._fill) if np.isfinite(v._fill) else "nan"))
+                out[v.name] = dict(shape=list(v.shape), dtype=str(v.dtype), fill=None if v._fill is None else ((int(v._fill) if v.dtype.kind in "iu" else float(v._fill)) if np.isfinite(v._fill) else "nan"))
         return out
 
     def save(self, path):
@@ -249,7 +262,8 @@ class NpzGroup:
         attrs = {k: v.get("attrs", {}) for k, v in self.walk().items() if v.get("attrs")}
         attrs["__unwritten__"] = lazy
         attrs["__nantail__"] = tails
-        attrs["__sparse__"] = {name: dict(shape=list(ds_.shape), dtype=str(ds_.dtype)) for name, ds_ in sparse.items()}
+        attrs["__sparse__"] = {name: dict(shape=list(ds_.shape), dtype=str(ds_.dtype), fill=0 if ds_._fill is None else int(ds_._fill))
+                               for name, ds_ in sparse.items()}
         json.dump(attrs, open(str(path) + ".attrs.json", "w"), sort_keys=True)
 
 
@@ -351,7 +365,7 @@ def load_npz(path):
             if "#" not in k:
                 out[k] = z[k]
         for k, m in sparse.items():              # datasets stored as runs (NpzGroup.save): back to dense
-            d_ = _Dataset(k, m["shape"], m["dtype"], fillvalue=0)
+            d_ = _Dataset(k, m["shape"], m["dtype"], fillvalue=m.get("fill", 0))
             d_.write_run_rows(z[k + "#row"], z[k + "#ptr"], z[k + "#start"], z[k + "#value"])
             out[k] = d_.arr
         for k, m in side_file.get("__nantail__", {}).items():     # traces stored as their finite prefixes: NaN put back behind them
@@ -365,6 +379,33 @@ def load_npz(path):
             a[...] = np.nan if m["fill"] == "nan" else m["fill"]
         out[k] = a
     return out
+
+
+def load_results(path):
+    """({hdf path: array}, {hdf path: attributes}) of a flight line's results container of either type: ``<line>.h5`` (read through h5py
+    where it is installed, else through the HDF5 C library: h5lite.read_tree -- the reference's own files open the same way) or the
+    stand-in ``<line>.results[.npz]``."""
+    p_ = str(path)
+    if p_.endswith(".h5") or p_.endswith(".hdf5"):
+        h5py = _h5py()
+        if h5py is None:
+            from . import h5lite
+            return h5lite.read_tree(p_)
+        arrays, attrs = {}, {}
+        with h5py.File(p_, "r") as f:
+            if len(f.attrs):
+                attrs["/"] = dict(f.attrs)
+
+            def visit(name, obj):
+                if len(obj.attrs):
+                    attrs["/" + name] = dict(obj.attrs)
+                if isinstance(obj, h5py.Dataset):
+                    arrays["/" + name] = obj[()]
+            f.visititems(visit)
+        return arrays, attrs
+    side = p_[:-4] if p_.endswith(".npz") else p_
+    a = json.load(open(side + ".attrs.json"))
+    return load_npz(p_), {k: v for k, v in a.items() if not k.startswith("__")}
 
 
 def _h5py():
@@ -429,12 +470,12 @@ def _attrs(obj, **kw):
             obj.attrs[k] = v
 
 
-def _data_array(parent, name, shape, dtype="f8", fill=np.nan, data=None, rep="DataArray", label=None, units=None):
+def _data_array(parent, name, shape, dtype="f8", fill=np.nan, data=None, rep="DataArray", label=None, units=None, data_fill=None):
     """DataArray.createHdf (core/DataArray.py:1011-1100): group <name> with dataset 'data' and the repr / name / units attributes."""
     g = parent.create_group(name)
     _attrs(g, repr=rep, name=label, units=units)
     if data is not None:
-        g.create_dataset("data", data=np.asarray(data, dtype=dtype))
+        g.create_dataset("data", data=np.asarray(data, dtype=dtype), **({} if data_fill is None else {"fillvalue": data_fill}))
     else:
         g.create_dataset("data", shape=shape, dtype=dtype, fillvalue=fill)
     return g
@@ -445,7 +486,7 @@ def _mesh1d(parent, name, edges, dimension, label="", units="", log=None, relati
     stored relative to a value of the sounding)."""
     g = parent.create_group(name)
     _attrs(g, repr="RectilinearMesh1D")
-    g.create_dataset("dimension", data=np.int32(dimension))
+    g.create_dataset("dimension", data=np.array([dimension], dtype=np.int32))      # (RectilinearMesh1D.py:1641: create_dataset(..., shape=(1,)))
     _data_array(g, "edges", None, data=np.asarray(edges, dtype=np.float64), label=label, units=units)
     if log is not None:
         g.create_dataset("log", data=np.int64(log))
@@ -468,7 +509,7 @@ def _histogram(parent, n, shape, axes, mesh_repr, name="posterior"):
     _index_axis(m, n)
     for name, kw in axes:
         _mesh1d(m, name, **kw)
-    _data_array(g, "values", (n,) + tuple(shape), dtype="i4", fill=None, label="Frequency")
+    _data_array(g, "values", (n,) + tuple(shape), dtype="i4", fill=np.nan, label="Frequency")
     return g
 
 
@@ -506,7 +547,7 @@ def _loop_rows(parent, name, n, sampled=None):
                         "RectilinearMesh2D")
             continue
         _data_array(g, key, (n,), label=label, units=units)
-    _data_array(g, "orientation", (n,), dtype="i4", fill=None, label="Orientation")
+    _data_array(g, "orientation", (n,), dtype="i4", fill=np.nan, label="Orientation")
     return g
 
 
@@ -582,7 +623,7 @@ def _create_fdem_data(parent, dp, g_, n, fid):
                                     rel_units=units))], "RectilinearMesh2D")
         else:
             _data_array(d, key, (n,), label=label, units=units)
-    _data_array(d, "fiducial", None, data=fid, label="fiducial")
+    _data_array(d, "fiducial", None, data=fid, label="fiducial", data_fill=np.nan)
     _data_array(d, "data", (n, N), label="Frequency domain data", units="ppm")
     _data_array(d, "std", (n, N), label="Standard deviation", units="ppm")
     _data_array(d, "predicted_data", (n, N), label="Predicted Data", units="ppm")
@@ -614,7 +655,7 @@ def _create_tdem_data(parent, dp, g_, n, fid, kind):
     for key, label, u in (("x", "Easting", "m"), ("y", "Northing", "m"), ("z", "Height", "m"), ("elevation", "Elevation", "m"),
                           ("line_number", "Line number", None)):
         _data_array(d, key, (n,), label=label, units=u)
-    _data_array(d, "fiducial", None, data=fid, label="fiducial")
+    _data_array(d, "fiducial", None, data=fid, label="fiducial", data_fill=np.nan)
     _data_array(d, "data", (n, N), label="Data" if tempest else "Secondary field", units=units)
     _data_array(d, "std", (n, N), label="Standard deviation", units=units)
     _data_array(d, "predicted_data", (n, N), label="Predicted Data" if tempest else "Predicted secondary field", units=units)
@@ -674,7 +715,9 @@ def create_inference1d(parent, inf, add_axis):
         parent.create_dataset("limits", data=np.asarray(inf.options["parameter_limits"], dtype=np.float64))
     parent.create_dataset("n_markov_chains", data=np.int64(inf.n_markov_chains))
     parent.create_dataset("nsystems", data=np.int64(dp.nSystems))
-    for key, dt, fill in (("iteration", "i8", 0), ("burned_in_iteration", "i8", 0), ("best_iteration", "i8", 0), ("burned_in", "?", 0),
+    # (the reference creates all of them with fillvalue = NaN, Inference1D.createHdf :1010-1030: the counters' rows nothing wrote to hold the
+    #  most negative int64 in its files -- _Dataset -- and so do these)
+    for key, dt, fill in (("iteration", "i8", np.nan), ("burned_in_iteration", "i8", np.nan), ("best_iteration", "i8", np.nan), ("burned_in", "?", 0),
                           ("multiplier", "f8", np.nan), ("invtime", "f8", np.nan), ("savetime", "f8", np.nan)):
         parent.create_dataset(key, shape=(n,), dtype=dt, fillvalue=fill)
     # per-iteration traces (Inference1D.acceptance_v / data_misfit_v :408, 414): 2 n_markov_chains entries per sounding.  A device
@@ -695,7 +738,7 @@ def create_inference1d(parent, inf, add_axis):
     _attrs(mesh, repr="RectilinearMesh2D_stitched")
     _index_axis(mesh, n)
     _stat_array(mesh, "nCells", n, (), "Number of cells", None, (K + 1,),
-                [("y", dict(edges=g_["layer_edges"], dimension=0, label="# of Layers", units=""))], "RectilinearMesh2D", dtype="i4", fill=None)
+                [("y", dict(edges=g_["layer_edges"], dimension=0, label="# of Layers", units=""))], "RectilinearMesh2D", dtype="i4", fill=np.nan)
     y = mesh.create_group("y")
     e = _data_array(y, "edges", (n, K + 1), rep="StatArray")
     e.create_dataset("n_posteriors", data=np.int64(1))

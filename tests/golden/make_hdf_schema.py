@@ -31,16 +31,23 @@ class Dataset:
         if data is not None:
             arr = np.array(data)
             self.arr = arr.astype(dtype) if dtype is not None else arr
+            if shape is not None:                     # h5py: data given with a shape is reshaped to it (RectilinearMesh1D 'dimension': shape=(1,))
+                self.arr = self.arr.reshape((shape,) if np.isscalar(shape) else tuple(int(s) for s in shape))
         else:
             shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
             dt = np.dtype(dtype if dtype is not None else "f8")
             self.arr = np.zeros(shape, dtype=dt)
             if fillvalue is not None:
-                with np.errstate(invalid="ignore"):
-                    try:
-                        self.arr[...] = fillvalue
-                    except (ValueError, TypeError):
-                        pass
+                if dt.kind == "i" and not np.isfinite(fillvalue):
+                    self.arr[...] = np.iinfo(dt).min      # what the library's double -> integer conversion of NaN leaves in a real file (x86-64)
+                elif dt.kind in "ub" and not np.isfinite(fillvalue):
+                    pass                                  # 0
+                else:
+                    with np.errstate(invalid="ignore"):
+                        try:
+                            self.arr[...] = fillvalue
+                        except (ValueError, TypeError):
+                            pass
         self.fillvalue = fillvalue
         self.attrs = Attrs()
 
@@ -125,6 +132,16 @@ class Group:
                 v.walk(out)
             else:
                 e = {"kind": "dataset", "shape": list(v.shape), "dtype": str(v.dtype)}
+                # the fill value as a real HDF5 file holds it (checked against a file the reference wrote through the real h5py,
+                # tests/ref_writes_h5.py): h5py hands the library a double; NaN -> most negative signed integer, 0 for unsigned / bool
+                fv = v.fillvalue
+                if fv is not None and np.ndim(fv) == 0:
+                    if v.dtype.kind == "f":
+                        e["fill"] = "nan" if np.isnan(fv) else float(fv)
+                    elif v.dtype.kind == "i":
+                        e["fill"] = int(np.iinfo(v.dtype).min) if not np.isfinite(fv) else int(fv)
+                    elif v.dtype.kind in "ub":
+                        e["fill"] = 0 if not np.isfinite(fv) else int(fv)
                 if v.attrs:
                     e["attrs"] = {a: (b.decode() if isinstance(b, bytes) else str(b)) for a, b in v.attrs.items()}
                 if v.arr.size <= 512 and v.arr.dtype.kind in "fiub":

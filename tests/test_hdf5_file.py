@@ -101,7 +101,9 @@ def test_the_reference_container_as_a_real_hdf5_file(tmp_path):
             assert int(np.isfinite(f).sum()) == r["n_finite"] and np.isclose(np.nansum(f[np.isfinite(f)]), r["nansum"], rtol=1e-9), p
     # datasets nothing wrote to take no space and read back as their fill value; the traces of soundings 0 and 2 are such rows
     assert info["/model/values/posterior/values/data"]["shape"] == [3, 250, 440]
-    assert np.all(arrays["/iteration"] == [0, meta["iteration"], 0])
+    lowest = np.iinfo(np.int64).min          # the counters' rows nothing wrote to: the reference's NaN fill as a real file holds it
+    assert np.all(arrays["/iteration"] == [lowest, meta["iteration"], lowest]) and info["/iteration"]["fillvalue"] == lowest
+    assert info["/model/values/posterior/values/data"]["fillvalue"] == np.iinfo(np.int32).min and info["/phids/data"]["fillvalue"] == "nan"
 
 
 def test_the_references_own_readers_open_our_file(tmp_path):
@@ -160,6 +162,72 @@ def test_the_references_own_readers_open_our_file(tmp_path):
     assert np.array_equal(arr(d["additive_error_posterior_counts"]), mem["/data/additive_error/posterior/values/data"][1].ravel().astype(np.float64))
     assert np.array_equal(arr(got["phids"]), mem["/phids/data"][1], equal_nan=True) and np.isfinite(arr(got["phids"])).sum() > 100
     assert got["h5py"] and got["hdf5"]
+
+
+def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path):
+    """Build container only.  tests/ref_writes_h5.py lets the REFERENCE write the seeded container into a real ``h5py.File`` (its own
+    createHdf / writeHdf, no stand-in anywhere); this package writes the same sounding through h5lite; the real h5py opens both.  Same
+    paths; per path the same kind, shape, dtype, attributes (and their Python types), FILL VALUE -- NaN for floats, the most negative
+    integer for the counters and posterior counts (the reference's NaN fill cast by the library), which is what the rows nothing wrote
+    to read -- and the same numbers (integers equal: the chains take the same decisions; floats to 1e-7: the checker's numpy / LAPACK
+    are older).  Two properties may differ and are listed: the mesh 'dimension' datasets are int64 in a file written under numpy < 2
+    (``np.int32 + 1``), int32 under numpy >= 2 and here; the hit map is chunked + deflated here, contiguous there.
+    The package's own reader (h5lite.read_tree, no h5py) reads the REFERENCE's file to the same arrays and attributes as h5py does.
+    This comparison is what found the three things the call-recording stand-in could not show (it ignored ``shape=`` next to ``data=`` and
+    kept zeros where a NaN fill meets an integer type): 'dimension' is shape (1,), integer fills are INT_MIN, 'fiducial' carries a NaN fill."""
+    _needs()
+    if not os.path.isdir("/root/reference/geobipy"):
+        pytest.skip("the reference tree is only present in the build container")
+    if subprocess.run([CHECKER, "-c", "import h5py, matplotlib, scipy"], capture_output=True).returncode != 0:
+        pytest.skip("the checker interpreter cannot import what the reference needs")
+    from geobipy_amd import h5lite, hdf
+    from test_hdf_layout import _run
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "PYTHONHOME")}
+    ref_path = str(tmp_path / "reference.h5")
+    r = subprocess.run([CHECKER, os.path.join(ROOT, "tests", "ref_writes_h5.py"), ref_path], capture_output=True, text=True, timeout=1800, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and os.path.getsize(ref_path) > 1_000_000, r.stderr[-4000:]
+    meta = json.load(open(os.path.join(GOLDEN, "hdf_schema.json")))["meta"]
+    inf = _run(meta["iterations"])
+    path = str(tmp_path / "ours.h5")
+    root = hdf.open_results(path, container="hdf5")
+    hdf.create_inference1d(root, inf, add_axis=meta["fiducials"])
+    for _ in range(meta["iterations"]):
+        inf.accept_reject()
+        inf.update()
+    inf.writeHdf(root)
+    root.save(path)
+    (za, a), (zb, b) = h5dump(ref_path, tmp_path), h5dump(path, tmp_path)
+    pa, pb = sorted(k for k in a if k != "__h5py__"), sorted(k for k in b if k != "__h5py__")
+    assert pa == pb, (sorted(set(pa) - set(pb)), sorted(set(pb) - set(pa)))
+    allowed = set()
+    for p in pa:
+        x, y = a[p], b[p]
+        for key in ("kind", "shape", "dtype", "attrs", "attr_types", "fillvalue", "chunks", "compression"):
+            if x.get(key) != y.get(key):
+                if key == "dtype" and p.endswith("/dimension") and {x[key], y[key]} == {"int32", "int64"}:
+                    allowed.add("dimension dtype")
+                elif key in ("chunks", "compression") and p == "/model/values/posterior/values/data":
+                    allowed.add("hit map layout")
+                else:
+                    raise AssertionError((p, key, x.get(key), y.get(key)))
+        if x["kind"] != "dataset" or p in ("/invtime", "/savetime"):
+            continue
+        u, v = za[p], zb[p]
+        if u.dtype.kind == "f":
+            assert np.array_equal(np.isnan(u), np.isnan(v)) and np.allclose(np.nan_to_num(u), np.nan_to_num(v), rtol=1e-7, atol=1e-10), p
+        else:
+            assert np.array_equal(u.astype(np.int64), v.astype(np.int64)), p
+    assert allowed <= {"dimension dtype", "hit map layout"}
+    assert a["/iteration"]["fillvalue"] == np.iinfo(np.int64).min and za["/iteration"][0] == np.iinfo(np.int64).min      # the reference's own file says so
+    assert abs(os.path.getsize(ref_path) - os.path.getsize(path)) < 0.01 * os.path.getsize(ref_path)
+    # this package's reader on the reference's file
+    arrays, attrs = hdf.load_results(ref_path)
+    assert sorted(arrays) == sorted(za)
+    for p in za:
+        assert arrays[p].dtype == za[p].dtype and np.array_equal(arrays[p], za[p], equal_nan=za[p].dtype.kind == "f"), p
+    for p, x in a.items():
+        if p != "__h5py__" and x["attrs"]:
+            assert attrs[p] == x["attrs"], p
 
 
 def test_line_containers_with_run_length_hit_maps_as_hdf5(tmp_path, monkeypatch):

@@ -47,6 +47,7 @@ def test_layout_and_values_match_the_reference_container():
         if r["kind"] != "dataset":
             continue
         assert o["shape"] == r["shape"] and o["dtype"] == r["dtype"], (path, o, r)
+        assert o.get("fill", 0) == r.get("fill", 0), (path, o.get("fill"), r.get("fill"))      # NaN for floats, the most negative integer for counters
         if path in ("/invtime", "/savetime"):                   # wall-clock fields: not written
             continue
         a = arrays[path].astype(np.float64)
@@ -74,7 +75,7 @@ def test_infer_writes_through_the_handle_and_the_fallback_file_round_trips(tmp_p
     hdf.create_inference1d(root, inf, add_axis=[29.0, 30.0, 31.0])
     failed = inf.infer(hdf_file_handle=root)
     assert failed is True and inf.iteration == 60               # never below chi^2 = 12 in 60 iterations: the reference returns True
-    assert root["iteration"][1] == 60 and root["iteration"][0] == 0
+    assert root["iteration"][1] == 60 and root["iteration"][0] == np.iinfo(np.int64).min      # (a row nothing wrote to: the reference's integer fill, hdf._Dataset)
     assert int(root["model/mesh/nCells/posterior/values/data"][1].sum()) == 60
     root.save(str(tmp_path / "0.npz"))
     z = np.load(str(tmp_path / "0.npz"))
@@ -131,7 +132,7 @@ def test_device_rows_fill_the_reference_layout():
     i[:, col["i_best_k"]] = [[3], [1]]
     i[:, col["i_k_hist"]] = rng.integers(0, 9, (2, K + 1)); i[:, col["i_hitmap"]] = rng.integers(0, 3, (2, nv * nd))
     hdf.write_device_rows(root, np.searchsorted(np.sort(meta["fiducials"]), f[:, col["fiducial"]][:, 0]), f, i, N, K, nd, nv, o)
-    assert root["iteration"][2] == 191 and root["iteration"][0] == 150 and root["iteration"][1] == 0
+    assert root["iteration"][2] == 191 and root["iteration"][0] == 150 and root["iteration"][1] == np.iinfo(np.int64).min
     assert bool(root["burned_in"][2]) and not bool(root["burned_in"][0]) and root["burned_in_iteration"][0] == 0
     e = root["model/mesh/y/edges/data"][2]
     assert e[:4].tolist() == [0.0, 10.0, 25.0, np.inf] and np.all(np.isnan(e[4:]))
