@@ -164,7 +164,8 @@ def test_the_references_own_readers_open_our_file(tmp_path):
     assert got["h5py"] and got["hdf5"]
 
 
-def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path):
+@pytest.mark.parametrize("kind", ["resolve", "skytem", "tempest"])
+def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path, kind):
     """Build container only.  tests/ref_writes_h5.py lets the REFERENCE write the seeded container into a real ``h5py.File`` (its own
     createHdf / writeHdf, no stand-in anywhere); this package writes the same sounding through h5lite; the real h5py opens both.  Same
     paths; per path the same kind, shape, dtype, attributes (and their Python types), FILL VALUE -- NaN for floats, the most negative
@@ -181,13 +182,18 @@ def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path):
     if subprocess.run([CHECKER, "-c", "import h5py, matplotlib, scipy"], capture_output=True).returncode != 0:
         pytest.skip("the checker interpreter cannot import what the reference needs")
     from geobipy_amd import h5lite, hdf
-    from test_hdf_layout import _run
+    import test_hdf_layout as L
     env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "PYTHONHOME")}
     ref_path = str(tmp_path / "reference.h5")
-    r = subprocess.run([CHECKER, os.path.join(ROOT, "tests", "ref_writes_h5.py"), ref_path], capture_output=True, text=True, timeout=1800, env=env, cwd=str(tmp_path))
+    r = subprocess.run([CHECKER, os.path.join(ROOT, "tests", "ref_writes_h5.py"), ref_path, kind], capture_output=True, text=True, timeout=1800, env=env, cwd=str(tmp_path))
     assert r.returncode == 0 and os.path.getsize(ref_path) > 1_000_000, r.stderr[-4000:]
-    meta = json.load(open(os.path.join(GOLDEN, "hdf_schema.json")))["meta"]
-    inf = _run(meta["iterations"])
+    # (the time-domain kinds: the reference runs on tests/golden/fake_gatdaem1d.py, whose physics is this repository's oracle, and the
+    #  host sampler here has the same oracle as its engine -- the CONTAINERS are what is compared, tests/ref_writes_h5.py)
+    if kind == "resolve":
+        meta = json.load(open(os.path.join(GOLDEN, "hdf_schema.json")))["meta"]
+        inf = L._run(meta["iterations"])
+    else:
+        inf, _, meta = L._skytem_inference() if kind == "skytem" else L._tempest_inference()
     path = str(tmp_path / "ours.h5")
     root = hdf.open_results(path, container="hdf5")
     hdf.create_inference1d(root, inf, add_axis=meta["fiducials"])
@@ -210,11 +216,16 @@ def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path):
                     allowed.add("hit map layout")
                 else:
                     raise AssertionError((p, key, x.get(key), y.get(key)))
-        if x["kind"] != "dataset" or p in ("/invtime", "/savetime"):
-            continue
+        if x["kind"] != "dataset" or any(p.endswith(q) for q in L.TD_VALUE_SKIP):     # (wall clocks; loop radius / moment / orientation are inputs the
+            continue                                                                  #  helpers set themselves: test_hdf_layout.TD_VALUE_SKIP)
         u, v = za[p], zb[p]
-        if u.dtype.kind == "f":
-            assert np.array_equal(np.isnan(u), np.isnan(v)) and np.allclose(np.nan_to_num(u), np.nan_to_num(v), rtol=1e-7, atol=1e-10), p
+        if u.dtype.kind == "f":      # (Tempest: an unconstrained third layer carries 5e-7 of accumulated rounding, test_hdf_layout.py)
+            assert np.array_equal(np.isnan(u), np.isnan(v)) and np.allclose(np.nan_to_num(u), np.nan_to_num(v), rtol=2e-6 if kind == "tempest" else 1e-7, atol=1e-10), p
+        elif kind != "resolve" and p == "/model/values/posterior/values/data":
+            # the conductivity-depth map of a 300-iteration chain run by the checker's older numpy / LAPACK: a conductivity within 1e-9 of a
+            # bin edge falls on the other side for a few samples (this package's container equals the reference's run under THIS
+            # interpreter's numpy cell for cell: SHA-1 in tests/test_hdf_layout.py) -- every depth cell holds the same number of samples
+            assert np.array_equal(u.sum(axis=1), v.sum(axis=1)) and (u != v).mean() < 0.05, (p, float((u != v).mean()))
         else:
             assert np.array_equal(u.astype(np.int64), v.astype(np.int64)), p
     assert allowed <= {"dimension dtype", "hit map layout"}
