@@ -405,3 +405,24 @@ def test_survey_writes_hdf5_containers_the_real_h5py_reads(tmp_path, kind):
                 assert info[p_]["attrs"] == a, (name, p_)
         assert info["/"]["kind"] == "group" and info["/model/values"]["attrs"]["repr"] == "StatArray"
         assert info["/data"]["attrs"]["repr"] == {"resolve": "FdemData", "skytem": "TdemData", "tempest": "TempestData"}[kind]
+
+
+@pytest.mark.gpu
+def test_command_line_writes_hdf5_containers_and_says_so(tmp_path, capsys):
+    """python -m geobipy_amd <options> <out> --container hdf5 (and the default, where an HDF5 library loads): <line>.h5 beside the
+    per-line summaries, the type and its writer named on the command line's output; readable by this package's reader and the real h5py."""
+    _needs()
+    from geobipy_amd import hdf
+    from geobipy_amd.__main__ import main
+    out = tmp_path / "out"
+    out.mkdir()
+    assert main([os.path.join(GOLDEN, "resolve_options_small"), str(out), "--index", "5", "--container", "hdf5"]) == 0
+    said = capsys.readouterr().out
+    assert "HDF5 files <line>.h5, written by libhdf5" in said and "through ctypes" in said
+    assert sorted(n_ for n_ in os.listdir(out) if n_.startswith("0.0")) == ["0.0.h5", "0.0.npz"]
+    arrays, attrs = hdf.load_results(str(out / "0.0.h5"))
+    by_h5py, info = h5dump(out / "0.0.h5", tmp_path)
+    assert sorted(arrays) == sorted(by_h5py) and attrs["/model/values"]["repr"] == info["/model/values"]["attrs"]["repr"] == "StatArray"
+    for k in by_h5py:
+        assert np.array_equal(arrays[k], by_h5py[k], equal_nan=by_h5py[k].dtype.kind == "f"), k
+    assert arrays["/data/fiducial/data"].tolist() == [5.0] and int(arrays["/iteration"][0]) > 0
