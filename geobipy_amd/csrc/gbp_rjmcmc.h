@@ -2005,11 +2005,14 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
                                                     const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                     int stage, unsigned char* deep_scratch, size_t deep_bytes,
                                                     const BinDesc* __restrict__ bins, int bin0, int n_bins,
-                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts)
+                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts, int out_offset)
 {
-    __shared__ double sh_out[2 * GBP_MAX_FREQ];
+    // The output row lives behind the stages' working set in the dynamic block (out_offset) instead of a static 2 * GBP_MAX_FREQ doubles:
+    // with two waves per chain the workgroup's LDS was 20 544 B -- 64 B more than an eighth of a CU's 160 KB -- i.e. seven resident
+    // workgroups (3.5 waves per SIMD) where the 128-VGPR budget allows eight; the sampler's rows are n_channels doubles (160 B).
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    double* sh_out = reinterpret_cast<double*>(sh_dyn + out_offset);
     const int b = blockIdx.x;
     const int action = c.action[b];
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
@@ -2615,7 +2618,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
 #ifdef GBP_RJ_PHYSICS_NW
             t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
 #endif
-            t.lds = std::max(dyn_lds_bytes(t.nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(t.nw, K < 8 ? K : 8));
+            t.lds = (std::max(dyn_lds_bytes(t.nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(t.nw, K < 8 ? K : 8)) + 15) & ~(size_t)15;     // + the output row, physics()
         }
         (void)deep_per_chain;
         if (P > 1) {
@@ -2641,14 +2644,16 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         auto physics = [&](const Part& t, int stage) {
             const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(t.nw, K) + 255) & ~(size_t)255) : 0;
             const rj::RjOpt ox = rj::extend(t.o);
+            const size_t out_bytes = (size_t)o->n_channels * sizeof(double);          // the output row behind the stages' block (k_rj_physics)
+            const int out_offset = (int)t.lds;
             if (o->exact_jacobian)
-                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B), dim3(64 * t.nw), t.lds, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B), dim3(64 * t.nw), t.lds + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                                   sys->d_bin_pts);
+                                   sys->d_bin_pts, out_offset);
             else
-                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B), dim3(64 * t.nw), t.lds, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B), dim3(64 * t.nw), t.lds + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                                   sys->d_bin_pts);
+                                   sys->d_bin_pts, out_offset);
         };
         // One host thread per sub-block issues that sub-block's launches (7 per iteration at ~9 us each: one thread issuing for
         // four sub-blocks would be slower than the GPU -- measured 31 vs 37.6 M chain-iterations/s at 8 192 chains; with a thread
