@@ -515,7 +515,7 @@ def main():
                 "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(Btot, L, world),
                 "flop_per_eval": fpe, "evals_per_launch": per_launch_evals, "kernel_ms": kernel_ms,
-                "kernel": "k_fdem_forward<true>",
+                "kernel": "k_fdem_forward<true, false>",
                 "hbm": {"algorithmic_bytes_per_eval": bpe,
                         "achieved_GBps": per_launch_evals * bpe / (kernel_ms * 1e-3) / 1e9,
                         "peak_GBps": HBM_PEAK_GBPS},
@@ -603,7 +603,7 @@ def main():
                     bk[it[0] % N_SIGMA_SETS].forward_loglike(want_pred=False); it[0] += 1
                 ms = per_call(one, max(50, int(200e3 / Bk) * 10))
                 line[key] = {"value": Bk / ms * 1e3, "unit": "evals/s", "soundings": Bk, "frequencies": F, "layers": Lk,
-                             "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true>"), "note": note}
+                             "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true, false>"), "note": note}
                 del bk
             Jbuf = batches[0].sensitivity()
             ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 100)
@@ -650,7 +650,7 @@ def main():
                                          "evals_per_launch": Bt, "kernel_ms": c4["ms"],
                                          "evaluated_flop_per_eval_at_35_m": (72 * Lt + 33) * c4["points_at_35_m"],
                                          "frac_of_evaluated_flops": ach_eval / FP64_VECTOR_PEAK_TFLOPS,
-                                         "kernel": "k_fdem_forward<false> on the spline nodes + k_td_apply (window operator)",
+                                         "kernel": "k_fdem_forward<false, false> on the spline nodes + k_td_apply (window operator)",
                                          "count": "builder's extension of SURVEY 8(d) (which defines the FDEM count only): (72 L + 33) flop per "
                                                   "(spline node, abscissa) point x 120 abscissae x the system's spline nodes; 100 timed launches "
                                                   "after a 50 ms warm-up"},

@@ -4,7 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 rnd = sys.argv[2] if len(sys.argv) > 2 else tag
 src = os.path.join(R, "gpurun_out", "prof", tag)
-KERNEL = "k_fdem_forward<true>"
+KERNEL = "k_fdem_forward<true"          # (round 4: <true, false> -- the row-scale template argument)
 B, L, F = 65536, 8, 10
 
 
