@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void k_hitmap_stats(int nv, int nz, const int*
     const double w = 2.0 * half_width;
     long long tot = 0;
     double wsum = 0.0;
+#pragma unroll 10                                  // (ten loads in flight per wave: bound by memory-level parallelism before bytes)
     for (int v = 0; v < nv; ++v) {
         const int h = col[(size_t)v * nz];
         tot += h;
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void k_hitmap_stats(int nv, int nz, const int*
     const double t = (double)(tot > 1 ? tot : 1);
     long long cum = 0;
     int i05 = 0, i50 = 0, i95 = 0;
+#pragma unroll 10
     for (int v = 0; v < nv; ++v) {
         cum += col[(size_t)v * nz];
         const double cdf = (double)cum / t;
