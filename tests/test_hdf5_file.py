@@ -426,3 +426,23 @@ def test_command_line_writes_hdf5_containers_and_says_so(tmp_path, capsys):
     for k in by_h5py:
         assert np.array_equal(arrays[k], by_h5py[k], equal_nan=by_h5py[k].dtype.kind == "f"), k
     assert arrays["/data/fiducial/data"].tolist() == [5.0] and int(arrays["/iteration"][0]) > 0
+
+
+def test_without_an_hdf5_library_the_stand_in_is_written_and_asking_for_hdf5_fails_loudly(tmp_path):
+    """GBP_LIBHDF5=none (no loadable HDF5 library, no h5py): "auto" falls back to the .npz stand-in, "hdf5" raises with the reason; and what
+    h5lite does not write (a complex dataset) is an error, not a silently different file."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from geobipy_amd import hdf, h5lite\n"
+            "assert not h5lite.available() and 'disabled' in h5lite.why_not()\n"
+            "assert hdf.container_type('auto') == 'npz' and hdf.hdf5_writer() is None\n"
+            "try:\n    hdf.container_type('hdf5'); raise SystemExit(3)\nexcept RuntimeError as e:\n    assert 'HDF5' in str(e)\n"
+            "print('FALLBACK_OK')\n") % ROOT
+    env = dict({k: v for k, v in os.environ.items() if k != "GBP_CONTAINER"}, GBP_LIBHDF5="none")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, (r.stdout, r.stderr[-2000:])
+    from geobipy_amd import h5lite, hdf
+    if h5lite.available():
+        g = hdf.NpzGroup("/", container="hdf5")
+        g.create_dataset("z", data=np.array([1 + 2j]))
+        with pytest.raises(h5lite.HDF5Error):
+            g.save(str(tmp_path / "c.h5"))
