@@ -1,5 +1,5 @@
 """CHECKER for tests/test_hdf5_file.py, run in the BUILD CONTAINER only by an interpreter that has the real h5py AND can import the
-reference (/opt/conda/bin/python3.9 there):   python tests/ref_writes_h5.py <out.h5> [resolve | skytem | tempest]
+reference (/opt/conda/bin/python3.9 there):   python tests/ref_writes_h5.py <out.h5> [resolve | skytem | tempest] [iterations to run]
 The REFERENCE writes a results container into a real h5py.File: the steps of tests/golden/make_hdf_schema.py (resolve_glacial.csv row 30,
 resolve_options, 150 iterations, a three-sounding line, index 1) with ``h5py.File(out, "w")`` where that script hands the reference a
 recording stand-in -- Inference1D.createHdf (what Inference2D.createHdf calls per line, Inference2D.py:2001-2015), 150 x accept_reject /
@@ -120,7 +120,7 @@ fid = np.sort(np.asarray(ds.fiducial)[[29, 30, 31]])
 with h5py.File(out, "w") as root:
     inf.createHdf(root, add_axis=fid)
     StatArray(fid).writeHdf(root, "data/fiducial")
-    for _ in range(n_it):
+    for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else n_it):      # (optionally fewer iterations than the container is sized for)
         inf.accept_reject()
         inf.update()
     inf.writeHdf(root, index=1)
