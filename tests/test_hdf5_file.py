@@ -164,6 +164,46 @@ def test_the_references_own_readers_open_our_file(tmp_path):
     assert got["h5py"] and got["hdf5"]
 
 
+def test_the_references_readers_open_a_file_the_device_path_wrote(tmp_path):
+    """tests/golden/device_survey_0.0.h5 is what survey.infer(container="hdf5") wrote on an MI355X for eight soundings of the Resolve wedge
+    file (tests/golden/make_device_h5.py: the device sampler's rows -> LineSpec tree, hit maps as deflated chunks made from their runs,
+    traces), device_survey_summary.npz what the same call returned.  In the build container the REFERENCE's readers open that file through
+    the real h5py and return the survey's numbers: best model, layer-count / interface / conductivity-depth posteriors, counters, the data
+    point.  Everywhere: this package's own reader (no h5py) against the summary."""
+    _needs()
+    from geobipy_amd import hdf
+    path = os.path.join(GOLDEN, "device_survey_0.0.h5")
+    s = np.load(os.path.join(GOLDEN, "device_survey_summary.npz"))
+    arrays, attrs = hdf.load_results(path)
+    order = np.argsort(s["fiducial"])
+    assert np.array_equal(arrays["/data/fiducial/data"], s["fiducial"][order]) and attrs["/data"]["repr"] == "FdemData"
+    assert np.array_equal(arrays["/model/mesh/nCells/posterior/values/data"], s["layer_count_posterior"][order])
+    assert np.array_equal(arrays["/model/mesh/y/edges/posterior/values/data"], s["interface_posterior"][order])
+    assert np.array_equal(arrays["/iteration"], s["iterations"][order]) and np.array_equal(arrays["/model/mesh/nCells/data"], s["best_n_layers"][order])
+    hm = arrays["/model/values/posterior/values/data"]
+    assert hm.shape == (8, 250, 440) and np.array_equal(hm.sum(axis=1), np.repeat(s["layer_count_posterior"][order].sum(axis=1)[:, None], 440, axis=1))
+    if not os.path.isdir("/root/reference/geobipy") or subprocess.run([CHECKER, "-c", "import h5py, matplotlib, scipy"], capture_output=True).returncode != 0:
+        return                                                       # (the reference's side: build container only)
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "PYTHONHOME")}
+    arr = lambda v: np.array([np.nan if q is None else q for q in v], dtype=np.float64)
+    for i in (0, 7):
+        out = str(tmp_path / "read{}.json".format(i))
+        r = subprocess.run([CHECKER, os.path.join(ROOT, "tests", "ref_reads_h5.py"), path, str(i), out], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-4000:]
+        got, j = json.load(open(out)), order[i]
+        k = int(s["best_n_layers"][j])
+        assert got["model"]["nCells"] == k and np.array_equal(arr(got["model"]["values"]), s["best_conductivity"][j, :k])
+        assert np.array_equal(arr(got["model"]["edges"])[1:k], s["best_edges"][j, :k - 1]) and arr(got["model"]["edges"])[0] == 0.0
+        assert np.array_equal(arr(got["ncells_posterior_counts"]), s["layer_count_posterior"][j].astype(np.float64))
+        assert np.array_equal(arr(got["interface_posterior_counts"]), s["interface_posterior"][j].astype(np.float64))
+        assert got["hitmap"]["shape"] == [250, 440] and got["hitmap"]["total"] == int(hm[i].sum())
+        assert got["hitmap"]["weighted"] == float((hm[i].astype(np.float64) * np.arange(hm[i].size).reshape(hm[i].shape)).sum())
+        assert got["iteration"] == s["iterations"][j] and got["burned_in"] == float(s["status"][j] == 1)
+        assert got["datapoint"]["type"] == "FdemDataPoint" and got["datapoint"]["fiducial"] == [float(s["fiducial"][j])]
+        assert np.array_equal(arr(got["datapoint"]["data"]), arrays["/data/data/data"][i]) and np.array_equal(arr(got["datapoint"]["predicted"]), arrays["/data/predicted_data/data"][i])
+        assert np.array_equal(arr(got["phids"]), arrays["/phids/data"][i], equal_nan=True)
+
+
 @pytest.mark.parametrize("kind", ["resolve", "skytem", "tempest"])
 def test_a_file_the_reference_wrote_and_ours_are_the_same_tree(tmp_path, kind):
     """Build container only.  tests/ref_writes_h5.py lets the REFERENCE write the seeded container into a real ``h5py.File`` (its own
