@@ -19,6 +19,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def native_library():
+    """The in-tree gfx950 library, built once if it is missing or older than its sources (hipcc cross-compiles without a GPU; the
+    built .so is not in the history).  A no-op when it is up to date."""
+    from geobipy_amd.build import build_native
+    try:
+        return build_native()
+    except (RuntimeError, OSError, Exception) as e:      # (no hipcc here: the tests that need the library say so themselves)
+        return None
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
