@@ -1164,9 +1164,9 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
 extern "C" gbp_status gbp_hitmap_statistics(int B, int nv, int nz, const int32_t* hitmap, const double* log_mean_prior, double half_width,
                                             double* mean, double* p05, double* p50, double* p95, void* stream)
 {
+    if (B == 0) return GBP_OK;                     // (an empty block: empty device arrays have no address)
     if (B < 0 || nv < 1 || nz < 1 || !hitmap || !log_mean_prior || !mean || !p05 || !p50 || !p95)
         return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_statistics: NULL pointer or non-positive size%s");
-    if (B == 0) return GBP_OK;
     hipLaunchKernelGGL(hitmap::k_hitmap_stats, dim3(B, (nz + 255) / 256), dim3(256), 0, (hipStream_t)stream, nv, nz, hitmap, log_mean_prior, half_width,
                        mean, p05, p50, p95);
     GBP_HIP(hipGetLastError());
@@ -1178,8 +1178,8 @@ extern "C" gbp_status gbp_hitmap_statistics(int B, int nv, int nz, const int32_t
 extern "C" gbp_status gbp_hitmap_runs(int B, int64_t M, const int32_t* hitmap, int64_t* counts, const int64_t* ptr, int32_t* start,
                                       int32_t* value, void* stream)
 {
-    if (B < 0 || M < 1 || M > 0x7fffffff || !hitmap) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: NULL pointer or size out of range%s");
     if (B == 0) return GBP_OK;
+    if (B < 0 || M < 1 || M > 0x7fffffff || !hitmap) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: NULL pointer or size out of range%s");
     static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");
     if (start == nullptr) {
         if (!counts) return fail(GBP_ERR_INVALID_ARG, "gbp_hitmap_runs: counts is NULL%s");

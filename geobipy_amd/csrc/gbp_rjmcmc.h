@@ -2162,6 +2162,7 @@ gbp_status rj_check(const gbp_rj_options* o, const gbp_rj_chains* c)
     if (c->B < 0) return fail(GBP_ERR_INVALID_ARG, "B must be >= 0%s");
     if (!(o->min_width > 0.0) || !(o->max_edge > o->min_edge) || !(o->min_edge > 0.0))
         return fail(GBP_ERR_INVALID_ARG, "need 0 < min_edge < max_edge and min_width > 0%s");
+    if (c->B == 0) return GBP_OK;       // an empty block (a rank without a flight line): no array is touched, and an empty device array has no address
     if (o->schedule == 1 && (!c->burned_in_iteration || !c->status))
         return fail(GBP_ERR_INVALID_ARG, "schedule 1 needs burned_in_iteration and status%s");
     if ((c->edge_hist || c->hitmap) && (o->n_depth_bins < 1 || !(o->depth_bin_width > 0.0)))

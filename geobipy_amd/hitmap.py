@@ -64,6 +64,8 @@ def runs(hitmap):
     dev = hm.device
     lib = _lib.load()
     ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    if B == 0:
+        return ptr, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gbp_hitmap_runs(B, M, hm.data_ptr(), ptr[1:].data_ptr(), None, None, None, _stream(dev)))
         torch.cumsum(ptr[1:], 0, out=ptr[1:])

@@ -711,6 +711,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         dc_, idx_ = state.pop("unfilled")
         if state.get("writer") is None:
             state["writer"] = _LineWriter(results_directory, ds, o, dc_, hitmap, container)
+        if idx_.size == 0:                          # (a rank that got no flight line: nothing to hand over)
+            return
         with _Phase("rows_to_host"):
             pl = payload(dc_, idx_, sparse=True)
         with _Phase("container_fill"):

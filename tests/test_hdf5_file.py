@@ -488,3 +488,36 @@ def test_without_an_hdf5_library_the_stand_in_is_written_and_asking_for_hdf5_fai
         g.create_dataset("z", data=np.array([1 + 2j]))
         with pytest.raises(h5lite.HDF5Error):
             g.save(str(tmp_path / "c.h5"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["dynamic", "lines"])
+def test_two_ranks_write_the_same_hdf5_containers_as_one(tmp_path, schedule):
+    """python -m geobipy_amd ... --container hdf5 by one process and by two ranks (gloo, sharing the GPU): rank 0 fills the containers from the
+    rows the ranks stream to it ("dynamic": dense hit-map columns, turned into runs on arrival) or every rank writes its own lines ("lines"):
+    the same <line>.h5 files, dataset for dataset."""
+    _needs()
+    import socket
+    from geobipy_amd import hdf
+    from geobipy_amd.__main__ import main
+    opts = os.path.join(GOLDEN, "resolve_options_small")
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    assert main([opts, str(one), "--container", "hdf5"]) == 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GBP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "geobipy_amd", opts, str(two), "--container", "hdf5", "--schedule", schedule, "--chunk", "16"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    names = sorted(n_ for n_ in os.listdir(one) if n_.endswith(".h5"))
+    assert names and names == sorted(n_ for n_ in os.listdir(two) if n_.endswith(".h5"))
+    for n_ in names:
+        (a, aa), (b, ab) = hdf.load_results(str(one / n_)), hdf.load_results(str(two / n_))
+        assert sorted(a) == sorted(b) and aa.keys() == ab.keys()
+        for k in a:
+            if k in ("/invtime", "/savetime"):
+                continue
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (n_, k)
