@@ -740,7 +740,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 # one process: the block's rows go to the line containers and are dropped (host memory holds the open lines, not the
                 # survey's hit maps) -- at the start of the next block, or, for the last one, once the summary file's thread is running
                 state["unfilled"] = (dc, idx)
-            elif results_directory is not None:
+            elif results_directory is not None and idx.size:      # (a rank that drew no chunk ships nothing)
                 shipped.append(payload(dc, idx))
             part = torch.cat([v for _, v in named], dim=1).contiguous()
             state.update(iterations=max(state["iterations"], dc.iteration), dc=dc, named=named)
