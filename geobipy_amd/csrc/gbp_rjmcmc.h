@@ -1569,6 +1569,48 @@ __global__ __launch_bounds__(64) void k_td_apply(int B, int K, int n_nodal, int 
         }
 }
 
+// The forward-only case of k_td_apply (what gbp_tdem_forward / TdemBatch.forward run: BASELINE config 4) with the window
+// operator in LDS: k_td_apply reads W[m, g] from L2 for every sounding -- n_nodal x N doubles = 12 KB each, 200 MB per 16 384 soundings,
+// which is what its 28 us were --; here a workgroup of four waves stages W once and walks GBP_TD_PLAIN_ROWS soundings, a wave each at a
+// time.  Every output is the same sum over the nodal values in the same order: the same bits.
+#define GBP_TD_PLAIN_ROWS 16
+__global__ __launch_bounds__(256) void k_td_apply_plain(int B, int n_nodal, int N, const int* __restrict__ nl, const double* __restrict__ W,
+                                                         const double* __restrict__ nodal, double* __restrict__ pred, gbp_td_mix mix)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];      // W[n_nodal][N] | nodal[4][n_nodal]
+    double* sW = reinterpret_cast<double*>(sh_dyn);
+    double* sn = sW + (size_t)n_nodal * N + (size_t)(threadIdx.x >> 6) * n_nodal;
+    for (int q = threadIdx.x; q < n_nodal * N; q += 256) sW[q] = W[q];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b_end = min(B, (int)(blockIdx.x + 1) * GBP_TD_PLAIN_ROWS);
+    for (int b = blockIdx.x * GBP_TD_PLAIN_ROWS + wave; b < b_end; b += 4) {
+        if (nl[b] <= 0) continue;                                                // (wave-uniform)
+        if (mix.n_in <= 0) {
+            for (int m = lane; m < n_nodal; m += 64) sn[m] = nodal[(size_t)b * n_nodal + m];
+        } else {                                                                 // the geometry mixing of the basis integrals, as in k_td_apply
+            const double* w = mix.weights + (size_t)b * mix.n_weights;
+            const double* in = nodal + (size_t)b * mix.n_in;
+            for (int m = lane; m < n_nodal; m += 64) {
+                double acc = 0.0;
+                for (int t = 0; t < mix.terms; ++t) {
+                    const int s_ = mix.src[m * mix.terms + t];
+                    if (s_ >= 0) acc += w[mix.col[m * mix.terms + t]] * in[s_];
+                }
+                sn[m] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int g = lane; g < N; g += 64) {
+            double acc = 0.0;
+            for (int m = 0; m < n_nodal; ++m) acc += sn[m] * sW[(size_t)m * N + g];
+            if (mix.offset != nullptr) acc += mix.offset[(size_t)b * N + g];
+            pred[(size_t)b * N + g] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Sampled attitude angles of a time-domain loop pair (gbp_td_moves; geobipy_amd/tdem_geometry.py is the host twin of the algebra).
 // ---------------------------------------------------------------------------------------------------------------
@@ -2778,8 +2820,12 @@ gbp_status gbp_td_apply_mix(int B, int K, int n_nodal, int N, const int32_t* nla
     }
     const size_t lds = ((size_t)n_nodal * (with_j ? K + 1 : 1)) * sizeof(double);
     if (lds > 60000) return fail(GBP_ERR_INVALID_ARG, "n_nodal * max_layers too large for the time-domain stage%s");
+    const size_t lds_plain = ((size_t)n_nodal * N + (size_t)4 * n_nodal) * sizeof(double);
     if (with_j)
         hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J, mx);
+    else if (lds_plain <= 40 * 1024 && B >= 4 * GBP_TD_PLAIN_ROWS)                     // forward only: the window operator once per workgroup
+        hipLaunchKernelGGL(rj::k_td_apply_plain, dim3((B + GBP_TD_PLAIN_ROWS - 1) / GBP_TD_PLAIN_ROWS), dim3(256), lds_plain, (hipStream_t)stream, B, n_nodal, N,
+                           nlayers, W, nodal, pred, mx);
     else
         hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, B, K, n_nodal, N, nlayers, W, nodal, J_nodal, pred, J, mx);
     GBP_HIP(hipGetLastError());
