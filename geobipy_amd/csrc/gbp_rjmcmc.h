@@ -2582,6 +2582,9 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         if (with_j)
             hipLaunchKernelGGL(rj::k_td_apply<true>, dim3(B), dim3(64), lds, q, B, K, td->n_nodal, N, nl, td->W,
                                td->nodal, td->J_nodal, pred, J, mix);
+        else if (((size_t)td->n_nodal * N + (size_t)4 * td->n_nodal) * sizeof(double) <= 40 * 1024 && B >= 4 * GBP_TD_PLAIN_ROWS)
+            hipLaunchKernelGGL(rj::k_td_apply_plain, dim3((B + GBP_TD_PLAIN_ROWS - 1) / GBP_TD_PLAIN_ROWS), dim3(256),
+                               ((size_t)td->n_nodal * N + (size_t)4 * td->n_nodal) * sizeof(double), q, B, td->n_nodal, N, nl, td->W, td->nodal, pred, mix);
         else
             hipLaunchKernelGGL(rj::k_td_apply<false>, dim3(B), dim3(64), lds, q, B, K, td->n_nodal, N, nl, td->W,
                                td->nodal, td->J_nodal, pred, J, mix);
