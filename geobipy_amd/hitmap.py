@@ -1,6 +1,7 @@
 """What leaves the device of a block's conductivity-depth hit maps (csrc/gbp_hitmap.h): per-depth statistics for the survey summary and
 the maps in run-length form for the results containers -- one streaming kernel each instead of transposes, cumulative sums and a
-``nonzero`` over 9e8 cells.  The torch formulations are kept (``*_torch``): the tests hold the kernels to them, and they serve CPU tensors."""
+``nonzero`` over 9e8 cells.  The torch formulations are kept (``*_torch``) as what the tests hold the kernels to; they are not a fallback: the
+product entries refuse tensors that are not on the device."""
 import numpy as np
 import torch
 
@@ -31,7 +32,7 @@ def statistics_torch(hitmap, log_mean_prior, half_width):
 def statistics(hitmap, log_mean_prior, half_width):
     """``statistics_torch`` as one kernel (gbp_hitmap_statistics): the percentile cells are the same cells, the mean agrees to rounding."""
     if hitmap.device.type != "cuda":
-        return statistics_torch(hitmap, log_mean_prior, half_width)
+        raise _lib.NativeLibraryError("hitmap.statistics runs on the device (gbp_hitmap_statistics); statistics_torch is the test reference, not a fallback")
     B, nv, nz = hitmap.shape
     hm = hitmap.contiguous()
     assert hm.dtype == torch.int32
@@ -57,7 +58,7 @@ def runs_torch(hitmap):
 def runs(hitmap):
     """``runs_torch`` as two passes of one kernel (gbp_hitmap_runs: count, prefix, write) -- identical output."""
     if hitmap.device.type != "cuda":
-        return runs_torch(hitmap)
+        raise _lib.NativeLibraryError("hitmap.runs runs on the device (gbp_hitmap_runs); runs_torch is the test reference, not a fallback")
     hm = hitmap.flatten(1).contiguous()
     assert hm.dtype == torch.int32
     B, M = hm.shape
