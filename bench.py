@@ -14,9 +14,13 @@ driver's 20 steps would be a 20 ms region); value = soundings x K x rounds_per_s
 are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      min-flop algorithmic FLOPs of SURVEY 8(d) / kernel time (HIP events on the launch
-                stream) against the MI355X fp64 vector peak (the path is fp64-VALU bound, not HBM/MFMA),
-                plus the algorithmic HBM bytes/s for reference;
+  roofline      frac = the flops the kernel EXECUTES -- SURVEY 8(d)'s min-flop count per (frequency, abscissa)
+                point x the abscissae of each sounding's own window -- / kernel time (HIP events on the launch
+                stream) / the MI355X fp64 vector peak (the path is fp64-VALU bound, not HBM/MFMA): a hardware
+                fraction.  frac_all_abscissae_equivalent counts all 120 abscissae per frequency as SURVEY 8(d)
+                does (useful-work equivalent); roofline.all_abscissae is the same batch with every abscissa
+                evaluated; plus the algorithmic HBM bytes/s for reference;
+  parity_vs_cpu within_bar against the CPU oracle with the test suite's bars; the run exits non-zero when false;
   cpu_baseline  the C oracle (a port of the reference's scalar algorithm) timed on this host's cores on a
                 bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -76,6 +80,30 @@ def measured_traffic(Btot, L, world):
     d = json.load(open(path))["derived"]
     TRAFFIC_SOURCES["headline"] = os.path.relpath(path, ROOT)
     return d["hbm_fetch_bytes_x2_gfx950_correction"] + d["hbm_write_bytes_raw"]
+
+
+def executed_points(handle, heights):
+    """Mean number of filter abscissae per sounding the kernels EVALUATE: every sounding takes the abscissa window of its own
+    altitude bin (1 m bins, gbp_fdem_system_bin_points); all abscissae for a handle without windows."""
+    if not hasattr(handle, "bin_points"):
+        return float(handle.npoints)
+    fl, cnt = np.unique(np.floor(np.asarray(heights, dtype=np.float64)), return_counts=True)
+    return float(sum(handle.bin_points(float(a)) * c for a, c in zip(fl, cnt)) / cnt.sum())
+
+
+def profiled_utilisation(case):
+    """VALU issue utilisation of the dominant kernel from the latest committed rocprofv3 PMC summary of `case` (profiles/r*/summary_<case>.json):
+    read, not measured by this run -- the file is named in the line."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_{case}.json")))
+    if not found:
+        return None, None
+    d = json.load(open(found[-1]))
+    u = d.get("derived", {}).get("valu_issue_utilisation_fp64_4cyc")
+    if u is None:                                        # sampler summaries: per kernel
+        ks = d.get("kernels", {})
+        u = {k.split("<")[0].replace("rj::", ""): round(v["valu_issue_utilisation"], 4) for k, v in ks.items() if v.get("share_of_kernel_time", 0) > 0.05}
+    return u, os.path.relpath(found[-1], ROOT)
 
 
 TRAFFIC_SOURCES = {}     # which committed profile each ``traffic`` figure of the line was read from (they are NOT measured in this run:
@@ -191,16 +219,22 @@ def rjmcmc_extra(system, height, obs, device, Btot):
                     "acceptance": float(sm[:, 4].mean()), "mean_layers": float(sm[:, 3].mean()),
                     "median_misfit": float(np.median(dc.misfit.cpu().numpy()))}
         cen = evaluation_census(dc, exact)
-        ach = out[key]["value"] * cen["flop_per_chain_iteration"] / 1e12
-        win = dc._h.bin_points(35.0) / float(dc._h.npoints) if hasattr(dc._h, "bin_points") else 1.0
+        ach_all = out[key]["value"] * cen["flop_per_chain_iteration"] / 1e12
+        win = executed_points(dc._h, height[:nrj]) / float(dc._h.npoints)
+        ach = ach_all * win
+        util, util_src = profiled_utilisation(f"rjmcmc_{nrj}")
         out[key]["roofline"] = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": rjmcmc_traffic(nrj),
-                                "frac_of_evaluated_flops": ach * win / FP64_VECTOR_PEAK_TFLOPS,
+                                "achieved_all_abscissae_equivalent": ach_all,
+                                "frac_all_abscissae_equivalent": ach_all / FP64_VECTOR_PEAK_TFLOPS,
+                                "evaluated_share_of_abscissae": win,
+                                "valu_issue_utilisation": util, "valu_issue_utilisation_source": util_src,
                                 "kernel": "k_rj_physics (fm_dlogc at the remapped models; fused forward / fm_dlogc at the proposals) "
                                           "+ propose / newton / accept stages", **cen,
-                                "note": "algorithmic min-flop count of all 120 abscissae per frequency (as the headline's) x the evaluations "
-                                        "one iteration makes, counted on the device over 64 iterations; wall time of the whole iteration "
-                                        "(physics + per-chain stages)"}
+                                "note": "frac = flops the kernels EXECUTE (min-flop count of SURVEY 8(d) per evaluated (frequency, abscissa, layer) "
+                                        "point x the evaluations one iteration makes, counted on the device over 64 iterations) / wall time of the "
+                                        "whole iteration (physics + per-chain stages) / fp64 vector peak; *_all_abscissae_equivalent counts all 120 "
+                                        "abscissae per frequency as SURVEY 8(d) does (useful-work equivalent, not a hardware fraction)"}
         del dc
     out["roofline"] = out["reference_jacobian"]["roofline"]
     out["value"] = out["reference_jacobian"]["value"]          # the pinned parity mode is the headline of this object
@@ -483,10 +517,15 @@ def main():
     if rank == 0:
         evals = Btot * n_rounds
         value = evals / elapsed
-        fpe = flop_per_eval(L, F)
+        fpe_all = flop_per_eval(L, F)                      # all 120 abscissae per frequency
+        pts_all = batches[0]._h.npoints
+        pts_exec = executed_points(batches[0]._h, height[sl])  # what the default path evaluates: each sounding's own abscissa window
+        fpe = (72 * L + 33) * pts_exec                     # flops the kernel EXECUTES per eval (same per-point count)
         per_launch_evals = int(np.ceil(Btot / world))
         achieved = per_launch_evals * fpe / (kernel_ms * 1e-3) / 1e12
+        achieved_all = per_launch_evals * fpe_all / (kernel_ms * 1e-3) / 1e12
         bpe = bytes_per_eval(L, F, with_pred=False)
+        util, util_src = profiled_utilisation(f"bench_{Btot}x{N_FREQ}x{L}") if world == 1 else (None, None)
         line = {
             "metric": "forward+likelihood evals/sec (whole node)",
             "value": value,
@@ -508,14 +547,22 @@ def main():
                        "soundings": Btot, "frequencies": F, "layers": L, "seed": synthetic.SEED,
                        "proposal_sets": N_SIGMA_SETS, "rounds_per_step": rounds_per_step,
                        "hankel_eps_ppm": batches[0].hankel_eps_ppm,
-                       "abscissa_points_per_sounding_at_35_m": batches[0]._h.bin_points(35.0) if hasattr(batches[0]._h, "bin_points") else batches[0]._h.npoints,
-                       "abscissa_points_all": batches[0]._h.npoints,
+                       "abscissa_points_per_sounding_mean": pts_exec,
+                       "abscissa_points_all": pts_all,
                        "step": "rounds_per_step proposal rounds over the whole batch (chosen so that the timed region is >= 1 s)"},
             "roofline": {
                 "bound": "fp64_valu", "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": measured_traffic(Btot, L, world),
                 "flop_per_eval": fpe, "evals_per_launch": per_launch_evals, "kernel_ms": kernel_ms,
                 "kernel": "k_fdem_forward<true, false>",
+                "definition": "frac = flops the kernel EXECUTES (SURVEY 8(d) min-flop count (72 L + 33) per evaluated (frequency, abscissa) "
+                              "point x the abscissae of every sounding's own window) / kernel time / fp64 vector peak -- a hardware fraction",
+                "achieved_all_abscissae_equivalent": achieved_all,
+                "frac_all_abscissae_equivalent": achieved_all / FP64_VECTOR_PEAK_TFLOPS,
+                "flop_per_eval_all_abscissae": fpe_all,
+                "all_abscissae_equivalent_note": "SURVEY 8(d)'s 730 800 flop/eval counts all 120 abscissae per frequency; the default path "
+                                                 "evaluates each sounding's abscissa window only: a useful-work equivalent, NOT a hardware fraction",
+                "valu_issue_utilisation": util, "valu_issue_utilisation_source": util_src,
                 "hbm": {"algorithmic_bytes_per_eval": bpe,
                         "achieved_GBps": per_launch_evals * bpe / (kernel_ms * 1e-3) / 1e9,
                         "peak_GBps": HBM_PEAK_GBPS},
@@ -559,8 +606,11 @@ def main():
                 "note": "default path: each sounding is evaluated with the filter abscissae whose terms can exceed eps_ppm in total at its "
                         "own altitude (1 m bins; bound |rTE| <= 1), independent of the batch; the full 120-point sums carry ~1e-8 ppm of "
                         "rounding error themselves and the parity bar is 1e-7 ppm.  all_abscissae = FdemBatch(hankel_eps_ppm=0) in the same run."}
-            line["roofline"]["evaluated_flop_per_eval_at_35_m"] = (72 * L + 33) * pts[1]
-            line["roofline"]["frac_of_evaluated_flops"] = line["roofline"]["frac"] * pts[1] / xb[0]._h.npoints
+            # (inside `roofline` so that a reader of the driver's parsed line sees both rates: with all abscissae evaluated the
+            #  executed and the SURVEY 8(d) counts coincide)
+            line["roofline"]["all_abscissae"] = {"value": Btot * xsteps / tw, "unit": "evals/s", "kernel_ms": xms, "achieved": xach,
+                                                 "frac": xach / FP64_VECTOR_PEAK_TFLOPS,
+                                                 "note": "FdemBatch(hankel_eps_ppm=0) in the same run: all 1 200 abscissa points per sounding"}
             del xb
         if world == 1 and not args.no_rjmcmc:
             # the caller of the hot path (BASELINE config 5): complete rjMCMC iterations, every chain resident on
@@ -582,10 +632,13 @@ def main():
                     fn()
                 e1.record(); torch.cuda.synchronize(device)
                 return e0.elapsed_time(e1) / n
-            def roof(Bk, Lk, Fk, ms, kernel):
-                ach = Bk * flop_per_eval(Lk, Fk) / (ms * 1e-3) / 1e12
+            def roof(Bk, Lk, Fk, ms, kernel, pts_exec_k, pts_all_k):
+                ach_all = Bk * flop_per_eval(Lk, Fk) / (ms * 1e-3) / 1e12
+                ach = ach_all * pts_exec_k / pts_all_k
                 return {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": flop_per_eval(Lk, Fk),
+                        "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": (72 * Lk + 33) * pts_exec_k,
+                        "achieved_all_abscissae_equivalent": ach_all, "frac_all_abscissae_equivalent": ach_all / FP64_VECTOR_PEAK_TFLOPS,
+                        "flop_per_eval_all_abscissae": flop_per_eval(Lk, Fk),
                         "evals_per_launch": Bk, "kernel_ms": ms, "kernel": kernel}
             # BASELINE config 2 (4 096 soundings x 10 frequencies x 5 layers, one GPU) and one GPU's shard of config 3 (8 192 of
             # the 65 536 soundings at 8 GPUs): same kernel, same generator, smaller launches
@@ -603,21 +656,30 @@ def main():
                     bk[it[0] % N_SIGMA_SETS].forward_loglike(want_pred=False); it[0] += 1
                 ms = per_call(one, max(50, int(200e3 / Bk) * 10))
                 line[key] = {"value": Bk / ms * 1e3, "unit": "evals/s", "soundings": Bk, "frequencies": F, "layers": Lk,
-                             "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true, false>"), "note": note}
+                             "ms_per_step": ms, "roofline": roof(Bk, Lk, F, ms, "k_fdem_forward<true, false>", executed_points(bk[0]._h, hk), bk[0]._h.npoints),
+                             "note": note}
                 del bk
             Jbuf = batches[0].sensitivity()
             ms = per_call(lambda: batches[0].sensitivity(out=Jbuf), 100)
-            fpj = flop_per_jacobian_point(L, exact=False) * F * 120
+            fpj_pt = flop_per_jacobian_point(L, exact=False)
+            fpj_all = fpj_pt * F * 120
+            ptsj = executed_points(batches[0]._h, height)
+            fpj = fpj_pt * ptsj
             achj = Btot * fpj / (ms * 1e-3) / 1e12
-            ptsj = batches[0]._h.bin_points(35.0) if hasattr(batches[0]._h, "bin_points") else batches[0]._h.npoints
+            achj_all = Btot * fpj_all / (ms * 1e-3) / 1e12
+            utilj, utilj_src = profiled_utilisation("jacobian_headline")
             line["jacobian"] = {"value": Btot / ms * 1e3, "unit": "Jacobians/s", "ms_per_launch": ms, "soundings": Btot,
                                 "roofline": {"bound": "fp64_valu", "achieved": achj, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                              "frac": achj / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "flop_per_eval": fpj,
-                                             "flop_per_abscissa_point": flop_per_jacobian_point(L, exact=False),
+                                             "flop_per_abscissa_point": fpj_pt,
+                                             "achieved_all_abscissae_equivalent": achj_all,
+                                             "frac_all_abscissae_equivalent": achj_all / FP64_VECTOR_PEAK_TFLOPS,
+                                             "flop_per_eval_all_abscissae": fpj_all,
+                                             "valu_issue_utilisation": utilj, "valu_issue_utilisation_source": utilj_src,
                                              "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, 8>",
-                                             "frac_of_evaluated_flops": achj / FP64_VECTOR_PEAK_TFLOPS * ptsj / batches[0]._h.npoints,
                                              "count": "builder's extension of SURVEY 8(d) to the prediction + Jacobian pass (flop_per_jacobian_point: "
-                                                      "same per-operation weights, all 120 abscissae per frequency); 100 timed launches after a 50 ms warm-up"},
+                                                      "same per-operation weights) x the abscissae each sounding's window evaluates (frac) or all 120 per "
+                                                      "frequency (*_all_abscissae_equivalent); 100 timed launches after a 50 ms warm-up"},
                                 "note": "d pred / d ln sigma [2F x L] of the same batch (gbp_fdem_sensitivity, reference expression)"}
             del Jbuf
             golden = os.path.join(ROOT, "tests", "golden")
@@ -637,23 +699,26 @@ def main():
                 ms = per_call(tb.forward, 100)
                 nodes = sum(sy.node_frequencies().size * sy.n_components for sy in systems)
                 td[key] = dict(ms=ms, nodes=nodes, gates=tb.nChannels, points=sum(h.npoints for h in tb._h),
-                               points_at_35_m=sum(h.bin_points(35.0) for h in tb._h), pred=tb.predicted.clone() if key.startswith("config4") else None)
+                               points_at_35_m=sum(h.bin_points(35.0) for h in tb._h), points_exec=sum(executed_points(h, ht) for h in tb._h), pred=tb.predicted.clone() if key.startswith("config4") else None)
                 del tb
             c4 = td["config4"]
             d4 = float(((c4["pred"] - td["config4_all"]["pred"]).abs() / td["config4_all"]["pred"].abs().max(dim=1, keepdim=True).values).max())
-            ach = Bt * (72 * Lt + 33) * c4["points"] / (c4["ms"] * 1e-3) / 1e12
-            ach_eval = Bt * (72 * Lt + 33) * c4["points_at_35_m"] / (c4["ms"] * 1e-3) / 1e12
+            ach_all = Bt * (72 * Lt + 33) * c4["points"] / (c4["ms"] * 1e-3) / 1e12
+            ach = Bt * (72 * Lt + 33) * c4["points_exec"] / (c4["ms"] * 1e-3) / 1e12
+            utilt, utilt_src = profiled_utilisation("tdem_config4")
             line["tdem"] = {"value": Bt / c4["ms"] * 1e3, "unit": "evals/s", "soundings": Bt, "layers": Lt, "gates": c4["gates"],
                             "spline_nodes": c4["nodes"], "ms_per_step": c4["ms"],
                             "roofline": {"bound": "fp64_valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": tdem_traffic(), "flop_per_eval": (72 * Lt + 33) * c4["points"],
+                                         "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": tdem_traffic(), "flop_per_eval": (72 * Lt + 33) * c4["points_exec"],
                                          "evals_per_launch": Bt, "kernel_ms": c4["ms"],
-                                         "evaluated_flop_per_eval_at_35_m": (72 * Lt + 33) * c4["points_at_35_m"],
-                                         "frac_of_evaluated_flops": ach_eval / FP64_VECTOR_PEAK_TFLOPS,
+                                         "achieved_all_abscissae_equivalent": ach_all,
+                                         "frac_all_abscissae_equivalent": ach_all / FP64_VECTOR_PEAK_TFLOPS,
+                                         "flop_per_eval_all_abscissae": (72 * Lt + 33) * c4["points"],
+                                         "valu_issue_utilisation": utilt, "valu_issue_utilisation_source": utilt_src,
                                          "kernel": "k_fdem_forward<false, false> on the spline nodes + k_td_apply (window operator)",
                                          "count": "builder's extension of SURVEY 8(d) (which defines the FDEM count only): (72 L + 33) flop per "
-                                                  "(spline node, abscissa) point x 120 abscissae x the system's spline nodes; 100 timed launches "
-                                                  "after a 50 ms warm-up"},
+                                                  "(spline node, abscissa) point x the abscissae of each sounding's window (frac) or all 120 "
+                                                  "(*_all_abscissae_equivalent) x the system's spline nodes; 100 timed launches after a 50 ms warm-up"},
                             "abscissa_window": {"eps_relative": 1e-12, "points_all_abscissae": c4["points"], "points_at_35_m": c4["points_at_35_m"],
                                                 "all_abscissae_value": Bt / td["config4_all"]["ms"] * 1e3,
                                                 "max_rel_diff_to_all_abscissae": d4},
@@ -735,15 +800,44 @@ def main():
                                     "single_thread": {"value": r1, "unit": "evals/s", "sample": f"first {min(Btot, 2048)} soundings, {d1:.1f} s"},
                                     "sample": f"first {sample} soundings of the same batch x {rounds} proposal round(s), C oracle "
                                               f"(oracle/fdem1d_oracle.c, gcc -O2, OpenMP {threads} threads), {dt:.1f} s"}
-            line["parity_vs_cpu"] = {"max_abs_pred_ppm": float(np.max(np.abs(p - p_ref))),
-                                     "max_abs_chi2": float(np.max(np.abs(chi2[:sample].cpu().numpy() - c_ref))),
-                                     "max_abs_logL": float(np.max(np.abs(logl[:sample].cpu().numpy() - l_ref)))}
+            c_gpu, l_gpu = chi2[:sample].cpu().numpy(), logl[:sample].cpu().numpy()
+            ok_p = bool(np.all(np.abs(p - p_ref) <= 1e-7 + 1e-9 * np.abs(p_ref)))
+            ok_c = bool(np.all(np.abs(c_gpu - c_ref) <= 1e-6 + 1e-9 * np.abs(c_ref)))
+            ok_l = bool(np.all(np.abs(l_gpu - l_ref) <= 1e-6 + 1e-9 * np.abs(l_ref)))
+            line["parity_vs_cpu"] = {"within_bar": ok_p and ok_c and ok_l,
+                                     "bar": "every value: |gpu - cpu| <= 1e-7 ppm + 1e-9 |cpu| (predictions), 1e-6 + 1e-9 |cpu| (chi^2, logL) "
+                                            "-- the bars of tests/test_gpu_parity.py; evaluated per element, so a large chi^2 passes through its relative term",
+                                     "pred_within_bar": ok_p, "chi2_within_bar": ok_c, "logL_within_bar": ok_l,
+                                     "max_abs_pred_ppm": float(np.max(np.abs(p - p_ref))),
+                                     "max_abs_chi2": float(np.max(np.abs(c_gpu - c_ref))),
+                                     "max_rel_chi2": float(np.max(np.abs(c_gpu - c_ref) / np.maximum(np.abs(c_ref), 1e-300))),
+                                     "max_abs_logL": float(np.max(np.abs(l_gpu - l_ref))),
+                                     "worst_chi2_excess_over_bar": float(np.max(np.abs(c_gpu - c_ref) - (1e-6 + 1e-9 * np.abs(c_ref)))),
+                                     "soundings_compared": int(sample)}
+            line["cpu_baseline"]["parity_within_bar"] = line["parity_vs_cpu"]["within_bar"]      # (visible in the driver's parsed line)
         if TRAFFIC_SOURCES:
             line["traffic_sources"] = dict(TRAFFIC_SOURCES, note="every 'traffic' figure is read from the committed rocprofv3 PMC summary named "
                                            "here (separate --pmc passes, gfx950 x2 fetch correction), not measured by this run")
+        # the other measured kernels in one compact object inside `roofline` (the driver's record keeps `roofline` whole)
+        others = {}
+        if "rjmcmc" in line and "value" in line["rjmcmc"]:
+            rj = line["rjmcmc"]
+            others["rjmcmc_8192_chains"] = {"value": rj["value"], "unit": "chain-iterations/s", "frac": rj["roofline"]["frac"],
+                                            "hbm_bytes_per_iteration": rj["roofline"]["traffic"]}
+            others["rjmcmc_block_of_1024"] = {"value": max(rj["block_of_1024"]["lockstep"], rj["block_of_1024"]["persistent"]), "unit": "chain-iterations/s"}
+        for key in ("jacobian", "tdem", "config2", "shard_8192"):
+            if key in line and "roofline" in line[key]:
+                others[key] = {"value": line[key]["value"], "unit": line[key]["unit"], "frac": line[key]["roofline"]["frac"]}
+        if others:
+            line["roofline"]["other_kernels"] = others
         print(json.dumps(line), flush=True)
+        parity_failed = "parity_vs_cpu" in line and not line["parity_vs_cpu"]["within_bar"]
+    else:
+        parity_failed = False
     if exchange:
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit("bench.py: the benchmarked kernel is outside the parity bar against the CPU oracle (parity_vs_cpu in the line above)")
 
 
 if __name__ == "__main__":

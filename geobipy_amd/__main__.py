@@ -35,10 +35,12 @@ def parse(argv=None):
                         "summary files <line>.npz are always written")
     p.add_argument("--container", choices=("auto", "hdf5", "npz"), default="auto",
                    help="file type of the results containers: hdf5 (<line>.h5), npz (the stand-in), auto = hdf5 when it can be written")
-    p.add_argument("--schedule", choices=("static", "dynamic", "lines"), default="static",
-                   help="static: one contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter "
-                        "(the reference's master / worker scheduling); lines: whole flight lines per rank, each rank writes the "
-                        "results containers of its own lines")
+    p.add_argument("--schedule", choices=("auto", "static", "dynamic", "lines"), default="auto",
+                   help="lines: whole flight lines per rank, each rank writes the results containers of its own lines and only the "
+                        "one-row summaries travel (one all_gather_into_tensor: the exchange that has run under RCCL); static: one "
+                        "contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter (the reference's "
+                        "master / worker scheduling) and ship their posterior rows to rank 0 point to point (tested over gloo only); "
+                        "auto = lines on more than one rank when every flight line is one run of rows of the data file, else static")
     p.add_argument("--chunk", type=int, default=None, help="soundings per block on the device (default: 16384 for static and lines; a 16th of a rank's share for dynamic)")
     a = p.parse_args(argv)
     if a.seed is not None:

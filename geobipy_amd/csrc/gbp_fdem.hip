@@ -99,6 +99,29 @@ __constant__ gbp::MathK GBP_K = GBP_MATHK_INIT;
 __device__ const double GBP_EXP2_64[64] = GBP_EXP2_64_LIST;
 __device__ const double GBP_SINCOS_64[128] = GBP_SINCOS_64_LIST;
 
+#ifdef GBP_RJ_PHYS_CLOCK
+// Measurement builds only (scripts/build_ab.sh NAME -DGBP_RJ_PHYS_CLOCK, scripts/phys_clock.py): s_memtime stamps of the sampler's physics
+// workgroups, summed per slot by thread 0 of every 16th workgroup.  [slot]: ticks of the 100 MHz constant clock; [slot + 32]: samples.
+__device__ long long GBP_PHYS_TICKS[64];
+struct PhysClk { bool on; int base; long long t0; };
+__device__ __forceinline__ void phys_tick(PhysClk* k, int slot)
+{
+    if (k != nullptr && k->on) {
+        const long long t1 = (long long)wall_clock64();
+        atomicAdd((unsigned long long*)&GBP_PHYS_TICKS[k->base + slot], (unsigned long long)(t1 - k->t0));
+        atomicAdd((unsigned long long*)&GBP_PHYS_TICKS[k->base + slot + 32], 1ull);
+        k->t0 = t1;
+    }
+}
+#define GBP_TICK(slot) phys_tick(gbp_clk, (slot))
+#define GBP_TICK_ARGS , PhysClk* gbp_clk = nullptr
+#define GBP_TICK_PASS , gbp_clk
+#else
+#define GBP_TICK(slot)
+#define GBP_TICK_ARGS
+#define GBP_TICK_PASS
+#endif
+
 // per-workgroup copy of the lookup tables in LDS + the scalar constants in SGPRs
 struct MathLds {
     double exp2_64[64];
@@ -301,7 +324,7 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
                                              int F, int Lmax, int L, const double* __restrict__ sig,
                                              const double* __restrict__ th, double alt, const double* __restrict__ obs_row,
                                              double rel_b, double add_b, double* __restrict__ pred_row, double* chi2_b,
-                                             double* logL_b, double sigma_direct, int nw_use, double row_scale = 1.0)
+                                             double* logL_b, double sigma_direct, int nw_use, double row_scale = 1.0 GBP_TICK_ARGS)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -314,6 +337,7 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
     double* sh_t2 = reinterpret_cast<double*>(sh_part + (size_t)2 * npass);
     for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
     __syncthreads();
+    GBP_TICK(3);
 
     if (wave < nwaves) {
         const int per = (npass + nwaves - 1) / nwaves;
@@ -324,7 +348,9 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
         else
             forward_passes<false>(M, chan, pts, npts_total, F, L, sig, sh_t2, sh_lay, Lmax, alt, p0, p1, lane, sh_part, row_scale);
     }
+    GBP_TICK(4);
     __syncthreads();
+    GBP_TICK(5);
 
     // out_f = 1e6 * scale * (H - H0) / H0 = g_f * sum of the frequency's per-pass partials in pass order
     for (int f = threadIdx.x; f < F; f += blockDim.x) {
@@ -343,6 +369,7 @@ __device__ __forceinline__ void forward_body(const gbp::MathCtx& M, double* sh_o
     if (pred_row != nullptr)
         for (int i = threadIdx.x; i < N; i += blockDim.x) pred_row[i] = sh_out[i];
     if (LIKE && wave == 0) loglike_wave(N, sh_out, obs_row, rel_b, add_b, lane, chi2_b, logL_b);
+    GBP_TICK(6);
 }
 
 template <bool LIKE, bool SCALED = false>   // SCALED: the rows carry a distance scale (gbp_fdem_forward_rows_scaled); the plain kernels do not pay for it (4 VGPRs, 36 B of scratch)
@@ -400,7 +427,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                                           const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
                                           const double* __restrict__ sig, const double* __restrict__ th, double alt,
                                           double* __restrict__ Jb /* [2F, Lmax] of this sounding */,
-                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0)
+                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0 GBP_TICK_ARGS)
 {   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
     // sampler, whose consumers never read a column >= L, passes L rounded up to 8 and leaves the rest of the row alone)
     const int lane = threadIdx.x & 63;
@@ -412,6 +439,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
     double* sh_t2 = reinterpret_cast<double*>(sh_dyn + (size_t)nwaves * Lalloc * (GBP_SENS_STRIDE * sizeof(cplx) + sizeof(gbp::LayerK)));
     for (int k = threadIdx.x; k < L - 1; k += blockDim.x) sh_t2[k] = -2.0 * th[k];
     __syncthreads();
+    GBP_TICK(3);
     if (wave >= nwaves) return;
 
     for (int f = wave; f < F; f += nwaves) {
@@ -485,6 +513,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
             Jb[(size_t)(F + f) * Lmax + m] = 0.0;
         }
     }
+    GBP_TICK(4);
 }
 
 template <bool EXACT, int NG>

@@ -743,10 +743,28 @@ __device__ __forceinline__ void newton_body(const RjOpt& o, const gbp_rj_chains&
     }
 }
 
+// The wave-per-chain bodies are for the models of more than 8 layers -- under a percent of the chains of a survey.  One workgroup per
+// chain meant a launch of B workgroups that exit at once (5 - 6 us of every iteration at 2 731 chains, profiles/r4); here a wave SCANS 64
+// chains (one coalesced read of their layer counts) and runs the body for those that are its own: B / 64 workgroups (round 5).
+template <class Body>
+__device__ __forceinline__ void for_deep_chains(int group, bool mine, Body body)
+{
+    const int b0 = group * 64;
+    unsigned long long todo = __ballot(mine);
+    while (todo != 0ull) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        body(b0 + l);
+        wave_sync();                                             // (the next chain reuses the LDS block)
+    }
+}
+
 __global__ __launch_bounds__(64) void k_rj_newton(RjOpt o, gbp_rj_chains c, uint32_t iter, int min_k)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    newton_body(o, c, iter, min_k, blockIdx.x, threadIdx.x, sh_dyn);
+    const int b = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    for_deep_chains(blockIdx.x, b < c.B && c.k_r[min(b, c.B - 1)] > min_k,
+                    [&](int bb) { newton_body(o, c, iter, min_k, bb, threadIdx.x, sh_dyn); });
 }
 
 // The same for chains with at most 8 layers -- the common case -- packed 8 lanes per chain, 8 chains per wave: row i of the
@@ -919,7 +937,11 @@ template <bool TRIPS>
 __global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter, int n_packed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    if ((int)blockIdx.x >= n_packed) { newton_body(o, c, iter, 8, (int)blockIdx.x - n_packed, threadIdx.x, sh_dyn); return; }
+    if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups: see k_rj_newton)
+        const int g = (int)blockIdx.x - n_packed, b = g * 64 + (int)threadIdx.x;
+        for_deep_chains(g, b < c.B && c.k_r[min(b, c.B - 1)] > 8, [&](int bb) { newton_body(o, c, iter, 8, bb, threadIdx.x, sh_dyn); });
+        return;
+    }
     newton8_body<TRIPS>(o, c, iter, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
@@ -1222,10 +1244,19 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     if (lane == 0 && c.step_flags != nullptr) c.step_flags[b] = (accept ? 1 : 0) | bk;
 }
 
-__global__ __launch_bounds__(64) void k_rj_accept(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
+// (whether a chain is the wave-per-chain stage's: accept_body's own rule -- the layer counts before and after the proposal)
+__device__ __forceinline__ bool accept_is_deep(const gbp_rj_chains& c, int b, int min_k)
 {
+    if (b >= c.B) return false;
+    const int k = c.k_r[b], action = c.action[b];
+    return max(k, k - (action == INSERT) + (action == DELETE)) > min_k;
+}
+
+__global__ __launch_bounds__(64) void k_rj_accept(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int min_k)
+{   // (scanning workgroups: see k_rj_newton)
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    accept_body(o, c, iter, accumulate, min_k, blockIdx.x, threadIdx.x, sh_dyn);
+    for_deep_chains(blockIdx.x, accept_is_deep(c, (int)blockIdx.x * 64 + (int)threadIdx.x, min_k),
+                    [&](int bb) { accept_body(o, c, iter, accumulate, min_k, bb, threadIdx.x, sh_dyn); });
 }
 
 // The same for chains whose current and proposed models have at most 8 layers, packed 8 lanes per chain like k_rj_newton8:
@@ -1469,7 +1500,11 @@ template <bool TRIPS>
 __global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed)
 {   // (workgroups as in k_rj_newton8)
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
-    if ((int)blockIdx.x >= n_packed) { accept_body(o, c, iter, accumulate, 8, (int)blockIdx.x - n_packed, threadIdx.x, sh_dyn); return; }
+    if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups)
+        const int g = (int)blockIdx.x - n_packed;
+        for_deep_chains(g, accept_is_deep(c, g * 64 + (int)threadIdx.x, 8), [&](int bb) { accept_body(o, c, iter, accumulate, 8, bb, threadIdx.x, sh_dyn); });
+        return;
+    }
     accept8_body<TRIPS>(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
 }
 
@@ -1707,7 +1742,9 @@ __global__ __launch_bounds__(64) void k_td_moves_propose(RjOpt o, gbp_rj_chains 
     for (int j = 0; j < 10; ++j) mv.geom_p[(size_t)b * 10 + j] = g[j];
     td_weights_of(mv, g, mv.weights_p + (size_t)b * n_weights, mv.offset_p != nullptr ? mv.offset_p + (size_t)b * N : nullptr);
     if (mv.rho_scale_p != nullptr) {                             // a moved position: the chain's table set at another distance / height
-        mv.rho_scale_p[b] = mv.rho_set[b] / hypot(g[4], g[5]);
+        // (an on-axis table set -- rho_set == 0: a central-loop system whose receiver or transmitter HEIGHT is sampled -- does not
+        //  depend on a horizontal distance at all: scale 1, never 0 / 0)
+        mv.rho_scale_p[b] = mv.rho_set[b] > 0.0 ? mv.rho_set[b] / hypot(g[4], g[5]) : 1.0;
         c.height_p[b] = g[0] + 0.5 * (g[6] - mv.dz_set[b]);
     }
 }
@@ -2056,8 +2093,16 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     double* sh_out = reinterpret_cast<double*>(sh_dyn + out_offset);
     const int b = blockIdx.x;
+#ifdef GBP_RJ_PHYS_CLOCK
+    PhysClk clk_{threadIdx.x == 0 && (b & 15) == 0, 0, (long long)wall_clock64()};
+    PhysClk* gbp_clk = &clk_;
+#endif
     const int action = c.action[b];
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
+#ifdef GBP_RJ_PHYS_CLOCK
+    clk_.base = (stage == 0 ? 0 : ((action == INSERT || action == DELETE) ? 8 : 16));
+#endif
+    GBP_TICK(0);
     const int K = o.max_layers, N = o.n_channels, L = c.k_r[b];
     // (a sampled height: the remapped model is evaluated at the chain's current height, the proposal at the proposed one)
     const double alt = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
@@ -2067,7 +2112,9 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         pts = bin_pts + d.pts_off;
         npts_total = d.npts_total;
     }
+    GBP_TICK(1);
     const gbp::MathCtx M = math_setup(sh_math);                   // ends with __syncthreads()
+    GBP_TICK(2);
     const bool jump = action == INSERT || action == DELETE;
     const int nw = (int)(blockDim.x >> 6);
     if (stage == 0 || jump) {
@@ -2076,13 +2123,13 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
         double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
         const double* th = c.thk_r + (size_t)b * K;
-        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8));
+        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS);
         else sens_body<EXACT, 8>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
                                  min(K, (L + 7) & ~7));
     } else {
         forward_body<true>(M, sh_out, sh_dyn, chan, pts, npts_total, F, K, L, c.sigma_p + (size_t)b * K, c.thk_r + (size_t)b * K, alt,
                            c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N, c.misfit_p + b, c.like_p + b,
-                           sigma_direct, nw);
+                           sigma_direct, nw, 1.0 GBP_TICK_PASS);
     }
 }
 
@@ -2102,8 +2149,8 @@ struct AuxStreams {
 #define GBP_AUX_STREAMS 3
 #endif
     static const int N = GBP_AUX_STREAMS;
-    hipStream_t q[N] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork[N] = {nullptr, nullptr, nullptr}, join[N] = {nullptr, nullptr, nullptr};
+    hipStream_t q[N] = {};
+    hipEvent_t fork[N] = {}, join[N] = {};
     hipEvent_t start = nullptr;
 };
 AuxStreams* aux_streams()
@@ -2284,16 +2331,25 @@ static bool packed_trips(int B)
 // (Folding the deep body into the packed WAVES was tried first: inlined it takes the accept stage from 111 to 178 VGPRs, as a call it
 // adds 1.1 - 1.3 KB of scratch per lane; so was running the deep bodies as calls inside the stage-1 physics launch: 104 -> 288 B of
 // scratch there.)
+// Round 5: the deep chains' part of a stage is B / 64 scanning workgroups (k_rj_newton) instead of B that exit at once.  A/B on one box
+// (scripts/ab_rj.py, ten frequencies, M chain-iterations/s; round-4 library | scanning + the round-4 rule below | scanning + one launch
+// at every size): 2 048 chains 19.0 | 18.7 | 18.7, 4 096: 31.3 | 30.8 | 30.6, 8 192: 44.3 | 43.2 | 44.2 -- measured together with the
+// round's re-cut physics prologue, which is what cost the 1 - 2 % at the middle sizes; GBP_RJ_ONE_STAGE_LAUNCH=1 selects the one launch.
 static bool one_stage_launch(int n, bool time_domain)
 {
+#ifdef GBP_RJ_ONE_STAGE_LAUNCH
+    (void)n; (void)time_domain;
+    return true;
+#else
     return time_domain || n <= 1536 || n >= 32768;
+#endif
 }
 
 static gbp_status rj_newton_launch(const gbp_rj_options* o, const gbp_rj_chains* c, int64_t iteration, bool one, void* stream)
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? c->B : 0;
+    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? (c->B + 63) / 64 : 0;      // (deep: scanning workgroups of 64 chains)
     const size_t lds8 = (size_t)16 * o->n_channels * sizeof(double), lds_deep = rj::Lds::bytes(o->max_layers, o->n_channels);
     auto launch = [&](int grid, size_t lds, int np) {
         if (packed_trips(c->B))
@@ -2314,7 +2370,7 @@ static gbp_status rj_accept_launch(const gbp_rj_options* o, const gbp_rj_chains*
 {
     gbp_status st = rj_check(o, c);
     if (st != GBP_OK || c->B == 0) return st;
-    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? c->B : 0;
+    const int n_packed = (c->B + 7) / 8, n_deep = o->max_layers > 8 ? (c->B + 63) / 64 : 0;      // (deep: scanning workgroups of 64 chains)
     const size_t lds8 = (size_t)8 * o->n_channels * sizeof(double), lds_deep = rj::Lds::bytes(o->max_layers, o->n_channels);
     auto launch = [&](int grid, size_t lds, int np) {
         if (packed_trips(c->B))
@@ -2499,6 +2555,17 @@ gbp_status gbp_rj_debug_stage_ticks(int64_t* out, int reset)
     }
     return GBP_OK;
 }
+
+#ifdef GBP_RJ_PHYS_CLOCK
+gbp_status gbp_debug_phys_ticks(int64_t* out, int reset)   // (measurement builds only: not declared in the header)
+{
+    long long h[64];
+    GBP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(GBP_PHYS_TICKS), sizeof(h)));
+    for (int i = 0; i < 64; ++i) out[i] = (int64_t)h[i];
+    if (reset) { std::memset(h, 0, sizeof(h)); GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(GBP_PHYS_TICKS), h, sizeof(h))); }
+    return GBP_OK;
+}
+#endif
 
 gbp_status gbp_rj_run(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
                       int n_iterations, int accumulate, void* stream)

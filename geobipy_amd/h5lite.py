@@ -350,21 +350,37 @@ def write_tree(path, root, compresslevel=1):
                 lib.H5Pclose(dcpl)
                 lib.H5Sclose(space)
 
-    with _LOCK:
-        f = _ok(lib.H5Fcreate(os.fsencode(str(path)), H5F_ACC_TRUNC, 0, 0), "H5Fcreate " + str(path))
+    # The file is built under a temporary name and renamed when it is complete: the large datasets are created with fill time NEVER and
+    # receive their bytes AFTER the library has closed the file, so an exception in between must not leave a structurally valid
+    # container whose large datasets hold whatever the blocks held.  (The file is created with the default creation properties -- no
+    # user block --, so H5Dget_offset is the absolute file address; an undefined address falls back to H5Dwrite above.)
+    tmp = "{}.tmp{}".format(path, os.getpid())
+    try:
+        with _LOCK:
+            f = _ok(lib.H5Fcreate(os.fsencode(tmp), H5F_ACC_TRUNC, 0, 0), "H5Fcreate " + tmp)
+            try:
+                emit(f, root)
+            finally:
+                _ok(lib.H5Fclose(f), "H5Fclose")
+        if direct:                                # outside the lock: the raw bytes of the large datasets, at the addresses the library gave
+            fd = os.open(tmp, os.O_WRONLY)
+            try:
+                size = os.fstat(fd).st_size
+                for addr, a in direct:
+                    if addr + a.nbytes > size:    # (early allocation reserves the block inside the file the library closed)
+                        raise HDF5Error("dataset block at {} + {} bytes lies outside the {}-byte file".format(addr, a.nbytes, size))
+                    view, done = memoryview(a.reshape(-1).view(np.uint8)), 0
+                    while done < len(view):
+                        done += os.pwrite(fd, view[done:], addr + done)
+            finally:
+                os.close(fd)
+        os.replace(tmp, str(path))
+    except BaseException:
         try:
-            emit(f, root)
-        finally:
-            _ok(lib.H5Fclose(f), "H5Fclose")
-    if direct:                                    # outside the lock: the raw bytes of the large datasets, at the addresses the library gave
-        fd = os.open(str(path), os.O_WRONLY)
-        try:
-            for addr, a in direct:
-                view, done = memoryview(a.reshape(-1).view(np.uint8)), 0
-                while done < len(view):
-                    done += os.pwrite(fd, view[done:], addr + done)
-        finally:
-            os.close(fd)
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
     return str(path)
 
 

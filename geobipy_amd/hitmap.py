@@ -1,8 +1,10 @@
 """What leaves the device of a block's conductivity-depth hit maps (csrc/gbp_hitmap.h): per-depth statistics for the survey summary and
 the maps in run-length form for the results containers -- one streaming kernel each instead of transposes, cumulative sums and a
-``nonzero`` over 9e8 cells.  The torch formulations are kept (``*_torch``) as what the tests hold the kernels to; they are not a fallback: the
-product entries refuse tensors that are not on the device."""
-import numpy as np
+``nonzero`` over 9e8 cells.  The statistics are the reference's ``Histogram.mean`` / ``Histogram.percentile`` along the value axis of
+the conductivity-depth posterior (statistics/Histogram.py:262-284, 369-401 -> mesh/Mesh.py:80-113, 173-215), in log10: pinned to values
+the imported reference computed (tests/golden/make_hitmap_stats.py -> hitmap_stats.npz, tests/test_hitmap_gpu.py).  There is no
+fallback: the entries refuse tensors that are not on the device (the torch formulations the kernels were first held to live in
+tests/hitmap_reference.py)."""
 import torch
 
 from . import _lib
@@ -12,27 +14,12 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def statistics_torch(hitmap, log_mean_prior, half_width):
-    """Mean and 5 / 50 / 95 % points of log10 conductivity per depth cell from the hit map [B, n_value, n_depth] (the reference derives the
-    same from its Histogram2D posterior)."""
-    B, nv, nz = hitmap.shape                                      # stored value-major, depth fastest
-    centres = (torch.arange(nv, dtype=torch.float64, device=hitmap.device) + 0.5) / nv * (2.0 * half_width) - half_width
-    h = hitmap.transpose(1, 2).to(torch.float64)                  # [B, nz, nv]
-    tot = h.sum(dim=2).clamp(min=1.0)
-    shift = (log_mean_prior / np.log(10.0))[:, None]
-    mean = (h * centres).sum(dim=2) / tot + shift
-    cdf = torch.cumsum(h, dim=2) / tot[:, :, None]
-    pct = []
-    for q in (0.05, 0.5, 0.95):
-        idx = (cdf < q).sum(dim=2).clamp(max=nv - 1)
-        pct.append(centres[idx] + shift)
-    return mean, pct
-
-
 def statistics(hitmap, log_mean_prior, half_width):
-    """``statistics_torch`` as one kernel (gbp_hitmap_statistics): the percentile cells are the same cells, the mean agrees to rounding."""
+    """Mean and 5 / 50 / 95 % points of log10 conductivity per depth cell from the hit maps [B, n_value, n_depth] (value-major, depth
+    fastest) in one kernel (gbp_hitmap_statistics): sum(count x cell centre) / total + the prior mean, and the centre of the first cell
+    whose cumulative share reaches the percentile (an empty column: the prior mean / the last cell, as the reference's)."""
     if hitmap.device.type != "cuda":
-        raise _lib.NativeLibraryError("hitmap.statistics runs on the device (gbp_hitmap_statistics); statistics_torch is the test reference, not a fallback")
+        raise _lib.NativeLibraryError("hitmap.statistics runs on the device (gbp_hitmap_statistics); there is no host fallback")
     B, nv, nz = hitmap.shape
     hm = hitmap.contiguous()
     assert hm.dtype == torch.int32
@@ -44,21 +31,11 @@ def statistics(hitmap, log_mean_prior, half_width):
     return out[0], [out[1], out[2], out[3]]
 
 
-def runs_torch(hitmap):
-    """(ptr int64 [B + 1], start int32, value) of the rows of ``hitmap`` flattened: a run starts at cell 0 and at every change of value."""
-    hm = hitmap.flatten(1)
-    edge = torch.ones_like(hm, dtype=torch.bool)
-    edge[:, 1:] = hm[:, 1:] != hm[:, :-1]
-    nz = torch.nonzero(edge)                                      # [runs, 2] row-major: sorted by row, then by flat position
-    ptr = torch.zeros(hm.shape[0] + 1, dtype=torch.int64, device=hm.device)
-    ptr[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=hm.shape[0]), 0)
-    return ptr, nz[:, 1].to(torch.int32), hm[nz[:, 0], nz[:, 1]]
-
-
 def runs(hitmap):
-    """``runs_torch`` as two passes of one kernel (gbp_hitmap_runs: count, prefix, write) -- identical output."""
+    """(ptr int64 [B + 1], start int32, value) of the rows of ``hitmap`` flattened -- a run starts at cell 0 and at every change of
+    value -- as two passes of one kernel (gbp_hitmap_runs: count, prefix, write)."""
     if hitmap.device.type != "cuda":
-        raise _lib.NativeLibraryError("hitmap.runs runs on the device (gbp_hitmap_runs); runs_torch is the test reference, not a fallback")
+        raise _lib.NativeLibraryError("hitmap.runs runs on the device (gbp_hitmap_runs); there is no host fallback")
     hm = hitmap.flatten(1).contiguous()
     assert hm.dtype == torch.int32
     B, M = hm.shape

@@ -474,13 +474,14 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
 
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
           exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
-          chunk=None, results_directory=None, timings=None, traces="auto", container=None, **overrides):
+          chunk=None, results_directory=None, timings=None, traces=1, container=None, **overrides):
     """Invert every sounding of the options file's data set.  One process per GPU: call from every rank of an initialised
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
     ``chunk``: soundings per block on the device (default 16 384 for "static" and "lines"; see "dynamic").
-    ``schedule``: "lines" -- whole flight lines per rank, longest first to the least loaded rank (``distributed.assign_lines``): every
+    ``schedule``: "auto" (the command line's default) -- "lines" on more than one rank when the data file allows it, else "static";
+    "lines" -- whole flight lines per rank, longest first to the least loaded rank (``distributed.assign_lines``): every
     rank writes the results containers of its own lines and no posterior row travels (the choice for many GPUs with containers);
     "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
     of ``chunk`` soundings (default: a 16th of a rank's static share, at least 256) from a shared counter until none are left
@@ -494,7 +495,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     which) -- every sounding's posteriors (layer count, interface depth, error levels, conductivity-depth hit
     map), best model and its predicted data.  The rows travel to rank 0 in bounded chunks (``distributed.stream_rows_to_root``).
     ``traces``: per-iteration misfit / acceptance traces for the containers' ``phids`` / ``acceptance_rate``, kept on the device at a stride --
-    "auto": at most 4 096 entries per sounding; an int: that stride (1 = the reference's arrays in full); None: none.
+    1 (default): the reference's arrays in full, 2 n_markov_chains columns, the shapes ``Inference1D.createHdf`` writes and its readers
+    index by iteration; an int > 1 or "auto" (opt-in: the smallest stride with at most 4 096 entries per sounding): every stride-th
+    entry side by side, ceil(2 n_markov_chains / stride) columns with the stride as the datasets' attribute ``trace_every`` -- NOT the
+    reference's shapes; None: none.
     ``timings``: a dict that receives the wall time by phase (the device is synchronised at the phase borders then; bench.py).
     ``index`` / ``fiducial`` + ``line_number`` / ``line_number``: the reference's single-point and single-line switches.
     ``exact_jacobian``: use the true derivative of the forward model in the proposals instead of the reference's
@@ -751,7 +755,14 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             out[torch.as_tensor(idx - first, device=part.device)] = part
         return out
 
-    assert schedule in ("static", "dynamic", "lines"), ValueError("schedule must be 'static', 'dynamic' or 'lines'")
+    assert schedule in ("auto", "static", "dynamic", "lines"), ValueError("schedule must be 'auto', 'static', 'dynamic' or 'lines'")
+    if schedule == "auto":
+        # more than one rank: whole lines per rank -- every rank writes its own containers and the job's only exchange is the gather of the
+        # one-row summaries (all_gather_into_tensor; the posterior rows of "static" / "dynamic" travel point to point, which has run over
+        # gloo only) -- whenever the data file allows it (every flight line one run of consecutive rows)
+        change_ = np.flatnonzero(np.diff(ds.lineNumber) != 0) + 1
+        firsts_ = np.r_[0, change_] if ds.nPoints else np.zeros(0, dtype=np.int64)
+        schedule = "lines" if (world > 1 and ds.nPoints and np.unique(ds.lineNumber[firsts_]).size == firsts_.size) else "static"
     if schedule == "lines":
         # whole flight lines per rank: every rank fills and writes the results files of its own lines (as the reference's ranks write
         # their own rows, Inference3D.py:586-635), only the one-row summaries are gathered

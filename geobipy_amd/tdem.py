@@ -853,7 +853,7 @@ class TdemDeviceChains(DeviceChains):
         self._geometry_rows_extra = None
         if self._pos_moves:                  # a moved position: the chain's table set at another distance / effective height (gbp_td_moves)
             rho_set, dz_set = self.t["rho_set"].cpu().numpy(), self.t["dz_set"].cpu().numpy()
-            self._geometry_rows_extra = dict(height=dev(g[:, 0] + 0.5 * (g[:, 6] - dz_set)), scale=dev(rho_set / np.hypot(g[:, 4], g[:, 5])))
+            self._geometry_rows_extra = dict(height=dev(g[:, 0] + 0.5 * (g[:, 6] - dz_set)), scale=dev(np.where(rho_set > 0.0, rho_set / np.maximum(np.hypot(g[:, 4], g[:, 5]), 1e-300), 1.0)))   # (on-axis sets: no distance to scale)
         if self._pred_offset0 is None:
             return dev(gm.weights), None, None
         pp = gm.primary_field()

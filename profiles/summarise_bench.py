@@ -26,10 +26,10 @@ fetch, write = m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
 cycles = m["GRBM_GUI_ACTIVE"] / 8.0
 timed = dur[-bench["steps"] * bench.get("rounds_per_step", 1):]
 cfg = bench.get("config", {})
-pts, pts_all = cfg.get("abscissa_points_per_sounding_at_35_m"), cfg.get("abscissa_points_all", 1200)
+pts, pts_all = cfg.get("abscissa_points_per_sounding_mean", cfg.get("abscissa_points_per_sounding_at_35_m")), cfg.get("abscissa_points_all", 1200)
 label = ("label unknown (bench line without config.abscissa_points_*)" if pts is None else
          "all %d abscissa points per sounding (hankel_eps_ppm = 0)" % pts_all if pts == pts_all else
-         "default path: per-sounding abscissa window, eps = %g ppm, %d of %d abscissa points per sounding at 35 m" % (cfg.get("hankel_eps_ppm"), pts, pts_all))
+         "default path: per-sounding abscissa window, eps = %g ppm, %.1f of %d abscissa points per sounding (batch mean)" % (cfg.get("hankel_eps_ppm"), pts, pts_all))
 out = {
     "command": "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-windowed --no-rjmcmc --no-extras (under rocprofv3, profiles/run_profile.sh; reduced by profiles/summarise_bench.py)",
     "kernel": KERNEL,

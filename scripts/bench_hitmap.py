@@ -3,6 +3,7 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests")); import hitmap_reference
 from geobipy_amd import hitmap
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 nv, nz = 250, 440
@@ -26,8 +27,8 @@ def timed(fn, n=20):
     return e0.elapsed_time(e1) / n, out
 ms_s, _ = timed(lambda: hitmap.statistics(hm, lmp, 2.3))
 ms_r, (ptr, start, val) = timed(lambda: hitmap.runs(hm))
-ms_st, _ = timed(lambda: hitmap.statistics_torch(hm[:1024], lmp[:1024], 2.3), 3)
-ms_rt, _ = timed(lambda: hitmap.runs_torch(hm[:1024]), 3)
+ms_st, _ = timed(lambda: hitmap_reference.statistics_torch(hm[:1024], lmp[:1024], 2.3), 3)
+ms_rt, _ = timed(lambda: hitmap_reference.runs_torch(hm[:1024]), 3)
 bytes_map = B * nv * nz * 4
 runs = int(ptr[-1])
 print(f"B={B}: maps {bytes_map / 1e9:.2f} GB, {runs / B:.0f} runs per sounding")

@@ -1,8 +1,51 @@
-"""csrc/gbp_hitmap.h on the GPU against the torch formulations it replaces (geobipy_amd.hitmap.*_torch): the run-length form of the hit maps
-bit for bit (rows of every kind: empty, constant, alternating, a change at every tile border, a length that is no multiple of the tile),
-the per-depth statistics cell for cell (the same percentile cells; centres and means to rounding: torch divides by a scalar through its reciprocal)."""
+"""csrc/gbp_hitmap.h: (i) the per-depth statistics against the imported REFERENCE's own ``Histogram.mean`` / ``Histogram.percentile``
+on recorded hit maps (tests/golden/make_hitmap_stats.py -> hitmap_stats.npz: layered posteriors, one cell per depth, cumulative shares
+that fall exactly on a percentile, empty columns) -- the torch formulation on the CPU tier, the kernel on the GPU tier; (ii) the kernels
+against the torch formulations (tests/hitmap_reference.py) on shapes the fixture does not hold: the run-length form of the hit maps bit
+for bit (rows of every kind: empty, constant, alternating, a change at every tile border, a length that is no multiple of the tile),
+the statistics cell for cell."""
+import os
+
 import numpy as np
 import pytest
+
+import hitmap_reference
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hitmap_stats.npz")
+
+
+def _fixture():
+    import torch
+    d = np.load(GOLDEN)
+    W = float(d["x_edges"][-1])
+    assert np.allclose(np.diff(d["x_edges"]), 2.0 * W / (d["x_edges"].size - 1), rtol=0, atol=1e-12) and abs(d["x_edges"][0] + W) < 1e-12
+    counts = torch.as_tensor(d["counts"])
+    lmp = torch.full((counts.shape[0],), float(d["relative_to"]) * np.log(10.0), dtype=torch.float64)   # the device carries ln, the mesh log10
+    # the reference returns S/m (10 ** (value + relative_to)); the kernel log10
+    return counts, lmp, W, np.log10(d["ref_mean"]), np.log10(d["ref_percentiles"])
+
+
+def _hold_to_reference(mean, pct, ref_mean, ref_pct, W, nv):
+    cell = 2.0 * W / nv
+    assert np.abs(mean - ref_mean).max() < 1e-12, np.abs(mean - ref_mean).max()
+    for q in range(3):                                # the SAME cell (its centre to rounding), ties and empty columns included
+        assert np.abs(pct[q] - ref_pct[:, q]).max() < 1e-9 * cell, (q, np.abs(pct[q] - ref_pct[:, q]).max() / cell)
+
+
+def test_torch_formulation_equals_the_reference_histogram():
+    counts, lmp, W, ref_mean, ref_pct = _fixture()
+    mean, pct = hitmap_reference.statistics_torch(counts, lmp, W)
+    _hold_to_reference(mean.numpy(), [p.numpy() for p in pct], ref_mean, ref_pct, W, counts.shape[1])
+
+
+@pytest.mark.gpu
+def test_hitmap_statistics_kernel_equals_the_reference_histogram():
+    import torch
+    from geobipy_amd import hitmap
+    counts, lmp, W, ref_mean, ref_pct = _fixture()
+    dev = torch.device("cuda", 0)
+    mean, pct = hitmap.statistics(counts.to(dev), lmp.to(dev), W)
+    _hold_to_reference(mean.cpu().numpy(), [p.cpu().numpy() for p in pct], ref_mean, ref_pct, W, counts.shape[1])
 
 
 @pytest.mark.gpu
@@ -31,12 +74,12 @@ def test_hitmap_runs_and_statistics_equal_the_torch_formulations():
                     hm[b, v, lo:hi + 1] += rng.integers(1, 900)
         t = torch.as_tensor(hm, device=dev)
         ptr, start, value = hitmap.runs(t)
-        ptr0, start0, value0 = hitmap.runs_torch(t)
+        ptr0, start0, value0 = hitmap_reference.runs_torch(t)
         assert torch.equal(ptr, ptr0) and torch.equal(start, start0) and torch.equal(value, value0.to(torch.int32)), (B, nv, nz)
         assert ptr.dtype == torch.int64 and start.dtype == torch.int32
         lmp = torch.as_tensor(rng.normal(-4.0, 0.5, B), device=dev)
         mean, pct = hitmap.statistics(t, lmp, 2.3)
-        mean0, pct0 = hitmap.statistics_torch(t, lmp, 2.3)
+        mean0, pct0 = hitmap_reference.statistics_torch(t, lmp, 2.3)
         assert torch.allclose(mean, mean0, rtol=0, atol=1e-12), float((mean - mean0).abs().max())
         for a_, b_ in zip(pct, pct0):                  # neighbouring cells are 2 * 2.3 / nv apart: the same cell, its centre to rounding
             assert torch.allclose(a_, b_, rtol=0, atol=1e-12), (B, nv, nz, float((a_ - b_).abs().max()))

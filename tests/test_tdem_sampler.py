@@ -174,7 +174,7 @@ def test_tempest_two_components_one_system():
     assert acc.sum() > 10
 
 
-@pytest.mark.parametrize("case", ["skytem_tx_rx", "tempest_total_field", "tempest_positions", "skytem_heights"])
+@pytest.mark.parametrize("case", ["skytem_tx_rx", "tempest_total_field", "tempest_positions", "skytem_heights", "central_loop_heights"])
 def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
     """gbp_td_moves -- the reference's solve_transmitter_pitch / solve_receiver_pitch / _roll (pinned to the reference on the host:
     test_tdem_object_api.py::test_host_sampler_walks_the_reference_chain_with_loop_pair_moves): CPU chains with the same
@@ -195,8 +195,11 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
                   solve_receiver_pitch=True, maximum_receiver_pitch_change=5.0, receiver_pitch_proposal_variance=0.5)
         moves = [("tx_pitch", 4.0, 0.4), ("rx_pitch", 5.0, 0.5)]
         att0 = (1.0, 2.0, 0.0, -1.5, 1.0, 0.5)           # GA-AEM convention: tx roll, pitch, yaw, rx roll, pitch, yaw
-    elif case == "skytem_heights":
-        off, stm, alt, n_it = OFFSET, ("SkytemLM.stm",), (30.0, 40.0), 150
+    elif case in ("skytem_heights", "central_loop_heights"):
+        # ("central_loop_heights": the receiver ON the transmitter loop's axis -- the table set has no horizontal distance, rho_set = 0;
+        #  the distance scale was 0 / 0 = NaN there)
+        off = OFFSET if case == "skytem_heights" else (0.0, 0.0, 2.0)
+        stm, alt, n_it = ("SkytemLM.stm",), (30.0, 40.0), 150
         mv = dict(solve_receiver_z=True, maximum_receiver_z_change=1.0, receiver_z_proposal_variance=0.15,
                   solve_transmitter_z=True, maximum_transmitter_z_change=2.0, transmitter_z_proposal_variance=0.3)
         moves = [("dz", 1.0, 0.15), ("tx_z", 2.0, 0.3)]
@@ -303,7 +306,9 @@ def test_sampled_attitude_angles_on_the_device_equal_cpu_chains(case):
         assert torch.all(torch.abs(best[m_[0]] - c0) <= m_[1] + 1e-12)
     if dc._pos_moves:                                             # the chains' table sets never changed: one per measured (rho, dz)
         g_now = dc.t["geom"].cpu().numpy()
-        assert np.allclose(dc.t["rho_scale"].cpu().numpy(), np.hypot(off[0], off[1]) / np.hypot(g_now[:, 4], g_now[:, 5]), rtol=1e-14)
+        rho_now, rho_set = np.hypot(g_now[:, 4], g_now[:, 5]), np.hypot(off[0], off[1])
+        want = rho_set / rho_now if rho_set > 0.0 else np.ones_like(rho_now)      # (an on-axis table set has no distance to scale: 1, not 0 / 0)
+        assert np.allclose(dc.t["rho_scale"].cpu().numpy(), want, rtol=1e-14) and bool(torch.isfinite(dc.misfit).all())
         assert np.allclose(dc.t["height"].cpu().numpy(), g_now[:, 0] + 0.5 * (g_now[:, 6] - off[2]), rtol=1e-14)
 
 
