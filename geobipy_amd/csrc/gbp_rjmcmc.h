@@ -325,12 +325,14 @@ __device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r
 
 // Small blocks of soundings: one wave per chain (4 chains per workgroup).  Lane j holds interface j and layer j, every
 // lane runs the same draws (wave-uniform control flow), neighbour look-ups are cross-lane reads, rows are written coalesced.
-__device__ __forceinline__ void propose_wave_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane)
-{
+// (k, e_row, s_row: the chain's current model -- c.k[b] and its rows of c.edges / c.sigma, or, right behind an accept stage in the same
+//  kernel, the layer count and the rows that stage has just made current: the fused step never reads back what it has just written)
+__device__ __forceinline__ int propose_wave_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane, int k,
+                                                 const double* e_row, const double* s_row)
+{   // returns the proposal's layer count
     const int K = o.max_layers;
-    const int k = c.k[b];
-    const double ej = lane < k - 1 ? c.edges[(size_t)b * K + lane] : INF;
-    const double sj = lane < k ? c.sigma[(size_t)b * K + lane] : 1.0;
+    const double ej = lane < k - 1 ? e_row[lane] : INF;
+    const double sj = lane < k ? s_row[lane] : 1.0;
     Rng r(o.seed, chain_key(o, c, b), iter, 0);
     int action, idx;
     double val;
@@ -348,6 +350,74 @@ __device__ __forceinline__ void propose_wave_body(const RjOpt& o, const gbp_rj_c
     }
     Rng r0 = r;                                                  // every lane continues the same stream; lane 0 writes
     if (lane == 0) write_move(o, c, r0, b, action, kr);
+    return kr;
+}
+__device__ __forceinline__ void propose_wave_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int b, int lane)
+{
+    const int K = o.max_layers;
+    (void)propose_wave_body(o, c, iter, b, lane, c.k[b], c.edges + (size_t)b * K, c.sigma + (size_t)b * K);
+}
+
+// The same proposal by the 8 lanes that hold a chain in the packed stages (models of at most 7 layers: a birth then still fits the group;
+// an 8-layer model takes the thread-per-chain rows on the group's first lane).  Lane j holds interface j and layer j; every lane of the
+// group runs the same draws; neighbour look-ups are reads within the group.  Same draws, same remapped rows, same records as the other
+// proposal kernels (tests/test_rjmcmc_gpu.py holds the drivers that use them against each other bit for bit).
+__device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b, int k,
+                                             const double* e_row, const double* s_row)
+{   // returns the proposal's layer count (to every lane of the group)
+    const int i = lane & 7, base = lane & ~7, K = o.max_layers;
+    if (k > 7 || K < 8) {                                        // (group-uniform)
+        int kr_out = 0;
+        if (i == 0) {
+            Rng r(o.seed, chain_key(o, c, b), iter, 0);
+            int action, idx;
+            double val;
+            choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return e_row[j]; },
+                        [&](double depth) { int pos = 0; while (pos < k - 1 && e_row[pos] < depth) ++pos; return pos; }, action, idx, val);
+            const int kr = k + (action == INSERT) - (action == DELETE);
+            double above = 0.0;
+            for (int j = 0; j < K; ++j) {                        // (rows read from e_row / s_row, written to the _r rows: never the same arrays)
+                const double e_j = j < k - 1 ? e_row[j] : INF, s_j = j < k ? s_row[j] : 1.0;
+                const double e_up = j > 0 ? (j - 1 < k - 1 ? e_row[j - 1] : INF) : e_j, s_up = j > 0 ? (j - 1 < k ? s_row[j - 1] : 1.0) : s_j;
+                const double e_dn = j + 1 < K ? (j + 1 < k - 1 ? e_row[j + 1] : INF) : e_j, s_dn = j + 1 < K ? (j + 1 < k ? s_row[j + 1] : 1.0) : s_j;
+                double ev, sv;
+                remap_entry(action, idx, val, kr, j, e_j, e_up, e_dn, s_j, s_up, s_dn, ev, sv);
+                c.edges_r[(size_t)b * K + j] = ev;
+                c.sigma_r[(size_t)b * K + j] = sv;
+                c.thk_r[(size_t)b * K + j] = j < kr - 1 ? ev - above : 0.0;
+                above = ev;
+            }
+            write_move(o, c, r, b, action, kr);
+            kr_out = kr;
+        }
+        return __shfl(kr_out, base, 64);
+    }
+    const double ej = i < k - 1 ? e_row[i] : INF;
+    const double sj = i < k ? s_row[i] : 1.0;
+    Rng r(o.seed, chain_key(o, c, b), iter, 0);
+    int action, idx;
+    double val;
+    choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return __shfl(ej, base + j, 64); },
+                [&](double depth) { return (int)__popcll((__ballot(ej < depth) >> base) & 0xFFull); }, action, idx, val);
+    const int kr = k + (action == INSERT) - (action == DELETE);
+    const int up = max(i - 1, 0), dn = min(i + 1, 7);
+    const double e_up = __shfl(ej, base + up, 64), s_up = __shfl(sj, base + up, 64);
+    const double e_dn_ = __shfl(ej, base + dn, 64), s_dn_ = __shfl(sj, base + dn, 64);
+    const double e_dn = i == 7 ? INF : e_dn_, s_dn = i == 7 ? 1.0 : s_dn_;      // (entry 8 of a model of at most 7 layers)
+    double ev, sv;
+    remap_entry(action, idx, val, kr, i, ej, e_up, e_dn, sj, s_up, s_dn, ev, sv);
+    const double ev_up = __shfl(ev, base + up, 64);
+    c.edges_r[(size_t)b * K + i] = ev;
+    c.sigma_r[(size_t)b * K + i] = sv;
+    c.thk_r[(size_t)b * K + i] = i < kr - 1 ? ev - (i > 0 ? ev_up : 0.0) : 0.0;
+    for (int j = i + 8; j < K; j += 8) {                         // (beyond the group: kr <= 8 layers -- the rows' empty entries)
+        c.edges_r[(size_t)b * K + j] = INF;
+        c.sigma_r[(size_t)b * K + j] = 1.0;
+        c.thk_r[(size_t)b * K + j] = 0.0;
+    }
+    Rng r0 = r;
+    if (i == 0) write_move(o, c, r0, b, action, kr);
+    return kr;
 }
 
 __global__ __launch_bounds__(256) void k_rj_propose_wave(RjOpt o, gbp_rj_chains c, uint32_t iter)
@@ -459,6 +529,12 @@ __global__ __launch_bounds__(GBP_RJ_PROPOSE_THREADS) void k_rj_propose_staged(Rj
     }
     __syncthreads();
     if (t < nb) propose_rows<false>(o, c, iter, b0 + t, se + t * KS, ss + t * KS, se + t * KS, ss + t * KS, st + t * KS);
+#ifdef GBP_RJ_PROPOSE_DELAY_TICKS
+    {   // (sensitivity builds only: is an iteration bound by the dependency chain of a sub-block or by the throughput of the physics launches?)
+        const long long d0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - d0 < GBP_RJ_PROPOSE_DELAY_TICKS) {}
+    }
+#endif
     __syncthreads();
     for (int p = t; p < n_pair; p += GBP_RJ_PROPOSE_THREADS) {
         const int i0 = 2 * p, r0 = i0 / K, c0 = i0 - r0 * K;
@@ -1097,8 +1173,12 @@ __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32
     return (best_replaced ? 2 : 0) | (posteriors_reset ? 4 : 0) | (accumulate ? 8 : 0);     // (gbp_rj_chains.step_flags, bits 1-3)
 }
 
+// What an accept stage tells the proposal that follows it in the same kernel (k_rj_step8): whether the move was taken and the layer count
+// the chain has now -- its rows are then the proposal's (edges_r, sigma_p) or the untouched current ones.
+struct StepState { bool accepted; int k_now; };
+
 __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int min_k, int b,
-                                            int lane, unsigned char* sh_dyn)
+                                            int lane, unsigned char* sh_dyn, StepState* st = nullptr)
 {   // one wave per chain; chains whose current and proposed models both have at most min_k layers are left to accept8_body
     const int K = o.max_layers, N = o.n_channels, KS = K + 1;
     Lds s(sh_dyn, K, N);
@@ -1198,6 +1278,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool frozen = o.schedule == 1 && c.status[b] != 0;     // a chain that is done (or failed) keeps its final state
     const bool accept = !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;        // NaN and -inf reject
+    if (st != nullptr) { st->accepted = accept; st->k_now = accept ? k : k_prev; }
     wave_sync();
     if (lane == 0) c.log_ratio[b] = log_ratio;
     if (frozen) {
@@ -1373,7 +1454,7 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: PR[8][N]
 template <bool TRIPS>
 __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int lane, int b,
-                                             unsigned char* sh_dyn, int b_idle = 0)
+                                             unsigned char* sh_dyn, int b_idle = 0, StepState* st = nullptr)
 {
     const int slot = lane >> 3, i = lane & 7, base = lane & ~7;
     const int K = o.max_layers, N = o.n_channels;
@@ -1457,6 +1538,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
     const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
     const bool accept = live && !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;
+    if (st != nullptr) { st->accepted = accept; st->k_now = accept ? k : k_prev; }
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (live && frozen && i == 0 && c.step_flags != nullptr) c.step_flags[bb] = 0;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
@@ -1506,6 +1588,65 @@ __global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uin
         return;
     }
     accept8_body<TRIPS>(o, c, iter, accumulate, threadIdx.x, blockIdx.x * 8 + (threadIdx.x >> 3), sh_dyn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The accept stage of iteration i and the proposal of iteration i + 1 in ONE launch (round 5).  An iteration of a sub-block is its chain
+// of dependent launches -- a build that parks the proposal kernel for 10 / 20 us longer loses exactly 10 / 20 us per iteration at 2 048,
+// 4 096 and 8 192 chains alike (scripts/ab_rj.py, docs/notes_r5.md) -- and the proposal launch was 28 us of it: 43 workgroups whose
+// first wave walks 64 chains' rows serially.  Here the lanes that have just decided a chain's move propose its next one: the packed
+// groups with propose8_body (8 lanes per chain, rows in registers), the deep chains' waves with propose_wave_body.  The proposal
+// rewrites k_r and the move -- what tells packed and deep workgroups of an accept stage whose chain is whose -- so ownership inside
+// this launch is read from `deep_cur`, flags the PROPOSAL of the iteration wrote (k_rj_propose_flags for the first one of a call), and
+// the flags of the next iteration go to `deep_next`.  Same functions, same draws: bit-identical chains.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t step_is_deep(int k_now, int kr) { return max(k_now, kr) > 8 ? 1 : 0; }
+
+template <bool TRIPS>
+__global__ __launch_bounds__(64) void k_rj_step8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed,
+                                                 const int32_t* __restrict__ deep_cur, int32_t* __restrict__ deep_next)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
+    const int K = o.max_layers, lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_packed) {                 // the deep chains' scanning workgroups
+        const int g = (int)blockIdx.x - n_packed, bl = g * 64 + lane;
+        for_deep_chains(g, bl < c.B && deep_cur[min(bl, c.B - 1)] != 0, [&](int bb) {
+            StepState st{false, 0};
+            const int k_before = c.k[bb];
+            const bool frozen = o.schedule == 1 && c.status[bb] != 0;
+            accept_body(o, c, iter, accumulate, 0, bb, lane, sh_dyn, &st);
+            if (frozen) { st.accepted = false; st.k_now = k_before; }
+            wave_sync();
+            const double* e_row = (st.accepted ? c.edges_r : c.edges) + (size_t)bb * K;
+            const double* s_row = (st.accepted ? c.sigma_p : c.sigma) + (size_t)bb * K;
+            // (the rows are read into registers before the proposal writes edges_r: propose_wave_body loads first, then stores)
+            const int kr = propose_wave_body(o, c, iter + 1, bb, lane, st.k_now, e_row, s_row);
+            if (lane == 0) deep_next[bb] = step_is_deep(st.k_now, kr);
+        });
+        return;
+    }
+    const int b = (int)blockIdx.x * 8 + (lane >> 3);
+    const bool mine = b < c.B && deep_cur[min(b, c.B - 1)] == 0;
+    StepState st{false, 0};
+    const int bq = min(b, c.B - 1);
+    const int k_before = c.k[bq];
+    const bool frozen = o.schedule == 1 && c.status[bq] != 0;
+    accept8_body<TRIPS>(o, c, iter, accumulate, lane, b, sh_dyn, 0, &st);
+    if (frozen) { st.accepted = false; st.k_now = k_before; }
+    wave_sync();
+    if (mine) {                                        // (group-uniform; the reads inside stay within the chain's own 8 lanes)
+        const double* e_row = (st.accepted ? c.edges_r : c.edges) + (size_t)b * K;
+        const double* s_row = (st.accepted ? c.sigma_p : c.sigma) + (size_t)b * K;
+        const int kr = propose8_body(o, c, iter + 1, lane, b, st.k_now, e_row, s_row);
+        if ((lane & 7) == 0) deep_next[b] = step_is_deep(st.k_now, kr);
+    }
+}
+
+// The ownership flags of an iteration whose proposal came from a stand-alone proposal launch (the first of a call)
+__global__ __launch_bounds__(256) void k_rj_propose_flags(gbp_rj_chains c, int32_t* __restrict__ deep)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < c.B) deep[b] = accept_is_deep(c, b, 8) ? 1 : 0;
 }
 
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
@@ -2331,17 +2472,18 @@ static bool packed_trips(int B)
 // (Folding the deep body into the packed WAVES was tried first: inlined it takes the accept stage from 111 to 178 VGPRs, as a call it
 // adds 1.1 - 1.3 KB of scratch per lane; so was running the deep bodies as calls inside the stage-1 physics launch: 104 -> 288 B of
 // scratch there.)
-// Round 5: the deep chains' part of a stage is B / 64 scanning workgroups (k_rj_newton) instead of B that exit at once.  A/B on one box
-// (scripts/ab_rj.py, ten frequencies, M chain-iterations/s; round-4 library | scanning + the round-4 rule below | scanning + one launch
-// at every size): 2 048 chains 19.0 | 18.7 | 18.7, 4 096: 31.3 | 30.8 | 30.6, 8 192: 44.3 | 43.2 | 44.2 -- measured together with the
-// round's re-cut physics prologue, which is what cost the 1 - 2 % at the middle sizes; GBP_RJ_ONE_STAGE_LAUNCH=1 selects the one launch.
+// Round 5: the deep chains' part of a stage is B / 64 scanning workgroups (k_rj_newton) instead of B that exit at once, so the one launch
+// no longer drags 2 731 empty workgroups through the packed kernel's register budget: ONE launch per stage at every size -- five launches
+// per iteration and sub-block instead of seven.  A/B on one box (scripts/ab_rj.py, ten frequencies, M chain-iterations/s, two repeats;
+// round-4 library | scanning workgroups with the round-4 rule | scanning + one launch): 2 048 chains 18.99 | 18.94 | 18.92, 4 096:
+// 31.23 | 31.20 | 31.19, 8 192: 44.30 | 43.35 | 44.89.  (GBP_RJ_TWO_STAGE_LAUNCHES restores the round-4 rule for A/B builds.)
 static bool one_stage_launch(int n, bool time_domain)
 {
-#ifdef GBP_RJ_ONE_STAGE_LAUNCH
+#ifdef GBP_RJ_TWO_STAGE_LAUNCHES
+    return time_domain || n <= 1536 || n >= 32768;
+#else
     (void)n; (void)time_domain;
     return true;
-#else
-    return time_domain || n <= 1536 || n >= 32768;
 #endif
 }
 
@@ -2489,6 +2631,18 @@ static gbp_status rj_run_persistent(const gbp_fdem_system* sys, const gbp_rj_opt
     if (st != GBP_OK) return st;
     if (le != hipSuccess) return fail(GBP_ERR_HIP, "persistent sampler launch: %s", hipGetErrorString(le));
     return GBP_OK;
+}
+
+// Waves per workgroup of the stage-0 physics launch (Jacobian pass at the remapped model; results do not depend on it) given the
+// sub-block's wave count `nw` of the stage-1 launch.
+static int stage0_waves(int nw)
+{
+#ifdef GBP_RJ_PHYSICS_NW_STAGE0
+    (void)nw;
+    return GBP_RJ_PHYSICS_NW_STAGE0;                         // (A/B builds under scripts/ab only)
+#else
+    return nw;
+#endif
 }
 
 // Concurrent sub-blocks of the fused lock-step driver by block size.  Each sub-block runs on one of the pool's three helper streams
@@ -2708,7 +2862,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         const int P = std::max(1, std::min(parts, (int)BlockStreams::MAX));
         BlockStreams* bs = P > 1 ? block_streams() : nullptr;
         if (P > 1 && bs == nullptr) return fail(GBP_ERR_HIP, "sub-block streams: %s", hipGetErrorString(hipGetLastError()));
-        struct Part { gbp_rj_options o; gbp_rj_chains c; hipStream_t q; unsigned char* deep; int nw; size_t lds; };
+        struct Part { gbp_rj_options o; gbp_rj_chains c; hipStream_t q; unsigned char* deep; int nw; size_t lds; int32_t* flags; };
         std::vector<Part> part(P);
         const size_t deep_per_chain = K > 8 ? 1 : 0;
         for (int p = 0; p < P; ++p) {
@@ -2719,6 +2873,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if (P > 1 && c->chain_id == nullptr) t.o.first_chain = o->first_chain + (uint64_t)b0;
             t.q = P > 1 ? bs->q[p] : main_q;
             t.deep = nullptr;
+            t.flags = nullptr;
             // Waves per workgroup of the physics launches (results do not depend on it).  Measured per sub-block size n
             // (scripts/bench_rj_parts.py through -DGBP_RJ_PHYSICS_NW builds, M chain-iterations/s with 1 / 2 / 3 / 4 waves; ten
             // frequencies | Resolve): n = 1 024: 11.9 15.3 16.5 17.1 | 14.6 17.5 18.5 19.6;  2 048: 20.4 25.9 27.0 27.5 | 25.7 30.1 31.0
@@ -2738,11 +2893,23 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             GBP_HIP(hipEventRecord(bs->start, main_q));
             for (int p = 0; p < P; ++p) GBP_HIP(hipStreamWaitEvent(part[p].q, bs->start, 0));
         }
+        // (the accept stage of an iteration and the proposal of the next share a launch -- k_rj_step8 -- from the second iteration of a call:
+        //  two rows of ownership flags per sub-block, written by the proposals, read by the accept stages)
+#ifdef GBP_RJ_NO_FUSED_STEP
+        const bool fused_step = false;                               // (A/B builds only)
+#else
+        const bool fused_step = n_iterations > 1;
+#endif
         bool alloc_failed = false;
         for (int p = 0; p < P && !alloc_failed; ++p) {
-            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(part[p].nw, K) + 255) & ~(size_t)255) : 0;
+            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(std::max(part[p].nw, stage0_waves(part[p].nw)), K) + 255) & ~(size_t)255) : 0;
             if (deep_bytes > 0 && hipMallocAsync((void**)&part[p].deep, deep_bytes * (size_t)part[p].c.B, part[p].q) != hipSuccess) {
                 part[p].deep = nullptr;
+                alloc_failed = true;
+            }
+            if (!alloc_failed && fused_step && part[p].c.B > 0 &&
+                hipMallocAsync((void**)&part[p].flags, sizeof(int32_t) * 2 * (size_t)part[p].c.B, part[p].q) != hipSuccess) {
+                part[p].flags = nullptr;
                 alloc_failed = true;
             }
         }
@@ -2750,21 +2917,26 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             const hipError_t e = hipGetLastError();
             for (int p = 0; p < P; ++p) {
                 if (part[p].deep != nullptr) (void)hipFreeAsync(part[p].deep, part[p].q);
+                if (part[p].flags != nullptr) (void)hipFreeAsync(part[p].flags, part[p].q);
                 if (P > 1) { (void)hipEventRecord(bs->done[p], part[p].q); (void)hipStreamWaitEvent(main_q, bs->done[p], 0); }
             }
             return fail(GBP_ERR_HIP, "sampler sub-blocks: working set of the deep models: %s", hipGetErrorString(e));
         }
         auto physics = [&](const Part& t, int stage) {
-            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(t.nw, K) + 255) & ~(size_t)255) : 0;
+            // (stage 0 -- the Jacobian pass at the remapped model: half of the workgroups leave at once -- may take a wave count of its own;
+            //  the deep models' global working set is sized for the larger of the two)
+            const int nw_s = stage == 0 ? stage0_waves(t.nw) : t.nw;
+            const size_t lds_s = stage == 0 ? ((std::max(dyn_lds_bytes(nw_s, K, (sys->t.npts + 63) / 64), sens_lds_bytes(nw_s, K < 8 ? K : 8)) + 15) & ~(size_t)15) : t.lds;
+            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(std::max(t.nw, stage0_waves(t.nw)), K) + 255) & ~(size_t)255) : 0;
             const rj::RjOpt ox = rj::extend(t.o);
             const size_t out_bytes = (size_t)o->n_channels * sizeof(double);          // the output row behind the stages' block (k_rj_physics)
-            const int out_offset = (int)t.lds;
+            const int out_offset = (int)lds_s;
             if (o->exact_jacobian)
-                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B), dim3(64 * t.nw), t.lds + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
                                    sys->d_bin_pts, out_offset);
             else
-                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B), dim3(64 * t.nw), t.lds + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
                                    sys->d_bin_pts, out_offset);
         };
@@ -2779,13 +2951,31 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             if (p > 0 && hipSetDevice(dev) != hipSuccess) { pst[p] = GBP_ERR_HIP; perr[p] = "hipSetDevice failed in a sub-block thread"; return; }
             const Part& t = part[p];
             gbp_status s2 = GBP_OK;
+            const bool step = fused_step && t.flags != nullptr && t.c.B > 0;
+            const int nB = t.c.B;
             for (int it = 0; it < n_iterations && s2 == GBP_OK; ++it) {
                 const int64_t iter = first_iteration + it;
-                if ((s2 = gbp_rj_propose(&t.o, &t.c, iter, t.q)) != GBP_OK) break;
+                if (it == 0 || !step) {
+                    if ((s2 = gbp_rj_propose(&t.o, &t.c, iter, t.q)) != GBP_OK) break;
+                    if (step) hipLaunchKernelGGL(rj::k_rj_propose_flags, dim3((nB + 255) / 256), dim3(256), 0, t.q, t.c, t.flags);
+                }
                 physics(t, 0);                                // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
                 if ((s2 = gbp_rj_newton(&t.o, &t.c, iter, t.q)) != GBP_OK) break;
                 physics(t, 1);                                // Inference1D.py:572-597 / Model.py:612: every proposal's evaluation
-                s2 = gbp_rj_accept(&t.o, &t.c, iter, accumulate, t.q);
+                if (step && it + 1 < n_iterations) {          // accept + the next iteration's proposal in one launch (k_rj_step8)
+                    const int n_packed = (nB + 7) / 8, n_deep = K > 8 ? (nB + 63) / 64 : 0;
+                    const size_t lds = std::max((size_t)8 * o->n_channels * sizeof(double), n_deep ? rj::Lds::bytes(K, o->n_channels) : (size_t)0);
+                    const int32_t* cur = t.flags + (size_t)(it & 1) * nB;
+                    int32_t* nxt = t.flags + (size_t)((it + 1) & 1) * nB;
+                    if (packed_trips(nB))
+                        hipLaunchKernelGGL(rj::k_rj_step8<true>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
+                                           n_packed, cur, nxt);
+                    else
+                        hipLaunchKernelGGL(rj::k_rj_step8<false>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
+                                           n_packed, cur, nxt);
+                } else {
+                    s2 = gbp_rj_accept(&t.o, &t.c, iter, accumulate, t.q);
+                }
             }
             if (s2 == GBP_OK && hipGetLastError() != hipSuccess) s2 = GBP_ERR_HIP;
             pst[p] = s2;
@@ -2807,8 +2997,10 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         for (int p = 0; p < P; ++p)
             if (pst[p] != GBP_OK && st == GBP_OK) st = fail(pst[p], "sampler sub-block: %s", perr[p].c_str());
         const hipError_t le = hipGetLastError();
-        for (int p = 0; p < P; ++p)
+        for (int p = 0; p < P; ++p) {
             if (part[p].deep != nullptr) (void)hipFreeAsync(part[p].deep, part[p].q);
+            if (part[p].flags != nullptr) (void)hipFreeAsync(part[p].flags, part[p].q);
+        }
         if (P > 1)
             for (int p = 0; p < P; ++p) {
                 (void)hipEventRecord(bs->done[p], part[p].q);

@@ -12,8 +12,11 @@ for q, v in byq.items():
     v.sort()
     v = v[int(len(v) * skip):]
     dur, gap = collections.defaultdict(list), collections.defaultdict(list)
-    prop = [s for s, e, n in v if "propose" in n]
+    prop = [s for s, e, n in v if "propose_staged" in n or "propose_thread" in n or "step8" in n]
     for i, (s, e, n) in enumerate(v):
+        if n == "k_rj_physics" and i > 0:                       # stage 0 follows a proposal (or the fused accept + proposal), stage 1 the Newton stage
+            n = "k_rj_physics stage " + ("1" if "newton" in v[i - 1][2] else "0")
+            v[i] = (s, e, n)
         dur[n].append(e - s)
         if i + 1 < len(v):
             gap[n + " -> " + v[i + 1][2]].append(v[i + 1][0] - e)

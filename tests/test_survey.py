@@ -198,7 +198,7 @@ def test_survey_writes_the_reference_results_containers(tmp_path):
     from geobipy_amd import hdf
     out = tmp_path / "res"
     out.mkdir()
-    res = survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out))
+    res = survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out), traces="auto")       # (opt-in: the decimated traces)
     ds = survey.FdemData.read_csv(survey.read_options(OPTIONS)["data_filename"], survey.read_options(OPTIONS)["system_filename"])
     lines = np.unique(ds.lineNumber)
     schema = json.load(open(os.path.join(GOLDEN, "hdf_schema.json")))["tree"]
@@ -244,12 +244,24 @@ def test_survey_writes_the_reference_results_containers(tmp_path):
     # the dynamic schedule delivers the same files
     out2 = tmp_path / "res2"
     out2.mkdir()
-    survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out2), schedule="dynamic", chunk=7)
+    survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out2), schedule="dynamic", chunk=7, traces="auto")
     for ln in lines:
         a, b = np.load(out / "{}.results.npz".format(ln)), np.load(out2 / "{}.results.npz".format(ln))
         assert a.files == b.files
         for k in a.files:
             assert np.array_equal(a[k], b[k], equal_nan=True), k
+    # the DEFAULT keeps the reference's shapes: 2 n_markov_chains columns, no stride attribute -- and the same chains,
+    # so every decimated entry above is the entry of the full arrays at its stride
+    out3 = tmp_path / "res3"
+    out3.mkdir()
+    survey.infer(OPTIONS, exact_jacobian=True, results_directory=str(out3))
+    n_mc = int(survey.read_options(OPTIONS)["n_markov_chains"])
+    for ln in lines:
+        z3, a3 = hdf.load_npz(str(out3 / "{}.results.npz".format(ln))), json.load(open(out3 / "{}.results.attrs.json".format(ln)))
+        z1 = hdf.load_npz(str(out / "{}.results.npz".format(ln)))
+        assert z3["/phids/data"].shape == (z1["/phids/data"].shape[0], 2 * n_mc) and "trace_every" not in a3.get("/phids", {})
+        assert np.array_equal(z3["/phids/data"][:, ::3][:, :4000], z1["/phids/data"], equal_nan=True)
+        assert np.array_equal(z3["/acceptance_rate/data"][:, ::3][:, :4000], z1["/acceptance_rate/data"])
 
 
 @pytest.mark.gpu
