@@ -365,6 +365,50 @@ def survey_extra(n_soundings=8192, n_lines=16, n_markov_chains=2000):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def survey_at_size(n_soundings, n_lines, n_markov_chains):
+    """ONE end-to-end run of the survey driver at a north-star size, with device-synchronised phase clocks and the
+    process's peak host memory: the synthetic Resolve survey of survey_extra (wedge rows repeated with 2 % noise), the reference's
+    burn-in / stop schedule, per-line HDF5 containers with the posterior payload (hit maps, full-length traces)."""
+    import resource, shutil, tempfile
+    import torch
+    from geobipy_amd import hdf, survey
+    golden = os.path.join(ROOT, "tests", "golden")
+    src = os.path.join(golden, "resolve_glacial_clean.csv")
+    hdr = open(src).readline().strip()
+    raw = np.loadtxt(src, delimiter=",", skiprows=1)
+    rng = np.random.default_rng(1)
+    rows = raw[rng.integers(0, raw.shape[0], n_soundings)].copy()
+    rows[:, 6:] *= 1.0 + 0.02 * rng.standard_normal((n_soundings, raw.shape[1] - 6))
+    rows[:, 0] = np.repeat(np.arange(n_lines), -(-n_soundings // n_lines))[:n_soundings] + 100.0
+    rows[:, 1] = np.arange(n_soundings)
+    d = tempfile.mkdtemp()
+    try:
+        np.savetxt(os.path.join(d, "survey.csv"), rows, delimiter=",", header=hdr, comments="")
+        kind = hdf.container_type("auto")
+        phases = {}
+        t0 = time.perf_counter()
+        ds = survey.FdemData.read_csv(os.path.join(d, "survey.csv"), os.path.join(golden, "resolve.stm"))
+        t_csv = time.perf_counter() - t0
+        res = survey.infer(os.path.join(golden, "resolve_options_small"), data=ds, n_markov_chains=n_markov_chains,
+                           burn_in_min_iterations=n_markov_chains // 4, results_directory=os.path.join(d, "out"),
+                           output=os.path.join(d, "summary.npz"), timings=phases, container=kind)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        phases = dict({"csv_read": t_csv}, **phases)
+        phases["other"] = dt - sum(phases.values())
+        size = sum(os.path.getsize(os.path.join(d, "out", f)) for f in os.listdir(os.path.join(d, "out")))
+        chains = phases.get("chains", 0.0)
+        return {"soundings": n_soundings, "lines": n_lines, "n_markov_chains": n_markov_chains, "seconds": dt,
+                "value": n_soundings / dt, "unit": "soundings/s", "burned_in": int((res["status"] == 1).sum()),
+                "mean_iterations": float(np.mean(res["iterations"])), "container": kind, "container_megabytes": size / 1e6,
+                "phases_seconds": {k_: round(v_, 3) for k_, v_ in phases.items()},
+                "chains_share_of_wall": (chains / dt) if chains else None,
+                "peak_host_memory_GB": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6,
+                "note": "one run, phase clocks on (the device is synchronised at the phase borders); peak host memory of the whole bench process so far"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +422,7 @@ def main():
     ap.add_argument("--no-windowed", action="store_true", help="skip the extra opt-in abscissa-window measurement")
     ap.add_argument("--no-rjmcmc", action="store_true", help="skip the extra full-rjMCMC-step measurement")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra Jacobian and time-domain measurements")
+    ap.add_argument("--no-survey-sizes", action="store_true", help="skip the end-to-end survey runs at the north-star sizes (~30 s)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: initialise RCCL with ONE rank and run the N > 1 exchange anyway (side stream + all_gather_into_tensor "
@@ -595,7 +640,7 @@ def main():
             c_e, l_e = xb[0].forward_loglike(want_pred=True)
             c_w, l_w = batches[0].forward_loglike(want_pred=True)
             torch.cuda.synchronize(device)
-            xach = per_launch_evals * fpe / (xms * 1e-3) / 1e12
+            xach = per_launch_evals * fpe_all / (xms * 1e-3) / 1e12          # (every abscissa evaluated: executed = SURVEY 8(d)'s count)
             pts = [batches[0]._h.bin_points(a) for a in (25.0, 35.0, 45.0)]
             line["abscissa_window"] = {
                 "eps_ppm": batches[0].hankel_eps_ppm, "points_per_sounding_at_25_35_45_m": pts, "points_all_abscissae": xb[0]._h.npoints,
@@ -777,6 +822,13 @@ def main():
                 line["survey"] = survey_extra()
             except Exception as e:                               # an extra, never the measurement
                 line["survey"] = {"error": repr(e)}
+            if not args.no_survey_sizes and "error" not in line["survey"]:
+                try:                                             # the north-star sizes end to end, one run each
+                    line["survey"]["north_star_sizes"] = {
+                        "config5_schedule_8192_x_10000": survey_at_size(8192, 16, 10000),
+                        "soundings_65536": survey_at_size(65536, 64, 2000)}
+                except Exception as e:
+                    line["survey"]["north_star_sizes"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             threads = usable_cores()
             sample = args.cpu_sample or max(256, min(Btot, 16 * threads))

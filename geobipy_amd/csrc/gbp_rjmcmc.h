@@ -114,6 +114,19 @@ __device__ __forceinline__ void wave_sync()
 // per iteration of the persistent kernel against a 64 KB instruction cache, for stages that run as one wave per SIMD and
 // cannot hide a fetch miss.  Same library routines, same bits.
 #define GBP_RJ_CALL __attribute__((noinline))
+// The packed per-chain stages are single-wave workgroups on a GPU they leave almost empty: occupancy is worth nothing to them, a register
+// spilled to scratch is a trip to memory on their dependency chain -- they may take the whole register file (spills go to AGPRs).
+#define GBP_RJ_LATENCY_KERNEL __attribute__((amdgpu_waves_per_eu(1, 1)))
+// channels whose Jacobian column the packed stages' one-trip variants hold in registers (N <= this: Resolve 12, ten frequencies 20)
+#ifndef GBP_RJ_COLUMN_ROWS
+#define GBP_RJ_COLUMN_ROWS 24
+#endif
+#ifndef GBP_RJ_ONE_TRIP_NEWTON          // (A/B switches of the two one-trip stages)
+#define GBP_RJ_ONE_TRIP_NEWTON 1
+#endif
+#ifndef GBP_RJ_ONE_TRIP_ACCEPT
+#define GBP_RJ_ONE_TRIP_ACCEPT 1
+#endif
 __device__ GBP_RJ_CALL double rj_log(double x) { return log(x); }
 __device__ GBP_RJ_CALL double rj_exp(double x) { return exp(x); }
 __device__ GBP_RJ_CALL U4 philox_call(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t n)
@@ -281,8 +294,9 @@ __device__ inline void remap_entry(int action, int idx, double val, int kr, int 
     }
 }
 
-__device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr)
+__device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr, const Levels* now = nullptr)
 {   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-2: by bucket), error proposals
+    // (`now`: the chain's current error levels when the caller holds them -- the fused accept + proposal launch --, else read from memory)
     const int bk = bucket_of(kr);
     const bool jump = action == INSERT || action == DELETE;
     for (int i = 0; i < 3; ++i) {
@@ -306,7 +320,7 @@ __device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r
         c.height_p[b] = x;
     }
     // error levels (DataPoint.perturb: relative then additive)
-    const Levels cur = load_levels(o, c.rel, c.add, (size_t)b);
+    const Levels cur = now != nullptr ? *now : load_levels(o, c.rel, c.add, (size_t)b);
     Levels out = cur;
     if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.log_rel_min, o.log_rel_max, out.rel);
     if (o.solve_additive_error && !o.additive_independent)
@@ -362,17 +376,20 @@ __device__ __forceinline__ void propose_wave_body(const RjOpt& o, const gbp_rj_c
 // an 8-layer model takes the thread-per-chain rows on the group's first lane).  Lane j holds interface j and layer j; every lane of the
 // group runs the same draws; neighbour look-ups are reads within the group.  Same draws, same remapped rows, same records as the other
 // proposal kernels (tests/test_rjmcmc_gpu.py holds the drivers that use them against each other bit for bit).
+// (have: the chain's entries i of the current rows and its error levels are in registers -- e_reg, s_reg, now)
 __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int lane, int b, int k,
-                                             const double* e_row, const double* s_row)
+                                             const double* e_row, const double* s_row, bool have = false, double e_reg = 0.0,
+                                             double s_reg = 0.0, const Levels* now = nullptr, int status = -1)
 {   // returns the proposal's layer count (to every lane of the group)
     const int i = lane & 7, base = lane & ~7, K = o.max_layers;
+    const bool idle = o.schedule == 1 && (status >= 0 ? status : c.status[b]) != 0;
     if (k > 7 || K < 8) {                                        // (group-uniform)
         int kr_out = 0;
         if (i == 0) {
             Rng r(o.seed, chain_key(o, c, b), iter, 0);
             int action, idx;
             double val;
-            choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return e_row[j]; },
+            choose_move(o, r, k, idle, [&](int j) { return e_row[j]; },
                         [&](double depth) { int pos = 0; while (pos < k - 1 && e_row[pos] < depth) ++pos; return pos; }, action, idx, val);
             const int kr = k + (action == INSERT) - (action == DELETE);
             double above = 0.0;
@@ -387,17 +404,17 @@ __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains
                 c.thk_r[(size_t)b * K + j] = j < kr - 1 ? ev - above : 0.0;
                 above = ev;
             }
-            write_move(o, c, r, b, action, kr);
+            write_move(o, c, r, b, action, kr, now);
             kr_out = kr;
         }
         return __shfl(kr_out, base, 64);
     }
-    const double ej = i < k - 1 ? e_row[i] : INF;
-    const double sj = i < k ? s_row[i] : 1.0;
+    const double ej = i < k - 1 ? (have ? e_reg : e_row[i]) : INF;
+    const double sj = i < k ? (have ? s_reg : s_row[i]) : 1.0;
     Rng r(o.seed, chain_key(o, c, b), iter, 0);
     int action, idx;
     double val;
-    choose_move(o, r, k, o.schedule == 1 && c.status[b] != 0, [&](int j) { return __shfl(ej, base + j, 64); },
+    choose_move(o, r, k, idle, [&](int j) { return __shfl(ej, base + j, 64); },
                 [&](double depth) { return (int)__popcll((__ballot(ej < depth) >> base) & 0xFFull); }, action, idx, val);
     const int kr = k + (action == INSERT) - (action == DELETE);
     const int up = max(i - 1, 0), dn = min(i + 1, 7);
@@ -416,7 +433,7 @@ __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains
         c.thk_r[(size_t)b * K + j] = 0.0;
     }
     Rng r0 = r;
-    if (i == 0) write_move(o, c, r0, b, action, kr);
+    if (i == 0) write_move(o, c, r0, b, action, kr, now);
     return kr;
 }
 
@@ -885,6 +902,25 @@ __device__ __forceinline__ double group_bcast(double v, int base, int j)   // j:
 __device__ __forceinline__ double lane_up(double v) { return dpp_mov64<0x111>(v); }
 __device__ __forceinline__ double lane_dn(double v) { return dpp_mov64<0x101>(v); }
 
+// Interface widths of RectilinearMesh1D.gradient_operator (width_x) from the group's registers: lane j holds interface j of the chain
+// (+inf beyond the last) -- the same differences in the same order as width_x on the row in memory, without its dependent loads.
+__device__ __forceinline__ double prior_t2_group(const RjOpt& o, double e_i, int k, int i, int base)
+{
+    const double e_up = lane_up(e_i), e_dn = lane_dn(e_i);
+    const double e_km2 = __shfl(e_i, base + max(k - 2, 0), 64), e_km3 = __shfl(e_i, base + max(k - 3, 0), 64), e_0 = __shfl(e_i, base, 64);
+    double t2 = 0.0;
+    if (i < k - 1 && o.solve_gradient) {
+        const double w_i = e_i - (i > 0 ? e_up : 0.0);                                   // width_x(e, k, i): i < k - 1
+        double w_n;                                                                      // width_x(e, k, i + 1)
+        if (i + 1 < k - 1) w_n = e_dn - e_i;
+        else if (k == 2) w_n = e_0;
+        else w_n = (e_km2 - (k > 2 ? e_km3 : 0.0)) + e_km2;
+        const double c2c = 0.5 * (w_i + w_n) * (double)(k - 1);
+        t2 = o.gradient_precision / (c2c * c2c);
+    }
+    return t2;
+}
+
 // `b`: the chain of this lane's 8-lane group, or >= c.B for an idle group; sh_dyn: P[8][N] | PR[8][N].
 // KM: the algebra runs on the leading KM x KM block -- every chain of the wave has at most KM layers.  Rows and columns >= k are
 // identity rows: their Cholesky column is a unit vector, they add 0 x (finite) to every substitution step, so leaving them out
@@ -905,17 +941,68 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
     const double* e = c.edges_r + bb * K;
     double* P = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * 2 * N;
     double* PR = P + N;
-    data_weights8<TRIPS>(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, P, PR);
-    double t2 = 0.0;
-    if (i < k - 1 && o.solve_gradient) {
-        const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
-        t2 = o.gradient_precision / (c2c * c2c);
+    // Round 5: an iteration is the dependency chain of a sub-block's launches (docs/notes_r5.md), and this stage's 21 us were dependent
+    // trips to memory -- data and prediction, then the interface row walked through pointers, then sigma, then the Jacobian column in
+    // three batches -- with a library call (which waits for every outstanding load) between them.  ONE_TRIP (the lock-step launches, up to
+    // GBP_RJ_COLUMN_ROWS channels): everything is requested in one batch behind the move, the normal draws are formed while it is in
+    // flight (inlined: a call would wait for the loads first), the widths come from the group's registers.  Same arithmetic, same order.
+    constexpr int NJ = GBP_RJ_COLUMN_ROWS;
+    const bool one_trip = TRIPS && GBP_RJ_ONE_TRIP_NEWTON && N <= NJ;          // (wave-uniform)
+    double t2 = 0.0, lmp, ls = 0.0, z0 = 0.0, z1 = 0.0;
+    double Jc[TRIPS ? NJ : 1];
+    if (one_trip) {
+        const int ic = i < K ? i : 0;
+        const Levels lev = load_levels(o, c.rel, c.add, bb);
+        const double* data = c.data + bb * N;
+        double d_[3], p_[3], as_[3];
+        int rg_[3], ag_[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int n = min(i + 8 * u, N - 1);
+            d_[u] = data[n]; p_[u] = pred[n];
+            rg_[u] = c.rel_group != nullptr ? c.rel_group[n] : 0;
+            ag_[u] = c.add_group != nullptr ? c.add_group[n] : 0;
+            as_[u] = c.add_scale != nullptr ? c.add_scale[n] : 1.0;
+        }
+        const double e_i = e[ic];
+        const double sr_i = c.sigma_r[bb * K + ic];
+        lmp = c.log_mean_prior[bb];
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) Jc[n] = J[(size_t)min(n, N - 1) * K + ic];
+        if (i < 4) {                                                          // (normal_pair, inlined: the same routines, the same bits)
+            const U4 r = philox(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)i);
+            const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
+            const double rad = sqrt(-2.0 * log(1.0 - u1)), ang = TWO_PI * u2;
+            z0 = rad * cos(ang); z1 = rad * sin(ang);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                                         // data_weights8, channels i, i + 8, i + 16
+            const int n = i + 8 * u;
+            if (n < N) {
+                const double rd = pick4(lev.rel, rg_[u]) * d_[u];
+                double an = pick4(lev.add, ag_[u]);
+                if (c.add_scale != nullptr) an *= as_[u];
+                const double var = rd * rd + an * an;
+                const bool act = d_[u] > 0.0;
+                const double w = act ? 1.0 / var : 0.0;
+                P[n] = w;
+                PR[n] = act ? w * (p_[u] - d_[u]) : 0.0;
+            }
+        }
+        t2 = prior_t2_group(o, e_i, k, i, base);
+        ls = i < k ? log(sr_i) : 0.0;
+    } else {
+        data_weights8<TRIPS>(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, P, PR);
+        if (i < k - 1 && o.solve_gradient) {
+            const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
+            t2 = o.gradient_precision / (c2c * c2c);
+        }
+        lmp = c.log_mean_prior[bb];
+        ls = i < k ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
     }
     // (cross-lane reads are issued by all lanes -- a lane that sits out of the instruction cannot be read from)
     const double t2_sh = lane_up(t2);
     const double t2_up = i > 0 ? t2_sh : 0.0;
-    const double lmp = c.log_mean_prior[bb];
-    const double ls = i < k ? rj_log(c.sigma_r[bb * K + i]) : 0.0;
     const double v = i < k ? ls - lmp : 0.0;
     const double v_sh_up = lane_up(v), v_sh_dn = lane_dn(v);
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
@@ -924,12 +1011,20 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
     double g = 0.0;
 #pragma unroll
     for (int j = 0; j < KM; ++j) { arow[j] = 0.0; acol[j] = 0.0; }
-    for_column<TRIPS>(J, K, N, i, i < k && i < K, [&](int n, double Ji) {        // J'PJ and J'P r
+    auto jtpj = [&](int n, double Ji) {                                        // J'PJ and J'P r
         const double jp = Ji * P[n];
         g += Ji * PR[n];
 #pragma unroll
         for (int j = 0; j < KM; ++j) arow[j] += jp * group_bcast(Ji, base, j);
-    });
+    };
+    if (one_trip) {
+        const bool on = i < k && i < K;
+#pragma unroll
+        for (int n = 0; n < NJ; ++n)
+            if (n < N) jtpj(n, on ? Jc[n] : 0.0);                              // (wave-uniform bound)
+    } else {
+        for_column<TRIPS>(J, K, N, i, i < k && i < K, jtpj);
+    }
     {   // + Wm'Wm (tridiagonal), Wm'Wm (ln sigma - ln sigma_ref)
         const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
         const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
@@ -979,14 +1074,13 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
         return x;
     };
     const double step = backward(forward(g));        // (C C')^-1 g
-    double z0 = 0.0, z1 = 0.0;
-    if (i < 4) normal_pair(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)i, z0, z1);
+    if (!one_trip && i < 4) normal_pair(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)i, z0, z1);
     const double za = __shfl(z0, base + (i >> 1), 64), zb = __shfl(z1, base + (i >> 1), 64);
     const double w = backward((i & 1) ? zb : za);    // C^-T z
     if (live && i < K) {                             // (max_layers may be smaller than the group)
         const double lp = i < k ? (ls - o.alpha * step) + w : 0.0;
         c.log_prop[bb * K + i] = lp;
-        c.sigma_p[bb * K + i] = i < k ? rj_exp(lp) : 1.0;
+        c.sigma_p[bb * K + i] = i < k ? (one_trip ? exp(lp) : rj_exp(lp)) : 1.0;
         for (int j = i + 8; j < K; j += 8) { c.log_prop[bb * K + j] = 0.0; c.sigma_p[bb * K + j] = 1.0; }
     }
 }
@@ -1010,7 +1104,7 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
 // k_rj_newton: a launch of workgroups that mostly exit at once is faster with that kernel's 69 VGPRs than with the 125 of this one).
 // Which of the two owns a chain follows from what neither of them writes (k_r and the move), so they need no order between them.
 template <bool TRIPS>
-__global__ __launch_bounds__(64) void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter, int n_packed)
+__global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter, int n_packed)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups: see k_rj_newton)
@@ -1027,6 +1121,19 @@ __device__ inline double log_uniform_prior(double x, double llo, double lhi, dou
     return (lx >= llo && lx <= lhi) ? nlog_span : -INF;
 }
 
+template <bool INL>       // INL: log inlined (the one-trip accept stage: a call would wait for its loads in flight); same routine, same bits
+__device__ __forceinline__ double levels_log_prior_t(const double* x, int G, const double* llo, const double* lhi, const double* nlog_span)
+{
+    double p = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (g < G) {
+            const double lx = INL ? log(x[g]) : rj_log(x[g]);
+            p += (lx >= llo[g] && lx <= lhi[g]) ? nlog_span[g] : -INF;
+        }
+    return p;
+}
+
 __device__ inline double levels_log_prior(const double* x, int G, const double* llo, const double* lhi, const double* nlog_span)
 {
     double p = 0.0;
@@ -1037,21 +1144,23 @@ __device__ inline double levels_log_prior(const double* x, int G, const double* 
 }
 
 // Error-level posteriors (DataPoint.set_posteriors :651-694): n_error_bins cells uniform in log10 between the prior bounds.
-__device__ inline void error_hist_add(const RjOpt& o, const gbp_rj_chains& c, size_t b, const Levels& e)
-{
+__device__ inline void error_hist_add(const RjOpt& o, const gbp_rj_chains& c, size_t b, const Levels& e, bool fast = false)
+{   // (fast: logarithms inlined, counters as atomic adds nobody waits for -- the one-trip accept stage)
     if (c.rel_hist == nullptr) return;
     const double inv_ln10 = 0.43429448190325182765, nb = (double)o.n_error_bins;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g < o.n_rel_groups) {
             const double r0 = o.log_rel_min[g] * inv_ln10, r1 = o.log_rel_max[g] * inv_ln10;
-            const int ir = min(max((int)floor((rj_log(e.rel[g]) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
-            c.rel_hist[(b * o.n_rel_groups + g) * o.n_error_bins + ir] += 1;
+            const int ir = min(max((int)floor(((fast ? log(e.rel[g]) : rj_log(e.rel[g])) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
+            if (fast) atomicAdd(c.rel_hist + (b * o.n_rel_groups + g) * o.n_error_bins + ir, 1);
+            else c.rel_hist[(b * o.n_rel_groups + g) * o.n_error_bins + ir] += 1;
         }
         if (g < o.n_add_groups) {
             const double a0 = o.log_add_min[g] * inv_ln10, a1 = o.log_add_max[g] * inv_ln10;
-            const int ia = min(max((int)floor((rj_log(e.add[g]) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
-            c.add_hist[(b * o.n_add_groups + g) * o.n_error_bins + ia] += 1;
+            const int ia = min(max((int)floor(((fast ? log(e.add[g]) : rj_log(e.add[g])) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
+            if (fast) atomicAdd(c.add_hist + (b * o.n_add_groups + g) * o.n_error_bins + ia, 1);
+            else c.add_hist[(b * o.n_add_groups + g) * o.n_error_bins + ia] += 1;
         }
     }
 }
@@ -1086,11 +1195,15 @@ __device__ inline double group_sum8(double v)
 // own the chain (64: one wave per chain; 8: packed).  The post-step model (ec, sc, kc) is passed from where it came from
 // (the proposal buffers when accepted, the untouched state otherwise), never read back from what other lanes just wrote;
 // all lanes of a chain sit in one wave, so program order is the only ordering needed between them.
+// (have_regs, W == 8: entry i of the post-step rows is in e_now / s_now -- the interface histogram then costs no loads, and the counters
+//  are atomic adds whose result nobody waits for: the stage is a latency chain, every read-modify-write was a trip to memory)
 template <int W>
 __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, size_t b, int i,
                                    int kc, const double* ec, const double* sc, double post, double best_prev, double misfit_now,
-                                   const Levels& lev, double lmp, int dwell, double height_now, bool accepted)
+                                   const Levels& lev, double lmp, int dwell, double height_now, bool accepted, bool have_regs = false,
+                                   double e_now = 0.0, double s_now = 0.0)
 {
+    const double s_dn_reg = (W == 8 && have_regs) ? lane_dn(s_now) : 0.0;      // (issued by every lane of the wave's live groups)
     const int K = o.max_layers, N = o.n_channels;
     const size_t nh = (size_t)o.n_depth_bins * o.n_value_bins;
     bool reset_best = false;
@@ -1147,17 +1260,18 @@ __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32
     }
     if (accumulate) {
         if (i == 0) {
-            c.k_hist[b * (K + 1) + kc] += 1;
-            error_hist_add(o, c, b, lev);
+            if (have_regs) atomicAdd(c.k_hist + b * (K + 1) + kc, 1);
+            else c.k_hist[b * (K + 1) + kc] += 1;
+            error_hist_add(o, c, b, lev, have_regs);
             if (c.height_hist != nullptr) {                      // Point.set_z_posterior: the cells of the uniform prior
                 const double u = (height_now - (c.height0[b] - o.height_half_width)) / (2.0 * o.height_half_width);
                 if (u >= 0.0 && u <= 1.0) c.height_hist[b * o.n_error_bins + min((int)floor(u * (double)o.n_error_bins), o.n_error_bins - 1)] += 1;
             }
         }
         if (c.edge_hist != nullptr && i < kc - 1) {              // interfaces across which sigma changes by > 50 %
-            const double ratio = sc[i + 1] / sc[i];              //   (RectilinearMesh1D.update_posteriors :1595-1610)
+            const double ratio = have_regs ? s_dn_reg / s_now : sc[i + 1] / sc[i];              //   (RectilinearMesh1D.update_posteriors :1595-1610)
             if (ratio <= 0.5 || ratio >= 1.5) {
-                const int bin = min(max((int)floor(ec[i] / o.depth_bin_width), 0), o.n_depth_bins - 1);
+                const int bin = min(max((int)floor((have_regs ? e_now : ec[i]) / o.depth_bin_width), 0), o.n_depth_bins - 1);
                 atomicAdd(c.edge_hist + b * o.n_depth_bins + bin, 1);
             }
         }
@@ -1170,12 +1284,18 @@ __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32
         }
         if (i == 0) c.hit_dwell[b] = dwell;
     }
-    return (best_replaced ? 2 : 0) | (posteriors_reset ? 4 : 0) | (accumulate ? 8 : 0);     // (gbp_rj_chains.step_flags, bits 1-3)
+    return (best_replaced ? 2 : 0) | (posteriors_reset ? 4 : 0) | (accumulate ? 8 : 0) | (finished ? 16 : 0);     // (gbp_rj_chains.step_flags: bits 1-3; bit 4: callers only)
 }
 
 // What an accept stage tells the proposal that follows it in the same kernel (k_rj_step8): whether the move was taken and the layer count
 // the chain has now -- its rows are then the proposal's (edges_r, sigma_p) or the untouched current ones.
-struct StepState { bool accepted; int k_now; };
+struct StepState {
+    bool accepted; int k_now;
+    bool have;                 // the one-trip accept stage: entry i of the chain's rows as they are now, its error levels, its status
+    double e_now, s_now;
+    Levels lev_now;
+    int status;
+};
 
 __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains& c, uint32_t iter, int accumulate, int min_k, int b,
                                             int lane, unsigned char* sh_dyn, StepState* st = nullptr)
@@ -1322,7 +1442,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     const int bk = bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
                                    accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c,
                                    best_prev, accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept);
-    if (lane == 0 && c.step_flags != nullptr) c.step_flags[b] = (accept ? 1 : 0) | bk;
+    if (lane == 0 && c.step_flags != nullptr) c.step_flags[b] = (accept ? 1 : 0) | (bk & 15);
 }
 
 // (whether a chain is the wave-per-chain stage's: accept_body's own rule -- the layer counts before and after the proposal)
@@ -1371,15 +1491,28 @@ __device__ inline void hitmap_add8(const RjOpt& o, int32_t* hm, const double* ec
     }
 }
 
+// What the one-trip accept stage (accept8_body, round 5) requests in ONE batch behind the move and holds in registers: entry i of the
+// proposal's interface row, of the remapped conductivities and of the chain's current rows, row i and column i of the Cholesky factor,
+// column i of the Jacobian the move needs (at the proposal for a dimension change -- the reverse-move gradient, and the chain's new
+// Jacobian if the move is taken --, at the remapped model for a perturbation).
+struct Acc8Pre {
+    bool on;
+    double e_i, sigma_rem, ce_i, cs_i;
+    double cr[8], cc[8];
+    double Jc[GBP_RJ_COLUMN_ROWS];
+};
+
 // Reverse-move proposal density of the packed accept stage (Model.proposal_probabilities :577-659) on the leading KM x KM block:
 // every dimension-changing proposal of the wave has at most KM layers (rows >= k are identity rows, as in newton8_core).
 template <int KM, bool TRIPS>
 __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_chains& c, int i, int base, int k, size_t bb, bool jump,
-                                                  const double* e, double lpv, double lmp, const double* PR)
+                                                  const double* e, double lpv, double lmp, const double* PR, const Acc8Pre& pre)
 {
     const int K = o.max_layers, N = o.n_channels;
     double t2 = 0.0;
-    if (i < k - 1 && o.solve_gradient) {
+    if (pre.on) {
+        t2 = prior_t2_group(o, pre.e_i, k, i, base);
+    } else if (i < k - 1 && o.solve_gradient) {
         const double c2c = 0.5 * (width_x(e, k, i) + width_x(e, k, i + 1)) * (double)(k - 1);
         t2 = o.gradient_precision / (c2c * c2c);
     }
@@ -1390,8 +1523,14 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
     const double v_up = i > 0 ? v_sh_up : 0.0, v_dn = i < 7 ? v_sh_dn : 0.0;
     double arow[KM], acol[KM];
     const bool row = jump && i < k;
-    const double sigma_rem = c.sigma_r[bb * K + (i < K ? i : 0)];
-    {
+    const double sigma_rem = pre.on ? pre.sigma_rem : c.sigma_r[bb * K + (i < K ? i : 0)];
+    if (pre.on) {
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            arow[j] = (row && j <= i) ? pre.cr[j] : (j == i ? 1.0 : 0.0);
+            acol[j] = (row && j >= i && j < k) ? pre.cc[j] : (j == i ? 1.0 : 0.0);
+        }
+    } else {
         const double* C = c.chol + bb * K * K;
         if constexpr (TRIPS) {                       // row i and column i of the factor, requested unconditionally (ic, jc: entries
             const int ic = i < K ? i : 0;            //   every lane may read) and selected afterwards
@@ -1420,7 +1559,13 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
         const double single = o.value_precision + (o.solve_gradient ? o.gradient_precision : 0.0);
         const double diag = k == 1 ? single : o.value_precision + t2_up + t2;
         if (row) grad = diag * v - t2_up * v_up - t2 * v_dn;
-        for_column<TRIPS>(c.J_p + bb * N * K, K, N, i, row, [&](int n, double Jn) { if (row) grad += Jn * PR[n]; });
+        if (pre.on) {
+#pragma unroll
+            for (int n = 0; n < GBP_RJ_COLUMN_ROWS; ++n)
+                if (n < N && row) grad += pre.Jc[n] * PR[n];
+        } else {
+            for_column<TRIPS>(c.J_p + bb * N * K, K, N, i, row, [&](int n, double Jn) { if (row) grad += Jn * PR[n]; });
+        }
     }
 #pragma unroll
     for (int j = 0; j < KM; ++j) {                   // C y = grad
@@ -1436,7 +1581,7 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
     }
     const double mean_r = lpv + o.alpha * grad;
     const bool bad = row && !(fabs(mean_r) < 11356.0);
-    const double lrem = row ? rj_log(sigma_rem) : 0.0;
+    const double lrem = row ? (pre.on ? log(sigma_rem) : rj_log(sigma_rem)) : 0.0;
     const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
     double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
 #pragma unroll
@@ -1467,9 +1612,53 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     if (!live) k = 0;
     const int action = live ? action_bb : NONE;
     const bool jump = action == INSERT || action == DELETE;
-    const bool frozen = o.schedule == 1 && c.status[bb] != 0;
+    const int status_bb = o.schedule == 1 ? c.status[bb] : 0;
+    const bool frozen = o.schedule == 1 && status_bb != 0;
     const double* e = c.edges_r + bb * K;
     const double lmp = c.log_mean_prior[bb];
+    // Round 5, ONE TRIP (the lock-step launches, up to GBP_RJ_COLUMN_ROWS channels; docs/notes_r5.md): an iteration is the chain of a
+    // sub-block's dependent launches and this stage was ~20 dependent trips to memory with library calls (which wait for every load in
+    // flight) between them.  Everything the decision, the state update, the posteriors and the proposal that follows can need is requested
+    // HERE in one batch, logarithms and the generator are inlined, counters are atomic adds nobody waits for.  Same arithmetic, same order.
+    constexpr int NJ = GBP_RJ_COLUMN_ROWS;
+    const bool one_trip = TRIPS && GBP_RJ_ONE_TRIP_ACCEPT && N <= NJ;          // (wave-uniform)
+    Acc8Pre pre;
+    pre.on = one_trip;
+    Levels lev_p1;
+    double d_[3], p_[3], as_[3];
+    int rg_[3], ag_[3];
+    if (one_trip) {
+        const int ic1 = i < K ? i : 0;
+        lev_p1 = load_levels(o, c.rel_p, c.add_p, bb);
+        const double* pp = c.pred_p + bb * N;
+        const double* ob = c.data + bb * N;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int n = min(i + 8 * u, N - 1);
+            d_[u] = ob[n]; p_[u] = pp[n];
+            rg_[u] = c.rel_group != nullptr ? c.rel_group[n] : 0;
+            ag_[u] = c.add_group != nullptr ? c.add_group[n] : 0;
+            as_[u] = c.add_scale != nullptr ? c.add_scale[n] : 1.0;
+        }
+        pre.e_i = e[ic1];
+        pre.sigma_rem = c.sigma_r[bb * K + ic1];
+        pre.ce_i = c.edges[bb * K + ic1];
+        pre.cs_i = c.sigma[bb * K + ic1];
+        if (__ballot(jump) != 0ull) {                                         // (wave-uniform)
+            const double* C = c.chol + bb * K * K;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int jc = j < K ? j : 0;
+                pre.cr[j] = C[(size_t)ic1 * K + jc];
+                pre.cc[j] = C[(size_t)jc * K + ic1];
+            }
+        }
+        if (__ballot(action != NONE) != 0ull) {
+            const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) pre.Jc[n] = Js[(size_t)min(n, N - 1) * K + ic1];
+        }
+    }
     // everything the decision reads from the chain's rows is requested here, unconditionally (column ic: one every lane may read),
     // and selected where it is used: one trip to memory for all of it
     const int ic = i < K ? i : 0;
@@ -1490,7 +1679,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     if (o.solve_gradient) {
         double g = 0.0;
-        if (i < k - 1) g = (lpv_dn - lpv) / rj_log(thk_ic);
+        if (i < k - 1) g = (lpv_dn - lpv) / (one_trip ? log(thk_ic) : rj_log(thk_ic));
         const double g2 = group_sum8(g * g);
         const double n = (double)max(1, k - 1);
         prior_p += -0.5 * n * LOG_2PI + 0.5 * n * o.log_gradient_precision - 0.5 * o.gradient_precision * g2;
@@ -1500,16 +1689,41 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
         const unsigned long long out = __ballot(!(sp >= o.value_min && sp <= o.value_max));
         if ((out >> base) & 0xFFull) prior_p = -INF;
     }
-    const Levels lev_p = load_levels(o, c.rel_p, c.add_p, bb);
-    if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
-    if (o.solve_additive_error && !o.additive_independent)
-        prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    const Levels lev_p = one_trip ? lev_p1 : load_levels(o, c.rel_p, c.add_p, bb);
+    if (one_trip) {
+        if (o.solve_relative_error) prior_p += levels_log_prior_t<true>(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
+        if (o.solve_additive_error && !o.additive_independent)
+            prior_p += levels_log_prior_t<true>(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    } else {
+        if (o.solve_relative_error) prior_p += levels_log_prior(lev_p.rel, o.n_rel_groups, o.log_rel_min, o.log_rel_max, o.nlog_rel_span);
+        if (o.solve_additive_error && !o.additive_independent)
+            prior_p += levels_log_prior(lev_p.add, o.n_add_groups, o.log_add_min, o.log_add_max, o.nlog_add_span);
+    }
     if (o.solve_height) prior_p += o.nlog_height_span;           // Point.probability: the proposal is inside the uniform prior by construction
     prior_p += o.extra_log_prior;
     // dimension-changing proposals: data weights at the proposal, chi^2 / logL of the prediction that came with the Jacobian
     double* PR = reinterpret_cast<double*>(sh_dyn) + (size_t)slot * N;
     double s2 = 0.0, logdet = 0.0, na = 0.0;
-    if (jump) {
+    if (jump && one_trip) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                                         // (for_channels8's channels i, i + 8, i + 16 from the registers)
+            const int n = i + 8 * u;
+            if (n < N) {
+                const double rd = pick4(lev_p.rel, rg_[u]) * d_[u];
+                double an = pick4(lev_p.add, ag_[u]);
+                if (c.add_scale != nullptr) an *= as_[u];
+                const double var = rd * rd + an * an;
+                const double ov = d_[u], pn = p_[u];
+                double pr = 0.0;
+                if (ov > 0.0) {
+                    const double r = (pn - ov) * (1.0 / sqrt(var));
+                    s2 += r * r; logdet += log(var); na += 1.0;
+                    pr = (1.0 / var) * (pn - ov);
+                }
+                PR[n] = pr;
+            }
+        }
+    } else if (jump) {
         const double* pp = c.pred_p + bb * N;
         const double* ob = c.data + bb * N;
         for_channels8<TRIPS>(c, ob, pp, lev_p, N, i, [&](int n, double ov, double pn, double var) {
@@ -1529,16 +1743,25 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     double dq = 0.0;
     {   // (wave-uniform: the cross-lane reads inside are issued by all 64 lanes; sized by the deepest jump of the wave)
         const unsigned long long any = __ballot(jump), deep4 = __ballot(jump && k > 4), deep2 = __ballot(jump && k > 2);
-        if (deep4 != 0ull) dq = accept8_reverse<8, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
-        else if (deep2 != 0ull) dq = accept8_reverse<4, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
-        else if (any != 0ull) dq = accept8_reverse<2, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR);
+        if (deep4 != 0ull) dq = accept8_reverse<8, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR, pre);
+        else if (deep2 != 0ull) dq = accept8_reverse<4, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR, pre);
+        else if (any != 0ull) dq = accept8_reverse<2, TRIPS>(o, c, i, base, k, bb, jump, e, lpv, lmp, PR, pre);
     }
     const double misfit_p = jump ? s2 : misfit_p0;
     const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : like_p0;
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
-    const U4 rr = philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
-    const bool accept = live && !frozen && rj_log(u53(rr.x, rr.y)) < log_ratio;
-    if (st != nullptr) { st->accepted = accept; st->k_now = accept ? k : k_prev; }
+    const U4 rr = one_trip ? philox(o.seed, chain_key(o, c, b), iter, 2, 0) : philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
+    const bool accept = live && !frozen && (one_trip ? log(u53(rr.x, rr.y)) : rj_log(u53(rr.x, rr.y))) < log_ratio;
+    if (st != nullptr) {
+        st->accepted = accept; st->k_now = accept ? k : k_prev;
+        st->have = one_trip;
+        if (one_trip) {
+            st->e_now = accept ? pre.e_i : pre.ce_i;
+            st->s_now = accept ? sp_ic : pre.cs_i;
+            st->lev_now = accept ? lev_p : lev_c;
+            st->status = status_bb;
+        }
+    }
     if (live && i == 0) c.log_ratio[bb] = log_ratio;
     if (live && frozen && i == 0 && c.step_flags != nullptr) c.step_flags[bb] = 0;
     if (!live || frozen) return;                     // (below: cross-lane reads only within a chain's own group)
@@ -1550,7 +1773,21 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
         hitmap_add8(o, c.hitmap + bb * nh, c.edges + bb * K, c.sigma + bb * K, k_prev, lmp, i, base, dwell, on);
         if (on) dwell = 0;
     }
-    if (accept) {
+    if (accept && one_trip) {
+        // (stores only: entry i of the rows is in registers; beyond the group's 8 entries the proposal's rows of a model of at most 8
+        //  layers hold the empty entries every proposal / Newton kernel writes there: +inf and 1)
+        if (i < K) { c.edges[bb * K + i] = pre.e_i; c.sigma[bb * K + i] = sp_ic; }
+        for (int j = i + 8; j < K; j += 8) { c.edges[bb * K + j] = INF; c.sigma[bb * K + j] = 1.0; }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (i + 8 * u < N) c.pred[bb * N + i + 8 * u] = p_[u];
+        if (action != NONE && i < K) {
+            double* Jd = c.J + bb * N * K;
+#pragma unroll
+            for (int n = 0; n < NJ; ++n)
+                if (n < N) Jd[(size_t)n * K + i] = pre.Jc[n];
+        }
+    } else if (accept) {
         copy_strided8<TRIPS>(c.edges + bb * K, e, c.sigma + bb * K, c.sigma_p + bb * K, K, i);
         copy_strided8<TRIPS>(c.pred + bb * N, c.pred_p + bb * N, nullptr, nullptr, N, i);
         if (action != NONE) {
@@ -1560,6 +1797,8 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
             for_column<TRIPS>((action == PERTURB ? c.J_r : c.J_p) + bb * N * K, K, N, i, i < K,
                               [&](int n, double v) { if (i < K) Jd[(size_t)n * K + i] = v; });
         }
+    }
+    if (accept) {
         if (i == 0) {
             c.k[bb] = k;
 #pragma unroll
@@ -1568,18 +1807,21 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
                 if (g < o.n_add_groups) c.add[bb * o.n_add_groups + g] = lev_p.add[g];
             }
             c.prior[bb] = prior_p; c.like[bb] = like_p; c.misfit[bb] = misfit_p;
-            c.n_accepted[bb] += 1;
+            if (one_trip) atomicAdd(reinterpret_cast<unsigned long long*>(c.n_accepted + bb), 1ull);
+            else c.n_accepted[bb] += 1;
             if (o.solve_height) const_cast<double*>(c.height)[bb] = height_now;
         }
     }
     const int bk = bookkeeping<8>(o, c, iter, accumulate, bb, i, accept ? k : k_prev, accept ? e : c.edges + bb * K,
                                   accept ? c.sigma_p + bb * K : c.sigma + bb * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
-                                  accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept);
-    if (i == 0 && c.step_flags != nullptr) c.step_flags[bb] = (accept ? 1 : 0) | bk;
+                                  accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept, one_trip,
+                                  accept ? pre.e_i : pre.ce_i, accept ? sp_ic : pre.cs_i);
+    if (st != nullptr && (bk & 16)) st->status = 1;             // (the chain stopped in this very iteration: its next proposal is the idle one)
+    if (i == 0 && c.step_flags != nullptr) c.step_flags[bb] = (accept ? 1 : 0) | (bk & 15);
 }
 
 template <bool TRIPS>
-__global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed)
+__global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed)
 {   // (workgroups as in k_rj_newton8)
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups)
@@ -1603,7 +1845,7 @@ __global__ __launch_bounds__(64) void k_rj_accept8(RjOpt o, gbp_rj_chains c, uin
 __device__ __forceinline__ int32_t step_is_deep(int k_now, int kr) { return max(k_now, kr) > 8 ? 1 : 0; }
 
 template <bool TRIPS>
-__global__ __launch_bounds__(64) void k_rj_step8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed,
+__global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_step8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed,
                                                  const int32_t* __restrict__ deep_cur, int32_t* __restrict__ deep_next)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
@@ -1611,7 +1853,7 @@ __global__ __launch_bounds__(64) void k_rj_step8(RjOpt o, gbp_rj_chains c, uint3
     if ((int)blockIdx.x >= n_packed) {                 // the deep chains' scanning workgroups
         const int g = (int)blockIdx.x - n_packed, bl = g * 64 + lane;
         for_deep_chains(g, bl < c.B && deep_cur[min(bl, c.B - 1)] != 0, [&](int bb) {
-            StepState st{false, 0};
+            StepState st{};
             const int k_before = c.k[bb];
             const bool frozen = o.schedule == 1 && c.status[bb] != 0;
             accept_body(o, c, iter, accumulate, 0, bb, lane, sh_dyn, &st);
@@ -1627,7 +1869,7 @@ __global__ __launch_bounds__(64) void k_rj_step8(RjOpt o, gbp_rj_chains c, uint3
     }
     const int b = (int)blockIdx.x * 8 + (lane >> 3);
     const bool mine = b < c.B && deep_cur[min(b, c.B - 1)] == 0;
-    StepState st{false, 0};
+    StepState st{};
     const int bq = min(b, c.B - 1);
     const int k_before = c.k[bq];
     const bool frozen = o.schedule == 1 && c.status[bq] != 0;
@@ -1637,7 +1879,8 @@ __global__ __launch_bounds__(64) void k_rj_step8(RjOpt o, gbp_rj_chains c, uint3
     if (mine) {                                        // (group-uniform; the reads inside stay within the chain's own 8 lanes)
         const double* e_row = (st.accepted ? c.edges_r : c.edges) + (size_t)b * K;
         const double* s_row = (st.accepted ? c.sigma_p : c.sigma) + (size_t)b * K;
-        const int kr = propose8_body(o, c, iter + 1, lane, b, st.k_now, e_row, s_row);
+        const int kr = propose8_body(o, c, iter + 1, lane, b, st.k_now, e_row, s_row, st.have, st.e_now, st.s_now, st.have ? &st.lev_now : nullptr,
+                                     st.have ? st.status : -1);
         if ((lane & 7) == 0) deep_next[b] = step_is_deep(st.k_now, kr);
     }
 }
@@ -2947,40 +3190,53 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         GBP_HIP(hipGetDevice(&dev));
         std::vector<gbp_status> pst(P, GBP_OK);
         std::vector<std::string> perr(P);
-        auto run_part = [&](int p) {
-            if (p > 0 && hipSetDevice(dev) != hipSuccess) { pst[p] = GBP_ERR_HIP; perr[p] = "hipSetDevice failed in a sub-block thread"; return; }
+        // the launches of ONE iteration of sub-block p
+        auto issue = [&](int p, int it) -> gbp_status {
             const Part& t = part[p];
-            gbp_status s2 = GBP_OK;
             const bool step = fused_step && t.flags != nullptr && t.c.B > 0;
             const int nB = t.c.B;
-            for (int it = 0; it < n_iterations && s2 == GBP_OK; ++it) {
-                const int64_t iter = first_iteration + it;
-                if (it == 0 || !step) {
-                    if ((s2 = gbp_rj_propose(&t.o, &t.c, iter, t.q)) != GBP_OK) break;
-                    if (step) hipLaunchKernelGGL(rj::k_rj_propose_flags, dim3((nB + 255) / 256), dim3(256), 0, t.q, t.c, t.flags);
-                }
-                physics(t, 0);                                // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
-                if ((s2 = gbp_rj_newton(&t.o, &t.c, iter, t.q)) != GBP_OK) break;
-                physics(t, 1);                                // Inference1D.py:572-597 / Model.py:612: every proposal's evaluation
-                if (step && it + 1 < n_iterations) {          // accept + the next iteration's proposal in one launch (k_rj_step8)
-                    const int n_packed = (nB + 7) / 8, n_deep = K > 8 ? (nB + 63) / 64 : 0;
-                    const size_t lds = std::max((size_t)8 * o->n_channels * sizeof(double), n_deep ? rj::Lds::bytes(K, o->n_channels) : (size_t)0);
-                    const int32_t* cur = t.flags + (size_t)(it & 1) * nB;
-                    int32_t* nxt = t.flags + (size_t)((it + 1) & 1) * nB;
-                    if (packed_trips(nB))
-                        hipLaunchKernelGGL(rj::k_rj_step8<true>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
-                                           n_packed, cur, nxt);
-                    else
-                        hipLaunchKernelGGL(rj::k_rj_step8<false>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
-                                           n_packed, cur, nxt);
-                } else {
-                    s2 = gbp_rj_accept(&t.o, &t.c, iter, accumulate, t.q);
-                }
+            const int64_t iter = first_iteration + it;
+            gbp_status s3;
+            if (it == 0 || !step) {
+                if ((s3 = gbp_rj_propose(&t.o, &t.c, iter, t.q)) != GBP_OK) return s3;
+                if (step) hipLaunchKernelGGL(rj::k_rj_propose_flags, dim3((nB + 255) / 256), dim3(256), 0, t.q, t.c, t.flags);
             }
+            physics(t, 0);                                    // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
+            if ((s3 = gbp_rj_newton(&t.o, &t.c, iter, t.q)) != GBP_OK) return s3;
+            physics(t, 1);                                    // Inference1D.py:572-597 / Model.py:612: every proposal's evaluation
+            if (step && it + 1 < n_iterations) {              // accept + the next iteration's proposal in one launch (k_rj_step8)
+                const int n_packed = (nB + 7) / 8, n_deep = K > 8 ? (nB + 63) / 64 : 0;
+                const size_t lds = std::max((size_t)8 * o->n_channels * sizeof(double), n_deep ? rj::Lds::bytes(K, o->n_channels) : (size_t)0);
+                const int32_t* cur = t.flags + (size_t)(it & 1) * nB;
+                int32_t* nxt = t.flags + (size_t)((it + 1) & 1) * nB;
+                if (packed_trips(nB))
+                    hipLaunchKernelGGL(rj::k_rj_step8<true>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
+                                       n_packed, cur, nxt);
+                else
+                    hipLaunchKernelGGL(rj::k_rj_step8<false>, dim3(n_packed + n_deep), dim3(64), lds, t.q, rj::extend(t.o), t.c, (uint32_t)iter, accumulate,
+                                       n_packed, cur, nxt);
+                return GBP_OK;
+            }
+            return gbp_rj_accept(&t.o, &t.c, iter, accumulate, t.q);
+        };
+        auto run_part = [&](int p) {
+            if (p > 0 && hipSetDevice(dev) != hipSuccess) { pst[p] = GBP_ERR_HIP; perr[p] = "hipSetDevice failed in a sub-block thread"; return; }
+            gbp_status s2 = GBP_OK;
+            for (int it = 0; it < n_iterations && s2 == GBP_OK; ++it) s2 = issue(p, it);
             if (s2 == GBP_OK && hipGetLastError() != hipSuccess) s2 = GBP_ERR_HIP;
             pst[p] = s2;
             if (s2 != GBP_OK) perr[p] = gbp_last_error();      // (the message is per host thread: hand it to the caller's)
         };
+#ifdef GBP_RJ_SINGLE_ISSUER
+        {   // (A/B builds only: the caller's thread issues for every sub-block in turn)
+            gbp_status s2 = GBP_OK;
+            for (int it = 0; it < n_iterations && s2 == GBP_OK; ++it)
+                for (int p = 0; p < P && s2 == GBP_OK; ++p) s2 = issue(p, it);
+            if (s2 == GBP_OK && hipGetLastError() != hipSuccess) s2 = GBP_ERR_HIP;
+            pst[0] = s2;
+            if (s2 != GBP_OK) perr[0] = gbp_last_error();
+        }
+#else
         {
             // (std::thread's constructor throws std::system_error when the process is out of threads: nothing may leave an
             //  extern "C" entry -- the sub-blocks that got no thread run on the caller's, after its own)
@@ -2994,6 +3250,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             for (int p : inline_parts) run_part(p);
             for (auto& w : workers) w.join();
         }
+#endif
         for (int p = 0; p < P; ++p)
             if (pst[p] != GBP_OK && st == GBP_OK) st = fail(pst[p], "sampler sub-block: %s", perr[p].c_str());
         const hipError_t le = hipGetLastError();

@@ -50,7 +50,7 @@ m_timed = re.search(r"warm-up \+ (\d+)", line)
 n_timed = int(m_timed.group(1)) if m_timed else None
 sq, fe, wr = counters("pmc_sq"), counters("pmc_fetch"), counters("pmc_write")
 total_ns = sum(sum(v) for v in dur.values())
-out = {"case": case, "command": "python scripts/prof_case.py %s under rocprofv3 (profiles/run_profile_r4.sh)" % case, "run": line, "kernels": {}}
+out = {"case": case, "command": "python scripts/prof_case.py %s under rocprofv3 (profiles/run_profile_%s.sh)" % (case, rnd), "run": line, "kernels": {}}
 for k in sorted(dur, key=lambda k: -sum(dur[k])):
     n = len(dur[k])
     d = {"launches": n, "avg_us": sum(dur[k]) / n / 1e3, "share_of_kernel_time": sum(dur[k]) / total_ns}
