@@ -121,11 +121,17 @@ __device__ __forceinline__ void wave_sync()
 #ifndef GBP_RJ_COLUMN_ROWS
 #define GBP_RJ_COLUMN_ROWS 24
 #endif
-#ifndef GBP_RJ_ONE_TRIP_NEWTON          // (A/B switches of the two one-trip stages)
-#define GBP_RJ_ONE_TRIP_NEWTON 1
+// The one-trip variants of the packed Newton / accept stages (everything requested in one batch behind the move, logarithms and the
+// generator inlined, interface widths from the group's registers, counters as atomic adds) are measurement variants, OFF in the product:
+// same-box A/B (scripts/ab_rj.py, M chain-it/s, off | Newton | accept | both): 8 192 chains 44.25 | 44.26 | 44.32 | 44.56, 4 096: 30.62 |
+// 30.53 | 30.38 | 30.31, 2 048: 21.01 | 21.18 | 21.06 | 21.33 -- + 1 % at best -- against + 30 MB of HBM traffic per iteration of 8 192
+// chains (203 vs 173 MB: the batch requests what the plain code skipped) and kernels no shorter under the profiler (Newton 25.5 vs 21 us,
+// accept + proposal 46.9 vs 44.2 us).  docs/notes_r5.md.
+#ifndef GBP_RJ_ONE_TRIP_NEWTON
+#define GBP_RJ_ONE_TRIP_NEWTON 0
 #endif
 #ifndef GBP_RJ_ONE_TRIP_ACCEPT
-#define GBP_RJ_ONE_TRIP_ACCEPT 1
+#define GBP_RJ_ONE_TRIP_ACCEPT 0
 #endif
 __device__ GBP_RJ_CALL double rj_log(double x) { return log(x); }
 __device__ GBP_RJ_CALL double rj_exp(double x) { return exp(x); }
@@ -3125,7 +3131,10 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             // beyond.  (More than four -- a 320- or 384-thread launch bound -- is 30 % slower at every size.)  With three sub-blocks
             // in flight (2 / 3 / 4 waves, block = 3 n): n = 1 707: - / 35.0 / 34.7 | - / 39.0 / 39.4;  2 048: 35.9 38.0 37.2 | 43.0 44.6
             // 43.6;  2 731: 43.6 44.1 41.3 | 51.3 49.7 48.1;  3 413: 47.8 44.6 43.7 | 56.4 51.8 50.0.
-            t.nw = std::min(n <= 1792 ? 4 : (n <= 2400 ? 3 : 2), GBP_RJ_PHYSICS_MAX_WAVES);
+            // Round 5, re-measured with four launches per iteration (scripts/ab_rj.py, one box, 2 / 3 / 4 waves, ten frequencies, block = 3 n):
+            // n = 910: 23.4 25.4 25.6;  1 365: 31.3 32.2 30.6;  1 820: 37.3 36.2 33.8;  2 731: 44.1 40.5 38.0 -- with a shorter chain per
+            // sub-block the physics launches of the three overlap more, and the switch points move down.
+            t.nw = std::min(n <= 1100 ? 4 : (n <= 1600 ? 3 : 2), GBP_RJ_PHYSICS_MAX_WAVES);
 #ifdef GBP_RJ_PHYSICS_NW
             t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
 #endif
