@@ -399,16 +399,18 @@ __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains
                         [&](double depth) { int pos = 0; while (pos < k - 1 && e_row[pos] < depth) ++pos; return pos; }, action, idx, val);
             const int kr = k + (action == INSERT) - (action == DELETE);
             double above = 0.0;
-            for (int j = 0; j < K; ++j) {                        // (rows read from e_row / s_row, written to the _r rows: never the same arrays)
-                const double e_j = j < k - 1 ? e_row[j] : INF, s_j = j < k ? s_row[j] : 1.0;
-                const double e_up = j > 0 ? (j - 1 < k - 1 ? e_row[j - 1] : INF) : e_j, s_up = j > 0 ? (j - 1 < k ? s_row[j - 1] : 1.0) : s_j;
-                const double e_dn = j + 1 < K ? (j + 1 < k - 1 ? e_row[j + 1] : INF) : e_j, s_dn = j + 1 < K ? (j + 1 < k ? s_row[j + 1] : 1.0) : s_j;
+            // (a rolling window over the rows, as propose_rows: behind an accepted move e_row IS the chain's row of edges_r, which this
+            //  loop rewrites -- entry j is written after entry j + 1 has been read, and the entry above comes from the window)
+            double e_j = 0 < k - 1 ? e_row[0] : INF, s_j = 0 < k ? s_row[0] : 1.0, e_up = e_j, s_up = s_j;
+            for (int j = 0; j < K; ++j) {
+                const double e_dn = j + 1 < k - 1 ? e_row[j + 1] : INF, s_dn = j + 1 < k ? s_row[j + 1] : 1.0;
                 double ev, sv;
-                remap_entry(action, idx, val, kr, j, e_j, e_up, e_dn, s_j, s_up, s_dn, ev, sv);
+                remap_entry(action, idx, val, kr, j, e_j, e_up, j + 1 < K ? e_dn : e_j, s_j, s_up, j + 1 < K ? s_dn : s_j, ev, sv);
                 c.edges_r[(size_t)b * K + j] = ev;
                 c.sigma_r[(size_t)b * K + j] = sv;
                 c.thk_r[(size_t)b * K + j] = j < kr - 1 ? ev - above : 0.0;
                 above = ev;
+                e_up = e_j; s_up = s_j; e_j = e_dn; s_j = s_dn;
             }
             write_move(o, c, r, b, action, kr, now);
             kr_out = kr;

@@ -650,6 +650,7 @@ def test_height_move_on_the_device_equals_cpu_chains_with_the_same_seeds():
 @pytest.mark.gpu
 @pytest.mark.parametrize("exact,kw", [(True, dict()), (False, dict()),
                                       (True, dict(options=dict(maximum_number_of_layers=8, probability_of_birth=0.4))),
+                                      (False, dict(options=dict(maximum_number_of_layers=5, probability_of_birth=0.4))),    # (rows shorter than the packed stages' 8-lane group)
                                       (True, dict(reference_schedule=True, burn_in_min_iterations=60, hitmap=True, n_value_bins=20,
                                                   options=dict(n_markov_chains=150)))])
 def test_persistent_kernel_walks_the_same_chains(exact, kw):
