@@ -155,37 +155,61 @@ __device__ __forceinline__ int table_slot(double alt, int set, int bin0, int n_b
     return n_bins + (set - 1) * (n_bins + 1) + (binned ? 1 + bi : 0);
 }
 
-#ifndef GBP_WAVE_SUM_BPERMUTE
-// Sum over the 64 lanes, returned to every lane as a wave-uniform value.  DPP tree (quad swaps, half-row and row mirrors, row
-// broadcasts: VALU moves, no LDS crossbar round trips), total read from lane 63 with v_readlane.
+// Sums over the 64 lanes by ONE balanced tree over the lane index (partners lane ^ 1, ^ 2, ^ 4, ... ^ 32): fp64 addition commutes,
+// so every implementation of that tree below returns the same bits.
+//   dpp_get<CTRL>: the value the DPP control names (VALU moves, no LDS crossbar round trip); lanes without a source read +0.0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v)
+__device__ __forceinline__ double dpp_add_rows(double v)      // (masked-off rows add +0.0)
 {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, CTRL, ROW_MASK, 0xf, false);
     const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
-    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // (masked-off rows add +0.0)
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// Sum of v, returned to every lane as a wave-uniform value.  Quad swaps, then row shifts by 4 and 8 (lanes 12 - 15 of a row hold the
+// row's sum), then the previous row's lane 15 broadcast into rows 1 - 3 and lane 31 into rows 2 - 3: lane 63 holds the total.
 __device__ __forceinline__ double wave_sum(double v)
 {
-    v = dpp_add<0xB1, 0xf>(v);       // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);       // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);      // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);      // row_mirror: every lane of a row holds the row's sum
-    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 -> rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 -> rows 2 and 3: lane 63 holds the total
+    v += dpp_get<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_get<0x114>(v);      // row_shr:4
+    v += dpp_get<0x118>(v);      // row_shr:8
+    v = dpp_add_rows<0x142, 0xa>(v);     // row_bcast:15 -> rows 1 and 3
+    v = dpp_add_rows<0x143, 0xc>(v);     // row_bcast:31 -> rows 2 and 3: lane 63 holds the total
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-#else
-__device__ __forceinline__ double wave_sum(double v)
+// Sums of a AND b with one tree instead of two: after the first exchange the even lanes carry a's partial sums and the odd lanes b's
+// (the partner of an even lane sends its a, the partner of an odd lane its b), every later step pairs lanes of the same parity.
+// Returns, in lane 62, the sum of a and, in lane 63, the sum of b -- the bits wave_sum(a) / wave_sum(b) return.  (The cross-row steps
+// go through the LDS crossbar: row_bcast only broadcasts lane 15, an odd one.)  ~24 VALU issues against 2 x 32.
+__device__ __forceinline__ double wave_sum_pair(double a, double b, int lane)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const bool odd = lane & 1;
+    double v = odd ? b : a;
+    v += dpp_get<0xB1>(odd ? a : b);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x114>(v);
+    v += dpp_get<0x118>(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
-#endif
+// ... stored as one complex number (lanes 62 and 63 write their halves)
+__device__ __forceinline__ void wave_sum_store(double re, double im, int lane, cplx* dst)
+{
+    const double v = wave_sum_pair(re, im, lane);
+    if (lane >= 62) reinterpret_cast<double*>(dst)[lane - 62] = v;
+}
 
 // Smallest conductivity of the sounding (wave-uniform, returned in SGPRs; each wave of the workgroup evaluates it).
 __device__ __forceinline__ double wave_min_sigma(const double* __restrict__ sig, int L, int lane)
@@ -268,12 +292,10 @@ __device__ __forceinline__ void forward_passes(const gbp::MathCtx& M, const Chan
         const bool real_ue = __ballot(pt.ue.im != 0.0) == 0ull;            // (wave-uniform: see hankel_term)
         const cplx t = gbp::hankel_term(M, num, den, pt.ue, hD, pt.coef, real_ue);
         if (has_next) {
-            const double sr = wave_sum(in_next ? 0.0 : t.re), si = wave_sum(in_next ? 0.0 : t.im);
-            const double nr = wave_sum(in_next ? t.re : 0.0), ni = wave_sum(in_next ? t.im : 0.0);
-            if (lane == 0) { sh_part[2 * p] = gbp::mk(sr, si); sh_part[2 * p + 1] = gbp::mk(nr, ni); }
+            wave_sum_store(in_next ? 0.0 : t.re, in_next ? 0.0 : t.im, lane, sh_part + 2 * p);
+            wave_sum_store(in_next ? t.re : 0.0, in_next ? t.im : 0.0, lane, sh_part + 2 * p + 1);
         } else {
-            const double sr = wave_sum(t.re), si = wave_sum(t.im);
-            if (lane == 0) sh_part[2 * p] = gbp::mk(sr, si);
+            wave_sum_store(t.re, t.im, lane, sh_part + 2 * p);
         }
         if (base + 64 >= end_cur) {   // frequency `cur` has no points beyond this pass
             ++cur;
@@ -485,11 +507,10 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                 __builtin_amdgcn_wave_barrier();
             }
             if (pred_row != nullptr && m0 == 0) {  // one wave owns the frequency: fixed summation order for any launch shape
-                const double sr = wave_sum(fw_re), si = wave_sum(fw_im);
-                if (lane == 0) {
-                    pred_row[f] = ch.g_re * sr - ch.g_im * si;
-                    pred_row[F + f] = ch.g_re * si + ch.g_im * sr;
-                }
+                const double mine = wave_sum_pair(fw_re, fw_im, lane);   // lane 62: the real sum, lane 63: the imaginary one
+                const double other = dpp_get<0xB1>(mine);
+                if (lane == 62) pred_row[f] = ch.g_re * mine - ch.g_im * other;
+                if (lane == 63) pred_row[F + f] = ch.g_re * mine + ch.g_im * other;
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {

@@ -28,7 +28,7 @@ def per_call(fn, n):
     return (time.perf_counter() - t0) / n
 
 G = os.path.join(ROOT, "tests", "golden")
-OPTS = dict(maximum_number_of_layers=30, minimum_depth=1.0, maximum_depth=150.0, initial_relative_error=0.05,
+OPTS = dict(maximum_number_of_layers=int(os.environ.get("GBP_PROF_K", "30")), minimum_depth=1.0, maximum_depth=150.0, initial_relative_error=0.05,
             minimum_relative_error=0.001, maximum_relative_error=0.5, initial_additive_error=5.0, minimum_additive_error=3.0,
             maximum_additive_error=20.0, relative_error_proposal_variance=1e-6, additive_error_proposal_variance=1e-6,
             probability_of_birth=1.0 / 6.0, probability_of_death=1.0 / 6.0, probability_of_perturb=1.0 / 6.0,
