@@ -188,10 +188,21 @@ __device__ __forceinline__ double wave_sum(double v)
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// v[lane] + v[lane ^ W] for W = 16, 32 in every lane, by gfx950's row swaps (v_permlane16_swap / v_permlane32_swap exchange the odd
+// 16- / 32-lane rows of one register with the even rows of another: VALU moves, where a shuffle would wait for the LDS crossbar)
+template <int W>
+__device__ __forceinline__ double row_pair_sum(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+    const auto a = W == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = W == 16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)b[0] << 32) | a[0]) + __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
+}
 // Sums of a AND b with one tree instead of two: after the first exchange the even lanes carry a's partial sums and the odd lanes b's
 // (the partner of an even lane sends its a, the partner of an odd lane its b), every later step pairs lanes of the same parity.
 // Returns, in lane 62, the sum of a and, in lane 63, the sum of b -- the bits wave_sum(a) / wave_sum(b) return.  (The cross-row steps
-// go through the LDS crossbar: row_bcast only broadcasts lane 15, an odd one.)  ~24 VALU issues against 2 x 32.
+// are row swaps: row_bcast only broadcasts lane 15, an odd one.)  26 VALU issues against 2 x 32.
 __device__ __forceinline__ double wave_sum_pair(double a, double b, int lane)
 {
     const bool odd = lane & 1;
@@ -200,8 +211,8 @@ __device__ __forceinline__ double wave_sum_pair(double a, double b, int lane)
     v += dpp_get<0x4E>(v);
     v += dpp_get<0x114>(v);
     v += dpp_get<0x118>(v);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = row_pair_sum<16>(v);
+    v = row_pair_sum<32>(v);
     return v;
 }
 // ... stored as one complex number (lanes 62 and 63 write their halves)
@@ -324,14 +335,14 @@ __device__ __forceinline__ void loglike_wave(int N, const double* p, const doubl
             na += 1.0;
         }
     }
-    s2 = wave_sum(s2);
-    logdet = wave_sum(logdet);
+    // chi^2 and log-determinant share one reduction tree (lane 62 ends with chi^2, lane 63 with the log-determinant: the bits of two
+    // wave_sums); the count of active channels -- a sum of ones, exact in any order -- goes through its own
+    const double mine = wave_sum_pair(s2, logdet, lane);
+    const double other = dpp_get<0xB1>(mine);
     na = wave_sum(na);
-    if (lane == 0) {
-        *chi2 = s2;
-        // MvNormalDistribution.py:209-216 with a diagonal covariance
-        *logL = -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2;
-    }
+    if (lane == 62) *chi2 = mine;
+    // MvNormalDistribution.py:209-216 with a diagonal covariance
+    if (lane == 63) *logL = -(0.5 * na) * 1.8378770664093453 - 0.5 * mine - 0.5 * other;
 }
 
 // Forward solve (+ chi^2 / logL) of ONE sounding by the calling workgroup: the body of k_fdem_forward, also called once per
