@@ -191,13 +191,21 @@ __device__ __forceinline__ double wave_sum(double v)
 // v[lane] + v[lane ^ W] for W = 16, 32 in every lane, by gfx950's row swaps (v_permlane16_swap / v_permlane32_swap exchange the odd
 // 16- / 32-lane rows of one register with the even rows of another: VALU moves, where a shuffle would wait for the LDS crossbar)
 template <int W>
-__device__ __forceinline__ double row_pair_sum(double v)
+__device__ __forceinline__ void row_pair(double v, double& x, double& y)     // {x, y} = {v[lane], v[lane ^ W]} in some order
 {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
     const auto a = W == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto b = W == 16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    return __builtin_bit_cast(double, ((unsigned long long)b[0] << 32) | a[0]) + __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
+    x = __builtin_bit_cast(double, ((unsigned long long)b[0] << 32) | a[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
+}
+template <int W>
+__device__ __forceinline__ double row_pair_sum(double v)
+{
+    double x, y;
+    row_pair<W>(v, x, y);
+    return x + y;
 }
 // Sums of a AND b with one tree instead of two: after the first exchange the even lanes carry a's partial sums and the odd lanes b's
 // (the partner of an even lane sends its a, the partner of an odd lane its b), every later step pairs lanes of the same parity.
@@ -227,8 +235,13 @@ __device__ __forceinline__ double wave_min_sigma(const double* __restrict__ sig,
 {
     double v = 1.7976931348623157e308;
     for (int k = lane; k < L; k += 64) v = fmin(v, sig[k]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    v = fmin(v, dpp_get<0xB1>(v));       // (a minimum does not depend on the order: quad swaps, the two mirrors of a row, row swaps)
+    v = fmin(v, dpp_get<0x4E>(v));
+    v = fmin(v, dpp_get<0x141>(v));
+    v = fmin(v, dpp_get<0x140>(v));
+    double x, y;
+    row_pair<16>(v, x, y); v = fmin(x, y);
+    row_pair<32>(v, x, y); v = fmin(x, y);
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
@@ -527,11 +540,9 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
             for (int g = 0; g < NG; ++g) {
                 if (m0 + 8 * g < L) {
                     double sr = acc_re[g], si = acc_im[g];
-#pragma unroll
-                    for (int o = 1; o < 8; o <<= 1) {
-                        sr += __shfl_xor(sr, o, 64);
-                        si += __shfl_xor(si, o, 64);
-                    }
+                    sr += dpp_get<0xB1>(sr); si += dpp_get<0xB1>(si);       // the 8 segment partials of a row: lane ^ 1, ^ 2, then the
+                    sr += dpp_get<0x4E>(sr); si += dpp_get<0x4E>(si);       // other quad of the 8 (row_half_mirror: every lane of a quad holds
+                    sr += dpp_get<0x141>(sr); si += dpp_get<0x141>(si);     // the quad's sum by now) -- the sums of the xor shuffles, bit for bit
                     const int m = m0 + 8 * g + row;
                     if (m < L && seg == 0) {
                         Jb[(size_t)f * Lmax + m] = ch.g_re * sr - ch.g_im * si;
