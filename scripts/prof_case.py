@@ -11,6 +11,9 @@ import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from geobipy_amd import _lib
+if os.environ.get("GBP_AB_LIB"):                     # A/B builds of the library (scripts/ab/*.so): measurement only
+    _lib.LIB_PATH = os.path.abspath(os.environ["GBP_AB_LIB"])
 from geobipy_amd import DeviceChains, FdemBatch, synthetic
 case = sys.argv[1]
 
