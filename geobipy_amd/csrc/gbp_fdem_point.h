@@ -167,7 +167,7 @@ GBP_HD cplx sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
         const cplx S = u + Y, De = u - Y;
         const cplx eDe = e * De;
         const cplx Dd = S + eDe, Nn = S - eDe;
-        const cplx inv = cdiv(mk(1.0, 0.0), Dd);
+        const cplx inv = crcp(Dd);
         const cplx inv2 = inv * inv;
         const cplx ue = u * e;
         const cplx P1 = mk(1.0 - e.re, -e.im) * (S * S + eDe * De);
@@ -179,7 +179,7 @@ GBP_HD cplx sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
         Y = (u * Nn) * inv;
         cplx fac = acc;
         if (k == 0) {  // top layer: fold d rTE / d Yh_1 and the Hankel factor Q into this last sweep
-            const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
+            const cplx i0 = crcp(u0 + Y);
             const cplx QQ = Q * ((u0 * (i0 * i0)) * -2.0);
             fac = acc * QQ;
             W = W * QQ;
@@ -190,7 +190,7 @@ GBP_HD cplx sens_point(const MathCtx& M, double a, int L, const LayerK* __restri
         D[k * stride] = W;
     }
     if (L == 1) {  // half-space only: no layer loop ran
-        const cplx i0 = cdiv(mk(1.0, 0.0), u0 + Y);
+        const cplx i0 = crcp(u0 + Y);
         D[0] = D[0] * (Q * ((u0 * (i0 * i0)) * -2.0));
         fwd = Q * ((u0 - Y) * i0);
     }

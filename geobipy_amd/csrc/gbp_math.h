@@ -233,4 +233,12 @@ GBP_HD cplx cdiv(cplx a, cplx b)
     return mk(n.re * inv, n.im * inv);
 }
 
+// 1 / b: the bits of cdiv(mk(1, 0), b) for finite b with b.re != 0 (there the products with the zero imaginary part of the numerator
+// only add signed zeros), without the four issues spent on them
+GBP_HD cplx crcp(cplx b)
+{
+    double inv = rcp(__builtin_fma(b.re, b.re, b.im * b.im));
+    return mk(b.re * inv, -b.im * inv);
+}
+
 }  // namespace gbp
