@@ -73,7 +73,7 @@ def measured_traffic(Btot, L, world):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected in
     separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note) -- only for the profiled shape."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_bench_{Btot}x{N_FREQ}x{L}.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]", f"summary_bench_{Btot}x{N_FREQ}x{L}.json")))
     if world != 1 or not found:
         return None
     path = found[-1]                                   # the latest round's PMC passes
@@ -95,7 +95,7 @@ def profiled_utilisation(case):
     """VALU issue utilisation of the dominant kernel from the latest committed rocprofv3 PMC summary of `case` (profiles/r*/summary_<case>.json):
     read, not measured by this run -- the file is named in the line."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_{case}.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]", f"summary_{case}.json")))
     if not found:
         return None, None
     d = json.load(open(found[-1]))
@@ -126,7 +126,7 @@ def usable_cores():
 def rjmcmc_traffic(n_chains):
     """HBM bytes per lock-step iteration of the sampler from the committed PMC passes (profiles/r*/summary_rjmcmc_<chains>.json)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"summary_rjmcmc_{n_chains}.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]", f"summary_rjmcmc_{n_chains}.json")))
     if not found:
         return None
     d = json.load(open(found[-1]))
@@ -136,7 +136,7 @@ def rjmcmc_traffic(n_chains):
 
 def tdem_traffic():
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary_tdem_config4.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]", "summary_tdem_config4.json")))
     if not found:
         return None
     TRAFFIC_SOURCES["tdem"] = os.path.relpath(found[-1], ROOT)
