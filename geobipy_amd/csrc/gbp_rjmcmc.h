@@ -117,6 +117,20 @@ __device__ __forceinline__ void wave_sync()
 // The packed per-chain stages are single-wave workgroups on a GPU they leave almost empty: occupancy is worth nothing to them, a register
 // spilled to scratch is a trip to memory on their dependency chain -- they may take the whole register file (spills go to AGPRs).
 #define GBP_RJ_LATENCY_KERNEL __attribute__((amdgpu_waves_per_eu(1, 1)))
+// ... and their waves share SIMDs with the physics waves of the other sub-blocks (a stand-alone k_rj_step8 wave lives 29 us, inside an
+// iteration 44): s_setprio 3 puts the few hundred waves that ARE the dependency chain ahead of the thousands that fill the machine.
+// Same-box A/B (scripts/ab_rj.py): 8 192 chains 45.6 -> 46.8 M chain-it/s, 4 096: 32.8 -> 33.3; the persistent kernel raises its serial
+// stages (wave 0 of a chain) the same way: 1 024 chains 19.2 -> 19.6 M, 512: + 4.5 %.  (A priority by model depth for the persistent
+// kernel's physics waves -- the launch ends with its slowest chain -- measured nothing.)
+#ifndef GBP_RJ_LATENCY_PRIO
+#define GBP_RJ_LATENCY_PRIO 3
+#endif
+#ifndef GBP_RJ_PERSISTENT_PRIO
+#define GBP_RJ_PERSISTENT_PRIO 3
+#endif
+
+#define GBP_RJ_SERIAL_PRIO(P) do { if (GBP_RJ_PERSISTENT_PRIO > 0) __builtin_amdgcn_s_setprio(P); } while (0)
+#define GBP_RJ_RAISE_PRIO() do { if (GBP_RJ_LATENCY_PRIO > 0) __builtin_amdgcn_s_setprio(GBP_RJ_LATENCY_PRIO); } while (0)
 // channels whose Jacobian column the packed stages' one-trip variants hold in registers (N <= this: Resolve 12, ten frequencies 20)
 #ifndef GBP_RJ_COLUMN_ROWS
 #define GBP_RJ_COLUMN_ROWS 24
@@ -1114,6 +1128,7 @@ __device__ __forceinline__ void newton8_body(const RjOpt& o, const gbp_rj_chains
 template <bool TRIPS>
 __global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_newton8(RjOpt o, gbp_rj_chains c, uint32_t iter, int n_packed)
 {
+    GBP_RJ_RAISE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups: see k_rj_newton)
         const int g = (int)blockIdx.x - n_packed, b = g * 64 + (int)threadIdx.x;
@@ -1831,6 +1846,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
 template <bool TRIPS>
 __global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_accept8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed)
 {   // (workgroups as in k_rj_newton8)
+    GBP_RJ_RAISE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     if ((int)blockIdx.x >= n_packed) {                 // (the deep chains' scanning workgroups)
         const int g = (int)blockIdx.x - n_packed;
@@ -1856,6 +1872,7 @@ template <bool TRIPS>
 __global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_step8(RjOpt o, gbp_rj_chains c, uint32_t iter, int accumulate, int n_packed,
                                                  const int32_t* __restrict__ deep_cur, int32_t* __restrict__ deep_next)
 {
+    GBP_RJ_RAISE_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     const int K = o.max_layers, lane = threadIdx.x;
     if ((int)blockIdx.x >= n_packed) {                 // the deep chains' scanning workgroups
@@ -2413,7 +2430,7 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
     for (int it = 0; it < n_iter; ++it) {
         const uint32_t iter = iter0 + (uint32_t)it;
         if (schedule == 1 && status[b] != 0) break;               // done / failed chains keep their final state (workgroup-uniform)
-        if (wave == 0) stage_propose(&sh_x, iter, lane);
+        if (wave == 0) { GBP_RJ_SERIAL_PRIO(GBP_RJ_PERSISTENT_PRIO); stage_propose(&sh_x, iter, lane); GBP_RJ_SERIAL_PRIO(0); }
         if (moving_height) {                                      // Point.perturb: this iteration's two heights and their windows
             __syncthreads();                                      //   (height_p is lane 0's write of the stage above; height its
             if (threadIdx.x == 0) set_windows(true);              //   write of the accept stage of the iteration before)
@@ -2426,14 +2443,14 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
             __syncthreads();
         }
         tick(1);
-        if (wave == 0) stage_newton(&sh_x, iter, lane);
+        if (wave == 0) { GBP_RJ_SERIAL_PRIO(GBP_RJ_PERSISTENT_PRIO); stage_newton(&sh_x, iter, lane); GBP_RJ_SERIAL_PRIO(0); }
         __syncthreads();
         tick(2);
         if (action == INSERT || action == DELETE) stage_fm_dlogc<EXACT>(&sh_x, 1);   // Model.py:612: Jacobian + prediction at the proposal
         else stage_forward(&sh_x);                                // Inference1D.py:572-597: forward + chi^2 + logL of the proposal
         __syncthreads();
         tick(3);
-        if (wave == 0) stage_accept(&sh_x, iter, accumulate, lane);
+        if (wave == 0) { GBP_RJ_SERIAL_PRIO(GBP_RJ_PERSISTENT_PRIO); stage_accept(&sh_x, iter, accumulate, lane); GBP_RJ_SERIAL_PRIO(0); }
         __syncthreads();
         tick(4);
         if (clocked) GBP_RJ_TICKS[5] += 1;
