@@ -103,6 +103,7 @@ __device__ const double GBP_SINCOS_64[128] = GBP_SINCOS_64_LIST;
 // Measurement builds only (scripts/build_ab.sh NAME -DGBP_RJ_PHYS_CLOCK, scripts/phys_clock.py): s_memtime stamps of the sampler's physics
 // workgroups, summed per slot by thread 0 of every 16th workgroup.  [slot]: ticks of the 100 MHz constant clock; [slot + 32]: samples.
 __device__ long long GBP_PHYS_TICKS[64];
+__device__ long long GBP_PHYS_LIFE[3 * 16 * 3];      // [kind][min(layers, 15)][sum of lives, workgroups, longest life]
 struct PhysClk { bool on; int base; long long t0; };
 __device__ __forceinline__ void phys_tick(PhysClk* k, int slot)
 {
@@ -473,8 +474,10 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                                           const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
                                           const double* __restrict__ sig, const double* __restrict__ th, double alt,
                                           double* __restrict__ Jb /* [2F, Lmax] of this sounding */,
-                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0 GBP_TICK_ARGS)
-{   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
+                                          double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0 GBP_TICK_ARGS,
+                                          int share = 0, int n_shares = 1)
+{   // share / n_shares: this workgroup evaluates the frequencies  wave * n_shares + share,  + nw_use * n_shares, ...  -- a frequency's
+    // rows of J and pred depend on nothing but that frequency, so n_shares workgroups split a sounding's evaluation and write the same bits   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
     // sampler, whose consumers never read a column >= L, passes L rounded up to 8 and leaves the rest of the row alone)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -488,7 +491,7 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
     GBP_TICK(3);
     if (wave >= nwaves) return;
 
-    for (int f = wave; f < F; f += nwaves) {
+    for (int f = wave * n_shares + share; f < F; f += nwaves * n_shares) {
         const Channel ch = chan[f];
         setup_layers(sh_lay, ch.wmu, sig, L, lane);
         const double hD = ch.hd0 - 2.0 * alt;

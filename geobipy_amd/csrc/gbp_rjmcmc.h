@@ -125,6 +125,9 @@ __device__ __forceinline__ void wave_sync()
 #ifndef GBP_RJ_LATENCY_PRIO
 #define GBP_RJ_LATENCY_PRIO 3
 #endif
+#ifndef GBP_RJ_SHARES_UP_TO
+#define GBP_RJ_SHARES_UP_TO 700
+#endif
 #ifndef GBP_RJ_PERSISTENT_PRIO
 #define GBP_RJ_PERSISTENT_PRIO 3
 #endif
@@ -2501,13 +2504,20 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     __shared__ MathLds sh_math;
     extern __shared__ __attribute__((aligned(16))) unsigned char sh_dyn[];
     double* sh_out = reinterpret_cast<double*>(sh_dyn + out_offset);
-    const int b = blockIdx.x;
+    // Workgroups B ... 2 B - 1 (launched when the Jacobian passes are split, GBP_RJ_JACOBIAN_SHARES = 2) are the second halves of the
+    // chains' Jacobian evaluations: a launch lasts as long as its slowest workgroup, the Jacobian workgroups are the slow ones, and a
+    // frequency's rows depend on nothing else -- two workgroups take five frequencies each and write the bits one would.
+    const int share = (int)blockIdx.x >= c.B ? 1 : 0;
+    const int n_shares = (int)gridDim.x > c.B ? 2 : 1;
+    const int b = (int)blockIdx.x - share * c.B;
 #ifdef GBP_RJ_PHYS_CLOCK
-    PhysClk clk_{threadIdx.x == 0 && (b & 15) == 0, 0, (long long)wall_clock64()};
+    const long long clk_start_ = (long long)wall_clock64();
+    PhysClk clk_{threadIdx.x == 0 && (b & 15) == 0, 0, clk_start_};
     PhysClk* gbp_clk = &clk_;
 #endif
     const int action = c.action[b];
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
+    if (share != 0 && ((stage == 1 && action != INSERT && action != DELETE) || c.k_r[b] > 8)) return;   // (a fused forward, or a deep model: one workgroup)
 #ifdef GBP_RJ_PHYS_CLOCK
     clk_.base = (stage == 0 ? 0 : ((action == INSERT || action == DELETE) ? 8 : 16));
 #endif
@@ -2532,7 +2542,7 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
         double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
         const double* th = c.thk_r + (size_t)b * K;
-        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS);
+        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS, share, n_shares);
         else sens_body<EXACT, 8>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
                                  min(K, (L + 7) & ~7));
     } else {
@@ -2540,6 +2550,15 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
                            c.data + (size_t)b * N, c.rel_p[b], c.add_p[b], c.pred_p + (size_t)b * N, c.misfit_p + b, c.like_p + b,
                            sigma_direct, nw, 1.0 GBP_TICK_PASS);
     }
+#ifdef GBP_RJ_PHYS_CLOCK
+    if (threadIdx.x == 0) {                            // life of every workgroup (thread 0's wave) by kind and layer count
+        const long long life = (long long)wall_clock64() - clk_start_;
+        long long* h = GBP_PHYS_LIFE + ((stage == 0 ? 0 : (jump ? 1 : 2)) * 16 + min(L, 15)) * 3;
+        atomicAdd((unsigned long long*)&h[0], (unsigned long long)life);
+        atomicAdd((unsigned long long*)&h[1], 1ull);
+        atomicMax((unsigned long long*)&h[2], (unsigned long long)life);
+    }
+#endif
 }
 
 }  // namespace rj
@@ -2920,6 +2939,19 @@ static int stage0_waves(int nw)
 // 17.4 / 17.5, 3 072: 26.9 / 27.8 | 23.4 / 24.1, 4 096: 32.1 / 33.9 | 27.8 / 29.5, 8 192: 47.6 / 50.0 | 41.0 / 42.9, 16 384:
 // 62.0 / 63.4 | 52.1 / 53.1, 32 768: 62.8 / 62.8 | 50.5 / 50.6 (one sub-block, Resolve: 18.1 / 28.1 / 38.0 / 50.7 at 2 048 ... 16 384).
 // Three never lose: the host issues 7 launches per iteration and sub-block at ~8 us each, which the GPU side still hides at three.
+// Workgroups per Jacobian evaluation of a chain in the lock-step physics launches (k_rj_physics: the frequencies are shared out).  A small
+// sub-block leaves most of the GPU idle and its launch lasts as long as its slowest workgroup: two workgroups of five frequencies finish
+// sooner than one of ten (2 048 chains = three sub-blocks of 683: 21.1 -> 21.5 M chain-it/s); from about 900 chains per launch the second
+// workgroup's prologue is capacity lost (sub-blocks of 900 / 910 / 1 100 chains: - 2 / - 4 / - 6 %; with the split at every size 4 096: 32.8 -> 31.7,
+// 8 192: 46.0 -> 42.4, 16 384: 51.6 -> 48.9).  Same bits either way (scripts/ab_bits.py).
+static int jacobian_shares(int chains_in_launch)
+{
+#ifdef GBP_RJ_JACOBIAN_SHARES
+    return GBP_RJ_JACOBIAN_SHARES;                           // (A/B builds under scripts/ab only)
+#endif
+    return chains_in_launch <= GBP_RJ_SHARES_UP_TO ? 2 : 1;
+}
+
 static int lockstep_parts(int B)
 {
 #ifdef GBP_RJ_LOCKSTEP_PARTS
@@ -2985,6 +3017,14 @@ gbp_status gbp_debug_phys_ticks(int64_t* out, int reset)   // (measurement build
     GBP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(GBP_PHYS_TICKS), sizeof(h)));
     for (int i = 0; i < 64; ++i) out[i] = (int64_t)h[i];
     if (reset) { std::memset(h, 0, sizeof(h)); GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(GBP_PHYS_TICKS), h, sizeof(h))); }
+    return GBP_OK;
+}
+gbp_status gbp_debug_phys_life(int64_t* out, int reset)    // [3][16][3], see GBP_PHYS_LIFE
+{
+    long long h[144];
+    GBP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(GBP_PHYS_LIFE), sizeof(h)));
+    for (int i = 0; i < 144; ++i) out[i] = (int64_t)h[i];
+    if (reset) { std::memset(h, 0, sizeof(h)); GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(GBP_PHYS_LIFE), h, sizeof(h))); }
     return GBP_OK;
 }
 #endif
@@ -3203,11 +3243,11 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             const size_t out_bytes = (size_t)o->n_channels * sizeof(double);          // the output row behind the stages' block (k_rj_physics)
             const int out_offset = (int)lds_s;
             if (o->exact_jacobian)
-                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B * jacobian_shares(t.c.B)), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
                                    sys->d_bin_pts, out_offset);
             else
-                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B * jacobian_shares(t.c.B)), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
                                    sys->d_bin_pts, out_offset);
         };

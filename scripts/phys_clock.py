@@ -21,6 +21,8 @@ dc.run(200); torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
 tk = (ctypes.c_int64 * 64)()
 lib.gbp_debug_phys_ticks(tk, 1)
+life = (ctypes.c_int64 * 144)()
+lib.gbp_debug_phys_life(life, 1)
 t0 = time.perf_counter(); dc.run(n_it); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 lib.gbp_debug_phys_ticks(tk, 0)
 print(f"B={B}: {B * n_it / dt / 1e6:.2f} M chain-it/s (clocked build), mean layers {dc.k.double().mean().item():.2f}")
@@ -37,3 +39,12 @@ for base, kind in ((0, "stage 0: Jacobian at the remapped model"), (8, "stage 1:
             tot += us
             print(f"   {names[base][s]:32s} {us:7.2f} us  (n = {n})")
     print(f"   {'total':32s} {tot:7.2f} us")
+lib.gbp_debug_phys_life(life, 0)
+print("life of a workgroup (thread 0's wave) by layer count: mean / longest us (workgroups)")
+for kind, name in enumerate(("stage 0 Jacobian", "stage 1 Jacobian", "stage 1 forward")):
+    row = []
+    for L in range(16):
+        s, n, m = (life[(kind * 16 + L) * 3 + j] for j in range(3))
+        if n:
+            row.append(f"L={L}: {s / n / 100.0:.1f} / {m / 100.0:.1f} ({n})")
+    print("  ", name, " | ".join(row))
