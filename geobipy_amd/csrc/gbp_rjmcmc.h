@@ -214,6 +214,16 @@ __device__ inline Levels load_levels(const RjOpt& o, const double* rel, const do
     return e;
 }
 
+// a ? x : y, entry by entry.  (The conditional operator on two Levels OBJECTS yields an lvalue -- a pointer chosen by a select -- and
+// both objects then live in scratch, 144 B per lane in the accept stages: every read of an error level a trip to memory.)
+__device__ inline Levels select_levels(bool a, const Levels& x, const Levels& y)
+{
+    Levels r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { r.rel[g] = a ? x.rel[g] : y.rel[g]; r.add[g] = a ? x.add[g] : y.add[g]; }
+    return r;
+}
+
 __device__ inline double pick4(const double* v, int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); }
 
 // variance of channel n with datum d: (rel_g d)^2 + (add_g' add_scale_n)^2
@@ -317,9 +327,11 @@ __device__ inline void remap_entry(int action, int idx, double val, int kr, int 
     }
 }
 
-__device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr, const Levels* now = nullptr)
+__device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r, int b, int action, int kr, const Levels* now = nullptr,
+                                  bool have_now = false)
 {   // per-chain scalars: layer counts for the kernels that follow (row 0: all, rows 1-2: by bucket), error proposals
-    // (`now`: the chain's current error levels when the caller holds them -- the fused accept + proposal launch --, else read from memory)
+    // (`now`, have_now: the chain's current error levels when the caller holds them -- the fused accept + proposal launch --, else read from
+    //  memory.  A flag beside a pointer that is always valid, not a null pointer: a pointer chosen by a select keeps the caller's object in scratch.)
     const int bk = bucket_of(kr);
     const bool jump = action == INSERT || action == DELETE;
     for (int i = 0; i < 3; ++i) {
@@ -343,7 +355,7 @@ __device__ inline void write_move(const RjOpt& o, const gbp_rj_chains& c, Rng& r
         c.height_p[b] = x;
     }
     // error levels (DataPoint.perturb: relative then additive)
-    const Levels cur = now != nullptr ? *now : load_levels(o, c.rel, c.add, (size_t)b);
+    const Levels cur = have_now ? *now : load_levels(o, c.rel, c.add, (size_t)b);
     Levels out = cur;
     if (o.solve_relative_error) propose_levels(r, cur.rel, o.n_rel_groups, o.rel_sd, o.log_rel_min, o.log_rel_max, out.rel);
     if (o.solve_additive_error && !o.additive_independent)
@@ -429,7 +441,7 @@ __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains
                 above = ev;
                 e_up = e_j; s_up = s_j; e_j = e_dn; s_j = s_dn;
             }
-            write_move(o, c, r, b, action, kr, now);
+            write_move(o, c, r, b, action, kr, now, have);
             kr_out = kr;
         }
         return __shfl(kr_out, base, 64);
@@ -458,7 +470,7 @@ __device__ __forceinline__ int propose8_body(const RjOpt& o, const gbp_rj_chains
         c.thk_r[(size_t)b * K + j] = 0.0;
     }
     Rng r0 = r;
-    if (i == 0) write_move(o, c, r0, b, action, kr, now);
+    if (i == 0) write_move(o, c, r0, b, action, kr, now, have);
     return kr;
 }
 
@@ -1467,7 +1479,7 @@ __device__ __forceinline__ void accept_body(const RjOpt& o, const gbp_rj_chains&
     }
     const int bk = bookkeeping<64>(o, c, iter, accumulate, (size_t)b, lane, accept ? k : k_prev, accept ? e : c.edges + (size_t)b * K,
                                    accept ? c.sigma_p + (size_t)b * K : c.sigma + (size_t)b * K, accept ? prior_p + like_p : prior_c + like_c,
-                                   best_prev, accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept);
+                                   best_prev, accept ? misfit_p : misfit_c, select_levels(accept, lev_p, lev_c), lmp, dwell, height_now, accept);
     if (lane == 0 && c.step_flags != nullptr) c.step_flags[b] = (accept ? 1 : 0) | (bk & 15);
 }
 
@@ -1784,7 +1796,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
         if (one_trip) {
             st->e_now = accept ? pre.e_i : pre.ce_i;
             st->s_now = accept ? sp_ic : pre.cs_i;
-            st->lev_now = accept ? lev_p : lev_c;
+            st->lev_now = select_levels(accept, lev_p, lev_c);
             st->status = status_bb;
         }
     }
@@ -1840,7 +1852,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     const int bk = bookkeeping<8>(o, c, iter, accumulate, bb, i, accept ? k : k_prev, accept ? e : c.edges + bb * K,
                                   accept ? c.sigma_p + bb * K : c.sigma + bb * K, accept ? prior_p + like_p : prior_c + like_c, best_prev,
-                                  accept ? misfit_p : misfit_c, accept ? lev_p : lev_c, lmp, dwell, height_now, accept, one_trip,
+                                  accept ? misfit_p : misfit_c, select_levels(accept, lev_p, lev_c), lmp, dwell, height_now, accept, one_trip,
                                   accept ? pre.e_i : pre.ce_i, accept ? sp_ic : pre.cs_i);
     if (st != nullptr && (bk & 16)) st->status = 1;             // (the chain stopped in this very iteration: its next proposal is the idle one)
     if (i == 0 && c.step_flags != nullptr) c.step_flags[bb] = (accept ? 1 : 0) | (bk & 15);
@@ -1907,7 +1919,7 @@ __global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_step8(RjOpt o, 
     if (mine) {                                        // (group-uniform; the reads inside stay within the chain's own 8 lanes)
         const double* e_row = (st.accepted ? c.edges_r : c.edges) + (size_t)b * K;
         const double* s_row = (st.accepted ? c.sigma_p : c.sigma) + (size_t)b * K;
-        const int kr = propose8_body(o, c, iter + 1, lane, b, st.k_now, e_row, s_row, st.have, st.e_now, st.s_now, st.have ? &st.lev_now : nullptr,
+        const int kr = propose8_body(o, c, iter + 1, lane, b, st.k_now, e_row, s_row, st.have, st.e_now, st.s_now, &st.lev_now,
                                      st.have ? st.status : -1);
         if ((lane & 7) == 0) deep_next[b] = step_is_deep(st.k_now, kr);
     }
