@@ -157,10 +157,13 @@ __device__ GBP_RJ_CALL U4 philox_call(uint64_t seed, uint32_t chain, uint32_t it
     return philox(seed, chain, iter, stream, n);
 }
 __device__ GBP_RJ_CALL double box_muller_cos(double u1, double u2) { return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2); }
-__device__ GBP_RJ_CALL void box_muller_pair(double u1, double u2, double* z0, double* z1)
+struct Pair { double a, b; };
+__device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (returned in registers: two output pointers of a call are two objects in scratch)
 {
     const double rad = sqrt(-2.0 * log(1.0 - u1)), ang = TWO_PI * u2;
-    *z0 = rad * cos(ang); *z1 = rad * sin(ang);
+    Pair z;
+    z.a = rad * cos(ang); z.b = rad * sin(ang);
+    return z;
 }
 
 struct Rng {                                                    // sequential draws of one (chain, iteration, stream)
@@ -183,7 +186,8 @@ struct Rng {                                                    // sequential dr
 __device__ inline void normal_pair(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t j, double& z0, double& z1)
 {
     const U4 r = philox_call(seed, chain, iter, stream, j);
-    box_muller_pair(u53(r.x, r.y), u53(r.z, r.w), &z0, &z1);
+    const Pair z = box_muller_pair(u53(r.x, r.y), u53(r.z, r.w));
+    z0 = z.a; z1 = z.b;
 }
 
 enum { NONE = 0, INSERT = 1, DELETE = 2, PERTURB = 3 };
@@ -224,7 +228,13 @@ __device__ inline Levels select_levels(bool a, const Levels& x, const Levels& y)
     return r;
 }
 
-__device__ inline double pick4(const double* v, int g) { return g == 0 ? v[0] : (g == 1 ? v[1] : (g == 2 ? v[2] : v[3])); }
+// entry g of a Levels array.  By value: selects on four loaded VALUES; handed a pointer, the compiler turns the selects into one load at
+// a selected address -- a dynamically indexed array, i.e. scratch, on every channel of the accept stages' misfit loop.
+__device__ inline double pick4(const double (&v)[4], int g)
+{
+    const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    return g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+}
 
 // variance of channel n with datum d: (rel_g d)^2 + (add_g' add_scale_n)^2
 __device__ inline double variance_at(const gbp_rj_chains& c, const Levels& e, double d, int n)
@@ -1288,10 +1298,13 @@ __device__ inline int bookkeeping(const RjOpt& o, const gbp_rj_chains& c, uint32
         for (int j = i; j < K; j += W) { c.best_edges[b * K + j] = ec[j]; c.best_sigma[b * K + j] = sc[j]; }
         if (i == 0) {
             c.best_posterior[b] = post; c.best_k[b] = kc;
-            if (c.best_rel != nullptr)                           // the error levels of the highest-posterior state (Inference1D.update
-                for (int g = 0; g < o.n_rel_groups; ++g) c.best_rel[b * o.n_rel_groups + g] = lev.rel[g];   //  :741-745 keeps the data point)
-            if (c.best_add != nullptr)
-                for (int g = 0; g < o.n_add_groups; ++g) c.best_add[b * o.n_add_groups + g] = lev.add[g];
+            // (the error levels of the highest-posterior state: Inference1D.update :741-745 keeps the data point.  Four unrolled, guarded
+            //  stores: a loop bounded by the run's group count indexes `lev` dynamically, and the accept stages' error levels then live in scratch)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (c.best_rel != nullptr && g < o.n_rel_groups) c.best_rel[b * o.n_rel_groups + g] = lev.rel[g];
+                if (c.best_add != nullptr && g < o.n_add_groups) c.best_add[b * o.n_add_groups + g] = lev.add[g];
+            }
             if (c.best_height != nullptr) c.best_height[b] = height_now;
             if (c.best_iteration != nullptr) c.best_iteration[b] = upd;
         }
