@@ -128,6 +128,13 @@ __device__ __forceinline__ void wave_sync()
 #ifndef GBP_RJ_SHARES_UP_TO
 #define GBP_RJ_SHARES_UP_TO 700
 #endif
+// Row groups (of 8 layers) the Jacobian pass of a model of MORE than 8 layers sums per evaluation (sens_body<EXACT, NG>; the pass is
+// repeated for the next 8 NG layers).  8 -- one evaluation for any model -- keeps 16 complex accumulators and costs the physics kernel 25
+// spilled registers and 104 B of scratch; 2 covers 16 layers per evaluation (two evaluations for 17 - 32 layers) with none: 118 VGPRs,
+// 0 B.  The rows are the same sums in the same order whatever the grouping: same bits (tests/test_rjmcmc_gpu.py, the deep cases).
+#ifndef GBP_RJ_DEEP_NG
+#define GBP_RJ_DEEP_NG 2
+#endif
 #ifndef GBP_RJ_PERSISTENT_PRIO
 #define GBP_RJ_PERSISTENT_PRIO 3
 #endif
@@ -2316,7 +2323,7 @@ __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_pro
     const double* pts = at_proposal ? x->pts_p : x->pts;
     const int npts = at_proposal ? x->npts_total_p : x->npts_total;
     if (L <= 8) sens_body<EXACT, 1>(M, x->sh_dyn, chan, pts, npts, x->F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, (int)(blockDim.x >> 6), min(K, 8));
-    else sens_body<EXACT, 8>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, chan, pts, npts, x->F, K, K, L,
+    else sens_body<EXACT, GBP_RJ_DEEP_NG>(M, x->deep_scratch != nullptr ? x->deep_scratch : x->sh_dyn, chan, pts, npts, x->F, K, K, L,
                              sig, th, alt, Jb, pr, x->nw_deep, min(K, (L + 7) & ~7));
 }
 
@@ -2568,7 +2575,7 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
         const double* th = c.thk_r + (size_t)b * K;
         if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS, share, n_shares);
-        else sens_body<EXACT, 8>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
+        else sens_body<EXACT, GBP_RJ_DEEP_NG>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
                                  min(K, (L + 7) & ~7));
     } else {
         forward_body<true>(M, sh_out, sh_dyn, chan, pts, npts_total, F, K, L, c.sigma_p + (size_t)b * K, c.thk_r + (size_t)b * K, alt,
