@@ -3225,7 +3225,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             // Round 5, re-measured with four launches per iteration (scripts/ab_rj.py, one box, 2 / 3 / 4 waves, ten frequencies, block = 3 n):
             // n = 910: 23.4 25.4 25.6;  1 365: 31.3 32.2 30.6;  1 820: 37.3 36.2 33.8;  2 731: 44.1 40.5 38.0 -- with a shorter chain per
             // sub-block the physics launches of the three overlap more, and the switch points move down.
-            t.nw = std::min(n <= 1100 ? 4 : (n <= 1600 ? 3 : 2), GBP_RJ_PHYSICS_MAX_WAVES);
+            t.nw = std::min(n <= GBP_RJ_SHARES_UP_TO ? 3 : (n <= 1100 ? 4 : (n <= 1600 ? 3 : 2)), GBP_RJ_PHYSICS_MAX_WAVES);   // (two workgroups per Jacobian in the smallest launches: three waves each, 2 048 chains 22.6 -> 23.3 M)
 #ifdef GBP_RJ_PHYSICS_NW
             t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
 #endif
