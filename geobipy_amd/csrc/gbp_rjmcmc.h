@@ -20,8 +20,9 @@
 //     k_rj_physics,    8 192 Resolve chains, lock-step                37.6 M             35.7 M          28.5 M
 //     k_rj_persistent, 1 024 Resolve chains                           16.9 M             18.3 M          19.2 M
 //     k_rj_persistent, 1 024 ten-frequency chains                     15.5 M             16.6 M          17.4 M
-// The lock-step physics kernel is throughput-bound: the fourth wave per SIMD buys more than the 25 spilled registers cost (they sit
-// outside the layer loops).  The persistent kernel is a latency chain per workgroup with at most 4 workgroups of 2 waves resident per
+// The lock-step physics kernel is throughput-bound: the fourth wave per SIMD buys more than the 25 spilled registers cost (they sat
+// in the Jacobian pass of models above 8 layers; since round 5 that pass sums two row groups per evaluation instead of eight and the
+// kernel has 118 VGPRs, none spilled, no scratch -- GBP_RJ_DEEP_NG below; the table is the measurement that chose four waves).  The persistent kernel is a latency chain per workgroup with at most 4 workgroups of 2 waves resident per
 // CU (LDS): it never uses more than 2 waves per SIMD, so the whole register file is free -- no spills, +13 %.
 #ifndef GBP_RJ_PHYSICS_WAVES_PER_EU
 #define GBP_RJ_PHYSICS_WAVES_PER_EU 4
