@@ -128,6 +128,9 @@ struct MathLds {
     double exp2_64[64];
     gbp::SinCos sincos_64[64];
 };
+// SYNC = false: the caller's next workgroup barrier (the one behind the layer-thickness fill of forward_body / sens_body) is the tables'
+// too -- the sampler's physics kernel fills them first thing, while its chain's move and layer count are still on their way
+template <bool SYNC = true>
 __device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
 {
     for (int i = threadIdx.x; i < 64; i += blockDim.x) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ gbp::MathCtx math_setup(MathLds& lds)
         lds.sincos_64[i].s = GBP_SINCOS_64[2 * i];
         lds.sincos_64[i].c = GBP_SINCOS_64[2 * i + 1];
     }
-    __syncthreads();
+    if (SYNC) __syncthreads();
     gbp::MathCtx M;
     M.k = GBP_K;
     M.e4_v = M.k.e4;

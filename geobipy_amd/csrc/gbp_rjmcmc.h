@@ -2548,16 +2548,27 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     PhysClk clk_{threadIdx.x == 0 && (b & 15) == 0, 0, clk_start_};
     PhysClk* gbp_clk = &clk_;
 #endif
+    // The chain's move, layer count and height are requested together, and the math tables go to LDS while they travel (no barrier of
+    // their own: forward_body / sens_body have one behind the layer-thickness fill) -- one trip to memory and one barrier less per workgroup
+#ifndef GBP_RJ_PHYSICS_LATE_TABLES
     const int action = c.action[b];
+    const int L_early = c.k_r[b];
+    const double alt_early = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
+    const gbp::MathCtx M = math_setup<false>(sh_math);
+#else
+    const int action = c.action[b];
+    const int L_early = c.k_r[b];
+    const double alt_early = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
+#endif
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
-    if (share != 0 && ((stage == 1 && action != INSERT && action != DELETE) || c.k_r[b] > 8)) return;   // (a fused forward, or a deep model: one workgroup)
+    if (share != 0 && ((stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) return;   // (a fused forward, or a deep model: one workgroup)
 #ifdef GBP_RJ_PHYS_CLOCK
     clk_.base = (stage == 0 ? 0 : ((action == INSERT || action == DELETE) ? 8 : 16));
 #endif
     GBP_TICK(0);
-    const int K = o.max_layers, N = o.n_channels, L = c.k_r[b];
+    const int K = o.max_layers, N = o.n_channels, L = L_early;
     // (a sampled height: the remapped model is evaluated at the chain's current height, the proposal at the proposed one)
-    const double alt = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
+    const double alt = alt_early;
     if (bins != nullptr && alt >= (double)bin0) {                 // the chain's abscissa window: the bin of its sounding's altitude
         const BinDesc d = bins[min((int)(alt - (double)bin0), n_bins - 1)];
         chan = bin_chan + d.chan_off;
@@ -2565,7 +2576,9 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         npts_total = d.npts_total;
     }
     GBP_TICK(1);
+#ifdef GBP_RJ_PHYSICS_LATE_TABLES
     const gbp::MathCtx M = math_setup(sh_math);                   // ends with __syncthreads()
+#endif
     GBP_TICK(2);
     const bool jump = action == INSERT || action == DELETE;
     const int nw = (int)(blockDim.x >> 6);
