@@ -409,6 +409,89 @@ def survey_at_size(n_soundings, n_lines, n_markov_chains):
         shutil.rmtree(d, ignore_errors=True)
 
 
+COMPACT_LIMIT = 3072     # bytes: the driver's record keeps the last 8 KB of stdout and parses the last line (BENCH_r05.parsed was null for a 22.8 KB line)
+EXTRAS_FILE = os.path.join("gpurun_out", "bench_extras.json")
+
+
+def _r(x, sig=6):
+    """Floats of the printed line at `sig` significant digits (the full-precision numbers are in the extras file)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    x = float(x)
+    return float(f"{x:.{sig}g}") if np.isfinite(x) else None
+
+
+def compact_line(full, extras_file=EXTRAS_FILE):
+    """The ONE line bench.py prints: the contract's keys, the headline roofline with one (value, frac) pair per other measured
+    kernel, the CPU baseline and the parity verdict -- under COMPACT_LIMIT bytes.  Everything else the run measured (notes,
+    definitions, survey phases, replay arms, the TDEM parity table) is `full`, written to `extras_file`."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "rounds_per_step", "timed_seconds", "finite")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "soundings", "frequencies", "layers", "rounds_per_step",
+                                          "abscissa_points_per_sounding_mean", "abscissa_points_all") if k in cfg}
+    rf = full.get("roofline", {})
+    roof = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "evals_per_launch",
+                                   "flop_per_eval", "valu_issue_utilisation", "frac_all_abscissae_equivalent")}
+    if "all_abscissae" in rf:
+        roof["all_abscissae"] = {k: rf["all_abscissae"][k] for k in ("value", "frac")}
+    others = {}
+    rj = full.get("rjmcmc", {})
+    if "value" in rj:
+        rr = rj.get("roofline", {})
+        others["rjmcmc_8192"] = {"value": rj["value"], "frac": rr.get("frac"), "unit": "chain-it/s"}
+        if rr.get("valu_issue_utilisation_aggregate") is not None:
+            others["rjmcmc_8192"]["valu_issue_utilisation"] = rr["valu_issue_utilisation_aggregate"]
+        blk = rj.get("block_of_1024", {})
+        if "lockstep" in blk:
+            best = max(blk["lockstep"], blk["persistent"])
+            others["rjmcmc_1024"] = {"value": best, "x8_projection": 8 * best,
+                                     "note": "config 5 over 8 GPUs = 1 024 chains per GPU; x8 is a projection, latency-bound per chain"}
+    for key in ("jacobian", "tdem", "config2", "shard_8192"):
+        if key in full and "roofline" in full[key]:
+            others[key] = {"value": full[key]["value"], "frac": full[key]["roofline"]["frac"]}
+    if others:
+        roof["other_kernels"] = others
+    line["roofline"] = roof
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:160], "single_thread": {"value": cb["single_thread"]["value"]},
+                                "parity_within_bar": cb.get("parity_within_bar")}
+    if "parity_vs_cpu" in full:
+        pv = full["parity_vs_cpu"]
+        line["parity_vs_cpu"] = {k: pv[k] for k in ("within_bar", "max_abs_pred_ppm", "soundings_compared") if k in pv}
+    sv = full.get("survey", {}).get("north_star_sizes", {})
+    if "soundings_65536" in sv:
+        line["survey"] = {k: {"seconds": sv[k]["seconds"], "chains_share_of_wall": sv[k]["chains_share_of_wall"]}
+                          for k in ("config5_schedule_8192_x_10000", "soundings_65536") if k in sv and "seconds" in sv[k]}
+    if "forced_collective" in full:                    # (--force-collective: the N > 1 round on a one-rank RCCL group)
+        line["forced_collective"] = {k: full["forced_collective"][k] for k in ("backend", "world", "rounds", "gathered_equals_local")}
+    line["extras_file"] = extras_file
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:                      # never print a line the driver cannot keep: drop the optional objects first
+        for k in ("survey", "parity_vs_cpu"):
+            line.pop(k, None)
+        line["roofline"].pop("other_kernels", None)
+    return line
+
+
+def write_extras(full, path=EXTRAS_FILE):
+    try:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, path)), exist_ok=True)
+        with open(os.path.join(ROOT, path), "w") as f:
+            json.dump(full, f, indent=1)
+        return True
+    except OSError:
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,6 +507,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra Jacobian and time-domain measurements")
     ap.add_argument("--no-survey-sizes", action="store_true", help="skip the end-to-end survey runs at the north-star sizes (~30 s)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="soundings in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--extras-file", default=EXTRAS_FILE, help="where the run's full record goes (relative to the repository root; '' = nowhere)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: initialise RCCL with ONE rank and run the N > 1 exchange anyway (side stream + all_gather_into_tensor "
                          "per round) -- executes the multi-GPU code path on a single-GPU box; not the headline configuration")
@@ -721,7 +805,7 @@ def main():
                                              "frac_all_abscissae_equivalent": achj_all / FP64_VECTOR_PEAK_TFLOPS,
                                              "flop_per_eval_all_abscissae": fpj_all,
                                              "valu_issue_utilisation": utilj, "valu_issue_utilisation_source": utilj_src,
-                                             "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, 8>",
+                                             "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, %d>" % (1 if L <= 8 else (2 if L <= 16 else 8)),
                                              "count": "builder's extension of SURVEY 8(d) to the prediction + Jacobian pass (flop_per_jacobian_point: "
                                                       "same per-operation weights) x the abscissae each sounding's window evaluates (frac) or all 120 per "
                                                       "frequency (*_all_abscissae_equivalent); 100 timed launches after a 50 ms warm-up"},
@@ -829,13 +913,15 @@ def main():
                         "soundings_65536": survey_at_size(65536, 64, 2000)}
                 except Exception as e:
                     line["survey"]["north_star_sizes"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0 times the C oracle on the host cores at EVERY N (the other ranks wait at the barrier in front of
+            # destroy_process_group); rank 0's shard starts at sounding 0, so the first `sample` rows of the whole-job arrays are its own
             threads = usable_cores()
-            sample = args.cpu_sample or max(256, min(Btot, 16 * threads))
+            sample = min(Bloc, args.cpu_sample or max(256, min(Btot, 16 * threads)))
             sigma0 = sig_sets[0]
             rate, dt, (p_ref, c_ref, l_ref) = cpu_baseline(system, nl, sigma0, thk, height, obs, sample, threads)
             if dt < 5.0 and not args.cpu_sample:   # scale the sample to ~15 s of CPU work
-                sample = int(min(Btot, max(sample, rate * 15.0)))
+                sample = int(min(Bloc, max(sample, rate * 15.0)))
                 rate, dt, (p_ref, c_ref, l_ref) = cpu_baseline(system, nl, sigma0, thk, height, obs, sample, threads)
             rounds = 1
             while dt < 10.0 and rounds < N_SIGMA_SETS and not args.cpu_sample:   # more proposal rounds of the same sample
@@ -847,9 +933,9 @@ def main():
             chi2, logl = batches[0].forward_loglike(want_pred=True)
             torch.cuda.synchronize(device)
             p = batches[0].predicted[:sample].cpu().numpy()
-            r1, d1, _ = cpu_baseline(system, nl, sigma0, thk, height, obs, min(Btot, 2048), 1)   # single thread beside all cores
+            r1, d1, _ = cpu_baseline(system, nl, sigma0, thk, height, obs, min(Bloc, 2048), 1)   # single thread beside all cores
             line["cpu_baseline"] = {"value": rate, "unit": "evals/s", "cores": threads, "kind": "port",
-                                    "single_thread": {"value": r1, "unit": "evals/s", "sample": f"first {min(Btot, 2048)} soundings, {d1:.1f} s"},
+                                    "single_thread": {"value": r1, "unit": "evals/s", "sample": f"first {min(Bloc, 2048)} soundings, {d1:.1f} s"},
                                     "sample": f"first {sample} soundings of the same batch x {rounds} proposal round(s), C oracle "
                                               f"(oracle/fdem1d_oracle.c, gcc -O2, OpenMP {threads} threads), {dt:.1f} s"}
             c_gpu, l_gpu = chi2[:sample].cpu().numpy(), logl[:sample].cpu().numpy()
@@ -882,11 +968,14 @@ def main():
                 others[key] = {"value": line[key]["value"], "unit": line[key]["unit"], "frac": line[key]["roofline"]["frac"]}
         if others:
             line["roofline"]["other_kernels"] = others
-        print(json.dumps(line), flush=True)
+        # the full record goes to a side file; the printed line is the compact one the driver's record can hold (<= 3 KB)
+        wrote = bool(args.extras_file) and write_extras(line, args.extras_file)
+        print(json.dumps(compact_line(line, args.extras_file if wrote else None), separators=(",", ":")), flush=True)
         parity_failed = "parity_vs_cpu" in line and not line["parity_vs_cpu"]["within_bar"]
     else:
         parity_failed = False
     if exchange:
+        dist.barrier()              # rank 0 may still be timing the CPU baseline: nobody tears the group down before it is done
         dist.destroy_process_group()
     if parity_failed:
         sys.exit("bench.py: the benchmarked kernel is outside the parity bar against the CPU oracle (parity_vs_cpu in the line above)")

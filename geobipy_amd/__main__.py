@@ -41,8 +41,12 @@ def parse(argv=None):
                         "contiguous block of soundings per rank; dynamic: ranks draw chunks from a shared counter (the reference's "
                         "master / worker scheduling) and ship their posterior rows to rank 0 point to point (tested over gloo only); "
                         "auto = lines on more than one rank when every flight line is one run of rows of the data file, else static")
-    p.add_argument("--chunk", type=int, default=None, help="soundings per block on the device (default: 16384 for static and lines; a 16th of a rank's share for dynamic)")
+    p.add_argument("--chunk", type=int, default=None, help="soundings per block on the device (default: 16384 for static and lines, fewer when full-length traces would not fit the device budget; a 16th of a rank's share for dynamic)")
+    p.add_argument("--traces", default="1",
+                   help="per-iteration misfit / acceptance traces of the containers: 1 = the reference's arrays in full (2 n_markov_chains "
+                        "columns), an integer stride > 1 or 'auto' (at most 4096 entries per sounding) keeps every stride-th entry, 0 = none")
     a = p.parse_args(argv)
+    a.traces = "auto" if a.traces == "auto" else (int(a.traces) or None)
     if a.seed is not None:
         a.seed = int(a.seed)
     return a
@@ -70,7 +74,7 @@ def main(argv=None):
     containers = None if a.no_containers else a.output_directory      # reference-layout containers: FdemData, TdemData, TempestData
     t0 = time.perf_counter()
     res = survey.infer(a.options_file, seed=a.seed, index=a.index, fiducial=a.fiducial, line_number=a.line_number,
-                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, results_directory=containers,
+                       exact_jacobian=a.exact_jacobian, hitmap=not a.no_hitmap, hankel_eps=a.hankel_eps, schedule=a.schedule, chunk=a.chunk, traces=a.traces, results_directory=containers,
                        container=None if a.container == "auto" else a.container, data_directory=a.data_directory,
                        data_filename=a.data_filename)
     if rank == 0:

@@ -192,6 +192,11 @@ __device__ __forceinline__ double wave_sum(double v)
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// This library is written for gfx950 alone (v_permlane16_swap / v_permlane32_swap below exist on no earlier CDNA part): say so at
+// compile time rather than with an unknown-builtin error in the middle of the reduction tree.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "geobipy_amd builds for gfx950 (MI355X) only: hipcc --offload-arch=gfx950"
+#endif
 // v[lane] + v[lane ^ W] for W = 16, 32 in every lane, by gfx950's row swaps (v_permlane16_swap / v_permlane32_swap exchange the odd
 // 16- / 32-lane rows of one register with the even rows of another: VALU moves, where a shuffle would wait for the LDS crossbar)
 template <int W>
@@ -480,7 +485,8 @@ __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* 
                                           double* __restrict__ pred_row /* [2F] or NULL */, int nw_use, int zero_to, double row_scale = 1.0 GBP_TICK_ARGS,
                                           int share = 0, int n_shares = 1)
 {   // share / n_shares: this workgroup evaluates the frequencies  wave * n_shares + share,  + nw_use * n_shares, ...  -- a frequency's
-    // rows of J and pred depend on nothing but that frequency, so n_shares workgroups split a sounding's evaluation and write the same bits   // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
+    // rows of J and pred depend on nothing but that frequency, so n_shares workgroups split a sounding's evaluation and write the same bits
+    // zero_to: the unused columns L .. zero_to - 1 of every row are set to 0 (Lmax: the whole row, the public entries; the
     // sampler, whose consumers never read a column >= L, passes L rounded up to 8 and leaves the rest of the row alone)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

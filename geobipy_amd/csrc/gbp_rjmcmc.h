@@ -1934,7 +1934,9 @@ __global__ __launch_bounds__(64) GBP_RJ_LATENCY_KERNEL void k_rj_step8(RjOpt o, 
     const int bq = min(b, c.B - 1);
     const int k_before = c.k[bq];
     const bool frozen = o.schedule == 1 && c.status[bq] != 0;
-    accept8_body<TRIPS>(o, c, iter, accumulate, lane, b, sh_dyn, 0, &st);
+    // (a chain flagged deep belongs to a scanning workgroup of this launch, which rewrites k_r and the move for iteration + 1 while
+    //  this group may still be reading them: a group acts on its chain only when deep_cur says so -- idle groups get chain index c.B)
+    accept8_body<TRIPS>(o, c, iter, accumulate, lane, mine ? b : c.B, sh_dyn, 0, &st);
     if (frozen) { st.accepted = false; st.k_now = k_before; }
     wave_sync();
     if (mine) {                                        // (group-uniform; the reads inside stay within the chain's own 8 lanes)

@@ -505,8 +505,12 @@ inline gbp_status run(gbp_tdem_system* s, int B, const double* geometry, int Lma
         gbp_tdem_system::Work* const ws = lease.w;
         // A workspace leased again on the SAME stream may still be the source of the previous call's pageable hipMemcpyAsync's (the
         // last run of a call is not synchronised): wait for that call's end before its host staging vectors are resized / overwritten.
-        if (ws->done != nullptr && hipEventQuery(ws->done) == hipErrorNotReady) (void)hipEventSynchronize(ws->done);
-        (void)hipGetLastError();
+        // (only hipErrorNotReady is cleared: a real asynchronous failure -- of the wait, or left by the previous call's kernels -- ends this call)
+        if (ws->done != nullptr) {
+            hipError_t qe = hipEventQuery(ws->done);
+            if (qe == hipErrorNotReady) { (void)hipGetLastError(); qe = hipEventSynchronize(ws->done); }
+            if (qe != hipSuccess) return fail(GBP_ERR_HIP, "the previous call on this workspace failed: %s", hipGetErrorString(qe));
+        }
         ws->h_height.resize(B);
         ws->h_set.resize(B);
         for (int b = 0; b < B; ++b) ws->h_height[b] = geometry[(size_t)b * 10];

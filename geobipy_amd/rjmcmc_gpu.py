@@ -86,8 +86,17 @@ class DeviceChains:
     def __init__(self, system, heights, data, seed=0, exact_jacobian=False, device=None, hitmap=False, n_value_bins=250,
                  first_chain=0, forward_waves=2, reference_schedule=False, burn_in_min_iterations=5000, hankel_eps_ppm=None,
                  min_altitude=None, add_scale=None, rel_group=None, add_group=None, chain_id=None, extra_log_prior=0.0,
-                 additive_independent=False, trace_every=0, trace_length=None, **options):
-        """``trace_every`` > 0: keep every ``trace_every``-th entry of the reference's per-iteration arrays ``data_misfit_v`` /
+                 additive_independent=False, trace_every=0, trace_length=None, ignore_likelihood=False, **options):
+        """``ignore_likelihood``: sample the PRIOR alone (the reference's option of that name, Inference1D.py:394, 519, 551, 596: no data
+        term in the stochastic-Newton step, likelihood constant).  The reference's own run of it ends at the first birth or death, where
+        Model.proposal_probabilities calls ``observation.sensitivity`` on None (model/Model.py:619); here the observation is left out
+        consistently -- Model.local_precision / local_gradient with ``observation is None`` for the forward AND the reverse proposal -- by
+        handing the sampler a block whose channels are all inactive once the starting half-space has been chosen from the measured data:
+        weights, residual terms, chi^2 and log-likelihood are then exact zeros in every stage (the same kernels, nothing skipped).  The
+        chains start burned in with ``burned_in_iteration = n_markov_chains`` (Inference1D.py:388-389): 2 n_markov_chains + 1 updates,
+        posteriors from the first.  The measured data stay available as ``observed``.
+
+        ``trace_every`` > 0: keep every ``trace_every``-th entry of the reference's per-iteration arrays ``data_misfit_v`` /
         ``acceptance_v`` (Inference1D.py:408, 414) on the device -- ``trace_misfit`` [B, trace_length] (NaN = not reached),
         ``trace_accept`` uint8 [B, trace_length]; ``trace_length`` defaults to the reference's 2 n_markov_chains / trace_every (needs
         n_markov_chains).  1 = the reference's arrays in full."""
@@ -215,7 +224,27 @@ class DeviceChains:
         self._bind()
         self.iteration = 0
         self.forward_waves = int(forward_waves)      # also passed explicitly to the forward calls of the initialisation
+        self.ignore_likelihood = bool(ignore_likelihood or o.get("ignore_likelihood", False))
         self._initialize()
+        if self.ignore_likelihood:
+            self._drop_observation()
+
+    @property
+    def observed(self):
+        """The measured data [B, N] (``t['data']`` unless the chains sample the prior alone: then the sampler's block is all-inactive)."""
+        return self.t["observed"] if self.t.get("observed") is not None else self.t["data"]
+
+    def _drop_observation(self):
+        """ignore_likelihood: from here on no channel is active (data <= 0 is the reference's own flag for an inactive channel,
+        EmDataPoint.py:54-56), the likelihood of every state is the constant 0 and the schedule starts burned in."""
+        t = self.t
+        t["observed"] = t["data"].clone()
+        t["data"].zero_()
+        for name in ("like", "misfit", "init_like", "init_misfit"):
+            t[name].zero_()
+        t["best_posterior"].copy_(t["prior"])
+        if self._o.schedule == 1:
+            t["burned_in_iteration"].fill_(int(self._o.n_markov_chains))
 
     def _bind(self):
         """(Re)build the gbp_rj_chains struct from the tensors in self.t."""

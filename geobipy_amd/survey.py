@@ -472,6 +472,9 @@ def select_soundings(ds, index=None, fiducial=None, line_number=None):
     return np.arange(ds.nPoints)
 
 
+BLOCK_PAYLOAD_BUDGET = 8 << 30      # bytes of traces + hit maps one device block may hold by default (infer's ``chunk``)
+
+
 def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min_iterations=5000, check_every=1000,
           exact_jacobian=False, data=None, index=None, fiducial=None, line_number=None, hankel_eps=None, schedule="static",
           chunk=None, results_directory=None, timings=None, traces=1, container=None, **overrides):
@@ -479,8 +482,10 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     ``torch.distributed`` group to shard the soundings (``distributed.shard``); rank 0 returns the SurveyResult of the
     whole survey (and writes ``output`` if given), the other ranks return None.
 
-    ``chunk``: soundings per block on the device (default 16 384 for "static" and "lines"; see "dynamic").
-    ``schedule``: "auto" (the command line's default) -- "lines" on more than one rank when the data file allows it, else "static";
+    ``chunk``: soundings per block on the device (default 16 384 for "static" and "lines", fewer when full-length traces and hit maps of
+    that many soundings would exceed BLOCK_PAYLOAD_BUDGET on the device; see "dynamic").
+    ``schedule``: "auto" (the command line's default) -- "lines" on more than one rank when containers are written, the data file allows
+    it and whole lines balance over the ranks (most loaded rank <= 1.2 x the mean), else "static";
     "lines" -- whole flight lines per rank, longest first to the least loaded rank (``distributed.assign_lines``): every
     rank writes the results containers of its own lines and no posterior row travels (the choice for many GPUs with containers);
     "static" -- each rank inverts one contiguous block (``distributed.shard``); "dynamic" -- the ranks draw chunks
@@ -521,10 +526,9 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     # (time-domain data: the loops' attitude angles are sampled on the device, gbp_td_moves; position moves raise in TdemDeviceChains)
     if o.get("solve_calibration"):
         raise NotImplementedError("solve_calibration is not supported by the device sampler")
-    if o.get("ignore_likelihood"):
-        # the reference then samples the prior alone (Inference1D.py:394, 519, 551, 596: no stochastic Newton step, no data term) -- until the
-        # first birth or death, where its Model.proposal_probabilities dereferences the None observation (Model.py:619): nothing to reproduce
-        raise NotImplementedError("ignore_likelihood (prior-only sampling) is not supported by the device sampler")
+    if o.get("ignore_likelihood") and time_domain:
+        raise NotImplementedError("ignore_likelihood (prior-only sampling) on time-domain data is not supported by the device sampler")
+    # (frequency-domain data: DeviceChains(ignore_likelihood=True) -- the prior alone, Inference1D.py:394, 519, 551, 596)
     # solve_height: the reference's datapoint only moves its height for the keys solve_z / maximum_z_change /
     # z_proposal_variance (pointcloud/Point.py:949-983), which its options files never set -- with the files as shipped the height
     # stays fixed there too.  An options file that DOES carry solve_z = True gets the move (frequency-domain data; DeviceChains).
@@ -546,7 +550,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     start, n = shard(ds.nPoints, rank, world)
     sl = slice(start, start + n)
     seed = o.get("seed", 0) if seed is None else seed
-    keys = ("n_markov_chains", "solve_gradient", "solve_parameter", "solve_relative_error", "solve_additive_error", "maximum_number_of_layers",
+    keys = ("ignore_likelihood", "n_markov_chains", "solve_gradient", "solve_parameter", "solve_relative_error", "solve_additive_error", "maximum_number_of_layers",
             "minimum_depth", "maximum_depth", "minimum_thickness", "initial_relative_error", "minimum_relative_error",
             "maximum_relative_error", "initial_additive_error", "minimum_additive_error", "maximum_additive_error",
             "relative_error_proposal_variance", "additive_error_proposal_variance", "probability_of_birth",
@@ -568,6 +572,16 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     if results_directory is not None and traces:
         n_mc2 = 2 * int(o["n_markov_chains"])
         common.update(trace_every=max(1, -(-n_mc2 // 4096)) if traces == "auto" else int(traces))
+    # Default block size: 16 384 soundings, less when a sounding's posterior payload on the device is large -- full-length traces at the
+    # reference's default n_markov_chains = 100 000 are 1.8 MB per sounding (29.5 GB for 16 384, plus their host copies): the default
+    # block keeps traces + hit maps under BLOCK_PAYLOAD_BUDGET.  Chains are keyed by row, so the block size never changes a result.
+    def default_block(limit=16384):
+        per = 0
+        if common.get("trace_every"):
+            per += -(-2 * int(o["n_markov_chains"]) // int(common["trace_every"])) * 9        # misfit f64 + acceptance u8 per kept entry
+        if hitmap and results_directory is not None:
+            per += 440 * 1024                                                                 # (the hit map's usual size; exact: DeviceChains)
+        return limit if per == 0 else int(max(256, min(limit, BLOCK_PAYLOAD_BUDGET // per)))
     if time_domain and hankel_eps is not None:
         common.update(hankel_eps=float(hankel_eps))
     elif not time_domain and hankel_eps is not None:
@@ -651,7 +665,8 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         # the error levels of the highest-posterior state, like Inference1D.writeHdf's best data point (:1076-1088)
         brel = torch.where(none[:, None], t["rel"], t["best_rel"]).contiguous()
         badd = torch.where(none[:, None], t["add"], t["best_add"]).contiguous()
-        pred = torch.empty_like(t["data"])
+        observed = dc.observed                     # (the measured data: t["data"] unless the chains sampled the prior alone)
+        pred = torch.empty_like(observed)
         chi2, logl = torch.empty_like(t["misfit"]), torch.empty_like(t["misfit"])
         # sampled attitude angles: the best data point's OWN geometry -- the prediction and the predicted primary field of the
         # highest-posterior angles, not of the chain's last state / the measured geometry (Inference1D.writeHdf :1076-1088 writes
@@ -667,13 +682,13 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                 best_mix["scale"], eval_height = extra["scale"], extra["height"]
         with torch.cuda.device(dev):                # one batched forward at the best models, through the sampler's own entry
             dc._eval_loglike(bk.contiguous(), bs.contiguous(), layer_widths(be, bk.to(torch.int64)).contiguous(),
-                             eval_height, t["data"], brel, badd, pred, chi2, logl, **best_mix)
+                             eval_height, observed, brel, badd, pred, chi2, logl, **best_mix)
         host = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)[idx], device=dev).reshape(idx.size, -1)
-        cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), t["data"], pred,
+        cols_f = [host(ds.x), host(ds.y), host(ds.z), host(ds.elevation), host(ds.lineNumber), host(ds.fiducial), observed, pred,
                   brel, badd, t["log_mean_prior"][:, None], be, bs]
         if time_domain:
             n_pf = ds.primary_field.shape[1] if ds.primary_field is not None else 0
-            cols_f += [dc.channel_std(t["data"], brel, badd), host(ds.offsets), host(ds.loop_angles)]
+            cols_f += [dc.channel_std(observed, brel, badd), host(ds.offsets), host(ds.loop_angles)]
             if n_pf:
                 cols_f += [host(ds.primary_field),
                            torch.as_tensor(dc.predicted_primary() if best_primary is None else best_primary, device=dev).reshape(idx.size, -1)]
@@ -762,7 +777,16 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         # gloo only) -- whenever the data file allows it (every flight line one run of consecutive rows)
         change_ = np.flatnonzero(np.diff(ds.lineNumber) != 0) + 1
         firsts_ = np.r_[0, change_] if ds.nPoints else np.zeros(0, dtype=np.int64)
-        schedule = "lines" if (world > 1 and ds.nPoints and np.unique(ds.lineNumber[firsts_]).size == firsts_.size) else "static"
+        lines_ok = bool(world > 1 and results_directory is not None and ds.nPoints and np.unique(ds.lineNumber[firsts_]).size == firsts_.size
+                        and firsts_.size >= world)
+        if lines_ok:
+            # ... and only when whole lines balance: the most loaded rank within 1.2 x the mean (a survey with fewer lines than ranks,
+            # or one dominant line, would leave GPUs idle where "static" uses all of them); without containers "lines" buys nothing
+            from .distributed import assign_lines as _assign
+            counts_ = np.diff(np.r_[firsts_, ds.nPoints])
+            loads = [int(sum(counts_[i] for i in mine_)) for mine_ in _assign(counts_, world)]
+            lines_ok = max(loads) <= 1.2 * ds.nPoints / world
+        schedule = "lines" if lines_ok else "static"
     if schedule == "lines":
         # whole flight lines per rank: every rank fills and writes the results files of its own lines (as the reference's ranks write
         # their own rows, Inference3D.py:586-635), only the one-row summaries are gathered
@@ -773,7 +797,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         if np.unique(ds.lineNumber[firsts]).size != firsts.size:
             raise ValueError("schedule='lines' needs every flight line in one run of consecutive rows of the data file (use 'static' or 'dynamic')")
         n = -1                                      # (every block is a selection: chains keyed by chain_id)
-        size = int(chunk) if chunk else 16384       # a long line goes through the device in pieces of this many soundings
+        size = int(chunk) if chunk else default_block()   # a long line goes through the device in pieces of this many soundings
         done_rows, done_vals = [], []
         for li in assign_lines(counts, world)[rank]:
             for first in range(int(firsts[li]), int(firsts[li] + counts[li]), size):
@@ -788,7 +812,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
         # a rank's block goes through the device in pieces of `chunk` soundings (default 16 384): the posteriors of a piece (440 KB of hit
         # map per sounding) leave the GPU, and with one process the host, before the next piece runs -- 65 536 soundings: 19.6 s and 16 GB
         # of host memory in pieces against 24.7 s and 38 GB in one block (scripts/bench_survey.py); the chains are keyed by row either way
-        piece = int(chunk) if chunk else 16384
+        piece = int(chunk) if chunk else default_block()
         if n > piece:
             local = torch.cat([process(first, min(piece, start + n - first)) for first in range(start, start + n, piece)])
         else:
@@ -802,7 +826,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
     else:
         from .distributed import ChunkQueue, gather_rows
         n = -1                                      # (every block is a selection: chains keyed by chain_id)
-        size = int(chunk) if chunk else max(256, -(-ds.nPoints // (16 * world)))
+        size = int(chunk) if chunk else default_block(max(256, -(-ds.nPoints // (16 * world))))
         done_rows, done_vals = [], []
         for first, count in ChunkQueue(ds.nPoints, size):
             done_vals.append(process(first, count))

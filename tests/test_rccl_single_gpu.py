@@ -73,7 +73,7 @@ def test_bench_rounds_with_the_gather_forced_over_rccl():
     """bench.py's N > 1 round -- fused kernel, event, side stream, all_gather_into_tensor, pending-work wait -- on a one-rank RCCL
     group; the gathered block equals the local summaries and the line keeps the contract's keys."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--soundings", "8192",
-                        "--force-collective", "--no-extras", "--no-rjmcmc", "--no-cpu-baseline", "--no-windowed"],
+                        "--force-collective", "--no-extras", "--no-rjmcmc", "--no-cpu-baseline", "--no-windowed", "--extras-file", ""],
                        env=dict(ENV, MASTER_PORT="29549"), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
