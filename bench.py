@@ -100,9 +100,12 @@ def profiled_utilisation(case):
         return None, None
     d = json.load(open(found[-1]))
     u = d.get("derived", {}).get("valu_issue_utilisation_fp64_4cyc")
-    if u is None:                                        # sampler summaries: per kernel
+    if u is None:                                        # sampler summaries: per kernel (+ the whole iteration's, summarise_case.py)
         ks = d.get("kernels", {})
         u = {k.split("<")[0].replace("rj::", ""): round(v["valu_issue_utilisation"], 4) for k, v in ks.items() if v.get("share_of_kernel_time", 0) > 0.05}
+        agg = d.get("derived", {}).get("valu_issue_utilisation_aggregate")
+        if agg is not None:
+            u["aggregate"] = round(agg, 4)
     return u, os.path.relpath(found[-1], ROOT)
 
 
@@ -229,6 +232,7 @@ def rjmcmc_extra(system, height, obs, device, Btot):
                                 "frac_all_abscissae_equivalent": ach_all / FP64_VECTOR_PEAK_TFLOPS,
                                 "evaluated_share_of_abscissae": win,
                                 "valu_issue_utilisation": util, "valu_issue_utilisation_source": util_src,
+                                "valu_issue_utilisation_aggregate": util.get("aggregate") if isinstance(util, dict) else None,
                                 "kernel": "k_rj_physics (fm_dlogc at the remapped models; fused forward / fm_dlogc at the proposals) "
                                           "+ propose / newton / accept stages", **cen,
                                 "note": "frac = flops the kernels EXECUTE (min-flop count of SURVEY 8(d) per evaluated (frequency, abscissa, layer) "
@@ -280,25 +284,14 @@ def rjmcmc_extra(system, height, obs, device, Btot):
                                                                                   if c["first_divergent_checkpoint"] >= 0],
                          "median_rel_misfit_diff_of_matching_chains": float(np.median([c["max_rel_misfit_diff"] for c in same])) if same else None}
             del dc
-        full = {}
-        for name, path in (("gpu_vs_cpu_64_chains_x_10000", "replay_arms_gpu_vs_cpu.json"), ("cpu_vs_perturbed_cpu_48_chains_x_10000", "replay_sensitivity_cpu.json")):
-            q = os.path.join(ROOT, "profiles", "r3", path)
-            if os.path.exists(q):
-                d = json.load(open(q))
-                full[name + "__read_from"] = "profiles/r3/" + path + " (committed result of an earlier build, not measured by this run)"
-                full[name] = ([{k: a[k] for k in ("exact_jacobian", "hankel_eps_ppm", "exact_matches", "chains", "drift_median_final")} for a in d]
-                              if isinstance(d, list) else d["summary"])
         out["cpu_replay"] = {"chains": n_rep, "iterations": it_rep, "exact_matches": arms["reference_jacobian"]["exact_matches"],
                              "first_divergence_iteration": arms["reference_jacobian"]["first_divergence_iteration"], "arms": arms,
-                             "full_size_arms_committed": full,
+                             "full_size": "tests/test_config5_gpu.py re-runs 64 chains x 10 000 iterations against the CPU replay on every GPU test run "
+                                          "of THIS build (its printed line: exact matches, divergent rows by iteration, drift of the matching chains)",
                              "note": "layer-count / interface-depth histograms and every checkpoint of (layers, accepted steps) equal to a CPU "
-                                     "replay (rjmcmc.py stage emulation + C oracle, same random streams).  Full size (64 chains x 10 000 "
-                                     "iterations, profiles/r3/replay_arms_gpu_vs_cpu.json): 58 / 58 / 59 / 59 of 64 identical in the four arms "
-                                     "{reference, exact Jacobian} x {abscissa window, all abscissae}, matching chains drift by 5e-11 (median, "
-                                     "not growing) -- and two CPU runs that differ by 1e-10-level perturbations of the oracle part at the same "
-                                     "rate (40 of 48, replay_sensitivity_cpu.json): the divergences are the chain map's own sensitivity in "
-                                     "ill-conditioned stretches (cond of the Newton precision ~1e4 - 4e5), not a property of either Jacobian "
-                                     "expression, of the window, or of the device"}
+                                     "replay (rjmcmc.py stage emulation + C oracle, same random streams); the chains that diverge do so in "
+                                     "ill-conditioned stretches of the chain map (cond of the Newton precision ~1e4 - 4e5): two CPU runs that differ "
+                                     "by 1e-10-level perturbations of the oracle part diverge at the same rate (docs/notes_r1_r4.md)"}
     except Exception as e:                                       # the replay is a checker, never the measurement
         out["cpu_replay"] = {"error": repr(e)}
     out["note"] = ("BASELINE config 5 on ONE GPU: full birth/death/perturb rjMCMC (gbp_rj_run), 10-frequency synthetic survey; value = "
@@ -805,7 +798,7 @@ def main():
                                              "frac_all_abscissae_equivalent": achj_all / FP64_VECTOR_PEAK_TFLOPS,
                                              "flop_per_eval_all_abscissae": fpj_all,
                                              "valu_issue_utilisation": utilj, "valu_issue_utilisation_source": utilj_src,
-                                             "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, %d>" % (1 if L <= 8 else (2 if L <= 16 else 8)),
+                                             "evals_per_launch": Btot, "kernel_ms": ms, "kernel": "k_fdem_sens<false, %d>" % (1 if L <= 8 else (2 if L <= 16 else 4)),
                                              "count": "builder's extension of SURVEY 8(d) to the prediction + Jacobian pass (flop_per_jacobian_point: "
                                                       "same per-operation weights) x the abscissae each sounding's window evaluates (frac) or all 120 per "
                                                       "frequency (*_all_abscissae_equivalent); 100 timed launches after a 50 ms warm-up"},

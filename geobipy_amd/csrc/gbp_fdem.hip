@@ -477,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_fdem_forward(const Channel* __restrict
 // J[f, m] = Re(g * sum), J[F + f, m] = Im(g * sum).  Every thread of the workgroup must call it (one workgroup barrier).
 //   sh_dyn: cplx D[nw_use][Lalloc][65] | LayerK lay[nw_use][Lalloc] | double t2[Lalloc]
 #define GBP_SENS_STRIDE 65
-template <bool EXACT, int NG>   // NG row groups of 8 layers are summed per evaluation: 1 for models of <= 8 layers, else 8
+template <bool EXACT, int NG>   // NG row groups of 8 layers are summed per evaluation: 1 / 2 / 4 for launches of <= 8 / 16 / more layers
 __device__ __forceinline__ void sens_body(const gbp::MathCtx& M, unsigned char* sh_dyn, const Channel* __restrict__ chan,
                                           const double* __restrict__ pts, int npts_total, int F, int Lmax, int Lalloc, int L,
                                           const double* __restrict__ sig, const double* __restrict__ th, double alt,
@@ -1230,10 +1230,13 @@ static gbp_status fm_dlogc_launch(const gbp_fdem_system* sys, int B, int Lmax, c
                            sys->d_bin_pts, compact_rows, set_of_row, row_scale);
         return GBP_OK;
     };
-    // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs
-    const int ng = max_layers <= 8 ? 1 : (max_layers <= 16 ? 2 : 8);
-    if (exact) st = ng == 1 ? launch(k_fdem_sens<true, 1>) : (ng == 2 ? launch(k_fdem_sens<true, 2>) : launch(k_fdem_sens<true, 8>));
-    else st = ng == 1 ? launch(k_fdem_sens<false, 1>) : (ng == 2 ? launch(k_fdem_sens<false, 2>) : launch(k_fdem_sens<false, 8>));
+    // launches capped at 8 (the sampler's common case) / 16 layers use variants with one / two row groups: fewer VGPRs.  Deeper launches
+    // sum FOUR row groups (32 layers) per evaluation -- 121 / 119 VGPRs, no scratch; the eight-group variant of rounds 1 - 5 spilled 11 - 13
+    // registers (48 - 56 B per lane) under the 128-VGPR budget -- and a model of 33 or more layers takes a second evaluation (sens_body's m0
+    // loop): the rows are the same sums in the same order, the same bits (tests/test_gpu_parity.py: the 30-layer fixtures)
+    const int ng = max_layers <= 8 ? 1 : (max_layers <= 16 ? 2 : 4);
+    if (exact) st = ng == 1 ? launch(k_fdem_sens<true, 1>) : (ng == 2 ? launch(k_fdem_sens<true, 2>) : launch(k_fdem_sens<true, 4>));
+    else st = ng == 1 ? launch(k_fdem_sens<false, 1>) : (ng == 2 ? launch(k_fdem_sens<false, 2>) : launch(k_fdem_sens<false, 4>));
     if (st != GBP_OK) return st;
     GBP_HIP(hipGetLastError());
     return GBP_OK;

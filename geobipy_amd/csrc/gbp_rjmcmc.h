@@ -129,6 +129,23 @@ __device__ __forceinline__ void wave_sync()
 #ifndef GBP_RJ_SHARES_UP_TO
 #define GBP_RJ_SHARES_UP_TO 700
 #endif
+// Round 6: the physics launches take their chains deepest model first (k_rj_order_by_layers, once per call and sub-block): a launch lasts as
+// long as its slowest workgroup, a workgroup's life grows with its chain's layer count (19.6 us + 3.6 us per layer for a Jacobian pass at
+// 8 192 chains), and layer counts change by one per accepted birth / death -- the order of the call's first iteration stays a good one.
+// Which workgroup evaluates which chain changes no bit.  GBP_RJ_SPLIT_DEEP = n > 0: the deepest 1 / n of a launch's chains also get
+// a second workgroup, which takes half of the frequencies of a Jacobian pass of 4 or more layers (share / n_shares of sens_body).
+#ifndef GBP_RJ_ORDERED_PHYSICS
+#define GBP_RJ_ORDERED_PHYSICS 1
+#endif
+#ifndef GBP_RJ_REORDER_EVERY
+#define GBP_RJ_REORDER_EVERY 256     // iterations between two sorts of a call
+#endif
+#ifndef GBP_RJ_SPLIT_DEEP
+#define GBP_RJ_SPLIT_DEEP 0
+#endif
+#ifndef GBP_RJ_SPLIT_MIN_LAYERS
+#define GBP_RJ_SPLIT_MIN_LAYERS 4
+#endif
 // Row groups (of 8 layers) the Jacobian pass of a model of MORE than 8 layers sums per evaluation (sens_body<EXACT, NG>; the pass is
 // repeated for the next 8 NG layers).  8 -- one evaluation for any model -- keeps 16 complex accumulators and costs the physics kernel 25
 // spilled registers and 104 B of scratch; 2 covers 16 layers per evaluation (two evaluations for 17 - 32 layers) with none: 118 VGPRs,
@@ -1955,6 +1972,24 @@ __global__ __launch_bounds__(256) void k_rj_propose_flags(gbp_rj_chains c, int32
     if (b < c.B) deep[b] = accept_is_deep(c, b, 8) ? 1 : 0;
 }
 
+// The chains of a launch by descending layer count (counting sort, one workgroup; ties in any order -- which workgroup evaluates which
+// chain changes no bit): the order in which k_rj_physics takes them (GBP_RJ_ORDERED_PHYSICS)
+__global__ __launch_bounds__(1024) void k_rj_order_by_layers(gbp_rj_chains c, int32_t* __restrict__ order)
+{
+    __shared__ int cnt[64], pos[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) cnt[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < c.B; b += 1024) atomicAdd(&cnt[63 - min(max(c.k[b], 0), 63)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int q = 0; q < 64; ++q) { pos[q] = run; run += cnt[q]; }
+    }
+    __syncthreads();
+    for (int b = tid; b < c.B; b += 1024) order[atomicAdd(&pos[63 - min(max(c.k[b], 0), 63)], 1)] = b;
+}
+
 // Settles what the chains' current models are still owed in the hit map (call before reading it).
 __global__ __launch_bounds__(64) void k_rj_flush(RjOpt o, gbp_rj_chains c)
 {
@@ -2272,6 +2307,12 @@ __global__ __launch_bounds__(64) void k_td_loglike(RjOpt o, gbp_rj_chains c, con
 #ifndef GBP_STAGE_ATTR
 #define GBP_STAGE_ATTR __attribute__((noinline))
 #endif
+#ifndef GBP_PHYS_STAGE_ATTR
+#define GBP_PHYS_STAGE_ATTR GBP_STAGE_ATTR
+#endif
+#ifndef GBP_ACCEPT_STAGE_ATTR
+#define GBP_ACCEPT_STAGE_ATTR GBP_STAGE_ATTR
+#endif
 struct PersistentCtx {
     const RjOpt* o;          // LDS copies
     const gbp_rj_chains* c;
@@ -2310,7 +2351,7 @@ __device__ __forceinline__ gbp::MathCtx math_ctx(MathLds* lds)    // math_setup 
 }
 
 template <bool EXACT>
-__device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_proposal)
+__device__ GBP_PHYS_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_proposal)
 {
     const RjOpt& o = *x->o;
     const gbp_rj_chains& c = *x->c;
@@ -2330,7 +2371,7 @@ __device__ GBP_STAGE_ATTR void stage_fm_dlogc(const PersistentCtx* x, int at_pro
                              sig, th, alt, Jb, pr, x->nw_deep, min(K, (L + 7) & ~7));
 }
 
-__device__ GBP_STAGE_ATTR void stage_forward(const PersistentCtx* x)
+__device__ GBP_PHYS_STAGE_ATTR void stage_forward(const PersistentCtx* x)
 {
     const RjOpt& o = *x->o;
     const gbp_rj_chains& c = *x->c;
@@ -2355,7 +2396,7 @@ __device__ GBP_STAGE_ATTR void stage_newton(const PersistentCtx* x, uint32_t ite
     else newton_body(*x->o, c, iter, 8, x->b, lane, x->sh_dyn);
 }
 
-__device__ GBP_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t iter, int accumulate, int lane)
+__device__ GBP_ACCEPT_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint32_t iter, int accumulate, int lane)
 {
     const gbp_rj_chains& c = *x->c;
     const int kr = c.k_r[x->b], kp = c.k[x->b];
@@ -2531,7 +2572,8 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
                                                     const double* __restrict__ pts, int npts_total, int F, double sigma_direct,
                                                     int stage, unsigned char* deep_scratch, size_t deep_bytes,
                                                     const BinDesc* __restrict__ bins, int bin0, int n_bins,
-                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts, int out_offset)
+                                                    const Channel* __restrict__ bin_chan, const double* __restrict__ bin_pts, int out_offset,
+                                                    const int32_t* __restrict__ order, int n_split)
 {
     // The output row lives behind the stages' working set in the dynamic block (out_offset) instead of a static 2 * GBP_MAX_FREQ doubles:
     // with two waves per chain the workgroup's LDS was 20 544 B -- 64 B more than an eighth of a CU's 160 KB -- i.e. seven resident
@@ -2542,9 +2584,14 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     // Workgroups B ... 2 B - 1 (launched when the Jacobian passes are split, GBP_RJ_JACOBIAN_SHARES = 2) are the second halves of the
     // chains' Jacobian evaluations: a launch lasts as long as its slowest workgroup, the Jacobian workgroups are the slow ones, and a
     // frequency's rows depend on nothing else -- two workgroups take five frequencies each and write the bits one would.
-    const int share = (int)blockIdx.x >= c.B ? 1 : 0;
-    const int n_shares = (int)gridDim.x > c.B ? 2 : 1;
-    const int b = (int)blockIdx.x - share * c.B;
+    // `order` (round 6): workgroup g takes chain order[g] -- the launch's chains by descending layer count at the start of the call;
+    // n_split > 0: the first n_split of them have a second workgroup each (workgroups B ... B + n_split - 1), used by the Jacobian passes
+    // of GBP_RJ_SPLIT_MIN_LAYERS or more layers (both workgroups read the same move and layer count: the same decision)
+    int share = (int)blockIdx.x >= c.B ? 1 : 0;
+    int n_shares = (int)gridDim.x > c.B ? 2 : 1;
+    const int slot = (int)blockIdx.x - share * c.B;
+    const int b = order != nullptr ? order[slot] : slot;
+    if (n_split > 0 && slot >= n_split) n_shares = 1;
 #ifdef GBP_RJ_PHYS_CLOCK
     const long long clk_start_ = (long long)wall_clock64();
     PhysClk clk_{threadIdx.x == 0 && (b & 15) == 0, 0, clk_start_};
@@ -2563,7 +2610,9 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
     const double alt_early = (stage == 1 && o.solve_height) ? c.height_p[b] : c.height[b];
 #endif
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
-    if (share != 0 && ((stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) return;   // (a fused forward, or a deep model: one workgroup)
+    if (n_split > 0 && n_shares == 2 && L_early < GBP_RJ_SPLIT_MIN_LAYERS) n_shares = 1;   // (a shallow model: not worth a second prologue)
+    if (share != 0 && (n_shares == 1 || (stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) return;   // (a fused forward, or a deep model: one workgroup)
+    if (n_shares == 2 && ((stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) n_shares = 1;
 #ifdef GBP_RJ_PHYS_CLOCK
     clk_.base = (stage == 0 ? 0 : ((action == INSERT || action == DELETE) ? 8 : 16));
 #endif
@@ -3218,7 +3267,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         const int P = std::max(1, std::min(parts, (int)BlockStreams::MAX));
         BlockStreams* bs = P > 1 ? block_streams() : nullptr;
         if (P > 1 && bs == nullptr) return fail(GBP_ERR_HIP, "sub-block streams: %s", hipGetErrorString(hipGetLastError()));
-        struct Part { gbp_rj_options o; gbp_rj_chains c; hipStream_t q; unsigned char* deep; int nw; size_t lds; int32_t* flags; };
+        struct Part { gbp_rj_options o; gbp_rj_chains c; hipStream_t q; unsigned char* deep; int nw; size_t lds; int32_t* flags; int32_t* order; };
         std::vector<Part> part(P);
         const size_t deep_per_chain = K > 8 ? 1 : 0;
         for (int p = 0; p < P; ++p) {
@@ -3230,6 +3279,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             t.q = P > 1 ? bs->q[p] : main_q;
             t.deep = nullptr;
             t.flags = nullptr;
+            t.order = nullptr;
             // Waves per workgroup of the physics launches (results do not depend on it).  Measured per sub-block size n
             // (scripts/bench_rj_parts.py through -DGBP_RJ_PHYSICS_NW builds, M chain-iterations/s with 1 / 2 / 3 / 4 waves; ten
             // frequencies | Resolve): n = 1 024: 11.9 15.3 16.5 17.1 | 14.6 17.5 18.5 19.6;  2 048: 20.4 25.9 27.0 27.5 | 25.7 30.1 31.0
@@ -3271,12 +3321,18 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
                 part[p].flags = nullptr;
                 alloc_failed = true;
             }
+            if (!alloc_failed && GBP_RJ_ORDERED_PHYSICS && n_iterations >= 4 && part[p].c.B > 64 &&
+                hipMallocAsync((void**)&part[p].order, sizeof(int32_t) * (size_t)part[p].c.B, part[p].q) != hipSuccess) {
+                part[p].order = nullptr;
+                alloc_failed = true;
+            }
         }
         if (alloc_failed) {          // give back what was allocated and join the sub-block streams the caller's stream was forked into
             const hipError_t e = hipGetLastError();
             for (int p = 0; p < P; ++p) {
                 if (part[p].deep != nullptr) (void)hipFreeAsync(part[p].deep, part[p].q);
                 if (part[p].flags != nullptr) (void)hipFreeAsync(part[p].flags, part[p].q);
+                if (part[p].order != nullptr) (void)hipFreeAsync(part[p].order, part[p].q);
                 if (P > 1) { (void)hipEventRecord(bs->done[p], part[p].q); (void)hipStreamWaitEvent(main_q, bs->done[p], 0); }
             }
             return fail(GBP_ERR_HIP, "sampler sub-blocks: working set of the deep models: %s", hipGetErrorString(e));
@@ -3290,14 +3346,18 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             const rj::RjOpt ox = rj::extend(t.o);
             const size_t out_bytes = (size_t)o->n_channels * sizeof(double);          // the output row behind the stages' block (k_rj_physics)
             const int out_offset = (int)lds_s;
+            // (the deepest 1 / GBP_RJ_SPLIT_DEEP of an ordered launch's chains get a second workgroup where the launch does not split every chain's)
+            const int shares = jacobian_shares(t.c.B);
+            const int n_split = (GBP_RJ_SPLIT_DEEP > 0 && shares == 1 && t.order != nullptr) ? t.c.B / GBP_RJ_SPLIT_DEEP : 0;
+            const int grid = t.c.B * shares + n_split;
             if (o->exact_jacobian)
-                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(t.c.B * jacobian_shares(t.c.B)), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<true>, dim3(grid), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                                   sys->d_bin_pts, out_offset);
+                                   sys->d_bin_pts, out_offset, t.order, n_split);
             else
-                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(t.c.B * jacobian_shares(t.c.B)), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
+                hipLaunchKernelGGL(rj::k_rj_physics<false>, dim3(grid), dim3(64 * nw_s), lds_s + out_bytes, t.q, ox, t.c, sys->d_chan, sys->d_pts, sys->t.npts,
                                    sys->t.nF, sys->sigma_direct, stage, t.deep, deep_bytes, sys->d_bins, sys->bin0, sys->n_bins, sys->d_bin_chan,
-                                   sys->d_bin_pts, out_offset);
+                                   sys->d_bin_pts, out_offset, t.order, n_split);
         };
         // One host thread per sub-block issues that sub-block's launches (7 per iteration at ~9 us each: one thread issuing for
         // four sub-blocks would be slower than the GPU -- measured 31 vs 37.6 M chain-iterations/s at 8 192 chains; with a thread
@@ -3317,6 +3377,8 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
                 if ((s3 = gbp_rj_propose(&t.o, &t.c, iter, t.q)) != GBP_OK) return s3;
                 if (step) hipLaunchKernelGGL(rj::k_rj_propose_flags, dim3((nB + 255) / 256), dim3(256), 0, t.q, t.c, t.flags);
             }
+            if (t.order != nullptr && it % GBP_RJ_REORDER_EVERY == 0)     // the launches' chain order: deepest model first (one small workgroup)
+                hipLaunchKernelGGL(rj::k_rj_order_by_layers, dim3(1), dim3(1024), 0, t.q, t.c, t.order);
             physics(t, 0);                                    // fm_dlogc at the remapped models whose structure changed (Model.py:383-384)
             if ((s3 = gbp_rj_newton(&t.o, &t.c, iter, t.q)) != GBP_OK) return s3;
             physics(t, 1);                                    // Inference1D.py:572-597 / Model.py:612: every proposal's evaluation
@@ -3373,6 +3435,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
         for (int p = 0; p < P; ++p) {
             if (part[p].deep != nullptr) (void)hipFreeAsync(part[p].deep, part[p].q);
             if (part[p].flags != nullptr) (void)hipFreeAsync(part[p].flags, part[p].q);
+            if (part[p].order != nullptr) (void)hipFreeAsync(part[p].order, part[p].q);
         }
         if (P > 1)
             for (int p = 0; p < P; ++p) {

@@ -246,8 +246,12 @@ class Inference1D:
                  reciprocate_parameters=False, reset_limit=1, save_hdf5=False, save_png=False, solve_gradient=True,
                  solve_parameter=False, update_plot_every=5000, world=None, engine=None, **kwargs):
         assert isinstance(prng, np.random.Generator), TypeError("prng must have type np.random.Generator")
-        if ignore_likelihood:
-            raise NotImplementedError("ignore_likelihood (prior-only sampling, Inference1D.py:394, 551, 596) is not supported")
+        # ignore_likelihood: the prior alone (Inference1D.py:394, 519, 551, 596).  The reference's own run of it ends at the first birth or
+        # death (Model.proposal_probabilities calls observation.sensitivity on None, model/Model.py:619); here the observation is left out
+        # of the forward AND the reverse proposal (Model.local_precision / local_gradient with observation None): once the starting
+        # half-space is chosen from the measured data, the sampler sees a sounding without an active channel -- weights, residual terms,
+        # chi^2 and log-likelihood are exact zeros -- and starts burned in (Inference1D.py:388-389).  Same as DeviceChains(ignore_likelihood).
+        self.ignore_likelihood = bool(ignore_likelihood)
         self.prng, self.engine, self.world = prng, engine, world
         self.options = dict(OPTION_DEFAULTS)
         self.options.update({k: v for k, v in kwargs.items() if v is not None})
@@ -284,6 +288,10 @@ class Inference1D:
         # sampled scalars of a time-domain loop pair (solve_transmitter_* / solve_receiver_*: all False in the reference's options files)
         self.geom_moves = datapoint.geometry_moves(**self.options) if hasattr(datapoint, "geometry_moves") else []
         self.priors, self.state = initial_state(self.engine, self.data, self.options, self.error_model, self.z_move, self.geom_moves)
+        if self.ignore_likelihood:
+            self.observed = self.data
+            self.data = np.zeros_like(self.data)               # no active channel from here on (data > 0 is the flag, EmDataPoint.py:54-56)
+            self.state.like, self.state.misfit = 0.0, 0.0
         self.halfspace = self.state.values.copy()
         self.iteration = 0
         self.data_misfit_v = np.zeros(2 * self.n_markov_chains + 2)
@@ -370,6 +378,8 @@ class Inference1D:
         window = int(self.options.get("update_plot_every") or 5000)
         reset_limit = int(self.options.get("reset_limit") or 1)
         self.burned_in, self.burned_in_iteration = False, 0
+        if self.ignore_likelihood:                             # Inference1D.py:388-389: burned in from the start, 2 n_markov_chains + 1 updates
+            self.burned_in, self.burned_in_iteration = True, self.n_markov_chains
         self.n_resets, self.n_zero_acceptance, limited = 0, 0, False
         while True:
             self.accept_reject()

@@ -135,14 +135,17 @@ class Model:
         (remapped_model, perturbed_model); ``observation`` (a data point with fm_dlogc / sensitivity_matrix / predictedData /
         std / data) supplies the Jacobian -- recomputed at the remapped model when the structure changed (:383-384).
         The variance limiters are inert in the reference (perturb ignores them) and here."""
-        assert observation is not None, NotImplementedError("prior-only proposals (ignore_likelihood) are not supported")
         sp, vp, prng = self._structure_prior, self._value_prior, self._prng
         action, index, value, edges, rem = rjmcmc.perturb_structure(prng, sp, self._interior_edges(), self.values)
         remapped = self._like(edges, rem, (_ACTION_NAMES[action], index, value))
-        if action != rjmcmc.NONE:
-            observation.fm_dlogc(remapped)
-        J = np.asarray(observation.sensitivity_matrix)[:, : rem.size]
-        mean, H = rjmcmc.stochastic_newton(vp, edges, rem, J, observation.predictedData, observation.data, observation.std, alpha)
+        if observation is None:                                 # prior-only proposals (ignore_likelihood; Model.py:380, 269, 352): no data term
+            none = np.zeros(0)
+            mean, H = rjmcmc.stochastic_newton(vp, edges, rem, np.zeros((0, rem.size)), none, none, none, alpha)
+        else:
+            if action != rjmcmc.NONE:
+                observation.fm_dlogc(remapped)
+            J = np.asarray(observation.sensitivity_matrix)[:, : rem.size]
+            mean, H = rjmcmc.stochastic_newton(vp, edges, rem, J, observation.predictedData, observation.data, observation.std, alpha)
         prop = rjmcmc.propose_values(prng, mean, H)
         perturbed = self._like(edges, prop, (_ACTION_NAMES[action], index, value))
         perturbed._proposal_covariance = H                      # values.proposal.variance in the reference
@@ -163,11 +166,13 @@ class Model:
             return 1.0, 1.0
         vp = self._value_prior
         H = self._proposal_covariance
-        observation.sensitivity(self)
-        J = np.asarray(observation.sensitivity_matrix)[:, : self.values.size]
-        data, pred, std = observation.data, observation.predictedData, observation.std
-        a = data > 0.0
-        grad = rjmcmc.model_prior_derivative(vp, self._interior_edges(), self.values, 1) + J[a].T @ ((pred[a] - data[a]) / std[a] ** 2.0)
+        grad = rjmcmc.model_prior_derivative(vp, self._interior_edges(), self.values, 1)
+        if observation is not None:         # (the reference dereferences a None observation here, Model.py:619: its prior-only run ends at the
+            observation.sensitivity(self)   #  first birth or death; local_gradient(observation=None) is what its other branches do)
+            J = np.asarray(observation.sensitivity_matrix)[:, : self.values.size]
+            data, pred, std = observation.data, observation.predictedData, observation.std
+            a = data > 0.0
+            grad = grad + J[a].T @ ((pred[a] - data[a]) / std[a] ** 2.0)
         mean_r = np.exp(np.longdouble(1.0) * (np.log(self.values) + alpha * (H @ grad)))
         if np.any(np.isinf(mean_r)) or np.any(mean_r == 0.0):
             return -np.inf, -np.inf

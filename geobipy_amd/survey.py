@@ -724,7 +724,12 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
                to_host(torch.cat([c_.to(torch.int32) for c_ in cols], dim=1).contiguous()))
         return out + (csr,) if sparse else out
 
-    def fill_containers():
+    def fill_containers(background=False):
+        """The finished block's rows -> host -> line containers.  ``background``: on a host thread with a device stream of its own, while
+        the caller's thread runs the NEXT block's chains (the block's sampler stays alive until its rows have left the device; one block is
+        in flight at a time, so the containers receive the blocks in order) -- 65 536 soundings: the rows of three of the four blocks no
+        longer stand between two blocks' chains.  The phase clocks of a background fill are host wall time, overlapped with "chains"."""
+        join_fill()
         if state.get("unfilled") is None:
             return
         dc_, idx_ = state.pop("unfilled")
@@ -732,10 +737,40 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             state["writer"] = _LineWriter(results_directory, ds, o, dc_, hitmap, container)
         if idx_.size == 0:                          # (a rank that got no flight line: nothing to hand over)
             return
-        with _Phase("rows_to_host"):
-            pl = payload(dc_, idx_, sparse=True)
-        with _Phase("container_fill"):
-            state["writer"].add_block(pl)
+        if not background or dc_.device.type != "cuda":
+            with _Phase("rows_to_host"):
+                pl = payload(dc_, idx_, sparse=True)
+            with _Phase("container_fill"):
+                state["writer"].add_block(pl)
+            return
+        import threading
+        side = state.get("fill_stream")
+        if side is None:
+            side = state["fill_stream"] = torch.cuda.Stream(device=dc_.device)
+        side.wait_stream(torch.cuda.current_stream(dc_.device))      # (the block's chains have ended: infer() read their status flags)
+        failed = state.setdefault("fill_failed", [])
+
+        def work():
+            try:
+                t0_ = _time.perf_counter()
+                with torch.cuda.device(dc_.device), torch.cuda.stream(side):
+                    pl = payload(dc_, idx_, sparse=True)
+                t1_ = _time.perf_counter()
+                state["writer"].add_block(pl)
+                if timings is not None:
+                    timings["rows_to_host_overlapped"] = timings.get("rows_to_host_overlapped", 0.0) + t1_ - t0_
+                    timings["container_fill_overlapped"] = timings.get("container_fill_overlapped", 0.0) + _time.perf_counter() - t1_
+            except BaseException as e:               # (handed to the caller's thread by join_fill)
+                failed.append(e)
+        th = state["fill_thread"] = threading.Thread(target=work)
+        th.start()
+
+    def join_fill():
+        th = state.pop("fill_thread", None)
+        if th is not None:
+            th.join()
+        if state.get("fill_failed"):
+            raise state["fill_failed"].pop(0)
 
     def process(first, count):
         """Result rows [count, width] of the soundings first .. first + count - 1 (count >= 0)."""
@@ -753,7 +788,7 @@ def infer(options, output=None, seed=None, device=None, hitmap=True, burn_in_min
             blocks = [(None, span)]
         out = None
         for off, idx in blocks:
-            fill_containers()                       # (the block before this one, if any: before its sampler is dropped)
+            fill_containers(background=True)        # (the block before this one, if any: its rows leave while this block's chains run)
             dc, named = run_block(idx, off)
             if results_directory is not None and (world == 1 or schedule == "lines"):
                 # one process: the block's rows go to the line containers and are dropped (host memory holds the open lines, not the

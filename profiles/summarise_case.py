@@ -86,6 +86,20 @@ if case.startswith("rjmcmc"):
     der["iterations_in_run"] = n_it
     der["hbm_bytes_per_iteration"] = sum(per_launch(k) * v["launches"] for k, v in out["kernels"].items() if "rj" in k or "fdem" in k) / n_it
     der["kernel_us_per_iteration"] = sum(v["avg_us"] * v["launches"] for k, v in out["kernels"].items() if "rj" in k or "fdem" in k) / n_it
+    # aggregate VALU issue utilisation of an iteration: wave-level VALU instructions of all sampler launches of one
+    # iteration (counted under the profiler) x 4 cycles / the issue slots of 1 024 SIMDs over the UN-PROFILED iteration time of the same
+    # case on the same box (plain.log, run_profile_r6.sh) at the 2.4 GHz peak engine clock
+    valu = sum(v.get("valu_insts_per_wave", 0.0) * v.get("waves_per_launch", 0.0) * v["launches"] for k, v in out["kernels"].items() if "rj" in k or "fdem" in k) / n_it
+    der["valu_instructions_per_iteration"] = valu
+    plain = os.path.join(src, "plain.log")
+    if os.path.exists(plain):
+        pl = next((l for l in open(plain).read().splitlines() if l.startswith("CASE")), None)
+        if pl:
+            ms = float(re.search(r"([0-9.]+) ms per iteration", pl).group(1))
+            der["unprofiled_run"] = pl
+            der["unprofiled_us_per_iteration"] = 1e3 * ms
+            der["issue_slots_per_iteration_2p4GHz"] = 1024.0 * ms * 1e-3 * 2.4e9 / 4.0
+            der["valu_issue_utilisation_aggregate"] = valu / der["issue_slots_per_iteration_2p4GHz"]
 out["derived"] = der
 os.makedirs(os.path.join(R, "profiles", rnd), exist_ok=True)
 json.dump(out, open(os.path.join(R, "profiles", rnd, "summary_%s.json" % case), "w"), indent=1)

@@ -422,6 +422,40 @@ def test_jacobian_random_batch_vs_oracle_and_finite_differences():
     assert close(J[:, :, L - 1], Je[:, :, L - 1], PRED_ATOL, 1e-8)
 
 
+def test_jacobian_of_models_deeper_than_one_evaluation():
+    """Launches of more than 16 layers sum four row groups (32 layers) per evaluation (k_fdem_sens<*, 4>); a model of 33 or more layers
+    takes a second evaluation for its remaining rows: rows 0 ... 31 and 32 ... against the oracle, both Jacobian expressions, and the
+    30-layer case (one evaluation) in the same launch."""
+    from geobipy_amd import FdemBatch, synthetic
+    from oracle import fdem_oracle as fo
+    s = synthetic.syn10_system()
+    osys = oracle_system("syn10")
+    Lmax = 44
+    nl, sig, thk, h = synthetic.draw_models(48, 40, seed=91, Lmax=Lmax)
+    thk[:, :40] = np.where(thk[:, :40] > 0, 1.0 + 0.1 * thk[:, :40], 0.0)           # thin layers: the deep rows stay above rounding level
+    nl[::3] = 30; nl[1::3] = 40; nl[2::3] = 44
+    sig[2::3, 40:44] = sig[2::3, 36:40][:, ::-1]
+    thk[2::3, 39:43] = 2.5
+    b = FdemBatch(s, nl, sig, thk, h)
+    J = b.sensitivity().cpu().numpy()
+    assert J.shape == (48, 20, Lmax) and np.isfinite(J).all()
+    for i in range(48):
+        L = int(nl[i])
+        Jo = fo.sensitivity(osys, sig[i, :L], thk[i, :L], h[i])
+        assert close(J[i, :, :L], np.vstack([Jo.real, Jo.imag]), PRED_ATOL, PRED_RTOL), i
+        assert np.all(J[i, :, L:] == 0.0)
+    assert np.abs(J[1::3, :, 32:40]).max() > 0.0                                      # (the second evaluation's rows are not trivially zero)
+    Je = b.sensitivity(exact=True).cpu().numpy()
+    eps = 1e-4
+    for m in (0, 31, 32, 39):
+        sp, sm = sig.copy(), sig.copy()
+        sp[:, m] *= np.exp(eps)
+        sm[:, m] *= np.exp(-eps)
+        fd = (FdemBatch(s, nl, sp, thk, h).forward().cpu().numpy() - FdemBatch(s, nl, sm, thk, h).forward().cpu().numpy()) / (2 * eps)
+        live = nl > m
+        assert np.all(np.abs(Je[live][:, :, m] - fd[live]) <= 2e-4 + 1e-6 * np.abs(fd[live]))
+
+
 def test_datapoint_sensitivity_and_fm_dlogc():
     from geobipy_amd import FdemDataPoint, Model, RectilinearMesh1D
     from oracle import fdem_oracle as fo
