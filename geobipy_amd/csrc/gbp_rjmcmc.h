@@ -27,6 +27,12 @@
 #ifndef GBP_RJ_PHYSICS_WAVES_PER_EU
 #define GBP_RJ_PHYSICS_WAVES_PER_EU 4
 #endif
+// Layers of a model whose Jacobian working set (one complex per lane and layer) the lock-step physics kernel keeps in LDS; deeper models
+// work in their chain's global block (sens_body's deep variant: same sums, same bits).  8: 16.6 KB per two-wave workgroup, eight
+// workgroups per CU; 6: 12.5 KB, ten per CU -- what a fifth wave per SIMD (GBP_RJ_PHYSICS_WAVES_PER_EU 5) needs.
+#ifndef GBP_RJ_PHYSICS_LDS_LAYERS
+#define GBP_RJ_PHYSICS_LDS_LAYERS 8
+#endif
 #ifndef GBP_RJ_PERSISTENT_WAVES_PER_EU
 #define GBP_RJ_PERSISTENT_WAVES_PER_EU 2
 #endif
@@ -2410,6 +2416,9 @@ __device__ GBP_ACCEPT_STAGE_ATTR void stage_accept(const PersistentCtx* x, uint3
 // propose | fm_dlogc at the remapped model | newton | forward or fm_dlogc at the proposal | accept | iterations.  Read with
 // gbp_rj_debug_stage_ticks; costs one branch per stage in the other workgroups.
 __device__ long long GBP_RJ_TICKS[8];
+// ... and, while the clock is armed, the life of EVERY workgroup of the launches: [0] sum, [1] count, [2] longest (ticks).  A persistent
+// launch ends with its slowest chain (round 6: chain 0's stages sum to 42 us per iteration where the launch takes 53).
+__device__ unsigned long long GBP_RJ_LIFE[3];
 
 template <bool EXACT>
 __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_chains c_arg, const Channel* __restrict__ chan,
@@ -2501,8 +2510,10 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
     const int32_t* status = c_arg.status;
     const int32_t* action_p = sh_c.action;
     const int schedule = o_arg.schedule;
-    const bool clocked = b == 0 && threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0;   // armed by gbp_rj_debug_stage_ticks(out, 1)
-    long long t0 = clocked ? (long long)wall_clock64() : 0;
+    const bool armed = threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0;                // armed by gbp_rj_debug_stage_ticks(out, 1)
+    const bool clocked = b == 0 && armed;
+    const long long t_start = armed ? (long long)wall_clock64() : 0;
+    long long t0 = t_start;
     auto tick = [&](int stage) {
         if (clocked) { const long long t1 = (long long)wall_clock64(); GBP_RJ_TICKS[stage] += t1 - t0; t0 = t1; }
     };
@@ -2533,6 +2544,12 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
         __syncthreads();
         tick(4);
         if (clocked) GBP_RJ_TICKS[5] += 1;
+    }
+    if (armed) {
+        const unsigned long long life = (unsigned long long)((long long)wall_clock64() - t_start);
+        atomicAdd(&GBP_RJ_LIFE[0], life);
+        atomicAdd(&GBP_RJ_LIFE[1], 1ull);
+        atomicMax(&GBP_RJ_LIFE[2], life);
     }
     {   // everything back to the block's arrays (scratch too: the arrays end as the lock-step driver leaves them)
         const double* p = ld;
@@ -2611,8 +2628,8 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
 #endif
     if (stage == 0 && action == NONE) return;                     // (workgroup-uniform)
     if (n_split > 0 && n_shares == 2 && L_early < GBP_RJ_SPLIT_MIN_LAYERS) n_shares = 1;   // (a shallow model: not worth a second prologue)
-    if (share != 0 && (n_shares == 1 || (stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) return;   // (a fused forward, or a deep model: one workgroup)
-    if (n_shares == 2 && ((stage == 1 && action != INSERT && action != DELETE) || L_early > 8)) n_shares = 1;
+    if (share != 0 && (n_shares == 1 || (stage == 1 && action != INSERT && action != DELETE) || L_early > GBP_RJ_PHYSICS_LDS_LAYERS)) return;   // (a fused forward, or a deep model: one workgroup)
+    if (n_shares == 2 && ((stage == 1 && action != INSERT && action != DELETE) || L_early > GBP_RJ_PHYSICS_LDS_LAYERS)) n_shares = 1;
 #ifdef GBP_RJ_PHYS_CLOCK
     clk_.base = (stage == 0 ? 0 : ((action == INSERT || action == DELETE) ? 8 : 16));
 #endif
@@ -2639,7 +2656,7 @@ __global__ GBP_RJ_PHYSICS_BOUNDS void k_rj_physics(RjOpt o, gbp_rj_chains c, con
         double* Jb = (at_proposal ? c.J_p : c.J_r) + (size_t)b * N * K;
         double* pr = (at_proposal ? c.pred_p : c.pred_r) + (size_t)b * N;
         const double* th = c.thk_r + (size_t)b * K;
-        if (L <= 8) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < 8 ? K : 8, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS, share, n_shares);
+        if (L <= GBP_RJ_PHYSICS_LDS_LAYERS) sens_body<EXACT, 1>(M, sh_dyn, chan, pts, npts_total, F, K, K < GBP_RJ_PHYSICS_LDS_LAYERS ? K : GBP_RJ_PHYSICS_LDS_LAYERS, L, sig, th, alt, Jb, pr, nw, min(K, 8), 1.0 GBP_TICK_PASS, share, n_shares);
         else sens_body<EXACT, GBP_RJ_DEEP_NG>(M, deep_scratch + (size_t)b * deep_bytes, chan, pts, npts_total, F, K, K, L, sig, th, alt, Jb, pr, nw,
                                  min(K, (L + 7) & ~7));
     } else {
@@ -3054,7 +3071,7 @@ static int lockstep_parts(int B)
 #ifdef GBP_RJ_LOCKSTEP_PARTS
     return B >= 2048 ? GBP_RJ_LOCKSTEP_PARTS : 1;              // (A/B builds under scripts/ab only)
 #endif
-    return B >= 2048 ? 3 : (B >= 1600 ? 2 : 1);      // (1 600 ... 2 047 chains, two against one: 17.5 vs 15.4, 19.2 vs 15.8, 20.8 vs 17.1 M Resolve; 15.5 vs 13.6 ... 18.3 vs 15.1 M ten frequencies)
+    return B >= 2048 ? 3 : (B >= 1200 ? 2 : 1);      // (1 600 ... 2 047 chains, two against one: 17.5 vs 15.4, 19.2 vs 15.8, 20.8 vs 17.1 M Resolve; 15.5 vs 13.6 ... 18.3 vs 15.1 M ten frequencies)
 }
 
 gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, const gbp_rj_chains* c, int64_t first_iteration,
@@ -3073,15 +3090,17 @@ gbp_status gbp_rj_run_mode(const gbp_fdem_system* sys, const gbp_rj_options* o, 
         // ~0.02 us per chain.  Measured (Resolve and the 10-frequency system, scripts/bench_rj_modes.py): the persistent kernel
         // wins while the whole block is resident at once (1 536 Resolve chains with one wave each: 20.2 vs 14.0 M
         // chain-iterations/s), the lock-step driver as soon as it would take a second round (2 048: 17.5 vs 16.6 M).
-        // A block up to a fifth beyond what is resident at once still runs faster persistently (the surplus workgroups start as the first
-        // finish) than as two lock-step sub-blocks: 1 600 / 1 802 chains 18.7 / 20.5 M against 17.5 / 19.2 M (Resolve, capacity 1 536; ten
-        // frequencies 16.6 / 18.3 against 15.5 / 17.1); at 2 000 the sub-blocks are level or ahead (20.8 = 20.9, 18.3 vs 16.9).  This is the
-        // size a survey block shrinks to when the chains that failed to burn in have stopped (survey.infer re-packs the running ones).
+        // (Rounds 4 - 5 ran blocks up to a fifth beyond the resident capacity persistently; with four launches per lock-step iteration
+        //  two sub-blocks are ahead from the first chain beyond it -- the measurements are beside `small` below.)  This is the size a
+        //  survey block shrinks to when the chains that failed to burn in have stopped (survey.infer re-packs the running ones).
         const int nw = persistent_waves(sys, o, c->B, false);
         bool small = false;
         if (nw > 0 && n_iterations >= 4) {
             const long long cap = persistent_capacity(sys, o, nw);
-            small = (long long)c->B <= cap + cap / 5;
+            // (round 6, with four launches per lock-step iteration: a block beyond what is resident at once is faster as two sub-blocks --
+            //  ten frequencies, capacity 1 280: 1 408 / 1 536 chains 13.6 / 15.0 M persistently against 16.5 / 17.9 M; Resolve, capacity
+            //  1 536: 1 700 chains 19.5 against 21.8 M -- the fifth of slack of rounds 4 - 5 is gone)
+            small = (long long)c->B <= cap;
         }
         if (small) return rj_run_persistent(sys, o, c, first_iteration, n_iterations, accumulate, false, stream);
         // (concurrent sub-blocks cost a host thread each and a fork / join of streams per call: they pay from about four iterations per
@@ -3097,12 +3116,18 @@ gbp_status gbp_rj_debug_stage_ticks(int64_t* out, int reset)
 {
     if (!out) return fail(GBP_ERR_INVALID_ARG, "out is NULL%s");
     long long h[8];
+    unsigned long long life[3];
     GBP_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(rj::GBP_RJ_TICKS), sizeof(h)));
-    for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
+    GBP_HIP(hipMemcpyFromSymbol(life, HIP_SYMBOL(rj::GBP_RJ_LIFE), sizeof(life)));
+    for (int i = 0; i < 6; ++i) out[i] = (int64_t)h[i];
+    out[6] = (int64_t)life[2];                                       // the longest workgroup life of the launches since the reset
+    out[7] = life[1] ? (int64_t)(life[0] / life[1]) : 0;             // ... and the mean
     if (reset) {                                 // 1: zero the counters and arm the clock; 2: zero and disarm
         std::memset(h, 0, sizeof(h));
+        std::memset(life, 0, sizeof(life));
         h[7] = reset == 1 ? 1 : 0;
         GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rj::GBP_RJ_TICKS), h, sizeof(h)));
+        GBP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rj::GBP_RJ_LIFE), life, sizeof(life)));
     }
     return GBP_OK;
 }
@@ -3295,7 +3320,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
 #ifdef GBP_RJ_PHYSICS_NW
             t.nw = GBP_RJ_PHYSICS_NW;                          // (A/B builds under scripts/ab only)
 #endif
-            t.lds = (std::max(dyn_lds_bytes(t.nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(t.nw, K < 8 ? K : 8)) + 15) & ~(size_t)15;     // + the output row, physics()
+            t.lds = (std::max(dyn_lds_bytes(t.nw, K, (sys->t.npts + 63) / 64), sens_lds_bytes(t.nw, K < GBP_RJ_PHYSICS_LDS_LAYERS ? K : GBP_RJ_PHYSICS_LDS_LAYERS)) + 15) & ~(size_t)15;     // + the output row, physics()
         }
         (void)deep_per_chain;
         if (P > 1) {
@@ -3311,7 +3336,7 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
 #endif
         bool alloc_failed = false;
         for (int p = 0; p < P && !alloc_failed; ++p) {
-            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(std::max(part[p].nw, stage0_waves(part[p].nw)), K) + 255) & ~(size_t)255) : 0;
+            const size_t deep_bytes = K > GBP_RJ_PHYSICS_LDS_LAYERS ? ((sens_lds_bytes(std::max(part[p].nw, stage0_waves(part[p].nw)), K) + 255) & ~(size_t)255) : 0;
             if (deep_bytes > 0 && hipMallocAsync((void**)&part[p].deep, deep_bytes * (size_t)part[p].c.B, part[p].q) != hipSuccess) {
                 part[p].deep = nullptr;
                 alloc_failed = true;
@@ -3341,8 +3366,8 @@ static gbp_status rj_run_lockstep(const gbp_fdem_system* sys, const gbp_td_opera
             // (stage 0 -- the Jacobian pass at the remapped model: half of the workgroups leave at once -- may take a wave count of its own;
             //  the deep models' global working set is sized for the larger of the two)
             const int nw_s = stage == 0 ? stage0_waves(t.nw) : t.nw;
-            const size_t lds_s = stage == 0 ? ((std::max(dyn_lds_bytes(nw_s, K, (sys->t.npts + 63) / 64), sens_lds_bytes(nw_s, K < 8 ? K : 8)) + 15) & ~(size_t)15) : t.lds;
-            const size_t deep_bytes = K > 8 ? ((sens_lds_bytes(std::max(t.nw, stage0_waves(t.nw)), K) + 255) & ~(size_t)255) : 0;
+            const size_t lds_s = stage == 0 ? ((std::max(dyn_lds_bytes(nw_s, K, (sys->t.npts + 63) / 64), sens_lds_bytes(nw_s, K < GBP_RJ_PHYSICS_LDS_LAYERS ? K : GBP_RJ_PHYSICS_LDS_LAYERS)) + 15) & ~(size_t)15) : t.lds;
+            const size_t deep_bytes = K > GBP_RJ_PHYSICS_LDS_LAYERS ? ((sens_lds_bytes(std::max(t.nw, stage0_waves(t.nw)), K) + 255) & ~(size_t)255) : 0;
             const rj::RjOpt ox = rj::extend(t.o);
             const size_t out_bytes = (size_t)o->n_channels * sizeof(double);          // the output row behind the stages' block (k_rj_physics)
             const int out_offset = (int)lds_s;

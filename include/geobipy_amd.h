@@ -573,7 +573,8 @@ gbp_status gbp_tdem_fm_dlogc(gbp_tdem_system *sys, int B, const double *geometry
                              const double *sigma, const double *thk, double *out, double *J, void *stream);
 
 /* Diagnostics: [host] out[8] = accumulated 100 MHz clock ticks of chain 0 in the persistent kernel's stages (propose, fm_dlogc at
- * the remapped model, newton, forward / fm_dlogc at the proposal, accept), out[5] = iterations counted; synchronises the device.
+ * the remapped model, newton, forward / fm_dlogc at the proposal, accept), out[5] = iterations counted, out[6] / out[7] = the longest /
+ * the mean life of the launches' workgroups in ticks (a persistent launch ends with its slowest chain); synchronises the device.
  * reset: 0 read only, 1 zero the counters and arm the clock (off by default: it costs chain 0 a few global updates per iteration),
  * 2 zero and disarm. */
 gbp_status gbp_rj_debug_stage_ticks(int64_t *out, int reset);

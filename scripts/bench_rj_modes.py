@@ -39,4 +39,5 @@ for B in [int(v) for v in (sys.argv[3].split(',') if len(sys.argv) > 3 else '256
                 _lib.check(_lib.load().gbp_rj_debug_stage_ticks(tk, 2))
                 if tk[5]:
                     out[-1] += " stages us/it [propose, fm_dlogc_r, newton, fwd|fm_dlogc_p, accept]: " + " ".join(f"{tk[i] / tk[5] / 100.0:.1f}" for i in range(5))
+                    out[-1] += f"; workgroup life us/it: mean {tk[7] / 100.0 / 200:.1f}, longest {tk[6] / 100.0 / 200:.1f}"
     print(f"{which} exact={int(exact)} B={B:6d}  " + " | ".join(out), flush=True)
