@@ -426,7 +426,7 @@ def compact_line(full, extras_file=EXTRAS_FILE):
             "dtype", "data", "rounds_per_step", "timed_seconds", "finite")
     line = {k: full[k] for k in keep if k in full}
     cfg = full.get("config", {})
-    line["config"] = {k: cfg[k] for k in ("workload", "soundings", "frequencies", "layers", "rounds_per_step",
+    line["config"] = {k: cfg[k] for k in ("workload", "soundings", "frequencies", "layers", "rounds_per_step", "hankel_eps_ppm",
                                           "abscissa_points_per_sounding_mean", "abscissa_points_all") if k in cfg}
     rf = full.get("roofline", {})
     roof = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "evals_per_launch",
