@@ -696,6 +696,8 @@ __global__ void k_debug_math(int op, int n, const double* __restrict__ x, const 
         case 4: r0 = gbp::rsq_seed(a); break;
         case 5: r0 = gbp::rcp_seed(a); break;
         case 6: gbp::sqrt_rsqrt(a, r0, r1); break;
+        case 7: r0 = gbp::log_pos(a); break;
+        case 8: gbp::sincos_quadrant(a, r0, r1); break;
         default: break;
         }
         o0[i] = r0;
@@ -1147,7 +1149,7 @@ gbp_status gbp_bench_time_forward_loglike(const gbp_fdem_system* sys, int B, int
 
 gbp_status gbp_debug_math(int op, int n, const double* x, const double* y, double* out0, double* out1, void* stream)
 {
-    if (n < 0 || op < 0 || op > 6) return fail(GBP_ERR_INVALID_ARG, "bad op or n%s");
+    if (n < 0 || op < 0 || op > 8) return fail(GBP_ERR_INVALID_ARG, "bad op or n%s");
     if (n == 0) return GBP_OK;
     if (!x || !out0) return fail(GBP_ERR_INVALID_ARG, "NULL device pointer%s");
     hipLaunchKernelGGL(k_debug_math, dim3(1024), dim3(256), 0, (hipStream_t)stream, op, n, x, y, out0, out1);

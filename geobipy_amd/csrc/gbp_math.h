@@ -225,6 +225,90 @@ GBP_HD cplx cexp_neg(const MathCtx& M, double x, double t)
     return mk(e * c, e * s);
 }
 
+// ------------------------------------------------------------------------------------------
+// ln x and sin / cos for the SAMPLER's per-chain stages (gbp_rjmcmc.h; round 6).  Those stages are dependency chains of a single wave
+// -- what they cost is the number of dependent instructions -- and 40 % of the instructions of an accept + proposal launch were the
+// library's log (98 VALU instructions), cos and sincos (~150 - 250: its argument reduction serves any double) behind the generator's
+// Box-Muller step, the error-level walks and the priors.  The arguments here are tame: positive normal numbers for the logarithm, an
+// angle in [0, 2 pi] for the circular functions.  No tables (the packed stages have no LDS to spare), ~1 ulp.
+//
+// ln x, x > 0 finite (0 -> -inf, +inf -> +inf, NaN / negative -> NaN): x = 2^e m with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1),
+//   ln m = 2 atanh s = 2 s + 2 s^3 (1/3 + s^2 / 5 + ... + s^20 / 23),  |s| <= 0.1716: the first neglected term is 3e-19 of 2 s;
+// s gets one correction step after the reciprocal (its error is the result's), e ln 2 is added in two parts.  ~34 VALU issues.
+GBP_HD double frexp_mant(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_frexp_mant(x);  // v_frexp_mant_f64: [0.5, 1)
+#else
+    int e;
+    return std::frexp(x, &e);
+#endif
+}
+GBP_HD double log_pos(double x)
+{
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;     // ln 2 = HI + LO, HI with 21 trailing zero bits
+    double m = frexp_mant(x);
+    int e = frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e -= low ? 1 : 0;
+    const double f = m - 1.0;                      // exact
+    const double d = 2.0 + f;                      // exact (m + 1 <= 2.42 carries every bit of m)
+    const double inv = rcp(d);
+    double s = f * inv;
+    s = __builtin_fma(__builtin_fma(-s, d, f), inv, s);
+    const double z = s * s;
+    double p = __builtin_fma(z, 1.0 / 23.0, 1.0 / 21.0);
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double ef = (double)e;
+    // e LN2_HI is exact for |e| <= 2^21 / ...: 1 074 needs 11 bits, HI has 21 spare
+    double r = __builtin_fma(ef, LN2_LO, (s + s) * (z * p));
+    r = r + (s + s);
+    r = __builtin_fma(ef, LN2_HI, r);
+    const double inf = __builtin_huge_val();
+    r = x == 0.0 ? -inf : r;
+    r = x == inf ? inf : r;
+    return x < 0.0 ? __builtin_nan("") : r;        // (NaN in -> NaN out through the arithmetic)
+}
+
+// sin a and cos a for a in [0, 2 pi] (any |a| < ~1e5 in fact): a = k pi/2 + r, |r| <= pi/4 (two-term Cody-Waite with fma), the
+// published minimax kernels of degree 13 / 14 on r (fdlibm's k_sin / k_cos coefficients), quadrant by selects.  ~40 VALU issues for both.
+GBP_HD void sincos_quadrant(double a, double& sn, double& cs)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01, PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    int k;
+    const double kf = round_mul(a, TWO_OVER_PI, k);
+    double r = __builtin_fma(-kf, PIO2_HI, a);
+    r = __builtin_fma(-kf, PIO2_LO, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double s = __builtin_fma(ps * z, r, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * (z * pc));      // (k_cos's compensated form of 1 - z/2 + z^2 P)
+    const bool swap = (k & 1) != 0;
+    const double s0 = swap ? c : s, c0 = swap ? s : c;
+    sn = (k & 2) ? -s0 : s0;
+    cs = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // a / b, no overflow guard: callers keep |b| in a safe range
 GBP_HD cplx cdiv(cplx a, cplx b)
 {

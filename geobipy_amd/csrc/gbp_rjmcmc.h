@@ -181,14 +181,23 @@ __device__ __forceinline__ void wave_sync()
 #ifndef GBP_RJ_ONE_TRIP_ACCEPT
 #define GBP_RJ_ONE_TRIP_ACCEPT 0
 #endif
+// Round 6: the logarithm and the circular functions of these stages are gbp_math.h's log_pos / sincos_quadrant -- 34 and ~40 VALU issues
+// where the library's log took 98 and its cos / sincos behind Box-Muller 150 - 250 (argument reductions for any double; here the arguments
+// are positive normal numbers and an angle in [0, 2 pi]), ~1 ulp either way.  These calls were 40 % of the instructions of an accept +
+// proposal launch, and the stages are dependency chains of one wave.  GBP_RJ_LIBM_MATH restores the library routines (A/B builds).
+#ifdef GBP_RJ_LIBM_MATH
 __device__ GBP_RJ_CALL double rj_log(double x) { return log(x); }
+#else
+__device__ GBP_RJ_CALL double rj_log(double x) { return gbp::log_pos(x); }
+#endif
 __device__ GBP_RJ_CALL double rj_exp(double x) { return exp(x); }
 __device__ GBP_RJ_CALL U4 philox_call(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t n)
 {
     return philox(seed, chain, iter, stream, n);
 }
-__device__ GBP_RJ_CALL double box_muller_cos(double u1, double u2) { return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2); }
 struct Pair { double a, b; };
+#ifdef GBP_RJ_LIBM_MATH
+__device__ GBP_RJ_CALL double box_muller_cos(double u1, double u2) { return sqrt(-2.0 * log(1.0 - u1)) * cos(TWO_PI * u2); }
 __device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (returned in registers: two output pointers of a call are two objects in scratch)
 {
     const double rad = sqrt(-2.0 * log(1.0 - u1)), ang = TWO_PI * u2;
@@ -196,6 +205,18 @@ __device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (return
     z.a = rad * cos(ang); z.b = rad * sin(ang);
     return z;
 }
+#else
+__device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (returned in registers: two output pointers of a call are two objects in scratch)
+{
+    const double rad = sqrt(-2.0 * gbp::log_pos(1.0 - u1)), ang = TWO_PI * u2;       // (the angle rounded as the host emulation rounds it)
+    double sn, cs;
+    gbp::sincos_quadrant(ang, sn, cs);
+    Pair z;
+    z.a = rad * cs; z.b = rad * sn;
+    return z;
+}
+__device__ __forceinline__ double box_muller_cos(double u1, double u2) { return box_muller_pair(u1, u2).a; }
+#endif
 
 struct Rng {                                                    // sequential draws of one (chain, iteration, stream)
     uint64_t seed; uint32_t chain, iter, stream, n; double buf; bool have;

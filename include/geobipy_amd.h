@@ -278,7 +278,8 @@ gbp_status gbp_bench_time_forward_loglike(const gbp_fdem_system *sys, int B, int
 
 /* Test hook: element-wise evaluation of the device math kernels (geobipy_amd/csrc/gbp_math.h) on
  * [dev] arrays of length n.  op: 0 exp_neg(x), 1 sincos(x) -> (sin, cos), 2 csqrt(x + i y) -> (re, im),
- * 3 rcp(x), 4 raw v_rsq_f64 seed, 5 raw v_rcp_f64 seed, 6 sqrt_rsqrt(x) -> (sqrt, 1/sqrt).
+ * 3 rcp(x), 4 raw v_rsq_f64 seed, 5 raw v_rcp_f64 seed, 6 sqrt_rsqrt(x) -> (sqrt, 1/sqrt), 7 log_pos(x) (the sampler's ln),
+ * 8 sincos_quadrant(x) -> (sin, cos) (the sampler's Box-Muller angle).
  * y and out1 may be NULL where unused. */
 gbp_status gbp_debug_math(int op, int n, const double *x, const double *y, double *out0, double *out1,
                           void *stream);

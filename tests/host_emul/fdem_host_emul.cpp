@@ -143,3 +143,13 @@ void emul_csqrt(int n, const double* a, const double* b, double* re, double* im)
 void emul_sqrt_rsqrt(int n, const double* x, double* g, double* y) { for (int i = 0; i < n; ++i) gbp::sqrt_rsqrt(x[i], g[i], y[i]); }
 void emul_rcp(int n, const double* x, double* y) { for (int i = 0; i < n; ++i) y[i] = gbp::rcp(x[i]); }
 }
+
+// the sampler's logarithm and circular functions (gbp_math.h: log_pos, sincos_quadrant), element-wise, for the CPU-tier accuracy test
+extern "C" void emul_log_pos(int n, const double* x, double* out)
+{
+    for (int i = 0; i < n; ++i) out[i] = gbp::log_pos(x[i]);
+}
+extern "C" void emul_sincos_quadrant(int n, const double* x, double* sn, double* cs)
+{
+    for (int i = 0; i < n; ++i) gbp::sincos_quadrant(x[i], sn[i], cs[i]);
+}

@@ -54,3 +54,25 @@ def test_hardware_seed_accuracy_is_what_the_iterations_assume():
     e_rcp = np.max(np.abs(rc * x - 1.0))
     print("v_rsq_f64 seed max rel err %.3e, v_rcp_f64 seed max rel err %.3e" % (e_rsq, e_rcp))
     assert e_rsq < 2.0 ** -20 and e_rcp < 2.0 ** -20
+
+
+def test_sampler_log_and_sincos_on_hardware():
+    """gbp_math.h log_pos / sincos_quadrant (the sampler's per-chain stages since round 6) on the device, against numpy in long double:
+    <= 2.5 ulp for the logarithm over the whole positive range (denormals, the neighbourhood of 1, the special values), <= 2 ulp for sin and
+    cos of the Box-Muller angle in [0, 2 pi]."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 1 << 19)), 1.0 + rng.uniform(-1e-3, 1e-3, 1 << 18), 1.0 - rng.uniform(0, 1, 1 << 18) ** 8,
+                        rng.uniform(0, 1, 1 << 18), [1.0, 2.0, 0.5, 1e-310, 5e-324, 1.7976931348623157e308, 0.7071067811865475, 0.7071067811865476]])
+    got = run(7, x)
+    ref = np.log(x.astype(np.longdouble))
+    ulp = np.abs(got.astype(np.longdouble) - ref) / np.spacing(np.maximum(np.abs(np.log(x)), 1e-300))
+    assert float(ulp.max()) < 2.5, (float(ulp.max()), x[int(np.argmax(ulp))])
+    sp = run(7, np.array([0.0, np.inf, -1.0, np.nan, 1.0]))
+    assert sp[0] == -np.inf and sp[1] == np.inf and np.isnan(sp[2]) and np.isnan(sp[3]) and sp[4] == 0.0
+    a = np.concatenate([rng.uniform(0, 2 * np.pi, 1 << 19), 2 * np.pi * rng.integers(0, 2 ** 53, 1 << 18) / 2.0 ** 53,
+                        [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, np.pi / 4]])
+    s, c = run(8, a, two=True)
+    al = a.astype(np.longdouble)
+    us = np.abs(s - np.sin(al)) / np.spacing(np.maximum(np.abs(np.sin(a)), 1e-300))
+    uc = np.abs(c - np.cos(al)) / np.spacing(np.maximum(np.abs(np.cos(a)), 1e-300))
+    assert float(us.max()) < 2.0 and float(uc.max()) < 2.0, (float(us.max()), float(uc.max()))

@@ -244,3 +244,24 @@ def test_abscissa_window_bound_on_host(emul, name):
             assert n_win < 0.75 * n_full
     finally:
         emul.emul_set_window(0.0, 0.0)
+
+
+def test_sampler_log_and_sincos_headers_built_for_the_host(emul):
+    """gbp_math.h log_pos / sincos_quadrant (the sampler's logarithm and Box-Muller angle since round 6), compiled by g++, against
+    numpy in long double; the device build of the same source is checked on the hardware by tests/test_gpu_math.py."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 200000)), 1.0 + rng.uniform(-1e-3, 1e-3, 100000), 1.0 - rng.uniform(0, 1, 100000) ** 8,
+                        rng.uniform(0, 1, 100000), [1.0, 2.0, 0.5, 1e-310, 5e-324, 1.7976931348623157e308]])
+    out = np.empty_like(x)
+    emul.emul_log_pos(ctypes.c_int(x.size), x.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    ulp = np.abs(out.astype(np.longdouble) - np.log(x.astype(np.longdouble))) / np.spacing(np.maximum(np.abs(np.log(x)), 1e-300))
+    assert float(ulp.max()) < 2.5
+    sp, o = np.array([0.0, np.inf, -1.0, np.nan]), np.empty(4)
+    emul.emul_log_pos(ctypes.c_int(4), sp.ctypes.data_as(dp), o.ctypes.data_as(dp))
+    assert o[0] == -np.inf and o[1] == np.inf and np.isnan(o[2]) and np.isnan(o[3])
+    a = np.concatenate([rng.uniform(0, 2 * np.pi, 400000), [0.0, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi]])
+    sn, cs = np.empty_like(a), np.empty_like(a)
+    emul.emul_sincos_quadrant(ctypes.c_int(a.size), a.ctypes.data_as(dp), sn.ctypes.data_as(dp), cs.ctypes.data_as(dp))
+    al = a.astype(np.longdouble)
+    assert float((np.abs(sn - np.sin(al)) / np.spacing(np.maximum(np.abs(np.sin(a)), 1e-300))).max()) < 2.0
+    assert float((np.abs(cs - np.cos(al)) / np.spacing(np.maximum(np.abs(np.cos(a)), 1e-300))).max()) < 2.0
