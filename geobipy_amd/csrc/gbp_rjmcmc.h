@@ -179,7 +179,7 @@ __device__ __forceinline__ void wave_sync()
 #define GBP_RJ_ONE_TRIP_NEWTON 0
 #endif
 #ifndef GBP_RJ_ONE_TRIP_ACCEPT
-#define GBP_RJ_ONE_TRIP_ACCEPT 0
+#define GBP_RJ_ONE_TRIP_ACCEPT 1     // (round 6: ON -- see below)
 #endif
 // Round 6: the logarithm and the circular functions of these stages are gbp_math.h's log_pos / sincos_quadrant -- 34 and ~40 VALU issues
 // where the library's log took 98 and its cos / sincos behind Box-Muller 150 - 250 (argument reductions for any double; here the arguments
@@ -191,6 +191,12 @@ __device__ GBP_RJ_CALL double rj_log(double x) { return log(x); }
 __device__ GBP_RJ_CALL double rj_log(double x) { return gbp::log_pos(x); }
 #endif
 __device__ GBP_RJ_CALL double rj_exp(double x) { return exp(x); }
+// (the one-trip stages inline their logarithms -- a call would wait for the loads in flight: the same routine, the same bits)
+#ifdef GBP_RJ_LIBM_MATH
+__device__ __forceinline__ double rj_log_inl(double x) { return log(x); }
+#else
+__device__ __forceinline__ double rj_log_inl(double x) { return gbp::log_pos(x); }
+#endif
 __device__ GBP_RJ_CALL U4 philox_call(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t stream, uint32_t n)
 {
     return philox(seed, chain, iter, stream, n);
@@ -205,8 +211,9 @@ __device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (return
     z.a = rad * cos(ang); z.b = rad * sin(ang);
     return z;
 }
+__device__ __forceinline__ Pair box_muller_pair_inl(double u1, double u2) { return box_muller_pair(u1, u2); }
 #else
-__device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (returned in registers: two output pointers of a call are two objects in scratch)
+__device__ __forceinline__ Pair box_muller_pair_inl(double u1, double u2)
 {
     const double rad = sqrt(-2.0 * gbp::log_pos(1.0 - u1)), ang = TWO_PI * u2;       // (the angle rounded as the host emulation rounds it)
     double sn, cs;
@@ -214,6 +221,10 @@ __device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (return
     Pair z;
     z.a = rad * cs; z.b = rad * sn;
     return z;
+}
+__device__ GBP_RJ_CALL Pair box_muller_pair(double u1, double u2)     // (returned in registers: two output pointers of a call are two objects in scratch)
+{
+    return box_muller_pair_inl(u1, u2);
 }
 __device__ __forceinline__ double box_muller_cos(double u1, double u2) { return box_muller_pair(u1, u2).a; }
 #endif
@@ -1071,8 +1082,8 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
         if (i < 4) {                                                          // (normal_pair, inlined: the same routines, the same bits)
             const U4 r = philox(o.seed, chain_key(o, c, b), iter, 1, (uint32_t)i);
             const double u1 = u53(r.x, r.y), u2 = u53(r.z, r.w);
-            const double rad = sqrt(-2.0 * log(1.0 - u1)), ang = TWO_PI * u2;
-            z0 = rad * cos(ang); z1 = rad * sin(ang);
+            const Pair z = box_muller_pair_inl(u1, u2);
+            z0 = z.a; z1 = z.b;
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {                                         // data_weights8, channels i, i + 8, i + 16
@@ -1089,7 +1100,7 @@ __device__ __forceinline__ void newton8_core(const RjOpt& o, const gbp_rj_chains
             }
         }
         t2 = prior_t2_group(o, e_i, k, i, base);
-        ls = i < k ? log(sr_i) : 0.0;
+        ls = i < k ? rj_log_inl(sr_i) : 0.0;
     } else {
         data_weights8<TRIPS>(c, c.data + bb * N, pred, load_levels(o, c.rel, c.add, bb), N, i, P, PR);
         if (i < k - 1 && o.solve_gradient) {
@@ -1228,7 +1239,7 @@ __device__ __forceinline__ double levels_log_prior_t(const double* x, int G, con
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         if (g < G) {
-            const double lx = INL ? log(x[g]) : rj_log(x[g]);
+            const double lx = INL ? rj_log_inl(x[g]) : rj_log(x[g]);
             p += (lx >= llo[g] && lx <= lhi[g]) ? nlog_span[g] : -INF;
         }
     return p;
@@ -1252,13 +1263,13 @@ __device__ inline void error_hist_add(const RjOpt& o, const gbp_rj_chains& c, si
     for (int g = 0; g < 4; ++g) {
         if (g < o.n_rel_groups) {
             const double r0 = o.log_rel_min[g] * inv_ln10, r1 = o.log_rel_max[g] * inv_ln10;
-            const int ir = min(max((int)floor(((fast ? log(e.rel[g]) : rj_log(e.rel[g])) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
+            const int ir = min(max((int)floor(((fast ? rj_log_inl(e.rel[g]) : rj_log(e.rel[g])) * inv_ln10 - r0) / (r1 - r0) * nb), 0), o.n_error_bins - 1);
             if (fast) atomicAdd(c.rel_hist + (b * o.n_rel_groups + g) * o.n_error_bins + ir, 1);
             else c.rel_hist[(b * o.n_rel_groups + g) * o.n_error_bins + ir] += 1;
         }
         if (g < o.n_add_groups) {
             const double a0 = o.log_add_min[g] * inv_ln10, a1 = o.log_add_max[g] * inv_ln10;
-            const int ia = min(max((int)floor(((fast ? log(e.add[g]) : rj_log(e.add[g])) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
+            const int ia = min(max((int)floor(((fast ? rj_log_inl(e.add[g]) : rj_log(e.add[g])) * inv_ln10 - a0) / (a1 - a0) * nb), 0), o.n_error_bins - 1);
             if (fast) atomicAdd(c.add_hist + (b * o.n_add_groups + g) * o.n_error_bins + ia, 1);
             else c.add_hist[(b * o.n_add_groups + g) * o.n_error_bins + ia] += 1;
         }
@@ -1684,7 +1695,7 @@ __device__ __forceinline__ double accept8_reverse(const RjOpt& o, const gbp_rj_c
     }
     const double mean_r = lpv + o.alpha * grad;
     const bool bad = row && !(fabs(mean_r) < 11356.0);
-    const double lrem = row ? (pre.on ? log(sigma_rem) : rj_log(sigma_rem)) : 0.0;
+    const double lrem = row ? (pre.on ? rj_log_inl(sigma_rem) : rj_log(sigma_rem)) : 0.0;
     const double d1 = row ? lrem - mean_r : 0.0, d2 = row ? lpv - lrem : 0.0;
     double a1 = 0.0, a2 = 0.0;                       // (C' d)_i = sum_{m >= i} C[m][i] d_m
 #pragma unroll
@@ -1747,7 +1758,17 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
         pre.sigma_rem = c.sigma_r[bb * K + ic1];
         pre.ce_i = c.edges[bb * K + ic1];
         pre.cs_i = c.sigma[bb * K + ic1];
-        if (__ballot(jump) != 0ull) {                                         // (wave-uniform)
+        // (round 6: requested by the groups whose move needs them -- the move is known here, a group's eight lanes share it -- instead of
+        //  by every group of a wave in which any chain jumps: the Cholesky factor for a third of the chains, a Jacobian column for half)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pre.cr[j] = 0.0; pre.cc[j] = 0.0; }
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) pre.Jc[n] = 0.0;
+#ifdef GBP_RJ_WAVE_PRELOAD
+        if (__ballot(jump) != 0ull) {
+#else
+        if (jump) {
+#endif
             const double* C = c.chol + bb * K * K;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1756,7 +1777,11 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
                 pre.cc[j] = C[(size_t)jc * K + ic1];
             }
         }
+#ifdef GBP_RJ_WAVE_PRELOAD
         if (__ballot(action != NONE) != 0ull) {
+#else
+        if (action != NONE) {
+#endif
             const double* Js = (action == PERTURB ? c.J_r : c.J_p) + bb * N * K;
 #pragma unroll
             for (int n = 0; n < NJ; ++n) pre.Jc[n] = Js[(size_t)min(n, N - 1) * K + ic1];
@@ -1782,7 +1807,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     }
     if (o.solve_gradient) {
         double g = 0.0;
-        if (i < k - 1) g = (lpv_dn - lpv) / (one_trip ? log(thk_ic) : rj_log(thk_ic));
+        if (i < k - 1) g = (lpv_dn - lpv) / (one_trip ? rj_log_inl(thk_ic) : rj_log(thk_ic));
         const double g2 = group_sum8(g * g);
         const double n = (double)max(1, k - 1);
         prior_p += -0.5 * n * LOG_2PI + 0.5 * n * o.log_gradient_precision - 0.5 * o.gradient_precision * g2;
@@ -1820,7 +1845,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
                 double pr = 0.0;
                 if (ov > 0.0) {
                     const double r = (pn - ov) * (1.0 / sqrt(var));
-                    s2 += r * r; logdet += log(var); na += 1.0;
+                    s2 += r * r; logdet += rj_log_inl(var); na += 1.0;
                     pr = (1.0 / var) * (pn - ov);
                 }
                 PR[n] = pr;
@@ -1854,7 +1879,7 @@ __device__ __forceinline__ void accept8_body(const RjOpt& o, const gbp_rj_chains
     const double like_p = jump ? -(0.5 * na) * 1.8378770664093453 - 0.5 * logdet - 0.5 * s2 : like_p0;
     const double log_ratio = (prior_p - prior_c) + (like_p - like_c) + dq;
     const U4 rr = one_trip ? philox(o.seed, chain_key(o, c, b), iter, 2, 0) : philox_call(o.seed, chain_key(o, c, b), iter, 2, 0);
-    const bool accept = live && !frozen && (one_trip ? log(u53(rr.x, rr.y)) : rj_log(u53(rr.x, rr.y))) < log_ratio;
+    const bool accept = live && !frozen && (one_trip ? rj_log_inl(u53(rr.x, rr.y)) : rj_log(u53(rr.x, rr.y))) < log_ratio;
     if (st != nullptr) {
         st->accepted = accept; st->k_now = accept ? k : k_prev;
         st->have = one_trip;
