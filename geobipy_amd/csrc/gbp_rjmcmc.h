@@ -170,7 +170,10 @@ __device__ __forceinline__ void wave_sync()
 #define GBP_RJ_COLUMN_ROWS 24
 #endif
 // The one-trip variants of the packed Newton / accept stages (everything requested in one batch behind the move, logarithms and the
-// generator inlined, interface widths from the group's registers, counters as atomic adds) are measurement variants, OFF in the product:
+// generator inlined, interface widths from the group's registers, counters as atomic adds).  Round 6: the ACCEPT variant is ON -- with its
+// Cholesky / Jacobian-column requests issued by the groups whose move needs them instead of by every group of a wave, 8 192 chains 52.4 ->
+// 53.5 M chain-it/s, 4 096: 38.0 -> 39.0, 2 048: 24.3 -> 25.1, HBM traffic 157 -> 142 MB per iteration (docs/notes_r6.md); the Newton variant
+// on top adds nothing (25.0 / 38.7 / 52.9) and stays off.  Round 5's measurement, when both were measurement variants only:
 // same-box A/B (scripts/ab_rj.py, M chain-it/s, off | Newton | accept | both): 8 192 chains 44.25 | 44.26 | 44.32 | 44.56, 4 096: 30.62 |
 // 30.53 | 30.38 | 30.31, 2 048: 21.01 | 21.18 | 21.06 | 21.33 -- + 1 % at best -- against + 30 MB of HBM traffic per iteration of 8 192
 // chains (203 vs 173 MB: the batch requests what the plain code skipped) and kernels no shorter under the profiler (Newton 25.5 vs 21 us,
@@ -179,7 +182,7 @@ __device__ __forceinline__ void wave_sync()
 #define GBP_RJ_ONE_TRIP_NEWTON 0
 #endif
 #ifndef GBP_RJ_ONE_TRIP_ACCEPT
-#define GBP_RJ_ONE_TRIP_ACCEPT 1     // (round 6: ON -- see below)
+#define GBP_RJ_ONE_TRIP_ACCEPT 1
 #endif
 // Round 6: the logarithm and the circular functions of these stages are gbp_math.h's log_pos / sincos_quadrant -- 34 and ~40 VALU issues
 // where the library's log took 98 and its cos / sincos behind Box-Muller 150 - 250 (argument reductions for any double; here the arguments
@@ -2379,6 +2382,7 @@ struct PersistentCtx {
     int npts_total, npts_total_p, F, nw_deep, b;
     double sigma_direct;
     double alt, alt_p;                // height of the current state / of the proposal
+    long long t_start;                // clock at the workgroup's start while gbp_rj_debug_stage_ticks is armed (GBP_RJ_LIFE)
 };
 
 // LDS block of one chain in the persistent kernel: the doubles of GBP_RJ_D + data[N], then the int32s of GBP_RJ_I
@@ -2556,10 +2560,10 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
     const int32_t* status = c_arg.status;
     const int32_t* action_p = sh_c.action;
     const int schedule = o_arg.schedule;
-    const bool armed = threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0;                // armed by gbp_rj_debug_stage_ticks(out, 1)
-    const bool clocked = b == 0 && armed;
-    const long long t_start = armed ? (long long)wall_clock64() : 0;
-    long long t0 = t_start;
+    const bool clocked = b == 0 && threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0;   // armed by gbp_rj_debug_stage_ticks(out, 1)
+    long long t0 = clocked ? (long long)wall_clock64() : 0;
+    // (the workgroup's start time waits in LDS, not in registers the iteration loop would carry across its calls)
+    if (threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0) sh_x.t_start = (long long)wall_clock64();
     auto tick = [&](int stage) {
         if (clocked) { const long long t1 = (long long)wall_clock64(); GBP_RJ_TICKS[stage] += t1 - t0; t0 = t1; }
     };
@@ -2591,8 +2595,8 @@ __global__ GBP_RJ_PERSISTENT_BOUNDS void k_rj_persistent(RjOpt o_arg, gbp_rj_cha
         tick(4);
         if (clocked) GBP_RJ_TICKS[5] += 1;
     }
-    if (armed) {
-        const unsigned long long life = (unsigned long long)((long long)wall_clock64() - t_start);
+    if (threadIdx.x == 0 && GBP_RJ_TICKS[7] != 0) {
+        const unsigned long long life = (unsigned long long)((long long)wall_clock64() - sh_x.t_start);
         atomicAdd(&GBP_RJ_LIFE[0], life);
         atomicAdd(&GBP_RJ_LIFE[1], 1ull);
         atomicMax(&GBP_RJ_LIFE[2], life);
@@ -3021,13 +3025,13 @@ static size_t persistent_lds_bytes(const gbp_fdem_system* sys, const gbp_rj_opti
 }
 
 // Chains resident at once on the GPU with `nw` waves per workgroup: a CU's 160 KB of LDS over the workgroup's block (dynamic
-// + ~4.75 KB of static: math tables, output row, the two parameter blocks) / its 16 wave slots at 128 VGPRs.  Checked against
+// + 4 928 B of static: math tables, output row, the two parameter blocks, the stage context) / its 16 wave slots at 128 VGPRs.  Checked against
 // measurements (scripts/bench_rj_modes.py): Resolve, 30 layers: 6 / 4 / 3 workgroups per CU with 1 / 2 / 3 waves.
 static long long persistent_capacity(const gbp_fdem_system* sys, const gbp_rj_options* o, int nw)
 {
     const size_t lds = persistent_lds_bytes(sys, o, nw);
     if (lds > 64 * 1024) return 0;
-    return (long long)device_cus() * std::min<long long>(160 * 1024 / (long long)(lds + 4864), 4 * GBP_RJ_PERSISTENT_WAVES_PER_EU / nw);
+    return (long long)device_cus() * std::min<long long>(160 * 1024 / (long long)(lds + 4928), 4 * GBP_RJ_PERSISTENT_WAVES_PER_EU / nw);
 }
 
 // Whether (and how) a block can run in the persistent per-chain kernel: frequency-domain data, one error level of each kind.
