@@ -654,6 +654,8 @@ class TdemDeviceChains(DeviceChains):
         _additive_error = the multiplier's), the relative error multiplies the total field."""
         systems = [systems] if isinstance(systems, TdemSystem) else list(systems)
         assert all(isinstance(s, TdemSystem) for s in systems), TypeError("systems must be geobipy_amd.TdemSystem objects")
+        if kw.get("ignore_likelihood"):
+            raise NotImplementedError("ignore_likelihood (prior-only sampling) is taken by the frequency-domain sampler only (DeviceChains)")
         heights = np.atleast_1d(np.asarray(heights, dtype=np.float64))
         # sampled attitude angles (solve_transmitter_pitch / _roll / _yaw, solve_receiver_pitch / _roll / _yaw: gbp_td_moves)
         self._moves = device_angle_moves(kw)
