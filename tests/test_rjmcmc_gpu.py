@@ -701,6 +701,48 @@ def test_persistent_kernel_walks_the_same_chains(exact, kw):
 
 
 @pytest.mark.gpu
+def test_fused_accept_and_proposal_across_the_eight_layer_border():
+    """in k_rj_step8 a packed 8-lane group and a deep chain's scanning workgroup must never both act on one chain, whatever side
+    of the 8-layer border the chain's current and proposed models are on.  Prior-only chains (births and deaths are accepted often) started
+    from models of 1 ... 10 layers cross the border hundreds of times; the fused launches (modes 1 and 4 from the second iteration of a
+    call) must leave every array as the persistent kernel -- a workgroup per chain, nothing shared -- leaves it, also when the run is cut
+    into calls of a few iterations."""
+    B, n_it = 2400, 300
+    runs, crossings = [], 0
+    for mode, cuts in ((2, (n_it,)), (1, (n_it,)), (4, (n_it,)), (4, (3,) + (2,) * 5 + (n_it - 13,)), (1, (2,) * (n_it // 2))):
+        d, s, dc = _chains(B, 57, ignore_likelihood=True,
+                           options=dict(maximum_number_of_layers=14, probability_of_birth=0.3, probability_of_death=0.3,
+                                        probability_of_perturb=0.2, probability_of_no_change=0.2))
+        _load_random_state(dc, np.random.default_rng(33), kmax=10)
+        dc.rel.fill_(0.05); dc.add.fill_(5.0)
+        thk = rg.layer_widths(dc.edges, dc.k.to(torch.int64)).contiguous()
+        dc._eval_loglike(dc.k, dc.sigma, thk, dc.height, dc.data, dc.rel, dc.add, dc.pred, dc.misfit, dc.like)
+        dc._eval_jacobian(dc.k, dc.sigma, thk, dc.height, dc.J, dc.K)
+        dc.prior.copy_(rg.model_log_prior(dc.edges, dc.sigma, dc.k.to(torch.int64), dc.K, dc.gradient_precision)
+                       + rg.log_uniform_prior(dc.rel[:, 0], dc._bounds["rel"][0][0], dc._bounds["rel"][1][0])
+                       + rg.log_uniform_prior(dc.add[:, 0], dc._bounds["add"][0][0], dc._bounds["add"][1][0]))
+        assert float(dc.like.abs().max()) == 0.0                  # (no channel is active: the likelihood of every state is the constant 0)
+        dc.run_mode = mode
+        k_prev = dc.k.clone()
+        for n in cuts:
+            dc.run(n)
+            if len(cuts) == n_it // 2:                            # (the run in calls of 2 iterations: border crossings between its snapshots)
+                crossings += int(((k_prev <= 8) != (dc.k <= 8)).sum())
+                k_prev = dc.k.clone()
+        torch.cuda.synchronize()
+        runs.append(dc)
+    ref = runs[0]
+    assert crossings > 200, crossings                             # (a lower bound: a chain that crosses twice inside a window is not seen)
+    assert int(ref.n_accepted.sum()) > 0.2 * B * n_it
+    names = ["k", "edges", "sigma", "rel", "add", "pred", "J", "prior", "like", "misfit", "n_accepted", "k_hist", "edge_hist", "rel_hist",
+             "add_hist", "best_posterior", "best_k", "best_edges", "best_sigma", "log_ratio"]
+    for other in runs[1:]:
+        for n in names:
+            a, b = getattr(ref, n), getattr(other, n)
+            assert torch.equal(torch.nan_to_num(a.double(), nan=-1.25), torch.nan_to_num(b.double(), nan=-1.25)), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exact", [False, True])
 def test_device_chains_sample_like_the_host_chains(exact):
     """The device sampler against the host sampler (rjmcmc.py through BatchedInference -- the code that reproduces

@@ -65,6 +65,26 @@ def test_select_soundings_and_cli_arguments():
     from geobipy_amd.__main__ import parse
     a = parse(["opts", "out", "--seed", "12", "--index", "3", "--line", "100.0", "--fiducial", "5", "--mpi"])
     assert (a.options_file, a.output_directory, a.seed, a.index, a.line_number, a.fiducial, a.mpi) == ("opts", "out", 12, 3, 100.0, 5.0, True)
+    # --traces: full-length arrays by default (the reference's shapes), a stride, "auto", or none
+    assert a.traces == 1 and parse(["o", "d", "--traces", "8"]).traces == 8 and parse(["o", "d", "--traces", "auto"]).traces == "auto"
+    assert parse(["o", "d", "--traces", "0"]).traces is None
+
+
+def test_default_block_and_schedule_follow_the_payload_and_the_lines():
+    """ADVICE r5: the default device block shrinks when full-length traces of a large n_markov_chains would not fit the payload budget;
+    --schedule auto takes whole lines per rank only when containers are written and the lines balance (checked through the pieces of
+    survey.infer that decide it: the budget constant and distributed.assign_lines)."""
+    from geobipy_amd.distributed import assign_lines
+    per = -(-2 * 100000 // 1) * 9 + 440 * 1024                    # bytes per sounding: full traces at the reference's default + a hit map
+    assert 256 <= survey.BLOCK_PAYLOAD_BUDGET // per < 16384 and (survey.BLOCK_PAYLOAD_BUDGET // per) * per <= survey.BLOCK_PAYLOAD_BUDGET
+    per_small = -(-2 * 2000 // 1) * 9 + 440 * 1024
+    assert survey.BLOCK_PAYLOAD_BUDGET // per_small >= 16384      # the bench's surveys keep blocks of 16 384
+    counts = np.array([1000, 10, 10, 10])                        # one dominant line over four ranks: "lines" would idle three of them
+    loads = [int(sum(counts[i] for i in mine)) for mine in assign_lines(counts, 4)]
+    assert max(loads) > 1.2 * counts.sum() / 4
+    counts = np.full(16, 512)
+    loads = [int(sum(counts[i] for i in mine)) for mine in assign_lines(counts, 8)]
+    assert max(loads) <= 1.2 * counts.sum() / 8
 
 
 def test_read_time_domain_csv_and_options():
