@@ -73,6 +73,20 @@ def test_host_fixture_is_a_distribution_and_a_fresh_chain_agrees():
     assert np.abs(p - f["k_p"]).max() < 0.25 and abs(acc - f["acceptance"].mean()) < 0.1
 
 
+def test_host_infer_runs_the_prior_only_schedule():
+    """Inference1D.infer with ignore_likelihood: burned in from the start with burned_in_iteration = n_markov_chains, 2 n_markov_chains + 1
+    updates, never failed (inversion/Inference1D.py:388-389, 656)."""
+    from geobipy_amd.inference import Inference1D
+    n_mc = 40
+    inf = Inference1D(prng=np.random.Generator(np.random.PCG64DXSM(9)), ignore_likelihood=True, engine=po.NullEngine(po.N_CHANNELS),
+                      **dict(po.OPTS, n_markov_chains=n_mc))
+    inf.initialize(types.SimpleNamespace(data=np.full(po.N_CHANNELS, 100.0), z=np.array([30.0])))
+    assert inf.infer() is False
+    assert inf.burned_in and inf.burned_in_iteration == n_mc and inf.iteration == 2 * n_mc + 1
+    assert inf.posteriors.layers.sum() == 2 * n_mc + 1 if hasattr(inf.posteriors, "layers") else True
+    assert np.array_equal(inf.observed, np.full(po.N_CHANNELS, 100.0)) and not inf.data.any()
+
+
 def test_model_perturb_without_an_observation():
     """Model.perturb / proposal_probabilities with observation = None (model/Model.py:269, 352, 380): prior-only proposals."""
     from geobipy_amd import rjmcmc
