@@ -67,3 +67,30 @@ def test_overlong_input_never_prints_an_overlong_line():
     line = bench.compact_line(full)
     assert len(json.dumps(line, separators=(",", ":"))) <= 4096
     assert "roofline" in line and "cpu_baseline" in line
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_parsable_line_on_the_gpu(tmp_path):
+    """python bench.py (bounded flags) on cuda:0: the LAST stdout line is the compact JSON line -- under 3 KB, the contract's keys, roofline and
+    cpu_baseline objects, parity within the bar -- and the full record lands in the extras file."""
+    import subprocess
+    extras = os.path.join(str(tmp_path), "extras.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--soundings", "8192",
+                        "--no-extras", "--no-rjmcmc", "--cpu-sample", "512", "--extras-file", extras],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) <= bench.COMPACT_LIMIT
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity_vs_cpu", "extras_file"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 2 and line["dtype"] == "f64" and line["value"] > 1e6
+    assert line["roofline"]["frac"] > 0.05 and line["roofline"]["kernel"].startswith("k_fdem_forward")
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["value"] > 0
+    assert line["parity_vs_cpu"]["within_bar"] is True
+    full = json.load(open(extras))
+    assert full["value"] == pytest.approx(line["value"], rel=1e-5) and "definition" in full["roofline"]
