@@ -45,3 +45,19 @@ print(f"workgroup life per iteration: mean {tk[7] / 100.0 / seg:.1f} us, longest
 k_mean = (ksum / n_seg).cpu().numpy(); km = kmax.cpu().numpy()
 print("layer count (sampled every %d iterations): mean over chains %.2f; chains whose count reached > 8: %d; largest %d; the ten largest per-chain means: %s" % (
     seg, k_mean.mean(), int((km > 8).sum()), int(km.max()), np.round(np.sort(k_mean)[-10:], 1)))
+
+if os.environ.get("GBP_DEEP_FIRST"):
+    # the same block with its deepest chain's sounding in row 0, so that the stage clock (chain 0) shows where a SLOW chain spends its time
+    r = int(np.argmax(k_mean))
+    perm = np.r_[r, np.delete(np.arange(B), r)]
+    dc2 = DeviceChains(system, height[:B][perm], obs[perm], seed=1, exact_jacobian=False, chain_id=perm.astype(np.int64), **opts)
+    dc2.run_mode = 2
+    dc2.run(100 + n_it); torch.cuda.synchronize()
+    _lib.check(lib.gbp_rj_debug_stage_ticks(tk, 1))
+    ks = 0.0
+    for _ in range(n_seg):
+        dc2.run(seg); ks += float(dc2.k[0])
+    torch.cuda.synchronize()
+    _lib.check(lib.gbp_rj_debug_stage_ticks(tk, 2))
+    print("deepest chain in row 0 (mean layers %.1f over the clocked run): stages us/it [propose, fm_dlogc_r, newton, fwd|fm_dlogc_p, accept]: %s; sum %.1f" % (
+        ks / n_seg, " ".join(f"{tk[i] / max(1, tk[5]) / 100.0:.1f}" for i in range(5)), sum(tk[i] for i in range(5)) / max(1, tk[5]) / 100.0))
